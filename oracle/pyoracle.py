@@ -1,0 +1,266 @@
+"""oracle/pyoracle.py -- TEST INFRASTRUCTURE ONLY.
+
+NumPy-facing access to the two CPU oracles:
+
+* ``port``  -- oracle/_build/liboracle_port.so, our C restatement (oracle/port/oracle_port.c); travels to
+  the GPU box.
+* ``ref``   -- oracle/_ref/libref_oracle.so, the reference's OWN arithmetic compiled from the line
+  ranges where they lie under /root/reference (oracle/ref_wrap.cpp); built in the dev container and
+  shipped as a binary, never as source.
+
+plus NumPy / torch-CPU restatements of the Python layers on the path (PointPillarsScatter, PFN,
+VoxelMean, HardVoxelizer glue).  Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline``
+leg may import this module; the product package ``paddle3d_amd`` never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from functools import lru_cache
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_SO = os.path.join(_HERE, "_build", "liboracle_port.so")
+REF_SO = os.path.join(_HERE, "_ref", "libref_oracle.so")
+
+_f = np.float32
+_i = np.int32
+
+
+def build(ref: bool = True) -> None:
+    """(Re)build the oracle libraries with gcc; ``ref`` only when /root/reference exists."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "port"])
+    if ref and os.path.isdir("/root/reference/paddle3d/ops"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+def _p(a, t=None):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+@lru_cache(maxsize=None)
+def _lib(kind: str):
+    path = PORT_SO if kind == "port" else REF_SO
+    if not os.path.exists(path):
+        if kind == "port":
+            build(ref=False)
+        else:
+            raise FileNotFoundError(f"{path} missing: run `make -C oracle ref` where /root/reference exists")
+    lib = C.CDLL(path)
+    return lib
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_SO)
+
+
+# ------------------------------------------------------------------------------------------------
+# hard_voxelize
+# ------------------------------------------------------------------------------------------------
+def hard_voxelize(points, voxel_size, pc_range, max_pts, max_voxels, kind="port"):
+    """Returns (voxels [V,P,D] f32, coords [V,3] i32 (z,y,x), num_points [V] i32, num_voxels int)."""
+    pts = _c(points, _f)
+    n, d = pts.shape
+    vs, pr = _c(voxel_size, _f), _c(pc_range, _f)
+    voxels = np.empty((max_voxels, max_pts, d), _f)
+    coords = np.empty((max_voxels, 3), _i)
+    npts = np.empty((max_voxels,), _i)
+    nv = np.zeros((1,), _i)
+    fn = _lib(kind).port_hard_voxelize if kind == "port" else _lib(kind).ref_hard_voxelize
+    fn.restype = C.c_int
+    fn(_p(pts), C.c_int64(n), C.c_int(d), _p(vs), _p(pr), C.c_int(max_pts), C.c_int(max_voxels),
+       _p(voxels), _p(coords), _p(npts), _p(nv))
+    return voxels, coords, npts, int(nv[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# iou3d_nms
+# ------------------------------------------------------------------------------------------------
+def boxes_iou_bev(a, b, kind="port"):
+    a, b = _c(a, _f), _c(b, _f)
+    out = np.empty((len(a), len(b)), _f)
+    fn = getattr(_lib(kind), ("port" if kind == "port" else "ref") + "_boxes_iou_bev")
+    fn(_p(a), C.c_int(len(a)), _p(b), C.c_int(len(b)), _p(out))
+    return out
+
+
+def boxes_overlap_bev(a, b, kind="port"):
+    a, b = _c(a, _f), _c(b, _f)
+    out = np.empty((len(a), len(b)), _f)
+    fn = getattr(_lib(kind), ("port" if kind == "port" else "ref") + "_boxes_overlap_bev")
+    fn(_p(a), C.c_int(len(a)), _p(b), C.c_int(len(b)), _p(out))
+    return out
+
+
+def nms(boxes, thresh, normal=False, kind="port"):
+    """Greedy NMS over score-sorted boxes [N,7]; returns keep indices (int32 [num])."""
+    bx = _c(boxes, _f)
+    keep = np.empty((max(len(bx), 1),), _i)
+    num = np.zeros((1,), _i)
+    fn = getattr(_lib(kind), ("port" if kind == "port" else "ref") + "_nms")
+    fn(_p(bx), C.c_int(len(bx)), C.c_float(thresh), C.c_int(int(normal)), _p(keep), _p(num))
+    return keep[: int(num[0])].copy()
+
+
+def iou_margin(boxes, thresh, normal=False):
+    """min |IoU - thresh| over all pairs: how far a test vector is from a libm-sensitive flip."""
+    iou = boxes_iou_bev(boxes, boxes) if not normal else None
+    if iou is None:
+        raise NotImplementedError
+    tri = iou[np.triu_indices(len(boxes), 1)]
+    return float(np.min(np.abs(tri - thresh))) if tri.size else float("inf")
+
+
+# ------------------------------------------------------------------------------------------------
+# PointPillarsScatter / voxel encoders (NumPy restatements of the Python layers)
+# ------------------------------------------------------------------------------------------------
+def pillar_scatter(feats, coords, batch, ny, nx):
+    """pillar_scatter.py:57-93 -> canvas [B, C, ny, nx]."""
+    f, c4 = _c(feats, _f), _c(coords, _i)
+    out = np.empty((batch, f.shape[1], ny, nx), _f)
+    _lib("port").port_pillar_scatter(_p(f), _p(c4), C.c_int64(len(f)), C.c_int(f.shape[1]),
+                                     C.c_int(batch), C.c_int(ny), C.c_int(nx), _p(out))
+    return out
+
+
+def pillar_scatter_numpy(feats, coords, batch, ny, nx):
+    """Independent NumPy statement of the same layer (zeros canvas, indexed assignment, transpose)."""
+    c = feats.shape[1]
+    out = []
+    for b in range(batch):
+        canvas = np.zeros((nx * ny, c), feats.dtype)
+        m = coords[:, 0] == b
+        idx = coords[m, 2] * nx + coords[m, 3]
+        canvas[idx] = feats[m]
+        out.append(canvas.T.reshape(1, c, ny, nx))
+    return np.concatenate(out, 0)
+
+
+def voxel_mean(voxels, num_points):
+    """voxel_encoder.py:44-57: sum over P / count."""
+    return voxels.sum(1, dtype=np.float32) / num_points.astype(np.float32).reshape(-1, 1)
+
+
+def pfn_forward_torch(voxels, num_points, coors, params, voxel_size, pc_range):
+    """PillarFeatureNet.forward in eval mode (pillar_encoder.py:156-210, PFNLayer :81-105), torch CPU fp32.
+
+    params: list of dicts per PFN layer with 'weight' [in, units] (Paddle Linear layout), 'gamma',
+    'beta', 'mean', 'var' (BatchNorm1D, eps 1e-3).
+    """
+    import torch
+
+    f = torch.as_tensor(voxels, dtype=torch.float32)
+    npv = torch.as_tensor(num_points).to(torch.float32).reshape(-1, 1, 1)
+    co = torch.as_tensor(coors)
+    P = f.shape[1]
+    vx, vy = float(voxel_size[0]), float(voxel_size[1])
+    x_off, y_off = vx / 2 + pc_range[0], vy / 2 + pc_range[1]
+    mean = f[:, :, :3].sum(1, keepdim=True) / npv
+    f_cluster = f[:, :, :3] - mean
+    f_center = torch.zeros_like(f[:, :, :2])
+    f_center[:, :, 0] = f[:, :, 0] - (co[:, 3].reshape(-1, 1).to(torch.float32) * vx + x_off)
+    f_center[:, :, 1] = f[:, :, 1] - (co[:, 2].reshape(-1, 1).to(torch.float32) * vy + y_off)
+    x = torch.cat([f, f_cluster, f_center], -1)
+    mask = (torch.as_tensor(num_points).reshape(-1, 1) > torch.arange(P).reshape(1, -1)).to(torch.float32)
+    x = x * mask.unsqueeze(-1)
+    for li, p in enumerate(params):
+        y = x @ torch.as_tensor(p["weight"])
+        y = (y - torch.as_tensor(p["mean"])) / torch.sqrt(torch.as_tensor(p["var"]) + 1e-3)
+        y = y * torch.as_tensor(p["gamma"]) + torch.as_tensor(p["beta"])
+        y = torch.relu(y)
+        ymax = y.max(dim=1, keepdim=True).values
+        if li == len(params) - 1:
+            x = ymax
+        else:
+            x = torch.cat([y, ymax.expand(-1, P, -1)], dim=2)
+    return x.squeeze(1).numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# centerpoint_postprocess
+# ------------------------------------------------------------------------------------------------
+def centerpoint_postprocess(tasks, voxel_size, pc_range, post_center_range, num_classes, down_ratio,
+                            score_threshold, nms_iou_threshold, nms_pre_max_size, nms_post_max_size,
+                            with_velocity=True, return_margins=False):
+    """tasks: list of dict(hm, reg, height, dim, vel, rot) float32 [1,c,H,W].  num_classes: label
+    offset per task (postprocess.cu:268-270).  Returns (bboxes [K,9|7], scores [K], labels int64 [K])."""
+    lib = _lib("port")
+    fn = lib.port_centerpoint_postprocess_task
+    fn.restype = C.c_int
+    dims = 9 if with_velocity else 7
+    vs, pr, pcr = _c(voxel_size, _f), _c(pc_range, _f), _c(post_center_range, _f)
+    outs_b, outs_s, outs_l, margins = [], [], [], []
+    h, w = tasks[0]["hm"].shape[2:]
+    for t_id, t in enumerate(tasks):
+        hm = _c(t["hm"], _f)
+        cap = max(1, nms_post_max_size)
+        ob = np.zeros((cap, dims), _f)
+        os_ = np.zeros((cap,), _f)
+        ol = np.zeros((cap,), np.int64)
+        mm = np.zeros((2,), _f)
+        arrs = [_c(t[k], _f) for k in ("reg", "height", "dim", "vel", "rot")]
+        rows = fn(_p(hm), C.c_int(hm.shape[1]), _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]),
+                  _p(arrs[4]), C.c_int(h), C.c_int(w), _p(vs), _p(pr), _p(pcr),
+                  C.c_int(int(num_classes[t_id])), C.c_int(int(down_ratio)), C.c_float(score_threshold),
+                  C.c_float(nms_iou_threshold), C.c_int(nms_pre_max_size), C.c_int(nms_post_max_size),
+                  C.c_int(int(with_velocity)), _p(ob), _p(os_), _p(ol), _p(mm))
+        outs_b.append(ob[:rows])
+        outs_s.append(os_[:rows])
+        outs_l.append(ol[:rows])
+        margins.append(mm.copy())
+    res = (np.concatenate(outs_b), np.concatenate(outs_s), np.concatenate(outs_l))
+    if return_margins:
+        return res + (np.stack(margins),)
+    return res
+
+
+def centerpoint_decode_ref(score, reg, height, expdim, vel, rot, score_threshold, feat_w, down_ratio,
+                           voxel_size, pc_range, post_center_range, with_velocity=True):
+    """The reference decode_kernel itself (oracle/_ref), for pinning the port's decode stage."""
+    lib = _lib("ref")
+    hw = score.size
+    dims = 9 if with_velocity else 7
+    boxes = np.zeros((hw, dims), _f)
+    mask = np.zeros((hw,), np.uint8)
+    sidx = np.zeros((hw,), _i)
+    pcr = _c(post_center_range, _f)
+    args = [_c(a, _f) for a in (score, reg, height, expdim, vel, rot)]
+    lib.ref_centerpoint_decode(*[_p(a) for a in args], C.c_float(score_threshold), C.c_int(feat_w),
+                               C.c_float(down_ratio), C.c_float(voxel_size[0]), C.c_float(voxel_size[1]),
+                               C.c_float(pc_range[0]), C.c_float(pc_range[1]), _p(pcr), C.c_int(hw),
+                               C.c_int(int(with_velocity)), _p(boxes), _p(mask), _p(sidx))
+    return boxes, mask.astype(bool), sidx
+
+
+# ------------------------------------------------------------------------------------------------
+# bev_pool_v2
+# ------------------------------------------------------------------------------------------------
+def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_lengths, interval_starts,
+                bev_feat_shape, kind="port"):
+    d, f = _c(depth, _f), _c(feat, _f)
+    rd, rf, rb = _c(ranks_depth, _i), _c(ranks_feat, _i), _c(ranks_bev, _i)
+    il, is_ = _c(interval_lengths, _i), _c(interval_starts, _i)
+    c = f.shape[-1]
+    out = np.zeros(tuple(bev_feat_shape), _f)
+    fn = getattr(_lib(kind), ("port" if kind == "port" else "ref") + "_bev_pool_v2")
+    fn(C.c_int(c), C.c_int(len(il)), _p(d), _p(f), _p(rd), _p(rf), _p(rb), _p(is_), _p(il), _p(out))
+    return out
+
+
+def bev_pool_v2_bkwd(out_grad, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_lengths,
+                     interval_starts, kind="port"):
+    g, d, f = _c(out_grad, _f), _c(depth, _f), _c(feat, _f)
+    rd, rf, rb = _c(ranks_depth, _i), _c(ranks_feat, _i), _c(ranks_bev, _i)
+    il, is_ = _c(interval_lengths, _i), _c(interval_starts, _i)
+    c = g.shape[-1]
+    dg, fg = np.zeros_like(d), np.zeros_like(f)
+    fn = getattr(_lib(kind), ("port" if kind == "port" else "ref") + "_bev_pool_v2_bkwd")
+    fn(C.c_int(c), C.c_int(len(il)), _p(g), _p(d), _p(f), _p(rd), _p(rf), _p(rb), _p(is_), _p(il),
+       _p(dg), _p(fg))
+    return dg, fg
