@@ -1,0 +1,171 @@
+/* paddle3d_amd.h -- C ABI of libpaddle3d_amd.so, the MI355X (gfx950) LiDAR-detection op library.
+ *
+ * Drop-in boundary: every entry point replaces one custom operator (or one layer built on Paddle-core
+ * scatter) of the reference's `paddle3d.ops` plugin API for the LiDAR hot path.  The reference
+ * registers its operators with PD_BUILD_OP(name).Inputs/.Outputs/.Attrs (file:line cited per
+ * function below); a maintainer binds these symbols from a Paddle custom-op shim or via ctypes --
+ * see INTEGRATION.md.  the modules under paddle3d_amd/ops/ are the ctypes binding used by this repository.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers unless a parameter is documented "host".
+ *   - Plain C types only; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - The library never allocates or frees device memory: outputs and `workspace` are caller-owned.
+ *     Query the workspace size with the matching *_workspace() function (bytes; 256-B aligned base).
+ *   - Every call is asynchronous on `stream` unless documented otherwise, re-entrant and thread-safe
+ *     given disjoint buffers.
+ *   - Return value: 0 ok; <0 argument error (PD3_E*); >0 a hipError_t from the launch.
+ *   - fp32 only, like the reference ops (voxelize_op.cc:104-106 hard-codes FLOAT32 outputs).
+ */
+#ifndef PADDLE3D_AMD_H
+#define PADDLE3D_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PD3_OK 0
+#define PD3_EINVAL (-1)
+#define PD3_EWORKSPACE (-2)
+#define PD3_EUNSUPPORTED (-3)
+
+/* Library/ABI version (major*10000 + minor*100 + patch) and the gfx target it was compiled for. */
+int pd3_version(void);
+const char *pd3_target_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * hard_voxelize -- replaces PD_BUILD_OP(hard_voxelize), paddle3d/ops/voxel/voxelize_op.cc:183-191
+ * (kernel fn hard_voxelize :149-166; CPU semantics hard_voxelize_cpu_kernel :19-82, which this
+ * implementation reproduces bit-exactly, unlike the reference's own CUDA path voxelize_op.cu:208-346
+ * whose atomics make voxel order and in-voxel point choice nondeterministic).
+ *
+ *   points            [batch, max_points, num_point_dim] fp32, row-major; frame b uses its first
+ *                     num_points[b] rows (num_points == NULL: all max_points rows).
+ *   voxel_size        host float[3] (x, y, z);  point_cloud_range host float[6] (xmin..zmin, xmax..zmax)
+ *   voxels            [batch, max_voxels, max_num_points_in_voxel, num_point_dim] fp32, zero padded
+ *   coords            [batch, max_voxels, 3] int32 (z, y, x), zero padded
+ *   num_points_per_voxel [batch, max_voxels] int32, zero padded
+ *   num_voxels        [batch] int32
+ * batch = 1 is exactly the reference op; batch > 1 is the reference's HardVoxelizer python loop
+ * (paddle3d/models/voxelizers/voxelize.py:60-82) in one launch sequence.
+ */
+size_t pd3_hard_voxelize_workspace(int batch, int64_t max_points, int num_point_dim,
+                                   const float *voxel_size, const float *point_cloud_range,
+                                   int max_num_points_in_voxel, int max_voxels);
+int pd3_hard_voxelize(const float *points, const int32_t *num_points, int batch, int64_t max_points,
+                      int num_point_dim, const float *voxel_size, const float *point_cloud_range,
+                      int max_num_points_in_voxel, int max_voxels, float *voxels, int32_t *coords,
+                      int32_t *num_points_per_voxel, int32_t *num_voxels, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * pointpillars_scatter -- replaces PointPillarsScatter.forward_batch,
+ * paddle3d/models/middle_encoders/pillar_scatter.py:57-93 (zeros canvas + paddle.scatter(overwrite) +
+ * transpose + concat), fused into one canvas-parallel pass.
+ *
+ *   voxel_features [num_pillars, channels] fp32;  coords [num_pillars, 4] int32 (batch, z, y, x)
+ *   canvas         [batch, channels, ny, nx] fp32 -- fully written (zero where no pillar)
+ * Pillars with batch index outside [0, batch) are ignored.  Duplicate (batch, y, x): last index wins,
+ * as paddle.scatter(overwrite=True) documents; the hot path never produces duplicates.
+ */
+size_t pd3_pointpillars_scatter_workspace(int batch, int ny, int nx);
+int pd3_pointpillars_scatter(const float *voxel_features, const int32_t *coords,
+                             int64_t num_pillars, int channels, int batch, int ny, int nx,
+                             float *canvas, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * pillar feature net (PFN) -- replaces PillarFeatureNet.forward / PFNLayer.forward in eval mode,
+ * paddle3d/models/voxel_encoders/pillar_encoder.py:156-210 / :81-105 (decorate with cluster and
+ * pillar-centre offsets, mask padded slots, Linear(no bias) -> BatchNorm1D(eps 1e-3) -> ReLU -> max
+ * over the points of a pillar; the non-last layer concatenates the max back).  BatchNorm is folded by
+ * the caller: scale = gamma / sqrt(var + eps), shift = beta - mean * scale.
+ *
+ *   voxels [M, P, D], num_points [M] int32, coors [M, 4] int32 (b, z, y, x)
+ *   w1 [D+5, C1] (Paddle Linear layout [in, out]), scale1/shift1 [C1]
+ *   w2 [2*C1, C2], scale2/shift2 [C2]   (w2 == NULL: single-layer PFN, output [M, C1])
+ *   out [M, C2]
+ * legacy == 0 only (the nuScenes configs); with_distance unsupported (no config on the path uses it).
+ */
+int pd3_pillar_feature_net(const float *voxels, const int32_t *num_points, const int32_t *coors,
+                           int64_t num_pillars, int max_points, int num_point_dim, float vx,
+                           float vy, float x_offset, float y_offset, const float *w1,
+                           const float *scale1, const float *shift1, int c1, const float *w2,
+                           const float *scale2, const float *shift2, int c2, float *out,
+                           void *stream);
+
+/* VoxelMean.forward, paddle3d/models/voxel_encoders/voxel_encoder.py:44-57: sum over P / count. */
+int pd3_voxel_mean(const float *voxels, const int32_t *num_points, int64_t num_voxels,
+                   int max_points, int num_point_dim, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * iou3d_nms -- replaces the five ops of paddle3d/ops/iou3d_nms/iou3d_nms_api.cpp:73-108.
+ * Boxes are [N, 7] fp32 (x, y, z, dx, dy, dz, heading).
+ *
+ * pd3_nms_bev / pd3_nms_normal: nms_gpu / nms_normal_gpu (iou3d_nms.cpp:86-141 / :143-204).
+ * The suppression bit-matrix AND the greedy sweep run on the device (the reference copies the mask to
+ * the host and sweeps there).  keep [N] int32 (first *num_to_keep entries valid) and num_to_keep [1]
+ * int32 are DEVICE buffers; the Python shim returns them as CPU int32 tensors like the reference.
+ */
+size_t pd3_nms_workspace(int num_boxes);
+int pd3_nms_bev(const float *boxes, int num_boxes, float nms_overlap_thresh, int32_t *keep,
+                int32_t *num_to_keep, void *workspace, size_t workspace_bytes, void *stream);
+int pd3_nms_normal(const float *boxes, int num_boxes, float nms_overlap_thresh, int32_t *keep,
+                   int32_t *num_to_keep, void *workspace, size_t workspace_bytes, void *stream);
+/* boxes_iou_bev_gpu / boxes_overlap_bev_gpu (iou3d_nms.cpp:44-84): dense [N, M] matrices. */
+int pd3_boxes_iou_bev(const float *boxes_a, int num_a, const float *boxes_b, int num_b,
+                      float *ans_iou, void *stream);
+int pd3_boxes_overlap_bev(const float *boxes_a, int num_a, const float *boxes_b, int num_b,
+                          float *ans_overlap, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * centerpoint_postprocess -- replaces PD_BUILD_OP(centerpoint_postprocess),
+ * paddle3d/ops/centerpoint_postprocess/postprocess.cc:91-104 (postprocess_gpu, postprocess.cu:104-280).
+ * All tasks of one frame in one launch sequence on one stream, no host round trip inside.
+ *
+ *   hm/reg/height/dim/vel/rot: host arrays of `num_tasks` device pointers to fp32 NCHW maps with
+ *     batch 1: hm[t] [1, hm_channels[t], H, W], reg [1,2,H,W], height [1,1,H,W], dim [1,3,H,W],
+ *     vel [1,2,H,W], rot [1,2,H,W].
+ *   hm_channels: host int[num_tasks];  label_offsets: host int[num_tasks] (the op's `num_classes` attr)
+ *   out_bboxes  [num_tasks * max(nms_post_max_size,1), 9 or 7] fp32
+ *   out_scores  [same rows] fp32;  out_labels [same rows] int64
+ *   out_count   [1] int32: number of valid leading rows (tasks concatenated in order; a task with no
+ *               candidate contributes the reference's fake row: zeros box, score -1, label 0).
+ */
+size_t pd3_centerpoint_postprocess_workspace(int num_tasks, int feat_h, int feat_w,
+                                             int nms_pre_max_size, int nms_post_max_size);
+int pd3_centerpoint_postprocess(const float *const *hm, const float *const *reg,
+                                const float *const *height, const float *const *dim,
+                                const float *const *vel, const float *const *rot, int num_tasks,
+                                const int *hm_channels, int feat_h, int feat_w,
+                                const float *voxel_size, const float *point_cloud_range,
+                                const float *post_center_range, const int *label_offsets,
+                                int down_ratio, float score_threshold, float nms_iou_threshold,
+                                int nms_pre_max_size, int nms_post_max_size, int with_velocity,
+                                float *out_bboxes, float *out_scores, int64_t *out_labels,
+                                int32_t *out_count, void *workspace, size_t workspace_bytes,
+                                void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * bev_pool_v2 / bev_pool_v2_bkwd -- replace PD_BUILD_OP(bev_pool_v2) (bev_pool_v2/bev_pool.cc:111-118,
+ * kernel bev_pool_cuda.cu:18-44) and PD_BUILD_OP(bev_pool_v2_bkwd)
+ * (bev_pool_v2_backward/bev_pool_bkwd.cc:75-80, kernel bev_pool_cuda_bkwd.cu:44-94).
+ * `out` / grads are fully written (zero where no interval lands), fp32 accumulation in interval order.
+ * n_points = length of the ranks_* arrays; the intervals tile [0, n_points).
+ */
+int pd3_bev_pool_v2(const float *depth, const float *feat, const int32_t *ranks_depth,
+                    const int32_t *ranks_feat, const int32_t *ranks_bev,
+                    const int32_t *interval_lengths, const int32_t *interval_starts,
+                    int n_intervals, int channels, int64_t out_elems, float *out, void *stream);
+int pd3_bev_pool_v2_bkwd(const float *out_grad, const float *depth, const float *feat,
+                         const int32_t *ranks_depth, const int32_t *ranks_feat,
+                         const int32_t *ranks_bev, const int32_t *interval_lengths,
+                         const int32_t *interval_starts, int n_intervals, int64_t n_points,
+                         int channels, int64_t depth_elems, int64_t feat_elems, float *depth_grad,
+                         float *feat_grad, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PADDLE3D_AMD_H */

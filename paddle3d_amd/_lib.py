@@ -1,0 +1,87 @@
+"""ctypes loader for libpaddle3d_amd.so (the C ABI declared in include/paddle3d_amd.h).
+
+There is NO fallback: if the shared object is missing, was built for another ABI, or lacks a symbol,
+importing an op raises.  A GPU box must never silently run a PyTorch/CPU substitute.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from functools import lru_cache
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpaddle3d_amd.so")
+
+c_f32p = C.c_void_p
+c_i32p = C.c_void_p
+
+# symbol -> (restype, argtypes); mirrors include/paddle3d_amd.h one to one
+_SIGNATURES = {
+    "pd3_version": (C.c_int, []),
+    "pd3_target_arch": (C.c_char_p, []),
+    "pd3_hard_voxelize_workspace": (C.c_size_t, [C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                                 C.c_int, C.c_int]),
+    "pd3_hard_voxelize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pd3_pointpillars_scatter_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "pd3_pointpillars_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pd3_pillar_feature_net": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_voxel_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                 C.c_void_p]),
+    "pd3_nms_workspace": (C.c_size_t, [C.c_int]),
+    "pd3_nms_bev": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_size_t, C.c_void_p]),
+    "pd3_nms_normal": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_size_t, C.c_void_p]),
+    "pd3_boxes_iou_bev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_boxes_overlap_bev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_void_p]),
+    "pd3_centerpoint_postprocess_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pd3_centerpoint_postprocess": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pd3_bev_pool_v2": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int64, C.c_void_p,
+                                                     C.c_void_p]),
+    "pd3_bev_pool_v2_bkwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64,
+                                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+SYMBOLS = tuple(_SIGNATURES)
+
+
+class Paddle3DAmdError(RuntimeError):
+    pass
+
+
+@lru_cache(maxsize=None)
+def lib() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise Paddle3DAmdError(
+            f"{LIB_PATH} not found: build it with `python -m paddle3d_amd.build` "
+            "(there is no CPU / PyTorch fallback for the HIP ops)")
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:  # pragma: no cover
+            raise Paddle3DAmdError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    return handle
+
+
+def check(status: int, what: str) -> None:
+    if status == 0:
+        return
+    if status < 0:
+        msg = {-1: "invalid argument", -2: "workspace too small", -3: "unsupported configuration"}.get(
+            status, "error")
+        raise Paddle3DAmdError(f"{what}: {msg} (status {status})")
+    raise Paddle3DAmdError(f"{what}: HIP error {status}")

@@ -1,0 +1,78 @@
+// Shared helpers for the gfx950 kernels.  Everything here is device/host glue with no policy.
+//
+// Build flags that matter for parity (see paddle3d_amd/build.py): -ffp-contract=off (the reference CPU
+// path is plain IEEE fp32 without FMA contraction) and hipcc's default correctly-rounded fp32 divide.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pd3 {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+#define PD3_OK 0
+#define PD3_EINVAL (-1)    // bad argument
+#define PD3_EWORKSPACE (-2)  // workspace too small
+#define PD3_EUNSUPPORTED (-3)
+
+// Returns the sticky launch error of the last kernel launch as a positive hipError_t (0 if none).
+static inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+__host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over the caller-provided workspace; all carve-outs are 256-byte aligned.
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  template <typename T>
+  T* take(size_t count) {
+    T* p = reinterpret_cast<T*>(base + off);
+    off = align_up(off + count * sizeof(T), 256);
+    return p;
+  }
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// Inclusive scan of one int across the 64 lanes of a wave.
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    int n = __shfl_up(v, d, kWave);
+    if (lane_id() >= d) v += n;
+  }
+  return v;
+}
+
+// Exclusive scan of one int per thread across a block of THREADS (multiple of 64, <= 1024).
+// `total` receives the block sum.  `smem` must hold THREADS/64 + 1 ints.
+template <int THREADS>
+__device__ __forceinline__ int block_exclusive_scan(int v, int* smem, int& total) {
+  constexpr int W = THREADS / kWave;
+  const int inc = wave_inclusive_scan(v);
+  if (lane_id() == kWave - 1) smem[wave_id()] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      int t = smem[w];
+      smem[w] = run;
+      run += t;
+    }
+    smem[W] = run;
+  }
+  __syncthreads();
+  const int out = smem[wave_id()] + inc - v;
+  total = smem[W];
+  __syncthreads();  // smem may be reused by the caller right away
+  return out;
+}
+
+}  // namespace pd3

@@ -1,0 +1,281 @@
+// centerpoint_postprocess for gfx950: all tasks of a frame in one launch sequence, no host round trip.
+// (reference: paddle3d/ops/centerpoint_postprocess/postprocess.cu:104-280 postprocess_gpu, decode_kernel
+//  :32-80, private NMS iou3d_nms_kernel.cu:274-352.)
+//
+// The reference runs ~20 Paddle/CUDA launches and two blocking host syncs PER TASK (masked_select's
+// numel, the NMS mask copy + host sweep).  Here grid.y / grid.z indexes the task and every count stays
+// on the device:
+//   1. decode_kernel     sigmoid->max/argmax, exp(dim), box decode, range/score mask, sort key
+//   2. stable radix sort  key = 0x3F800000 - bits(score) for masked-in cells (descending score, ties in
+//                         cell order = masked_select order + stable argsort), 0x3FFFFFFF otherwise
+//   3. nms_boxes_kernel   top min(selected, nms_pre_max_size) boxes remapped (dx<->dy, -rot - pi/2)
+//   4. nms_mask_kernel + nms_sweep_kernel (nms_kernels.hpp), counts read on the device
+//   5. output_kernel      concatenates the tasks' kept rows (or the reference's fake row) in task order
+// Work is tiny (4.6 MB read per nuScenes frame); the op is launch-latency bound, which is why the
+// launch count (15 + 5) and the absence of syncs are what matter.
+#include "../../include/paddle3d_amd.h"
+#include "common.hpp"
+#include "nms_kernels.hpp"
+#include "radix_sort.hpp"
+
+#include <algorithm>
+
+namespace pd3 {
+
+constexpr int kMaxTasks = 16;
+constexpr uint32_t kKeyOut = 0x3FFFFFFFu;   // sorts after every selected cell
+constexpr uint32_t kKeyOne = 0x3F800000u;   // bits of 1.0f
+
+struct CpHeads {
+  const float* hm[kMaxTasks];
+  const float* reg[kMaxTasks];
+  const float* height[kMaxTasks];
+  const float* dim[kMaxTasks];
+  const float* vel[kMaxTasks];
+  const float* rot[kMaxTasks];
+  int ncls[kMaxTasks];
+  int label_offset[kMaxTasks];
+};
+
+struct CpCfg {
+  int hw, feat_w, dims, with_velocity;
+  float down_ratio, vx, vy, pc_x, pc_y;
+  float r[6];  // post_center_range
+  float score_threshold;
+};
+
+__device__ __forceinline__ float exp_rn(float x) { return (float)exp((double)x); }
+
+__global__ __launch_bounds__(256) void cp_decode_kernel(CpHeads h, CpCfg c, float* __restrict__ boxes,
+                                                        float* __restrict__ scores,
+                                                        int* __restrict__ labels,
+                                                        uint32_t* __restrict__ keys,
+                                                        int* __restrict__ counts) {
+  const int t = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int selected = 0;
+  if (i < c.hw) {
+    // postprocess.cu:145-149  sigmoid, then max / argmax over the class axis (first maximum wins)
+    const float* hm = h.hm[t];
+    float best = 0.f;
+    int arg = 0;
+    for (int k = 0; k < h.ncls[t]; ++k) {
+      const float s = 1.0f / (1.0f + exp_rn(-hm[(int64_t)k * c.hw + i]));
+      if (k == 0 || s > best) {
+        best = s;
+        arg = k;
+      }
+    }
+    // decode_kernel :41-70
+    const int xs = i % c.feat_w, ys = i / c.feat_w;
+    const float x = h.reg[t][i], y = h.reg[t][i + c.hw], z = h.height[t][i];
+    float* bx = boxes + ((int64_t)t * c.hw + i) * c.dims;
+    bx[0] = (x + xs) * c.down_ratio * c.vx + c.pc_x;
+    bx[1] = (y + ys) * c.down_ratio * c.vy + c.pc_y;
+    bx[2] = z;
+    bx[3] = exp_rn(h.dim[t][i]);  // :151 exp(dim)
+    bx[4] = exp_rn(h.dim[t][i + c.hw]);
+    bx[5] = exp_rn(h.dim[t][i + 2 * c.hw]);
+    const float ang = atan2_rn(h.rot[t][i], h.rot[t][i + c.hw]);
+    if (c.with_velocity) {
+      bx[6] = h.vel[t][i];
+      bx[7] = h.vel[t][i + c.hw];
+      bx[8] = ang;
+    } else {
+      bx[6] = ang;
+    }
+    // :72-77  mask on the RAW reg / height values
+    const bool m = best > c.score_threshold && x <= c.r[3] && y <= c.r[4] && z <= c.r[5] &&
+                   x >= c.r[0] && y >= c.r[1] && z >= c.r[2];
+    scores[(int64_t)t * c.hw + i] = best;
+    labels[(int64_t)t * c.hw + i] = arg;
+    uint32_t key = kKeyOut;
+    if (m) {
+      const uint32_t bits = __float_as_uint(best);
+      key = bits <= kKeyOne ? kKeyOne - bits : 0u;
+      selected = 1;
+    }
+    keys[(int64_t)t * c.hw + i] = key;
+  }
+  // block count of selected cells -> counts[t]
+  const unsigned long long ball = __ballot(selected);
+  __shared__ int wsum[4];
+  if (lane_id() == 0) wsum[wave_id()] = __popcll(ball);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (s) atomicAdd(&counts[t], s);
+  }
+}
+
+// iou3d_nms_kernel.cu:294-308 remap of the top-n boxes (sorted order) into NMS layout
+__global__ __launch_bounds__(256) void cp_nms_boxes_kernel(const float* __restrict__ boxes,
+                                                           const uint32_t* __restrict__ sidx,
+                                                           const int* __restrict__ counts, int hw,
+                                                           int dims, int cap,
+                                                           float* __restrict__ nms_boxes) {
+  const int t = blockIdx.y;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = min(counts[t], cap);
+  if (r >= n) return;
+  const uint32_t cell = sidx[(int64_t)t * hw + r];
+  const float* bx = boxes + ((int64_t)t * hw + cell) * dims;
+  float* o = nms_boxes + ((int64_t)t * cap + r) * 7;
+  o[0] = bx[0];
+  o[1] = bx[1];
+  o[2] = bx[2];
+  o[3] = bx[4];
+  o[4] = bx[3];
+  o[5] = bx[5];
+  o[6] = (float)(-(double)bx[dims - 1] - 3.141592653589793 / 2);
+}
+
+// One workgroup: concatenate tasks in order (postprocess.cu:247-278).
+__global__ __launch_bounds__(256) void cp_output_kernel(
+    const float* __restrict__ boxes, const float* __restrict__ scores,
+    const int* __restrict__ labels, const uint32_t* __restrict__ sidx,
+    const int* __restrict__ counts, const int32_t* __restrict__ keep,
+    const int32_t* __restrict__ nkeep, CpHeads h, int num_tasks, int hw, int dims, int cap,
+    int post_max, float* __restrict__ out_boxes, float* __restrict__ out_scores,
+    int64_t* __restrict__ out_labels, int32_t* __restrict__ out_count) {
+  int offset = 0;
+  for (int t = 0; t < num_tasks; ++t) {
+    const int sel = counts[t];
+    if (sel <= 0) {  // :190-201 fake row
+      if ((int)threadIdx.x < dims) out_boxes[(int64_t)offset * dims + threadIdx.x] = 0.f;
+      if (threadIdx.x == 0) {
+        out_scores[offset] = -1.f;
+        out_labels[offset] = 0;
+      }
+      offset += 1;
+      continue;
+    }
+    const int rows = min(nkeep[t], post_max);
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+      const int pos = keep[(int64_t)t * cap + r];          // index into the sorted order
+      const uint32_t cell = sidx[(int64_t)t * hw + pos];   // selected_score_idx[sorted_index[keep]]
+      const float* bx = boxes + ((int64_t)t * hw + cell) * dims;
+      for (int k = 0; k < dims; ++k) out_boxes[(int64_t)(offset + r) * dims + k] = bx[k];
+      out_scores[offset + r] = scores[(int64_t)t * hw + cell];
+      out_labels[offset + r] = (int64_t)labels[(int64_t)t * hw + cell] + h.label_offset[t];
+    }
+    offset += rows;
+  }
+  if (threadIdx.x == 0) out_count[0] = offset;
+}
+
+struct CpWorkspace {
+  float *boxes, *scores, *nms_boxes;
+  int *labels, *counts, *hist, *partial;
+  uint32_t *keys_a, *vals_a, *keys_b, *vals_b;
+  unsigned long long* mask;
+  int32_t *keep, *nkeep;
+  size_t bytes;
+};
+
+static CpWorkspace cp_carve(void* base, int tasks, int hw, int pre_max, const RadixPlan& plan) {
+  Carver c(base);
+  CpWorkspace w;
+  const size_t th = (size_t)tasks * hw;
+  const int cap = std::max(pre_max, 1);
+  const size_t cb = ((size_t)cap + 63) / 64;
+  w.boxes = c.take<float>(th * 9);
+  w.scores = c.take<float>(th);
+  w.labels = c.take<int>(th);
+  w.counts = c.take<int>((size_t)tasks);
+  w.keys_a = c.take<uint32_t>(th);
+  w.vals_a = c.take<uint32_t>(th);
+  w.keys_b = c.take<uint32_t>(th);
+  w.vals_b = c.take<uint32_t>(th);
+  w.hist = c.take<int>((size_t)tasks * radix_hist_ints(plan));
+  w.partial = c.take<int>((size_t)tasks * scan_num_tiles((int64_t)radix_hist_ints(plan)));
+  w.nms_boxes = c.take<float>((size_t)tasks * cap * 7);
+  w.mask = c.take<unsigned long long>((size_t)tasks * cap * cb);
+  w.keep = c.take<int32_t>((size_t)tasks * cap);
+  w.nkeep = c.take<int32_t>((size_t)tasks);
+  w.bytes = c.off;
+  return w;
+}
+
+}  // namespace pd3
+
+using namespace pd3;
+
+extern "C" size_t pd3_centerpoint_postprocess_workspace(int num_tasks, int feat_h, int feat_w,
+                                                        int nms_pre_max_size,
+                                                        int nms_post_max_size) {
+  (void)nms_post_max_size;
+  if (num_tasks <= 0 || feat_h <= 0 || feat_w <= 0) return 0;
+  const int hw = feat_h * feat_w;
+  return cp_carve(nullptr, num_tasks, hw, nms_pre_max_size, radix_plan(kKeyOut, hw)).bytes;
+}
+
+extern "C" int pd3_centerpoint_postprocess(
+    const float* const* hm, const float* const* reg, const float* const* height,
+    const float* const* dim, const float* const* vel, const float* const* rot, int num_tasks,
+    const int* hm_channels, int feat_h, int feat_w, const float* voxel_size,
+    const float* point_cloud_range, const float* post_center_range, const int* label_offsets,
+    int down_ratio, float score_threshold, float nms_iou_threshold, int nms_pre_max_size,
+    int nms_post_max_size, int with_velocity, float* out_bboxes, float* out_scores,
+    int64_t* out_labels, int32_t* out_count, void* workspace, size_t workspace_bytes,
+    void* stream) {
+  if (!hm || !reg || !height || !dim || !vel || !rot || !hm_channels || !label_offsets ||
+      !voxel_size || !point_cloud_range || !post_center_range || !out_bboxes || !out_scores ||
+      !out_labels || !out_count || !workspace)
+    return PD3_EINVAL;
+  if (num_tasks <= 0 || num_tasks > kMaxTasks || feat_h <= 0 || feat_w <= 0 ||
+      nms_pre_max_size < 0 || nms_post_max_size < 0)
+    return PD3_EINVAL;
+  const int hw = feat_h * feat_w;
+  const int cap = std::max(nms_pre_max_size, 1);
+  const int cb = (cap + 63) / 64;
+  if (cb > kNmsMaxWords) return PD3_EUNSUPPORTED;
+  const RadixPlan plan = radix_plan(kKeyOut, hw);
+  CpWorkspace w = cp_carve(workspace, num_tasks, hw, nms_pre_max_size, plan);
+  if (workspace_bytes < w.bytes) return PD3_EWORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+
+  CpHeads h;
+  for (int t = 0; t < num_tasks; ++t) {
+    h.hm[t] = hm[t];
+    h.reg[t] = reg[t];
+    h.height[t] = height[t];
+    h.dim[t] = dim[t];
+    h.vel[t] = vel[t];
+    h.rot[t] = rot[t];
+    h.ncls[t] = hm_channels[t];
+    h.label_offset[t] = label_offsets[t];
+    if (!hm[t] || !reg[t] || !height[t] || !dim[t] || !vel[t] || !rot[t] || hm_channels[t] <= 0)
+      return PD3_EINVAL;
+  }
+  CpCfg c;
+  c.hw = hw;
+  c.feat_w = feat_w;
+  c.with_velocity = with_velocity ? 1 : 0;
+  c.dims = with_velocity ? 9 : 7;
+  c.down_ratio = (float)down_ratio;  // int attr received as float, postprocess.cu:35,85
+  c.vx = voxel_size[0];
+  c.vy = voxel_size[1];
+  c.pc_x = point_cloud_range[0];
+  c.pc_y = point_cloud_range[1];
+  for (int k = 0; k < 6; ++k) c.r[k] = post_center_range[k];
+  c.score_threshold = score_threshold;
+
+  hipError_t e = hipMemsetAsync(w.counts, 0, sizeof(int) * num_tasks, s);
+  if (e != hipSuccess) return (int)e;
+  dim3 dgrid((hw + 255) / 256, num_tasks);
+  cp_decode_kernel<<<dgrid, 256, 0, s>>>(h, c, w.boxes, w.scores, w.labels, w.keys_a, w.counts);
+  const int where = enqueue_radix_sort(w.keys_a, w.vals_a, w.keys_b, w.vals_b, hw, hw, num_tasks,
+                                       plan, /*identity_vals=*/true, w.hist, w.partial, s);
+  const uint32_t* sidx = where ? w.vals_b : w.vals_a;
+  dim3 bgrid((cap + 255) / 256, num_tasks);
+  cp_nms_boxes_kernel<<<bgrid, 256, 0, s>>>(w.boxes, sidx, w.counts, hw, c.dims, cap, w.nms_boxes);
+  dim3 mgrid(cb, cb, num_tasks);
+  nms_mask_kernel<false><<<mgrid, 64, 0, s>>>(w.nms_boxes, w.counts, 0, cap, cb, nms_iou_threshold,
+                                              w.mask);
+  nms_sweep_kernel<<<num_tasks, 64, 0, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);
+  cp_output_kernel<<<1, 256, 0, s>>>(w.boxes, w.scores, w.labels, sidx, w.counts, w.keep, w.nkeep, h,
+                                     num_tasks, hw, c.dims, cap, nms_post_max_size, out_bboxes,
+                                     out_scores, out_labels, out_count);
+  return launch_status();
+}

@@ -1,0 +1,254 @@
+// hard_voxelize for gfx950 -- deterministic, bit-exact with the reference CPU operator
+// (reference: paddle3d/ops/voxel/voxelize_op.cc:19-82).
+//
+// The reference CPU kernel is a sequential scan: voxel ids are handed out in order of each cell's
+// FIRST point, every voxel keeps its FIRST max_num_points_in_voxel points in input order, and once
+// max_voxels voxels exist, points that would open a new voxel are dropped (:60-64).  Restated as
+// order-independent facts:
+//   voxel id of a cell  = rank of the cell's minimum point index among all occupied cells,
+//                         dropped when rank >= max_voxels;
+//   slot of a point     = number of earlier points in the same cell, dropped when >= max points.
+// Both follow from ONE stable sort of the points by cell id (radix_sort.hpp): cells become contiguous
+// segments whose elements stay in input order.  Pipeline per launch sequence (grid.y = frame):
+//   1. cell_key_kernel     point -> uint32 cell key (INVALID = ncells for out-of-range points)
+//   2. stable radix sort   (key, point index)
+//   3. seg_head_kernel     mark[point] = sorted position if the point is its cell's first, else -1
+//   4. exclusive scan of (mark >= 0) in ORIGINAL point order = voxel id; fused epilogue records the
+//      segment start of every voxel id < max_voxels
+//   5. gather_kernel       voxel-parallel: writes the complete fixed-shape outputs (data AND zero
+//                          padding) exactly once, fully coalesced -- no separate memset of `voxels`.
+// HBM traffic per frame ~= the algorithmic bytes (points read once, outputs written once); the sort
+// scratch (a few MB per frame) lives in L2 / Infinity Cache.
+#include "../../include/paddle3d_amd.h"
+#include "common.hpp"
+#include "radix_sort.hpp"
+#include "scan.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace pd3 {
+
+struct VoxGrid {
+  float min_x, min_y, min_z;
+  float size_x, size_y, size_z;
+  int gx, gy, gz;
+  uint32_t ncells;
+};
+
+// floor((p - min) / size) exactly as voxelize_op.cc:37-45 (fp32 subtract, correctly rounded fp32
+// divide, floor), then the int conversion.  On the reference's x86 host a NaN / out-of-int-range
+// value converts to INT_MIN (cvttss2si "integer indefinite") and is therefore rejected by the
+// `coord < 0` test; v_cvt_i32_f32 would saturate / return 0 instead, so reject those explicitly.
+__device__ __forceinline__ bool axis_cell(float p, float lo, float size, int extent, int& c) {
+  const float q = floorf((p - lo) / size);
+  if (!(q >= 0.0f && q < (float)extent)) return false;  // also false for NaN
+  c = (int)q;
+  return c < extent;
+}
+
+__global__ __launch_bounds__(256) void cell_key_kernel(const float* __restrict__ points,
+                                                       const int32_t* __restrict__ num_points,
+                                                       int64_t max_points, int dim, VoxGrid g,
+                                                       uint32_t* __restrict__ keys) {
+  const int frame = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= max_points) return;
+  const int64_t n = num_points ? (int64_t)num_points[frame] : max_points;
+  uint32_t key = g.ncells;
+  if (i < n) {
+    const float* p = points + ((int64_t)frame * max_points + i) * dim;
+    int cx, cy, cz;
+    if (axis_cell(p[0], g.min_x, g.size_x, g.gx, cx) && axis_cell(p[1], g.min_y, g.size_y, g.gy, cy) &&
+        axis_cell(p[2], g.min_z, g.size_z, g.gz, cz)) {
+      key = ((uint32_t)cz * (uint32_t)g.gy + (uint32_t)cy) * (uint32_t)g.gx + (uint32_t)cx;
+    }
+  }
+  keys[(int64_t)frame * max_points + i] = key;
+}
+
+__global__ __launch_bounds__(256) void seg_head_kernel(const uint32_t* __restrict__ skey,
+                                                       const uint32_t* __restrict__ sidx,
+                                                       int64_t n, uint32_t ncells,
+                                                       int* __restrict__ mark) {
+  const int frame = blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t* k = skey + (int64_t)frame * n;
+  const uint32_t key = k[j];
+  const bool head = key < ncells && (j == 0 || k[j - 1] != key);
+  mark[(int64_t)frame * n + sidx[(int64_t)frame * n + j]] = head ? (int)j : -1;
+}
+
+// Epilogue of the flag scan: element i (original point order) is a cell's first point iff
+// mark[i] >= 0; its exclusive prefix is the voxel id the sequential reference would hand out.
+struct EpiVoxelStart {
+  const int* mark;
+  int* vox_start;
+  int64_t n;
+  int max_voxels;
+  __device__ __forceinline__ void operator()(int frame, int64_t i, int flag, int prefix, int) const {
+    if (flag && prefix < max_voxels)
+      vox_start[(int64_t)frame * max_voxels + prefix] = mark[(int64_t)frame * n + i];
+  }
+};
+
+// One thread per output float of `voxels` (coalesced 4-byte lanes over the contiguous [V,P,D] block).
+__global__ __launch_bounds__(256) void gather_voxels_kernel(
+    const float* __restrict__ points, const uint32_t* __restrict__ skey,
+    const uint32_t* __restrict__ sidx, const int* __restrict__ vox_start,
+    const int* __restrict__ totals, int64_t n, int dim, int max_pts, int max_voxels,
+    float* __restrict__ voxels) {
+  const int frame = blockIdx.y;
+  const int64_t per_frame = (int64_t)max_voxels * max_pts * dim;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= per_frame) return;
+  const int row = max_pts * dim;
+  const int v = (int)(e / row);
+  const int r = (int)(e - (int64_t)v * row);
+  const int k = r / dim, c = r - k * dim;
+  const int nv = min(totals[frame], max_voxels);
+  float out = 0.0f;
+  if (v < nv) {
+    const int64_t s = vox_start[(int64_t)frame * max_voxels + v];
+    const uint32_t* keyp = skey + (int64_t)frame * n;
+    if (s + k < n && keyp[s + k] == keyp[s]) {
+      const uint32_t pi = sidx[(int64_t)frame * n + s + k];
+      out = points[((int64_t)frame * n + pi) * dim + c];
+    }
+  }
+  voxels[(int64_t)frame * per_frame + e] = out;
+}
+
+// One thread per voxel slot: coords (z, y, x), num_points_per_voxel, and num_voxels.
+__global__ __launch_bounds__(256) void voxel_meta_kernel(
+    const uint32_t* __restrict__ skey, const int* __restrict__ vox_start,
+    const int* __restrict__ totals, int64_t n, int max_pts, int max_voxels, VoxGrid g,
+    int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ num_voxels) {
+  const int frame = blockIdx.y;
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nv = min(totals[frame], max_voxels);
+  if (v == 0) num_voxels[frame] = nv;
+  if (v >= max_voxels) return;
+  int cz = 0, cy = 0, cx = 0, cnt = 0;
+  if (v < nv) {
+    const int64_t s = vox_start[(int64_t)frame * max_voxels + v];
+    const uint32_t* keyp = skey + (int64_t)frame * n;
+    const uint32_t key = keyp[s];
+    cx = (int)(key % (uint32_t)g.gx);
+    const uint32_t t = key / (uint32_t)g.gx;
+    cy = (int)(t % (uint32_t)g.gy);
+    cz = (int)(t / (uint32_t)g.gy);
+    for (int k = 0; k < max_pts; ++k) {
+      if (s + k < n && keyp[s + k] == key) ++cnt; else break;
+    }
+  }
+  int32_t* co = coords + ((int64_t)frame * max_voxels + v) * 3;
+  co[0] = cz;
+  co[1] = cy;
+  co[2] = cx;
+  num_pts[(int64_t)frame * max_voxels + v] = cnt;
+}
+
+static bool make_grid(const float* voxel_size, const float* range, VoxGrid& g) {
+  // voxelize_op.cc:97-102: static_cast<int>(round((max - min) / size)) with fp32 operands
+  g.min_x = range[0];
+  g.min_y = range[1];
+  g.min_z = range[2];
+  g.size_x = voxel_size[0];
+  g.size_y = voxel_size[1];
+  g.size_z = voxel_size[2];
+  g.gx = (int)std::round((double)((range[3] - range[0]) / voxel_size[0]));
+  g.gy = (int)std::round((double)((range[4] - range[1]) / voxel_size[1]));
+  g.gz = (int)std::round((double)((range[5] - range[2]) / voxel_size[2]));
+  if (g.gx <= 0 || g.gy <= 0 || g.gz <= 0) return false;
+  const int64_t cells = (int64_t)g.gx * g.gy * g.gz;
+  if (cells >= (int64_t)1 << 31) return false;
+  g.ncells = (uint32_t)cells;
+  return true;
+}
+
+struct VoxWorkspace {
+  uint32_t *keys_a, *vals_a, *keys_b, *vals_b;
+  int *mark, *vox_start, *hist, *partial, *totals;
+  size_t bytes;
+};
+
+static VoxWorkspace carve(void* base, int batch, int64_t n, int max_voxels, const RadixPlan& plan) {
+  Carver c(base);
+  VoxWorkspace w;
+  const size_t bn = (size_t)batch * n;
+  w.keys_a = c.take<uint32_t>(bn);
+  w.vals_a = c.take<uint32_t>(bn);
+  w.keys_b = c.take<uint32_t>(bn);
+  w.vals_b = c.take<uint32_t>(bn);
+  w.mark = c.take<int>(bn);
+  w.vox_start = c.take<int>((size_t)batch * max_voxels);
+  w.hist = c.take<int>((size_t)batch * radix_hist_ints(plan));
+  const size_t scan_tiles =
+      (size_t)std::max(scan_num_tiles((int64_t)radix_hist_ints(plan)), scan_num_tiles(n));
+  w.partial = c.take<int>((size_t)batch * scan_tiles);
+  w.totals = c.take<int>((size_t)batch);
+  w.bytes = c.off;
+  return w;
+}
+
+}  // namespace pd3
+
+using namespace pd3;
+
+extern "C" size_t pd3_hard_voxelize_workspace(int batch, int64_t max_points, int num_point_dim,
+                                              const float* voxel_size,
+                                              const float* point_cloud_range,
+                                              int max_num_points_in_voxel, int max_voxels) {
+  (void)num_point_dim;
+  (void)max_num_points_in_voxel;
+  VoxGrid g;
+  if (batch <= 0 || max_points <= 0 || max_voxels <= 0 || !make_grid(voxel_size, point_cloud_range, g))
+    return 0;
+  const RadixPlan plan = radix_plan(g.ncells, max_points);
+  return carve(nullptr, batch, max_points, max_voxels, plan).bytes;
+}
+
+extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points, int batch,
+                                 int64_t max_points, int num_point_dim, const float* voxel_size,
+                                 const float* point_cloud_range, int max_num_points_in_voxel,
+                                 int max_voxels, float* voxels, int32_t* coords,
+                                 int32_t* num_points_per_voxel, int32_t* num_voxels,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  VoxGrid g;
+  if (!points || !voxels || !coords || !num_points_per_voxel || !num_voxels || !workspace)
+    return PD3_EINVAL;
+  if (batch <= 0 || max_points <= 0 || max_points >= ((int64_t)1 << 31) || num_point_dim < 3 ||
+      max_num_points_in_voxel <= 0 || max_voxels <= 0)
+    return PD3_EINVAL;
+  if (!make_grid(voxel_size, point_cloud_range, g)) return PD3_EINVAL;
+  const RadixPlan plan = radix_plan(g.ncells, max_points);
+  VoxWorkspace w = carve(workspace, batch, max_points, max_voxels, plan);
+  if (workspace_bytes < w.bytes) return PD3_EWORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t n = max_points;
+
+  dim3 pgrid((unsigned)ceil_div(n, 256), batch);
+  cell_key_kernel<<<pgrid, 256, 0, s>>>(points, num_points, n, num_point_dim, g, w.keys_a);
+  const int where = enqueue_radix_sort(w.keys_a, w.vals_a, w.keys_b, w.vals_b, n, n, batch, plan,
+                                       /*identity_vals=*/true, w.hist, w.partial, s);
+  const uint32_t* skey = where ? w.keys_b : w.keys_a;
+  const uint32_t* sidx = where ? w.vals_b : w.vals_a;
+  seg_head_kernel<<<pgrid, 256, 0, s>>>(skey, sidx, n, g.ncells, w.mark);
+  EpiVoxelStart epi{w.mark, w.vox_start, n, max_voxels};
+  enqueue_exclusive_scan(w.mark, n, n, batch, w.partial, w.totals, (int*)nullptr, LoadNonNegative{},
+                         epi, s);
+  const int64_t per_frame = (int64_t)max_voxels * max_num_points_in_voxel * num_point_dim;
+  dim3 ggrid((unsigned)ceil_div(per_frame, 256), batch);
+  gather_voxels_kernel<<<ggrid, 256, 0, s>>>(points, skey, sidx, w.vox_start, w.totals, n,
+                                             num_point_dim, max_num_points_in_voxel, max_voxels,
+                                             voxels);
+  dim3 mgrid((unsigned)ceil_div(max_voxels, 256), batch);
+  voxel_meta_kernel<<<mgrid, 256, 0, s>>>(skey, w.vox_start, w.totals, n, max_num_points_in_voxel,
+                                          max_voxels, g, coords, num_points_per_voxel, num_voxels);
+  return launch_status();
+}
+
+extern "C" int pd3_version(void) { return 100; }
+extern "C" const char* pd3_target_arch(void) { return "gfx950"; }
