@@ -1,0 +1,78 @@
+"""`paddle3d.ops.centerpoint_postprocess` mirror.
+
+centerpoint_postprocess(hm, reg, height, dim, vel, rot, voxel_size, point_cloud_range,
+    post_center_range, num_classes, down_ratio, score_threshold, nms_iou_threshold, nms_pre_max_size,
+    nms_post_max_size, with_velocity) -> (bboxes [K, 9|7] fp32, scores [K] fp32, labels [K] int64)
+
+Reference operator: paddle3d/ops/centerpoint_postprocess/postprocess.cc:91-104, postprocess.cu:104-280;
+caller CenterHead.predict_by_custom_op, paddle3d/models/detection/centerpoint/center_head.py:294-339.
+hm..rot are lists (one entry per task) of [1, c, H, W] GPU tensors.  `num_classes` is the list the
+reference caller builds (len(tasks)**2 long, center_head.py:306-309); only entry t is used for task t.
+The single device->host read is the final row count K (the reference syncs twice per task).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._common import check, host_f32, lib, ptr, require_gpu, stream_ptr, workspace
+
+__all__ = ["centerpoint_postprocess", "centerpoint_postprocess_device"]
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def centerpoint_postprocess_device(hm, reg, height, dim, vel, rot, voxel_size, point_cloud_range,
+                                   post_center_range, num_classes, down_ratio, score_threshold,
+                                   nms_iou_threshold, nms_pre_max_size, nms_post_max_size, with_velocity):
+    """No-sync variant: returns padded (bboxes, scores, labels) plus the device int32 row count."""
+    op = "centerpoint postprocess"
+    t_n = len(hm)
+    lists = []
+    for group in (hm, reg, height, dim, vel, rot):
+        if len(group) != t_n:
+            raise RuntimeError("centerpoint_postprocess: every head list needs one tensor per task")
+        lists.append([require_gpu(t, op) for t in group])
+    hm0 = lists[0][0]
+    if hm0.shape[0] != 1:
+        raise RuntimeError("hm[0] batch size must be 1.")  # CHECK_INPUT_BATCHSIZE, postprocess.cu:19-20
+    h, w = int(hm0.shape[2]), int(hm0.shape[3])
+    dev = hm0.device
+    dims = 9 if with_velocity else 7
+    rows = t_n * max(int(nms_post_max_size), 1)
+    out_b = torch.empty((rows, dims), dtype=torch.float32, device=dev)
+    out_s = torch.empty((rows,), dtype=torch.float32, device=dev)
+    out_l = torch.empty((rows,), dtype=torch.int64, device=dev)
+    out_n = torch.empty((1,), dtype=torch.int32, device=dev)
+    ncls = np.ascontiguousarray([int(t.shape[1]) for t in lists[0]], dtype=np.int32)
+    offs = np.ascontiguousarray([int(num_classes[t]) for t in range(t_n)], dtype=np.int32)
+    vs, pr, pcr = host_f32(voxel_size)[:2], host_f32(point_cloud_range)[:2], host_f32(post_center_range, 6)
+    vs = np.ascontiguousarray(np.concatenate([vs, [0.0]]).astype(np.float32))
+    pr = np.ascontiguousarray(np.concatenate([pr, [0.0] * 4]).astype(np.float32))
+    L = lib()
+    ws = workspace(L.pd3_centerpoint_postprocess_workspace(t_n, h, w, int(nms_pre_max_size),
+                                                           int(nms_post_max_size)), dev)
+    arrays = [_ptr_array(g) for g in lists]
+    check(L.pd3_centerpoint_postprocess(*[C.cast(a, C.c_void_p) for a in arrays], t_n, ptr(ncls), h, w,
+                                        ptr(vs), ptr(pr), ptr(pcr), ptr(offs), int(down_ratio),
+                                        C.c_float(score_threshold), C.c_float(nms_iou_threshold),
+                                        int(nms_pre_max_size), int(nms_post_max_size),
+                                        int(bool(with_velocity)), ptr(out_b), ptr(out_s), ptr(out_l),
+                                        ptr(out_n), ptr(ws), ws.numel(), stream_ptr(dev)), op)
+    return out_b, out_s, out_l, out_n
+
+
+def centerpoint_postprocess(hm, reg, height, dim, vel, rot, voxel_size, point_cloud_range,
+                            post_center_range, num_classes, down_ratio, score_threshold,
+                            nms_iou_threshold, nms_pre_max_size, nms_post_max_size, with_velocity):
+    b, s, l, n = centerpoint_postprocess_device(hm, reg, height, dim, vel, rot, voxel_size,
+                                                point_cloud_range, post_center_range, num_classes,
+                                                down_ratio, score_threshold, nms_iou_threshold,
+                                                nms_pre_max_size, nms_post_max_size, with_velocity)
+    k = int(n.item())
+    return b[:k], s[:k], l[:k]

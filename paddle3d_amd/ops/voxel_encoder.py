@@ -1,0 +1,57 @@
+"""Fused voxel encoders: pillar_feature_net (PillarFeatureNet eval forward) and voxel_mean (VoxelMean).
+
+Reference layers: paddle3d/models/voxel_encoders/pillar_encoder.py:156-210 / :81-105 and
+voxel_encoder.py:44-57.  BatchNorm1D is folded on the host into (scale, shift).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._common import check, lib, ptr, require_gpu, stream_ptr
+
+__all__ = ["pillar_feature_net", "voxel_mean", "fold_batchnorm"]
+
+
+def fold_batchnorm(gamma, beta, mean, var, eps):
+    scale = gamma / torch.sqrt(var + eps)
+    return scale.contiguous(), (beta - mean * scale).contiguous()
+
+
+def pillar_feature_net(voxels, num_points, coors, vx, vy, x_offset, y_offset, w1, scale1, shift1,
+                       w2=None, scale2=None, shift2=None):
+    """voxels [M,P,D], num_points [M] i32, coors [M,4] i32 (b,z,y,x); w* in Paddle Linear layout [in,out]."""
+    v = require_gpu(voxels, "pillar_feature_net")
+    n = require_gpu(num_points, "pillar_feature_net", torch.int32)
+    c = require_gpu(coors, "pillar_feature_net", torch.int32)
+    m, p, d = v.shape
+    w1 = require_gpu(w1, "pillar_feature_net")
+    c1 = w1.shape[1]
+    if w1.shape[0] != d + 5:
+        raise RuntimeError(f"pillar_feature_net: w1 must be [{d + 5}, C1]")
+    two = w2 is not None
+    if two:
+        w2 = require_gpu(w2, "pillar_feature_net")
+        if w2.shape[0] != 2 * c1:
+            raise RuntimeError("pillar_feature_net: w2 must be [2*C1, C2]")
+        c2 = w2.shape[1]
+    else:
+        c2 = 0
+    out = torch.empty((m, c2 if two else c1), dtype=torch.float32, device=v.device)
+    check(lib().pd3_pillar_feature_net(ptr(v), ptr(n), ptr(c), m, p, d, C.c_float(vx), C.c_float(vy),
+                                       C.c_float(x_offset), C.c_float(y_offset), ptr(w1),
+                                       ptr(scale1.contiguous()), ptr(shift1.contiguous()), c1,
+                                       ptr(w2), ptr(scale2.contiguous() if two else None),
+                                       ptr(shift2.contiguous() if two else None), c2, ptr(out),
+                                       stream_ptr(v.device)), "pillar_feature_net")
+    return out
+
+
+def voxel_mean(voxels, num_points):
+    v = require_gpu(voxels, "voxel_mean")
+    n = require_gpu(num_points, "voxel_mean", torch.int32)
+    m, p, d = v.shape
+    out = torch.empty((m, d), dtype=torch.float32, device=v.device)
+    check(lib().pd3_voxel_mean(ptr(v), ptr(n), m, p, d, ptr(out), stream_ptr(v.device)), "voxel_mean")
+    return out

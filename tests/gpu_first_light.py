@@ -1,0 +1,53 @@
+"""First-light timing script for the GPU box (not a test): times each op on C3-sized inputs."""
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from paddle3d_amd import synth  # noqa: E402
+from paddle3d_amd.ops import pointpillars_scatter as ps  # noqa: E402
+from paddle3d_amd.ops import voxelize  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / iters
+
+
+res = {"device": torch.cuda.get_device_name(0)}
+for batch in (1, 8, 32):
+    frames = np.stack([synth.nuscenes_sweep(100 + i) for i in range(min(batch, 4))])
+    frames = np.concatenate([frames] * (batch // len(frames) or 1))[:batch]
+    pts = torch.from_numpy(frames).cuda()
+    for v in (30000, 60000):
+        dt = timeit(lambda: voxelize.hard_voxelize_batch(pts, list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20, v))
+        alg = 4 * 300000 * 5 + 4 * v * 20 * 5 + 16 * v + 4
+        res[f"voxelize_b{batch}_v{v}"] = dict(ms=dt * 1e3, us_per_frame=dt * 1e6 / batch,
+                                              GBps=alg * batch / dt / 1e9)
+feats = torch.randn(30000, 64, device="cuda")
+co = torch.zeros(30000, 4, dtype=torch.int32, device="cuda")
+cells = torch.randperm(512 * 512, device="cuda")[:30000]
+co[:, 2] = (cells // 512).int()
+co[:, 3] = (cells % 512).int()
+for batch in (1, 8):
+    f = feats.repeat(batch, 1)
+    c = co.repeat(batch, 1)
+    c[:, 0] = torch.arange(batch, device="cuda").repeat_interleave(30000).int()
+    out = torch.empty(batch, 64, 512, 512, device="cuda")
+    dt = timeit(lambda: ps.pointpillars_scatter(f, c, batch, 512, 512, out=out))
+    res[f"scatter_b{batch}"] = dict(ms=dt * 1e3, GBps=75268864 * batch / dt / 1e9)
+# plain device copy ceiling
+a = torch.empty(256 * 1024 * 1024 // 4, device="cuda")
+b = torch.empty_like(a)
+dt = timeit(lambda: b.copy_(a))
+res["copy_256MB_GBps"] = 2 * a.numel() * 4 / dt / 1e9
+print(json.dumps(res, indent=1))

@@ -1,0 +1,160 @@
+"""iou3d_nms, centerpoint_postprocess and bev_pool_v2 HIP paths vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from paddle3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CP_CFG = dict(voxel_size=[0.2, 0.2], point_cloud_range=[-51.2, -51.2],
+              post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], down_ratio=4, score_threshold=0.1,
+              nms_iou_threshold=0.2, nms_pre_max_size=1000, nms_post_max_size=83)
+LABEL_OFFSETS = [0, 1, 3, 5, 6, 8]
+
+
+def _cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("n", [1, 64, 65, 300, 1000])
+def test_pairwise_iou_overlap(oracle, n):
+    from paddle3d_amd.ops import iou3d_nms
+
+    a, _ = synth.nms_boxes(n, n=min(n, 200))
+    b, _ = synth.nms_boxes(n + 1, n=min(n, 150) + 1)
+    iou = iou3d_nms.boxes_iou_bev_gpu(_cuda(a), _cuda(b)).cpu().numpy()
+    ov = iou3d_nms.boxes_overlap_bev_gpu(_cuda(a), _cuda(b)).cpu().numpy()
+    r_iou, r_ov = oracle.boxes_iou_bev(a, b), oracle.boxes_overlap_bev(a, b)
+    # libm differences (device fp64-rounded sin/cos/atan2 vs glibc fp32) stay within a few ulp of the
+    # vertex coordinates: areas agree to 1e-4 abs, and the overwhelming majority are bit-identical.
+    assert np.abs(ov - r_ov).max() < 1e-3
+    assert np.abs(iou - r_iou).max() < 1e-4
+    same = (iou.view(np.uint32) == r_iou.view(np.uint32)).mean()
+    assert same > 0.98, same
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (64, 1), (65, 2), (129, 3), (1000, 4), (1000, 5), (2500, 6)])
+@pytest.mark.parametrize("normal", [False, True])
+def test_nms_keep_exact(oracle, n, seed, normal):
+    from paddle3d_amd.ops import iou3d_nms
+
+    boxes, _ = synth.nms_boxes(seed, n=n)
+    fn = iou3d_nms.nms_normal_gpu if normal else iou3d_nms.nms_gpu
+    for thr in (0.2, 0.5):
+        keep, num = fn(_cuda(boxes), thr)
+        assert keep.dtype == torch.int32 and not keep.is_cuda and num.shape == (1,)
+        got = keep[: int(num[0])].numpy()
+        want = oracle.nms(boxes, thr, normal=normal)
+        np.testing.assert_array_equal(got, want)
+
+
+def test_nms_empty():
+    from paddle3d_amd.ops import iou3d_nms
+
+    keep, num = iou3d_nms.nms_gpu(torch.zeros((0, 7)).cuda(), 0.5)
+    assert int(num[0]) == 0
+
+
+def _post(oracle, tasks, with_velocity=True, **over):
+    from paddle3d_amd.ops import centerpoint_postprocess as cp
+
+    cfg = dict(CP_CFG, **over)
+    lists = {k: [_cuda(t[k]) for t in tasks] for k in ("hm", "reg", "height", "dim", "vel", "rot")}
+    num_classes = LABEL_OFFSETS * len(tasks)  # the len(tasks)**2 list the reference caller builds
+    b, s, l = cp.centerpoint_postprocess(lists["hm"], lists["reg"], lists["height"], lists["dim"], lists["vel"],
+                                         lists["rot"], cfg["voxel_size"], cfg["point_cloud_range"],
+                                         cfg["post_center_range"], num_classes, cfg["down_ratio"],
+                                         cfg["score_threshold"], cfg["nms_iou_threshold"],
+                                         cfg["nms_pre_max_size"], cfg["nms_post_max_size"], with_velocity)
+    rb, rs, rl, margins = oracle.centerpoint_postprocess(
+        tasks, cfg["voxel_size"] + [8.0], cfg["point_cloud_range"] + [0.0] * 4, cfg["post_center_range"],
+        LABEL_OFFSETS[: len(tasks)], cfg["down_ratio"], cfg["score_threshold"], cfg["nms_iou_threshold"],
+        cfg["nms_pre_max_size"], cfg["nms_post_max_size"], with_velocity, return_margins=True)
+    return (b.cpu().numpy(), s.cpu().numpy(), l.cpu().numpy()), (rb, rs, rl), margins
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("with_velocity", [True, False])
+def test_centerpoint_postprocess(oracle, seed, with_velocity):
+    tasks = synth.center_head_outputs(seed)
+    (b, s, l), (rb, rs, rl), margins = _post(oracle, tasks, with_velocity)
+    assert l.dtype == np.int64
+    assert b.shape == rb.shape, (b.shape, rb.shape, margins)
+    np.testing.assert_array_equal(l, rl)
+    np.testing.assert_allclose(s, rs, rtol=0, atol=2e-7)
+    np.testing.assert_allclose(b, rb, rtol=2e-6, atol=2e-6)
+
+
+def test_centerpoint_postprocess_edges(oracle):
+    # a task with no candidate -> the reference's fake row (zeros, -1, 0); small pre/post caps
+    tasks = synth.center_head_outputs(3, feat_h=32, feat_w=48, n_peaks=20)
+    tasks[1]["hm"][:] = -20.0
+    (b, s, l), (rb, rs, rl), _ = _post(oracle, tasks, nms_pre_max_size=50, nms_post_max_size=7)
+    assert b.shape == rb.shape
+    np.testing.assert_array_equal(l, rl)
+    np.testing.assert_allclose(s, rs, atol=2e-7)
+    np.testing.assert_allclose(b, rb, rtol=2e-6, atol=2e-6)
+    assert (s == -1).sum() == 1
+    # everything above threshold: exercises the pre-NMS cap with ties-free random scores
+    tasks = synth.center_head_outputs(4, feat_h=32, feat_w=32, n_peaks=0)
+    for t in tasks:
+        t["hm"] += 6.0
+    (b, s, l), (rb, rs, rl), _ = _post(oracle, tasks, nms_pre_max_size=200, nms_post_max_size=83)
+    assert b.shape == rb.shape
+    np.testing.assert_array_equal(l, rl)
+    np.testing.assert_allclose(b, rb, rtol=2e-6, atol=2e-6)
+
+
+def test_postprocess_batch_check():
+    from paddle3d_amd.ops import centerpoint_postprocess as cp
+
+    t = synth.center_head_outputs(0, feat_h=8, feat_w=8, num_classes=(1,))[0]
+    two = {k: _cuda(np.concatenate([v, v], 0)) for k, v in t.items()}
+    with pytest.raises(RuntimeError, match="batch size must be 1"):
+        cp.centerpoint_postprocess([two["hm"]], [two["reg"]], [two["height"]], [two["dim"]], [two["vel"]],
+                                   [two["rot"]], [0.2, 0.2], [-51.2, -51.2], CP_CFG["post_center_range"], [0], 4,
+                                   0.1, 0.2, 1000, 83, True)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_bev_pool_v2_exact(oracle, seed):
+    from paddle3d_amd.ops import bev_pool_v2 as bp
+
+    d = synth.bev_pool_inputs(seed, n_cam=2, depth_bins=30, fh=8, fw=22, channels=80, bev=64)
+    args = [d[k] for k in ("depth", "feat", "ranks_depth", "ranks_feat", "ranks_bev", "interval_lengths",
+                           "interval_starts")]
+    out = bp.bev_pool_v2(*[_cuda(a) for a in args], d["bev_feat_shape"]).cpu().numpy()
+    ref = oracle.bev_pool_v2(*args, d["bev_feat_shape"])
+    np.testing.assert_array_equal(out.view(np.uint32), ref.view(np.uint32))
+    # backward op: intervals by ranks_feat
+    order = np.argsort(d["ranks_feat"], kind="stable")
+    rb, rd, rf = d["ranks_bev"][order], d["ranks_depth"][order], d["ranks_feat"][order]
+    flag = np.ones(len(rf), bool)
+    flag[1:] = rf[1:] != rf[:-1]
+    starts = np.nonzero(flag)[0].astype(np.int32)
+    lengths = np.diff(np.append(starts, len(rf))).astype(np.int32)
+    g = np.random.default_rng(seed).normal(size=d["bev_feat_shape"]).astype(np.float32)
+    dg, fg = bp.bev_pool_v2_bkwd(_cuda(g), _cuda(d["depth"]), _cuda(d["feat"]), _cuda(rd), _cuda(rf), _cuda(rb),
+                                 _cuda(lengths), _cuda(starts))
+    rdg, rfg = oracle.bev_pool_v2_bkwd(g, d["depth"], d["feat"], rd, rf, rb, lengths, starts)
+    np.testing.assert_array_equal(dg.cpu().numpy().view(np.uint32), rdg.view(np.uint32))
+    np.testing.assert_array_equal(fg.cpu().numpy().view(np.uint32), rfg.view(np.uint32))
+
+
+def test_bev_pool_v2_full_size_linearity():
+    """BEVDet4D-sized op: linearity in feat (a size-independent property; no oracle involved)."""
+    from paddle3d_amd.ops import bev_pool_v2 as bp
+
+    d = synth.bev_pool_inputs(9)
+    idx = [_cuda(d[k]) for k in ("ranks_depth", "ranks_feat", "ranks_bev", "interval_lengths", "interval_starts")]
+    depth, f1 = _cuda(d["depth"]), _cuda(d["feat"])
+    f2 = torch.randn_like(f1)
+    o1 = bp.bev_pool_v2(depth, f1, *idx, d["bev_feat_shape"])
+    o2 = bp.bev_pool_v2(depth, f2, *idx, d["bev_feat_shape"])
+    o12 = bp.bev_pool_v2(depth, f1 + f2, *idx, d["bev_feat_shape"])
+    assert (o12 - (o1 + o2)).abs().max().item() < 1e-4
+    # cells without an interval stay zero
+    touched = torch.zeros(o1.shape[1] * o1.shape[2], dtype=torch.bool, device="cuda")
+    touched[idx[2].long()] = True
+    assert not o1.view(-1, o1.shape[-1])[~touched].any()

@@ -1,0 +1,97 @@
+"""pointpillars_scatter (exact), pillar_feature_net / voxel_mean (1e-3 abs) vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from paddle3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pillars(oracle, seed, v=30000):
+    pts = synth.nuscenes_sweep(seed)
+    vox, co, npv, nv = oracle.hard_voxelize(pts, synth.NUSC_PILLAR, synth.NUSC_RANGE, 20, v)
+    return vox[:nv], co[:nv], npv[:nv]
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_scatter_exact(oracle, batch):
+    from paddle3d_amd.ops import pointpillars_scatter as ps
+
+    rng = np.random.default_rng(0)
+    feats, coords = [], []
+    for b in range(batch):
+        _, co, _ = _pillars(oracle, 30 + b, v=20000)
+        f = rng.normal(size=(len(co), 64)).astype(np.float32)
+        c4 = np.concatenate([np.full((len(co), 1), b, np.int32), co], 1)
+        feats.append(f)
+        coords.append(c4)
+    f, c4 = np.concatenate(feats), np.concatenate(coords)
+    out = ps.pointpillars_scatter(torch.from_numpy(f).cuda(), torch.from_numpy(c4).cuda(), batch, 512, 512)
+    ref = oracle.pillar_scatter(f, c4, batch, 512, 512)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    np.testing.assert_array_equal(ref, oracle.pillar_scatter_numpy(f, c4, batch, 512, 512))
+
+
+def test_scatter_odd_shapes(oracle):
+    from paddle3d_amd.ops import pointpillars_scatter as ps
+
+    rng = np.random.default_rng(1)
+    ny, nx, c = 37, 41, 7  # plane and channels not multiples of 4 -> scalar path
+    m = 300
+    cells = rng.choice(ny * nx, m, replace=False)
+    c4 = np.stack([np.zeros(m), np.zeros(m), cells // nx, cells % nx], 1).astype(np.int32)
+    f = rng.normal(size=(m, c)).astype(np.float32)
+    out = ps.pointpillars_scatter(torch.from_numpy(f).cuda(), torch.from_numpy(c4).cuda(), 1, ny, nx)
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.pillar_scatter(f, c4, 1, ny, nx))
+    # empty input -> all-zero canvas
+    out = ps.pointpillars_scatter(torch.zeros((0, 8)).cuda(), torch.zeros((0, 4), dtype=torch.int32).cuda(), 2,
+                                  16, 16)
+    assert not out.cpu().numpy().any()
+
+
+def _pfn_params(rng, d, c1, c2):
+    def layer(i, o):
+        return dict(weight=rng.uniform(-1, 1, (i, o)).astype(np.float32) / np.sqrt(i),
+                    gamma=rng.uniform(0.5, 1.5, o).astype(np.float32), beta=rng.normal(0, 0.2, o).astype(np.float32),
+                    mean=rng.normal(0, 0.2, o).astype(np.float32), var=rng.uniform(0.5, 1.5, o).astype(np.float32))
+
+    ps = [layer(d + 5, c1)]
+    if c2:
+        ps.append(layer(2 * c1, c2))
+    return ps
+
+
+@pytest.mark.parametrize("two_layers", [True, False])
+def test_pfn(oracle, two_layers):
+    from paddle3d_amd.ops import voxel_encoder as ve
+
+    rng = np.random.default_rng(2)
+    vox, co, npv = _pillars(oracle, 40)
+    c4 = np.concatenate([np.zeros((len(co), 1), np.int32), co], 1)
+    c1, c2 = (32, 64) if two_layers else (64, 0)
+    params = _pfn_params(rng, 5, c1, c2)
+    ref = oracle.pfn_forward_torch(vox, npv, c4, params, synth.NUSC_PILLAR, synth.NUSC_RANGE)
+    dev = torch.device("cuda")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    folded = []
+    for p in params:
+        s, sh = ve.fold_batchnorm(t(p["gamma"]), t(p["beta"]), t(p["mean"]), t(p["var"]), 1e-3)
+        folded.append((t(p["weight"]), s, sh))
+    vx, vy = synth.NUSC_PILLAR[0], synth.NUSC_PILLAR[1]
+    args = [t(vox), t(npv), t(c4), vx, vy, vx / 2 + synth.NUSC_RANGE[0], vy / 2 + synth.NUSC_RANGE[1], *folded[0]]
+    if two_layers:
+        args += list(folded[1])
+    out = ve.pillar_feature_net(*args).cpu().numpy()
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() < 1e-3, np.abs(out - ref).max()
+
+
+def test_voxel_mean(oracle):
+    from paddle3d_amd.ops import voxel_encoder as ve
+
+    pts = synth.nuscenes_sweep(50)
+    vox, co, npv, nv = oracle.hard_voxelize(pts, synth.NUSC_VOXEL, synth.NUSC_VOXEL_RANGE, 10, 120000)
+    out = ve.voxel_mean(torch.from_numpy(vox[:nv]).cuda(), torch.from_numpy(npv[:nv]).cuda()).cpu().numpy()
+    ref = oracle.voxel_mean(vox[:nv], npv[:nv])
+    assert np.abs(out - ref).max() < 1e-4

@@ -1,0 +1,133 @@
+"""hard_voxelize HIP path vs the CPU oracle (bit-exact: voxels, coords, num_points, num_voxels)."""
+import numpy as np
+import pytest
+import torch
+
+from paddle3d_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(points, voxel_size, pc_range, p, v):
+    from paddle3d_amd.ops import voxelize
+
+    t = torch.from_numpy(points).cuda()
+    out = voxelize.hard_voxelize(t, list(voxel_size), list(pc_range), p, v)
+    torch.cuda.synchronize()
+    return [o.cpu().numpy() for o in out]
+
+
+def _check(oracle, points, voxel_size, pc_range, p, v, kind="port"):
+    vox, co, npv, nv = _run(points, voxel_size, pc_range, p, v)
+    rv, rc, rn, rnv = oracle.hard_voxelize(points, voxel_size, pc_range, p, v, kind)
+    assert int(nv[0]) == rnv
+    np.testing.assert_array_equal(co, rc)
+    np.testing.assert_array_equal(npv, rn)
+    # bit-exact payload (compare as uint32 so that -0.0 / NaN payloads would be caught too)
+    np.testing.assert_array_equal(vox.view(np.uint32), rv.view(np.uint32))
+    return rnv
+
+
+CONFIGS = {
+    # name: (generator, voxel_size, range, P, V)
+    "c1_kitti": (lambda s: synth.kitti_frame(s), synth.KITTI_PILLAR, synth.KITTI_RANGE, 32, 16000),
+    "c3_nusc_train_cap": (lambda s: synth.nuscenes_sweep(s), synth.NUSC_PILLAR, synth.NUSC_RANGE, 20, 30000),
+    "c3_nusc_test_cap": (lambda s: synth.nuscenes_sweep(s), synth.NUSC_PILLAR, synth.NUSC_RANGE, 20, 60000),
+    "c3_nusc_d4_shuffled": (lambda s: synth.nuscenes_sweep(s, dims=4, shuffle=True), synth.NUSC_PILLAR,
+                            synth.NUSC_RANGE, 20, 30000),
+    "c4_voxel": (lambda s: synth.nuscenes_sweep(s), synth.NUSC_VOXEL, synth.NUSC_VOXEL_RANGE, 10, 120000),
+    "c5_bevfusion": (lambda s: synth.nuscenes_sweep(s, dims=4), (0.25, 0.25, 8.0),
+                     (-50.0, -50.0, -5.0, 50.0, 50.0, 3.0), 64, 30000),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("seed", [0, 1])
+def test_matches_oracle(oracle, name, seed):
+    gen, vs, pr, p, v = CONFIGS[name]
+    nv = _check(oracle, gen(seed), vs, pr, p, v)
+    assert nv > 0
+
+
+def test_matches_reference_code(oracle):
+    """Same check against the reference's own compiled kernel (oracle/_ref), when it travelled."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built")
+    gen, vs, pr, p, v = CONFIGS["c3_nusc_train_cap"]
+    _check(oracle, gen(7), vs, pr, p, v, kind="ref")
+
+
+def test_edge_cases(oracle):
+    vs, pr = synth.NUSC_PILLAR, synth.NUSC_RANGE
+    rng = np.random.default_rng(5)
+    # all points outside the range -> zero voxels
+    far = np.full((1000, 5), 500.0, np.float32)
+    _check(oracle, far, vs, pr, 20, 100)
+    # one cell hammered by many points (in-voxel overflow), tiny cap
+    one = np.zeros((5000, 5), np.float32)
+    one[:, :2] = 0.05
+    one[:, 3] = np.arange(5000)
+    _check(oracle, one, vs, pr, 20, 10)
+    # max_voxels = 1: only the first cell survives, later points of that cell still join
+    pts = synth.nuscenes_sweep(3, n_points=20000)
+    _check(oracle, pts, vs, pr, 20, 1)
+    # single point, odd sizes around tile boundaries of the sort (2048) and scan (4096)
+    for n in (1, 2047, 2048, 2049, 4095, 4097):
+        _check(oracle, synth.nuscenes_sweep(11, n_points=max(n, 10))[:n], vs, pr, 5, 50)
+    # NaN / inf coordinates are dropped like the x86 reference drops them
+    bad = synth.nuscenes_sweep(4, n_points=5000)
+    bad[rng.choice(5000, 50, replace=False), 0] = np.nan
+    bad[rng.choice(5000, 50, replace=False), 1] = np.inf
+    bad[rng.choice(5000, 50, replace=False), 2] = -np.inf
+    _check(oracle, bad, vs, pr, 20, 3000)
+
+
+def test_batch_and_ragged(oracle):
+    from paddle3d_amd.ops import voxelize
+
+    frames = [synth.nuscenes_sweep(20 + i, n_points=50000) for i in range(3)]
+    lens = [50000, 31234, 1]
+    pts = torch.from_numpy(np.stack(frames)).cuda()
+    num = torch.tensor(lens, dtype=torch.int32).cuda()
+    vox, co, npv, nv = voxelize.hard_voxelize_batch(pts, list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20,
+                                                    30000, num_points=num)
+    torch.cuda.synchronize()
+    for b in range(3):
+        rv, rc, rn, rnv = oracle.hard_voxelize(frames[b][: lens[b]], synth.NUSC_PILLAR, synth.NUSC_RANGE, 20,
+                                               30000)
+        assert int(nv[b]) == rnv
+        np.testing.assert_array_equal(co[b].cpu().numpy(), rc)
+        np.testing.assert_array_equal(npv[b].cpu().numpy(), rn)
+        np.testing.assert_array_equal(vox[b].cpu().numpy().view(np.uint32), rv.view(np.uint32))
+
+
+def test_properties_full_size():
+    """Size-independent properties at the full benchmark size (no oracle involved)."""
+    from paddle3d_amd.ops import voxelize
+
+    pts_np = synth.nuscenes_sweep(42)
+    pts = torch.from_numpy(pts_np).cuda()
+    vox, co, npv, nv = voxelize.hard_voxelize(pts, list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20, 60000)
+    n = int(nv.item())
+    co, npv, vox = co.cpu().numpy(), npv.cpu().numpy(), vox.cpu().numpy()
+    # coords unique and inside the grid, counts in [1, P], padding is zero
+    lin = co[:n, 1].astype(np.int64) * 512 + co[:n, 2]
+    assert len(np.unique(lin)) == n
+    assert (co[:n, 0] == 0).all() and (co[:n, 1:] >= 0).all() and (co[:n, 1:] < 512).all()
+    assert (npv[:n] >= 1).all() and (npv[:n] <= 20).all() and (npv[n:] == 0).all()
+    assert not vox[n:].any() and not co[n:].any()
+    pad = np.arange(20)[None, :] >= npv[:, None]
+    assert not vox[pad].any()
+    # every stored point lies in its voxel's cell, and is an input point
+    k = np.arange(20)[None, :] < npv[:n, None]
+    cx = np.floor((vox[:n, :, 0] - np.float32(-51.2)) / np.float32(0.2)).astype(np.int64)
+    cy = np.floor((vox[:n, :, 1] - np.float32(-51.2)) / np.float32(0.2)).astype(np.int64)
+    assert (cx[k] == np.broadcast_to(co[:n, 2:3], cx.shape)[k]).all()
+    assert (cy[k] == np.broadcast_to(co[:n, 1:2], cy.shape)[k]).all()
+    # idempotence: voxelising the stored points again reproduces the same voxel set and counts
+    stored = torch.from_numpy(np.ascontiguousarray(vox[:n][k])).cuda()
+    vox2, co2, npv2, nv2 = voxelize.hard_voxelize(stored, list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20,
+                                                  60000)
+    assert int(nv2.item()) == n
+    np.testing.assert_array_equal(co2.cpu().numpy()[:n], co[:n])
+    np.testing.assert_array_equal(npv2.cpu().numpy()[:n], npv[:n])
