@@ -87,6 +87,7 @@ int pd3_pointpillars_scatter(const float *voxel_features, const int32_t *coords,
  *   w2 [2*C1, C2], scale2/shift2 [C2]   (w2 == NULL: single-layer PFN, output [M, C1])
  *   out [M, C2]
  * legacy == 0 only (the nuScenes configs); with_distance unsupported (no config on the path uses it).
+ * Rows with num_points <= 0 (padding of a fixed-shape batch) produce zeros.
  */
 int pd3_pillar_feature_net(const float *voxels, const int32_t *num_points, const int32_t *coors,
                            int64_t num_pillars, int max_points, int num_point_dim, float vx,
@@ -124,21 +125,24 @@ int pd3_boxes_overlap_bev(const float *boxes_a, int num_a, const float *boxes_b,
  * paddle3d/ops/centerpoint_postprocess/postprocess.cc:91-104 (postprocess_gpu, postprocess.cu:104-280).
  * All tasks of one frame in one launch sequence on one stream, no host round trip inside.
  *
- *   hm/reg/height/dim/vel/rot: host arrays of `num_tasks` device pointers to fp32 NCHW maps with
- *     batch 1: hm[t] [1, hm_channels[t], H, W], reg [1,2,H,W], height [1,1,H,W], dim [1,3,H,W],
- *     vel [1,2,H,W], rot [1,2,H,W].
+ *   hm/reg/height/dim/vel/rot: host arrays of `num_tasks` device pointers to contiguous fp32 NCHW
+ *     maps: hm[t] [batch, hm_channels[t], H, W], reg [batch,2,H,W], height [batch,1,H,W],
+ *     dim [batch,3,H,W], vel [batch,2,H,W], rot [batch,2,H,W].  batch = 1 is exactly the reference op
+ *     (it rejects anything else, postprocess.cu:19-20,138); batch > 1 runs the per-frame op for every
+ *     frame in the same launch sequence.
  *   hm_channels: host int[num_tasks];  label_offsets: host int[num_tasks] (the op's `num_classes` attr)
- *   out_bboxes  [num_tasks * max(nms_post_max_size,1), 9 or 7] fp32
- *   out_scores  [same rows] fp32;  out_labels [same rows] int64
- *   out_count   [1] int32: number of valid leading rows (tasks concatenated in order; a task with no
- *               candidate contributes the reference's fake row: zeros box, score -1, label 0).
+ *   out_bboxes  [batch, num_tasks * max(nms_post_max_size,1), 9 or 7] fp32
+ *   out_scores  [batch, same rows] fp32;  out_labels [batch, same rows] int64
+ *   out_count   [batch] int32: number of valid leading rows per frame (tasks concatenated in order;
+ *               a task with no candidate contributes the reference's fake row: zeros box, score -1,
+ *               label 0).
  */
-size_t pd3_centerpoint_postprocess_workspace(int num_tasks, int feat_h, int feat_w,
+size_t pd3_centerpoint_postprocess_workspace(int batch, int num_tasks, int feat_h, int feat_w,
                                              int nms_pre_max_size, int nms_post_max_size);
 int pd3_centerpoint_postprocess(const float *const *hm, const float *const *reg,
                                 const float *const *height, const float *const *dim,
-                                const float *const *vel, const float *const *rot, int num_tasks,
-                                const int *hm_channels, int feat_h, int feat_w,
+                                const float *const *vel, const float *const *rot, int batch,
+                                int num_tasks, const int *hm_channels, int feat_h, int feat_w,
                                 const float *voxel_size, const float *point_cloud_range,
                                 const float *post_center_range, const int *label_offsets,
                                 int down_ratio, float score_threshold, float nms_iou_threshold,

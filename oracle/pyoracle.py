@@ -170,9 +170,11 @@ def pfn_forward_torch(voxels, num_points, coors, params, voxel_size, pc_range):
     mask = (torch.as_tensor(num_points).reshape(-1, 1) > torch.arange(P).reshape(1, -1)).to(torch.float32)
     x = x * mask.unsqueeze(-1)
     for li, p in enumerate(params):
-        y = x @ torch.as_tensor(p["weight"])
-        y = (y - torch.as_tensor(p["mean"])) / torch.sqrt(torch.as_tensor(p["var"]) + 1e-3)
-        y = y * torch.as_tensor(p["gamma"]) + torch.as_tensor(p["beta"])
+        w, g, b, mu, var = (torch.as_tensor(np.asarray(p[k]), dtype=torch.float32)
+                            for k in ("weight", "gamma", "beta", "mean", "var"))
+        y = x @ w
+        y = (y - mu) / torch.sqrt(var + 1e-3)
+        y = y * g + b
         y = torch.relu(y)
         ymax = y.max(dim=1, keepdim=True).values
         if li == len(params) - 1:

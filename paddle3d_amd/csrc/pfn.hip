@@ -68,7 +68,11 @@ __global__ __launch_bounds__(kPfnWaves * 64) void pfn_kernel(PfnArgs a) {
   const int64_t stride = (int64_t)gridDim.x * kPfnWaves;
   for (int64_t pil = (int64_t)blockIdx.x * kPfnWaves + wave; pil < a.m; pil += stride) {
     const int np_raw = a.num_points[pil];
-    const int np = min(max(np_raw, 0), a.p);
+    if (np_raw <= 0) {  // padding row of a fixed-shape [B*V] batch: no pillar here
+      if (lane < out_c) a.out[pil * out_c + lane] = 0.f;
+      continue;
+    }
+    const int np = min(np_raw, a.p);
     const int rows = np + (np < a.p ? 1 : 0);  // + one representative padded row
     const float* vox = a.voxels + pil * a.p * a.d;
     // ---- decorate (pillar_encoder.py:166-199) ------------------------------------------------
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(kPfnWaves * 64) void pfn_kernel(PfnArgs a) {
     }
     if (!two) {
       if (lane < out_c) a.out[pil * out_c + lane] = m1;
+      wave_lds_sync();
       continue;
     }
     // ---- layer 2 on [y1 | max(y1)] (the concat of :100-104) -------------------------------------

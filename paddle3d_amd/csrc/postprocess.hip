@@ -38,7 +38,7 @@ struct CpHeads {
 };
 
 struct CpCfg {
-  int hw, feat_w, dims, with_velocity;
+  int hw, feat_w, dims, with_velocity, num_tasks;
   float down_ratio, vx, vy, pc_x, pc_y;
   float r[6];  // post_center_range
   float score_threshold;
@@ -51,12 +51,18 @@ __global__ __launch_bounds__(256) void cp_decode_kernel(CpHeads h, CpCfg c, floa
                                                         int* __restrict__ labels,
                                                         uint32_t* __restrict__ keys,
                                                         int* __restrict__ counts) {
-  const int t = blockIdx.y;
+  const int set = blockIdx.y;  // frame * num_tasks + task
+  const int t = set % c.num_tasks, frame = set / c.num_tasks;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int selected = 0;
   if (i < c.hw) {
     // postprocess.cu:145-149  sigmoid, then max / argmax over the class axis (first maximum wins)
-    const float* hm = h.hm[t];
+    const float* hm = h.hm[t] + (int64_t)frame * h.ncls[t] * c.hw;
+    const float* regp = h.reg[t] + (int64_t)frame * 2 * c.hw;
+    const float* heip = h.height[t] + (int64_t)frame * c.hw;
+    const float* dimp = h.dim[t] + (int64_t)frame * 3 * c.hw;
+    const float* velp = h.vel[t] + (int64_t)frame * 2 * c.hw;
+    const float* rotp = h.rot[t] + (int64_t)frame * 2 * c.hw;
     float best = 0.f;
     int arg = 0;
     for (int k = 0; k < h.ncls[t]; ++k) {
@@ -68,18 +74,18 @@ __global__ __launch_bounds__(256) void cp_decode_kernel(CpHeads h, CpCfg c, floa
     }
     // decode_kernel :41-70
     const int xs = i % c.feat_w, ys = i / c.feat_w;
-    const float x = h.reg[t][i], y = h.reg[t][i + c.hw], z = h.height[t][i];
-    float* bx = boxes + ((int64_t)t * c.hw + i) * c.dims;
+    const float x = regp[i], y = regp[i + c.hw], z = heip[i];
+    float* bx = boxes + ((int64_t)set * c.hw + i) * c.dims;
     bx[0] = (x + xs) * c.down_ratio * c.vx + c.pc_x;
     bx[1] = (y + ys) * c.down_ratio * c.vy + c.pc_y;
     bx[2] = z;
-    bx[3] = exp_rn(h.dim[t][i]);  // :151 exp(dim)
-    bx[4] = exp_rn(h.dim[t][i + c.hw]);
-    bx[5] = exp_rn(h.dim[t][i + 2 * c.hw]);
-    const float ang = atan2_rn(h.rot[t][i], h.rot[t][i + c.hw]);
+    bx[3] = exp_rn(dimp[i]);  // :151 exp(dim)
+    bx[4] = exp_rn(dimp[i + c.hw]);
+    bx[5] = exp_rn(dimp[i + 2 * c.hw]);
+    const float ang = atan2_rn(rotp[i], rotp[i + c.hw]);
     if (c.with_velocity) {
-      bx[6] = h.vel[t][i];
-      bx[7] = h.vel[t][i + c.hw];
+      bx[6] = velp[i];
+      bx[7] = velp[i + c.hw];
       bx[8] = ang;
     } else {
       bx[6] = ang;
@@ -87,15 +93,15 @@ __global__ __launch_bounds__(256) void cp_decode_kernel(CpHeads h, CpCfg c, floa
     // :72-77  mask on the RAW reg / height values
     const bool m = best > c.score_threshold && x <= c.r[3] && y <= c.r[4] && z <= c.r[5] &&
                    x >= c.r[0] && y >= c.r[1] && z >= c.r[2];
-    scores[(int64_t)t * c.hw + i] = best;
-    labels[(int64_t)t * c.hw + i] = arg;
+    scores[(int64_t)set * c.hw + i] = best;
+    labels[(int64_t)set * c.hw + i] = arg;
     uint32_t key = kKeyOut;
     if (m) {
       const uint32_t bits = __float_as_uint(best);
       key = bits <= kKeyOne ? kKeyOne - bits : 0u;
       selected = 1;
     }
-    keys[(int64_t)t * c.hw + i] = key;
+    keys[(int64_t)set * c.hw + i] = key;
   }
   // block count of selected cells -> counts[t]
   const unsigned long long ball = __ballot(selected);
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256) void cp_decode_kernel(CpHeads h, CpCfg c, floa
   __syncthreads();
   if (threadIdx.x == 0) {
     const int s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (s) atomicAdd(&counts[t], s);
+    if (s) atomicAdd(&counts[set], s);
   }
 }
 
@@ -138,8 +144,14 @@ __global__ __launch_bounds__(256) void cp_output_kernel(
     const int32_t* __restrict__ nkeep, CpHeads h, int num_tasks, int hw, int dims, int cap,
     int post_max, float* __restrict__ out_boxes, float* __restrict__ out_scores,
     int64_t* __restrict__ out_labels, int32_t* __restrict__ out_count) {
+  const int frame = blockIdx.x;
+  const int rows_cap = num_tasks * max(post_max, 1);
+  out_boxes += (int64_t)frame * rows_cap * dims;
+  out_scores += (int64_t)frame * rows_cap;
+  out_labels += (int64_t)frame * rows_cap;
   int offset = 0;
-  for (int t = 0; t < num_tasks; ++t) {
+  for (int task = 0; task < num_tasks; ++task) {
+    const int t = frame * num_tasks + task;  // set index
     const int sel = counts[t];
     if (sel <= 0) {  // :190-201 fake row
       if ((int)threadIdx.x < dims) out_boxes[(int64_t)offset * dims + threadIdx.x] = 0.f;
@@ -157,11 +169,11 @@ __global__ __launch_bounds__(256) void cp_output_kernel(
       const float* bx = boxes + ((int64_t)t * hw + cell) * dims;
       for (int k = 0; k < dims; ++k) out_boxes[(int64_t)(offset + r) * dims + k] = bx[k];
       out_scores[offset + r] = scores[(int64_t)t * hw + cell];
-      out_labels[offset + r] = (int64_t)labels[(int64_t)t * hw + cell] + h.label_offset[t];
+      out_labels[offset + r] = (int64_t)labels[(int64_t)t * hw + cell] + h.label_offset[task];
     }
     offset += rows;
   }
-  if (threadIdx.x == 0) out_count[0] = offset;
+  if (threadIdx.x == 0) out_count[frame] = offset;
 }
 
 struct CpWorkspace {
@@ -201,19 +213,19 @@ static CpWorkspace cp_carve(void* base, int tasks, int hw, int pre_max, const Ra
 
 using namespace pd3;
 
-extern "C" size_t pd3_centerpoint_postprocess_workspace(int num_tasks, int feat_h, int feat_w,
-                                                        int nms_pre_max_size,
+extern "C" size_t pd3_centerpoint_postprocess_workspace(int batch, int num_tasks, int feat_h,
+                                                        int feat_w, int nms_pre_max_size,
                                                         int nms_post_max_size) {
   (void)nms_post_max_size;
-  if (num_tasks <= 0 || feat_h <= 0 || feat_w <= 0) return 0;
+  if (batch <= 0 || num_tasks <= 0 || feat_h <= 0 || feat_w <= 0) return 0;
   const int hw = feat_h * feat_w;
-  return cp_carve(nullptr, num_tasks, hw, nms_pre_max_size, radix_plan(kKeyOut, hw)).bytes;
+  return cp_carve(nullptr, batch * num_tasks, hw, nms_pre_max_size, radix_plan(kKeyOut, hw)).bytes;
 }
 
 extern "C" int pd3_centerpoint_postprocess(
     const float* const* hm, const float* const* reg, const float* const* height,
-    const float* const* dim, const float* const* vel, const float* const* rot, int num_tasks,
-    const int* hm_channels, int feat_h, int feat_w, const float* voxel_size,
+    const float* const* dim, const float* const* vel, const float* const* rot, int batch,
+    int num_tasks, const int* hm_channels, int feat_h, int feat_w, const float* voxel_size,
     const float* point_cloud_range, const float* post_center_range, const int* label_offsets,
     int down_ratio, float score_threshold, float nms_iou_threshold, int nms_pre_max_size,
     int nms_post_max_size, int with_velocity, float* out_bboxes, float* out_scores,
@@ -223,7 +235,7 @@ extern "C" int pd3_centerpoint_postprocess(
       !voxel_size || !point_cloud_range || !post_center_range || !out_bboxes || !out_scores ||
       !out_labels || !out_count || !workspace)
     return PD3_EINVAL;
-  if (num_tasks <= 0 || num_tasks > kMaxTasks || feat_h <= 0 || feat_w <= 0 ||
+  if (batch <= 0 || num_tasks <= 0 || num_tasks > kMaxTasks || feat_h <= 0 || feat_w <= 0 ||
       nms_pre_max_size < 0 || nms_post_max_size < 0)
     return PD3_EINVAL;
   const int hw = feat_h * feat_w;
@@ -231,7 +243,8 @@ extern "C" int pd3_centerpoint_postprocess(
   const int cb = (cap + 63) / 64;
   if (cb > kNmsMaxWords) return PD3_EUNSUPPORTED;
   const RadixPlan plan = radix_plan(kKeyOut, hw);
-  CpWorkspace w = cp_carve(workspace, num_tasks, hw, nms_pre_max_size, plan);
+  const int sets = batch * num_tasks;
+  CpWorkspace w = cp_carve(workspace, sets, hw, nms_pre_max_size, plan);
   if (workspace_bytes < w.bytes) return PD3_EWORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
 
@@ -251,6 +264,7 @@ extern "C" int pd3_centerpoint_postprocess(
   CpCfg c;
   c.hw = hw;
   c.feat_w = feat_w;
+  c.num_tasks = num_tasks;
   c.with_velocity = with_velocity ? 1 : 0;
   c.dims = with_velocity ? 9 : 7;
   c.down_ratio = (float)down_ratio;  // int attr received as float, postprocess.cu:35,85
@@ -261,20 +275,20 @@ extern "C" int pd3_centerpoint_postprocess(
   for (int k = 0; k < 6; ++k) c.r[k] = post_center_range[k];
   c.score_threshold = score_threshold;
 
-  hipError_t e = hipMemsetAsync(w.counts, 0, sizeof(int) * num_tasks, s);
+  hipError_t e = hipMemsetAsync(w.counts, 0, sizeof(int) * sets, s);
   if (e != hipSuccess) return (int)e;
-  dim3 dgrid((hw + 255) / 256, num_tasks);
+  dim3 dgrid((hw + 255) / 256, sets);
   cp_decode_kernel<<<dgrid, 256, 0, s>>>(h, c, w.boxes, w.scores, w.labels, w.keys_a, w.counts);
-  const int where = enqueue_radix_sort(w.keys_a, w.vals_a, w.keys_b, w.vals_b, hw, hw, num_tasks,
+  const int where = enqueue_radix_sort(w.keys_a, w.vals_a, w.keys_b, w.vals_b, hw, hw, sets,
                                        plan, /*identity_vals=*/true, w.hist, w.partial, s);
   const uint32_t* sidx = where ? w.vals_b : w.vals_a;
-  dim3 bgrid((cap + 255) / 256, num_tasks);
+  dim3 bgrid((cap + 255) / 256, sets);
   cp_nms_boxes_kernel<<<bgrid, 256, 0, s>>>(w.boxes, sidx, w.counts, hw, c.dims, cap, w.nms_boxes);
-  dim3 mgrid(cb, cb, num_tasks);
+  dim3 mgrid(cb, cb, sets);
   nms_mask_kernel<false><<<mgrid, 64, 0, s>>>(w.nms_boxes, w.counts, 0, cap, cb, nms_iou_threshold,
                                               w.mask);
-  nms_sweep_kernel<<<num_tasks, 64, 0, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);
-  cp_output_kernel<<<1, 256, 0, s>>>(w.boxes, w.scores, w.labels, sidx, w.counts, w.keep, w.nkeep, h,
+  nms_sweep_kernel<<<sets, 64, 0, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);
+  cp_output_kernel<<<batch, 256, 0, s>>>(w.boxes, w.scores, w.labels, sidx, w.counts, w.keep, w.nkeep, h,
                                      num_tasks, hw, c.dims, cap, nms_post_max_size, out_bboxes,
                                      out_scores, out_labels, out_count);
   return launch_status();

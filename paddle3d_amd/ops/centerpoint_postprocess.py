@@ -29,8 +29,11 @@ def _ptr_array(tensors):
 
 def centerpoint_postprocess_device(hm, reg, height, dim, vel, rot, voxel_size, point_cloud_range,
                                    post_center_range, num_classes, down_ratio, score_threshold,
-                                   nms_iou_threshold, nms_pre_max_size, nms_post_max_size, with_velocity):
-    """No-sync variant: returns padded (bboxes, scores, labels) plus the device int32 row count."""
+                                   nms_iou_threshold, nms_pre_max_size, nms_post_max_size, with_velocity,
+                                   allow_batch=False):
+    """No-sync variant: returns padded (bboxes [B,R,dims], scores [B,R], labels [B,R]) plus the device
+    int32 row counts [B].  allow_batch=True lifts the reference's batch-1 restriction (frames are
+    processed independently in one launch sequence)."""
     op = "centerpoint postprocess"
     t_n = len(hm)
     lists = []
@@ -39,26 +42,29 @@ def centerpoint_postprocess_device(hm, reg, height, dim, vel, rot, voxel_size, p
             raise RuntimeError("centerpoint_postprocess: every head list needs one tensor per task")
         lists.append([require_gpu(t, op) for t in group])
     hm0 = lists[0][0]
-    if hm0.shape[0] != 1:
+    batch = int(hm0.shape[0])
+    if batch != 1 and not allow_batch:
         raise RuntimeError("hm[0] batch size must be 1.")  # CHECK_INPUT_BATCHSIZE, postprocess.cu:19-20
+    if any(int(t.shape[0]) != batch for g in lists for t in g):
+        raise RuntimeError("centerpoint_postprocess: inconsistent batch size")
     h, w = int(hm0.shape[2]), int(hm0.shape[3])
     dev = hm0.device
     dims = 9 if with_velocity else 7
     rows = t_n * max(int(nms_post_max_size), 1)
-    out_b = torch.empty((rows, dims), dtype=torch.float32, device=dev)
-    out_s = torch.empty((rows,), dtype=torch.float32, device=dev)
-    out_l = torch.empty((rows,), dtype=torch.int64, device=dev)
-    out_n = torch.empty((1,), dtype=torch.int32, device=dev)
+    out_b = torch.empty((batch, rows, dims), dtype=torch.float32, device=dev)
+    out_s = torch.empty((batch, rows), dtype=torch.float32, device=dev)
+    out_l = torch.empty((batch, rows), dtype=torch.int64, device=dev)
+    out_n = torch.empty((batch,), dtype=torch.int32, device=dev)
     ncls = np.ascontiguousarray([int(t.shape[1]) for t in lists[0]], dtype=np.int32)
     offs = np.ascontiguousarray([int(num_classes[t]) for t in range(t_n)], dtype=np.int32)
     vs, pr, pcr = host_f32(voxel_size)[:2], host_f32(point_cloud_range)[:2], host_f32(post_center_range, 6)
     vs = np.ascontiguousarray(np.concatenate([vs, [0.0]]).astype(np.float32))
     pr = np.ascontiguousarray(np.concatenate([pr, [0.0] * 4]).astype(np.float32))
     L = lib()
-    ws = workspace(L.pd3_centerpoint_postprocess_workspace(t_n, h, w, int(nms_pre_max_size),
+    ws = workspace(L.pd3_centerpoint_postprocess_workspace(batch, t_n, h, w, int(nms_pre_max_size),
                                                            int(nms_post_max_size)), dev)
     arrays = [_ptr_array(g) for g in lists]
-    check(L.pd3_centerpoint_postprocess(*[C.cast(a, C.c_void_p) for a in arrays], t_n, ptr(ncls), h, w,
+    check(L.pd3_centerpoint_postprocess(*[C.cast(a, C.c_void_p) for a in arrays], batch, t_n, ptr(ncls), h, w,
                                         ptr(vs), ptr(pr), ptr(pcr), ptr(offs), int(down_ratio),
                                         C.c_float(score_threshold), C.c_float(nms_iou_threshold),
                                         int(nms_pre_max_size), int(nms_post_max_size),
@@ -75,4 +81,4 @@ def centerpoint_postprocess(hm, reg, height, dim, vel, rot, voxel_size, point_cl
                                                 down_ratio, score_threshold, nms_iou_threshold,
                                                 nms_pre_max_size, nms_post_max_size, with_velocity)
     k = int(n.item())
-    return b[:k], s[:k], l[:k]
+    return b[0, :k], s[0, :k], l[0, :k]

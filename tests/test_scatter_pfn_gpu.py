@@ -52,7 +52,7 @@ def test_scatter_odd_shapes(oracle):
 
 def _pfn_params(rng, d, c1, c2):
     def layer(i, o):
-        return dict(weight=rng.uniform(-1, 1, (i, o)).astype(np.float32) / np.sqrt(i),
+        return dict(weight=(rng.uniform(-1, 1, (i, o)) / np.sqrt(i)).astype(np.float32),
                     gamma=rng.uniform(0.5, 1.5, o).astype(np.float32), beta=rng.normal(0, 0.2, o).astype(np.float32),
                     mean=rng.normal(0, 0.2, o).astype(np.float32), var=rng.uniform(0.5, 1.5, o).astype(np.float32))
 

@@ -73,7 +73,7 @@ def test_edge_cases(oracle):
     _check(oracle, pts, vs, pr, 20, 1)
     # single point, odd sizes around tile boundaries of the sort (2048) and scan (4096)
     for n in (1, 2047, 2048, 2049, 4095, 4097):
-        _check(oracle, synth.nuscenes_sweep(11, n_points=max(n, 10))[:n], vs, pr, 5, 50)
+        _check(oracle, synth.nuscenes_sweep(11, n_points=6000)[:n], vs, pr, 5, 50)
     # NaN / inf coordinates are dropped like the x86 reference drops them
     bad = synth.nuscenes_sweep(4, n_points=5000)
     bad[rng.choice(5000, 50, replace=False), 0] = np.nan
