@@ -23,9 +23,12 @@
 #include "common.hpp"
 #include "radix_sort.hpp"
 #include "scan.hpp"
+#include "voxelize_tiled.hpp"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 namespace pd3 {
 
@@ -193,6 +196,124 @@ static VoxWorkspace carve(void* base, int batch, int64_t n, int max_voxels, cons
   return w;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// tiled fast path (voxelize_tiled.hpp)
+// ---------------------------------------------------------------------------------------------------
+struct VtWorkspace {
+  uint32_t *recs, *dir, *bitmap, *owner, *plist, *vid2key;
+  int *cell_npts, *wsum, *totals;
+  int64_t bitmap_words;
+  int assign_blocks;
+  size_t zero_bytes;  // the bitmap is zeroed per call
+  size_t bytes;
+};
+
+static VtWorkspace vt_carve(void* base, int batch, int64_t n, int max_pts, int max_voxels,
+                            uint32_t ncells, const VtPlan& p) {
+  Carver c(base);
+  VtWorkspace w;
+  w.bitmap_words = ceil_div(n, 32);
+  w.assign_blocks = (int)ceil_div(w.bitmap_words, kVtAssignThreads);
+  w.bitmap = c.take<uint32_t>((size_t)batch * w.bitmap_words);
+  w.zero_bytes = c.off;
+  w.recs = c.take<uint32_t>((size_t)batch * p.tiles * kVtTile);
+  w.dir = c.take<uint32_t>((size_t)batch * p.tiles * p.groups);
+  w.owner = c.take<uint32_t>((size_t)batch * w.bitmap_words * 32);
+  w.cell_npts = c.take<int>((size_t)batch * ncells);
+  w.plist = c.take<uint32_t>((size_t)batch * ncells * max_pts);
+  w.vid2key = c.take<uint32_t>((size_t)batch * max_voxels);
+  w.wsum = c.take<int>((size_t)batch * w.assign_blocks);
+  w.totals = c.take<int>((size_t)batch);
+  w.bytes = c.off;
+  return w;
+}
+
+// 0 = automatic, 1 = force the generic sort path, 2 = force the tiled path (error if not applicable).
+static int path_override() {
+  const char* e = std::getenv("PD3_VOXELIZE_PATH");
+  if (!e) return 0;
+  if (!std::strcmp(e, "sort")) return 1;
+  if (!std::strcmp(e, "tiled")) return 2;
+  return 0;
+}
+
+static bool tiled_applicable(const VoxGrid& g, int64_t n, int dim, int max_pts, int max_voxels,
+                             VtPlan& plan) {
+  plan = vt_plan(g.ncells, n, max_pts);
+  const int64_t row = (int64_t)max_pts * dim;
+  const int64_t rowq = (row % 4 == 0) ? row / 4 : row;
+  return plan.ok && (int64_t)max_voxels * rowq < ((int64_t)1 << 24);
+}
+
+template <int VEC>
+static void launch_write(int dim, dim3 grid, hipStream_t s, const float* points, VtCells cells,
+                         const uint32_t* vid2key, const int* totals, int64_t n, uint32_t ncells,
+                         int max_pts, int max_voxels, int rowq, VtGrid vg, float* voxels,
+                         int32_t* coords, int32_t* num_pts, int32_t* num_voxels) {
+  const float inv = 1.0f / (float)rowq;
+#define PD3_VT_WRITE(D)                                                                           \
+  vt_write_kernel<VEC, D><<<grid, 256, 0, s>>>(points, cells, vid2key, totals, n, ncells, dim,     \
+                                               max_pts, max_voxels, rowq, inv, vg, voxels, coords, \
+                                               num_pts, num_voxels)
+  switch (dim) {
+    case 3: PD3_VT_WRITE(3); break;
+    case 4: PD3_VT_WRITE(4); break;
+    case 5: PD3_VT_WRITE(5); break;
+    case 6: PD3_VT_WRITE(6); break;
+    default: PD3_VT_WRITE(0); break;
+  }
+#undef PD3_VT_WRITE
+}
+
+static int run_tiled(const float* points, const int32_t* num_points, int batch, int64_t n, int dim,
+                     const VoxGrid& g, int max_pts, int max_voxels, const VtPlan& plan,
+                     float* voxels, int32_t* coords, int32_t* num_pts, int32_t* num_voxels,
+                     void* workspace, hipStream_t s) {
+  VtWorkspace w = vt_carve(workspace, batch, n, max_pts, max_voxels, g.ncells, plan);
+  VtGrid vg{g.min_x, g.min_y, g.min_z, g.size_x, g.size_y, g.size_z, g.gx, g.gy, g.gz, g.ncells};
+  hipError_t e = hipMemsetAsync(w.bitmap, 0, w.zero_bytes, s);
+  if (e != hipSuccess) return (int)e;
+  const size_t lds_a = (size_t)kVtRouteWaves * plan.groups * 8 + (size_t)plan.groups * 4 +
+                       (kVtRouteWaves + 2) * 4;
+  const size_t lds_b_wave = ((size_t)plan.cpg * 12 + (size_t)(2 * plan.tiles + 2) * 4 + 15) / 16 * 16;
+  const size_t lds_b = lds_b_wave * kVtGroupWaves;
+  if (lds_a > 48 * 1024) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(vt_route_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (lds_b > 48 * 1024) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(vt_group_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+    if (e != hipSuccess) return (int)e;
+  }
+  dim3 agrid(plan.tiles, batch);
+  vt_route_kernel<<<agrid, kVtRouteThreads, lds_a, s>>>(points, num_points, n, dim, vg, plan.low,
+                                                        plan.groups, plan.tiles, w.recs, w.dir);
+  VtCells cells{w.cell_npts, w.plist};
+  dim3 bgrid((unsigned)ceil_div(plan.groups, kVtGroupWaves), batch);
+  vt_group_kernel<<<bgrid, kVtGroupThreads, lds_b, s>>>(w.recs, w.dir, plan.low, plan.groups,
+                                                        plan.tiles, max_pts, n, g.ncells, cells,
+                                                        w.owner, w.bitmap, w.bitmap_words);
+  dim3 cgrid(w.assign_blocks, batch);
+  vt_count_kernel<<<cgrid, kVtAssignThreads, 0, s>>>(w.bitmap, w.bitmap_words, w.wsum);
+  vt_assign_kernel<<<cgrid, kVtAssignThreads, 0, s>>>(w.bitmap, w.bitmap_words, w.owner, w.wsum,
+                                                      w.bitmap_words * 32, max_voxels, w.vid2key,
+                                                      w.totals);
+  const int64_t row = (int64_t)max_pts * dim;
+  const bool vec4 = (row % 4 == 0) && (reinterpret_cast<uintptr_t>(voxels) % 16 == 0);
+  const int rowq = (int)(vec4 ? row / 4 : row);
+  dim3 dgrid((unsigned)ceil_div((int64_t)max_voxels * rowq, 256), batch);
+  if (vec4)
+    launch_write<4>(dim, dgrid, s, points, cells, w.vid2key, w.totals, n, g.ncells, max_pts,
+                    max_voxels, rowq, vg, voxels, coords, num_pts, num_voxels);
+  else
+    launch_write<1>(dim, dgrid, s, points, cells, w.vid2key, w.totals, n, g.ncells, max_pts,
+                    max_voxels, rowq, vg, voxels, coords, num_pts, num_voxels);
+  return launch_status();
+}
+
 }  // namespace pd3
 
 using namespace pd3;
@@ -201,13 +322,15 @@ extern "C" size_t pd3_hard_voxelize_workspace(int batch, int64_t max_points, int
                                               const float* voxel_size,
                                               const float* point_cloud_range,
                                               int max_num_points_in_voxel, int max_voxels) {
-  (void)num_point_dim;
-  (void)max_num_points_in_voxel;
   VoxGrid g;
   if (batch <= 0 || max_points <= 0 || max_voxels <= 0 || !make_grid(voxel_size, point_cloud_range, g))
     return 0;
   const RadixPlan plan = radix_plan(g.ncells, max_points);
-  return carve(nullptr, batch, max_points, max_voxels, plan).bytes;
+  size_t bytes = carve(nullptr, batch, max_points, max_voxels, plan).bytes;
+  VtPlan vp;
+  if (tiled_applicable(g, max_points, num_point_dim, max_num_points_in_voxel, max_voxels, vp))
+    bytes = std::max(bytes, vt_carve(nullptr, batch, max_points, max_num_points_in_voxel, max_voxels, g.ncells, vp).bytes);
+  return bytes;
 }
 
 extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points, int batch,
@@ -223,11 +346,23 @@ extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points,
       max_num_points_in_voxel <= 0 || max_voxels <= 0)
     return PD3_EINVAL;
   if (!make_grid(voxel_size, point_cloud_range, g)) return PD3_EINVAL;
-  const RadixPlan plan = radix_plan(g.ncells, max_points);
-  VoxWorkspace w = carve(workspace, batch, max_points, max_voxels, plan);
-  if (workspace_bytes < w.bytes) return PD3_EWORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t n = max_points;
+  if (workspace_bytes < pd3_hard_voxelize_workspace(batch, max_points, num_point_dim, voxel_size,
+                                                    point_cloud_range, max_num_points_in_voxel,
+                                                    max_voxels))
+    return PD3_EWORKSPACE;
+  {
+    VtPlan vp;
+    const bool can = tiled_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, vp);
+    const int ov = path_override();
+    if (ov == 2 && !can) return PD3_EUNSUPPORTED;
+    if (can && ov != 1)
+      return run_tiled(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel,
+                       max_voxels, vp, voxels, coords, num_points_per_voxel, num_voxels, workspace, s);
+  }
+  const RadixPlan plan = radix_plan(g.ncells, max_points);
+  VoxWorkspace w = carve(workspace, batch, max_points, max_voxels, plan);
 
   dim3 pgrid((unsigned)ceil_div(n, 256), batch);
   cell_key_kernel<<<pgrid, 256, 0, s>>>(points, num_points, n, num_point_dim, g, w.keys_a);

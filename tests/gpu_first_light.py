@@ -23,16 +23,20 @@ def timeit(fn, iters=20, warm=3):
     return (time.perf_counter() - t) / iters
 
 
+import os
 res = {"device": torch.cuda.get_device_name(0)}
-for batch in (1, 8, 32):
+for path in ("tiled", "sort"):
+  os.environ["PD3_VOXELIZE_PATH"] = path
+  for batch in (1, 8, 32):
     frames = np.stack([synth.nuscenes_sweep(100 + i) for i in range(min(batch, 4))])
     frames = np.concatenate([frames] * (batch // len(frames) or 1))[:batch]
     pts = torch.from_numpy(frames).cuda()
     for v in (30000, 60000):
         dt = timeit(lambda: voxelize.hard_voxelize_batch(pts, list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20, v))
         alg = 4 * 300000 * 5 + 4 * v * 20 * 5 + 16 * v + 4
-        res[f"voxelize_b{batch}_v{v}"] = dict(ms=dt * 1e3, us_per_frame=dt * 1e6 / batch,
-                                              GBps=alg * batch / dt / 1e9)
+        res[f"voxelize_{path}_b{batch}_v{v}"] = dict(ms=round(dt * 1e3, 4), us_per_frame=round(dt * 1e6 / batch, 2),
+                                              GBps=round(alg * batch / dt / 1e9, 1))
+os.environ.pop("PD3_VOXELIZE_PATH")
 feats = torch.randn(30000, 64, device="cuda")
 co = torch.zeros(30000, 4, dtype=torch.int32, device="cuda")
 cells = torch.randperm(512 * 512, device="cuda")[:30000]

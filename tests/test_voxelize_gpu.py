@@ -8,6 +8,15 @@ from paddle3d_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["auto", "sort"], autouse=True)
+def vox_path(request, monkeypatch):
+    """Every test runs on the automatic path choice (tiled fast path where applicable) and with the generic
+    sort path forced."""
+    if request.param != "auto":
+        monkeypatch.setenv("PD3_VOXELIZE_PATH", request.param)
+    return request.param
+
+
 def _run(points, voxel_size, pc_range, p, v):
     from paddle3d_amd.ops import voxelize
 
