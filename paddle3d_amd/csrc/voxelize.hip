@@ -201,28 +201,29 @@ static VoxWorkspace carve(void* base, int batch, int64_t n, int max_voxels, cons
 // tiled fast path (voxelize_tiled.hpp)
 // ---------------------------------------------------------------------------------------------------
 struct VtWorkspace {
-  uint32_t *recs, *dir, *bitmap, *owner, *plist, *vid2key;
-  int *cell_npts, *wsum, *totals;
-  int64_t bitmap_words;
+  uint32_t *recs, *dir, *owner, *plist, *vid2key;
+  unsigned char* isfirst;
+  int *owner_npts, *wsum, *totals, *vid_npts;
+  int64_t stride;  // tiles * kVtTile: per-frame length of the per-point arrays
   int assign_blocks;
-  size_t zero_bytes;  // the bitmap is zeroed per call
   size_t bytes;
 };
 
 static VtWorkspace vt_carve(void* base, int batch, int64_t n, int max_pts, int max_voxels,
                             uint32_t ncells, const VtPlan& p) {
+  (void)n;
   Carver c(base);
   VtWorkspace w;
-  w.bitmap_words = ceil_div(n, 32);
-  w.assign_blocks = (int)ceil_div(w.bitmap_words, kVtAssignThreads);
-  w.bitmap = c.take<uint32_t>((size_t)batch * w.bitmap_words);
-  w.zero_bytes = c.off;
-  w.recs = c.take<uint32_t>((size_t)batch * p.tiles * kVtTile);
+  w.stride = (int64_t)p.tiles * kVtTile;
+  w.assign_blocks = (int)(w.stride / kVtAssignPoints);
+  w.isfirst = c.take<unsigned char>((size_t)batch * w.stride);
+  w.recs = c.take<uint32_t>((size_t)batch * w.stride);
   w.dir = c.take<uint32_t>((size_t)batch * p.tiles * p.groups);
-  w.owner = c.take<uint32_t>((size_t)batch * w.bitmap_words * 32);
-  w.cell_npts = c.take<int>((size_t)batch * ncells);
+  w.owner = c.take<uint32_t>((size_t)batch * w.stride);
+  w.owner_npts = c.take<int>((size_t)batch * w.stride);
   w.plist = c.take<uint32_t>((size_t)batch * ncells * max_pts);
   w.vid2key = c.take<uint32_t>((size_t)batch * max_voxels);
+  w.vid_npts = c.take<int>((size_t)batch * max_voxels);
   w.wsum = c.take<int>((size_t)batch * w.assign_blocks);
   w.totals = c.take<int>((size_t)batch);
   w.bytes = c.off;
@@ -248,14 +249,14 @@ static bool tiled_applicable(const VoxGrid& g, int64_t n, int dim, int max_pts, 
 
 template <int VEC>
 static void launch_write(int dim, dim3 grid, hipStream_t s, const float* points, VtCells cells,
-                         const uint32_t* vid2key, const int* totals, int64_t n, uint32_t ncells,
+                         const uint32_t* vid2key, const int* vid_npts, const int* totals, int64_t n,
+                         uint32_t ncells,
                          int max_pts, int max_voxels, int rowq, VtGrid vg, float* voxels,
                          int32_t* coords, int32_t* num_pts, int32_t* num_voxels) {
-  const float inv = 1.0f / (float)rowq;
 #define PD3_VT_WRITE(D)                                                                           \
-  vt_write_kernel<VEC, D><<<grid, 256, 0, s>>>(points, cells, vid2key, totals, n, ncells, dim,     \
-                                               max_pts, max_voxels, rowq, inv, vg, voxels, coords, \
-                                               num_pts, num_voxels)
+  vt_write_kernel<VEC, D><<<grid, dim3(32, kVtWriteRows), 0, s>>>(                                  \
+      points, cells, vid2key, vid_npts, totals, n, ncells, dim, max_pts, max_voxels, rowq, vg, voxels,   \
+      coords, num_pts, num_voxels)
   switch (dim) {
     case 3: PD3_VT_WRITE(3); break;
     case 4: PD3_VT_WRITE(4); break;
@@ -272,12 +273,10 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
                      void* workspace, hipStream_t s) {
   VtWorkspace w = vt_carve(workspace, batch, n, max_pts, max_voxels, g.ncells, plan);
   VtGrid vg{g.min_x, g.min_y, g.min_z, g.size_x, g.size_y, g.size_z, g.gx, g.gy, g.gz, g.ncells};
-  hipError_t e = hipMemsetAsync(w.bitmap, 0, w.zero_bytes, s);
-  if (e != hipSuccess) return (int)e;
-  const size_t lds_a = (size_t)kVtRouteWaves * plan.groups * 8 + (size_t)plan.groups * 4 +
-                       (kVtRouteWaves + 2) * 4;
-  const size_t lds_b_wave = ((size_t)plan.cpg * 12 + (size_t)(2 * plan.tiles + 2) * 4 + 15) / 16 * 16;
-  const size_t lds_b = lds_b_wave * kVtGroupWaves;
+  hipError_t e = hipSuccess;
+  const size_t lds_a = (size_t)kVtRouteWaves * plan.groups * 12 + (kVtRouteWaves + 2) * 4;
+  const size_t lds_b = (size_t)kVtGroupWaves * plan.cpg * 12 + (size_t)plan.cpg * 8 +
+                       (size_t)(2 * plan.tiles + 1) * 4 + (kVtGroupWaves + 2) * 4;
   if (lds_a > 48 * 1024) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(vt_route_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
@@ -290,26 +289,26 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
   }
   dim3 agrid(plan.tiles, batch);
   vt_route_kernel<<<agrid, kVtRouteThreads, lds_a, s>>>(points, num_points, n, dim, vg, plan.low,
-                                                        plan.groups, plan.tiles, w.recs, w.dir);
-  VtCells cells{w.cell_npts, w.plist};
-  dim3 bgrid((unsigned)ceil_div(plan.groups, kVtGroupWaves), batch);
+                                                        plan.groups, plan.tiles, w.recs, w.dir, w.isfirst);
+  VtCells cells{w.plist};
+  dim3 bgrid(plan.groups, batch);
   vt_group_kernel<<<bgrid, kVtGroupThreads, lds_b, s>>>(w.recs, w.dir, plan.low, plan.groups,
-                                                        plan.tiles, max_pts, n, g.ncells, cells,
-                                                        w.owner, w.bitmap, w.bitmap_words);
+                                                        plan.tiles, max_pts, g.ncells, cells, w.owner,
+                                                        w.owner_npts, w.isfirst);
   dim3 cgrid(w.assign_blocks, batch);
-  vt_count_kernel<<<cgrid, kVtAssignThreads, 0, s>>>(w.bitmap, w.bitmap_words, w.wsum);
-  vt_assign_kernel<<<cgrid, kVtAssignThreads, 0, s>>>(w.bitmap, w.bitmap_words, w.owner, w.wsum,
-                                                      w.bitmap_words * 32, max_voxels, w.vid2key,
+  vt_count_kernel<<<cgrid, kVtAssignThreads, 0, s>>>(w.isfirst, w.stride, w.wsum);
+  vt_assign_kernel<<<cgrid, kVtAssignThreads, 0, s>>>(w.isfirst, w.stride, w.owner, w.owner_npts,
+                                                      w.wsum, max_voxels, w.vid2key, w.vid_npts,
                                                       w.totals);
   const int64_t row = (int64_t)max_pts * dim;
   const bool vec4 = (row % 4 == 0) && (reinterpret_cast<uintptr_t>(voxels) % 16 == 0);
   const int rowq = (int)(vec4 ? row / 4 : row);
-  dim3 dgrid((unsigned)ceil_div((int64_t)max_voxels * rowq, 256), batch);
+  dim3 dgrid((unsigned)ceil_div(max_voxels, kVtWriteRows * kVtWriteIlp), batch);
   if (vec4)
-    launch_write<4>(dim, dgrid, s, points, cells, w.vid2key, w.totals, n, g.ncells, max_pts,
+    launch_write<4>(dim, dgrid, s, points, cells, w.vid2key, w.vid_npts, w.totals, n, g.ncells, max_pts,
                     max_voxels, rowq, vg, voxels, coords, num_pts, num_voxels);
   else
-    launch_write<1>(dim, dgrid, s, points, cells, w.vid2key, w.totals, n, g.ncells, max_pts,
+    launch_write<1>(dim, dgrid, s, points, cells, w.vid2key, w.vid_npts, w.totals, n, g.ncells, max_pts,
                     max_voxels, rowq, vg, voxels, coords, num_pts, num_voxels);
   return launch_status();
 }

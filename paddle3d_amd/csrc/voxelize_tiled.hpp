@@ -12,12 +12,12 @@
 //   B  group_kernel   (one workgroup per group, 256 threads)
 //        walks the directory column of its group in tile order -> its points in INPUT ORDER, and keeps the
 //        running per-cell count of its 2^LOW cells in LDS.  Exact in-cell ranks come from the same bitmask
-//        trick, 256 points a step; a point with rank < P drops its index into the cell's list
-//        (plist[cell][rank], a dense per-frame array that only occupied cells ever touch).  The cell's
-//        first point sets a bit in a per-frame bitmap over point indices and records its cell there.
-//   C  count + assign kernels (one bitmap word per thread)
-//        prefix popcount over the bitmap = voxel id in first-point order (the reference's hand-out
-//        order); voxel id < max_voxels -> cell key.
+//        trick; a point with rank < P drops its index into the cell's list (plist[cell][rank], a dense
+//        per-frame array that only occupied cells ever touch).  The cell's first point raises a byte flag
+//        at its own point index and parks the cell key (and later the final count) there.
+//   C  count + assign kernels
+//        prefix count over the flags = voxel id in first-point order (the reference's hand-out order);
+//        voxel id < max_voxels -> (cell key, count).
 //   D  write_kernel   voxel-parallel, float4 lanes: the complete fixed-shape outputs (rows, zero padding,
 //        coords, counts) are written exactly once, coalesced; points are gathered from L2.
 //
@@ -104,32 +104,50 @@ __device__ __forceinline__ bool vt_axis_cell(float p, float lo, float size, int 
   return c < extent;
 }
 
+// LDS written by some lanes of a wave and read by others: DS ops of one wave execute in order, so only the
+// compiler has to be kept from reordering across this point (no s_barrier: waves run independently).
+__device__ __forceinline__ void vt_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------------------------------------ A
+// Wave w of the workgroup owns the CONTIGUOUS 512 points [w*512, (w+1)*512) of the tile (8 steps of 64),
+// so "stable in point order" = (wave, step, lane) order and almost everything is wave-synchronous:
+//   phase 1 (no barrier)  keys + per-wave histogram over groups (private LDS table)
+//   barrier, phase 2      thread g: tile histogram of group g, exclusive scan over groups, per-wave start
+//                         offsets; directory row written
+//   barrier, phase 3 (no barrier)  per-wave stable ranking with the bitmask table, records written
+// Three workgroup barriers per 4096 points in total.
 __global__ __launch_bounds__(kVtRouteThreads) void vt_route_kernel(
     const float* __restrict__ points, const int32_t* __restrict__ num_points, int64_t n, int dim,
     VtGrid g, int low, int groups, int tiles, uint32_t* __restrict__ recs,
-    uint32_t* __restrict__ dir) {
+    uint32_t* __restrict__ dir, unsigned char* __restrict__ isfirst) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
-  unsigned long long* mask = reinterpret_cast<unsigned long long*>(vt_smem);  // [waves][groups]
-  int* run = reinterpret_cast<int*>(mask + (size_t)kVtRouteWaves * groups);    // [groups]
-  int* scan_tmp = run + groups;                                                // [waves + 1]
+  unsigned long long* mask_all = reinterpret_cast<unsigned long long*>(vt_smem);  // [waves][groups]
+  int* run_all = reinterpret_cast<int*>(mask_all + (size_t)kVtRouteWaves * groups);  // [waves][groups]
+  int* scan_tmp = run_all + (size_t)kVtRouteWaves * groups;                          // [waves + 1]
   const int frame = blockIdx.y, tile = blockIdx.x;
   const int lane = lane_id(), wave = wave_id();
+  unsigned long long* mask = mask_all + (size_t)wave * groups;
+  int* run = run_all + (size_t)wave * groups;
   const int64_t nf = num_points ? min((int64_t)num_points[frame], n) : n;
   const float inv_g = 1.0f / (float)groups;
 
-  for (int d = threadIdx.x; d < groups; d += kVtRouteThreads) {
+  for (int d = lane; d < groups; d += kWave) {
     run[d] = 0;
-#pragma unroll
-    for (int w = 0; w < kVtRouteWaves; ++w) mask[(size_t)w * groups + d] = 0ull;
+    mask[d] = 0ull;
   }
-  __syncthreads();
-  // phase 1: keys + tile histogram over groups
+  vt_wave_sync();
+  // the "is the first point of its cell" flags of this tile start out clear (8 bytes per thread)
+  reinterpret_cast<unsigned long long*>(isfirst + ((int64_t)frame * tiles + tile) * kVtTile)[threadIdx.x] = 0ull;
+  // phase 1: keys + per-wave histogram over groups
   uint32_t key[kVtRounds];
   const float* pf = points + (int64_t)frame * n * dim;
+  const int64_t wave_base = (int64_t)tile * kVtTile + (int64_t)wave * (kVtRounds * kWave);
 #pragma unroll
   for (int r = 0; r < kVtRounds; ++r) {
-    const int64_t i = (int64_t)tile * kVtTile + r * kVtRouteThreads + threadIdx.x;
+    const int64_t i = wave_base + r * kWave + lane;
     uint32_t k = 0xFFFFFFFFu;
     if (i < nf) {
       const float* p = pf + i * dim;
@@ -146,25 +164,38 @@ __global__ __launch_bounds__(kVtRouteThreads) void vt_route_kernel(
     key[r] = k;
   }
   __syncthreads();
-  // phase 1b: exclusive scan of the histogram (<= 1024 bins, 2 per thread) -> tile-local offsets
+  // phase 2: tile-level offsets.  Groups are spread over the threads, two per thread (groups <= 1024).
   {
     const int d0 = threadIdx.x * 2;
-    const int c0 = d0 < groups ? run[d0] : 0;
-    const int c1 = d0 + 1 < groups ? run[d0 + 1] : 0;
+    int c0 = 0, c1 = 0;
+    if (d0 < groups)
+      for (int w = 0; w < kVtRouteWaves; ++w) c0 += run_all[(size_t)w * groups + d0];
+    if (d0 + 1 < groups)
+      for (int w = 0; w < kVtRouteWaves; ++w) c1 += run_all[(size_t)w * groups + d0 + 1];
     int total;
     const int ex = block_exclusive_scan<kVtRouteThreads>(c0 + c1, scan_tmp, total);
     uint32_t* drow = dir + ((int64_t)frame * tiles + tile) * groups;
     if (d0 < groups) {
-      run[d0] = ex;
       drow[d0] = (uint32_t)ex | ((uint32_t)c0 << 16);
+      int acc = ex;
+      for (int w = 0; w < kVtRouteWaves; ++w) {  // per-wave start of group d0 inside the tile
+        const int c = run_all[(size_t)w * groups + d0];
+        run_all[(size_t)w * groups + d0] = acc;
+        acc += c;
+      }
     }
     if (d0 + 1 < groups) {
-      run[d0 + 1] = ex + c0;
       drow[d0 + 1] = (uint32_t)(ex + c0) | ((uint32_t)c1 << 16);
+      int acc = ex + c0;
+      for (int w = 0; w < kVtRouteWaves; ++w) {
+        const int c = run_all[(size_t)w * groups + d0 + 1];
+        run_all[(size_t)w * groups + d0 + 1] = acc;
+        acc += c;
+      }
     }
   }
   __syncthreads();
-  // phase 2: stable rank inside the tile, write records grouped
+  // phase 3: per-wave stable ranking, records written grouped
   uint32_t* out = recs + (int64_t)frame * tiles * kVtTile + (int64_t)tile * kVtTile;
   const unsigned long long below_me = (1ull << lane) - 1ull;
   const uint32_t low_mask = (1u << low) - 1u;
@@ -173,173 +204,213 @@ __global__ __launch_bounds__(kVtRouteThreads) void vt_route_kernel(
     const uint32_t k = key[r];
     const bool valid = k != 0xFFFFFFFFu;
     const int grp = valid ? (int)(k >> low) : 0;
-    if (valid) atomicOr(&mask[(size_t)wave * groups + grp], 1ull << lane);
-    __syncthreads();
+    if (valid) atomicOr(&mask[grp], 1ull << lane);
+    vt_wave_sync();
     int rank = 0, total = 0, pos = 0;
     if (valid) {
-#pragma unroll
-      for (int w = 0; w < kVtRouteWaves; ++w) {
-        const unsigned long long m = mask[(size_t)w * groups + grp];
-        const int c = __popcll(m);
-        total += c;
-        if (w < wave) rank += c;
-        if (w == wave) rank += __popcll(m & below_me);
-      }
+      const unsigned long long m = mask[grp];
+      rank = __popcll(m & below_me);
+      total = __popcll(m);
       pos = run[grp] + rank;
     }
-    __syncthreads();
+    vt_wave_sync();
     if (valid) {
       if (rank == 0) {
         run[grp] += total;
-#pragma unroll
-        for (int w = 0; w < kVtRouteWaves; ++w) mask[(size_t)w * groups + grp] = 0ull;
+        mask[grp] = 0ull;
       }
-      const uint32_t idx = (uint32_t)(tile * kVtTile + r * kVtRouteThreads + threadIdx.x);
+      const uint32_t idx = (uint32_t)(wave_base + r * kWave + lane);
       out[pos] = (idx << low) | (k & low_mask);
     }
-    __syncthreads();
+    vt_wave_sync();
   }
 }
 
 // ------------------------------------------------------------------------------------------------ B
-// Per-cell results live in DENSE per-frame arrays indexed by cell key; only occupied cells are ever
-// touched, so nothing needs initialising: cell_npts[key] = min(count, P), plist[key][k] = k-th point.
+// Per-cell point lists live in a DENSE per-frame array indexed by cell key; only occupied cells are ever
+// touched, so nothing needs initialising: plist[key][k] = index of the cell's k-th point (k < P).
 struct VtCells {
-  int* npts;        // [frames][ncells]
   uint32_t* plist;  // [frames][ncells][P]
 };
 
-// LDS written by some lanes of a wave and read by others: DS ops of one wave execute in order, so only the
-// compiler has to be kept from reordering across this point (no s_barrier: waves run independently).
-__device__ __forceinline__ void vt_wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
+constexpr int kVtGroupSteps = 4;                                    // 64-record steps per wave per pass
+constexpr int kVtGroupPass = kVtGroupThreads * kVtGroupSteps;        // 1024 records per pass
 
-// One WAVE per group (4 groups per workgroup), fully wave-synchronous: no workgroup barrier anywhere, so a
-// heavy group (a BEV row through the sensor) never stalls its neighbours, and 64-record steps keep the
-// per-step latency at one LDS round trip.  The next step's records are fetched before the current step is
-// ranked (software prefetch).
+// One workgroup per group.  The group's record stream (its points in input order) is cut into passes of
+// 1024 records; inside a pass wave w owns the w-th contiguous quarter, so the exact in-order rank of a
+// point is  (count of its cell in earlier passes) + (count in earlier waves of this pass) + (rank inside
+// its wave) -- the same three-phase scheme as the route kernel: per-wave counts, a per-cell prefix over
+// the waves, then wave-synchronous bitmask ranking.  All of a wave's records of a pass are fetched with
+// independent loads up front, so a pass costs ONE global round trip.
 __global__ __launch_bounds__(kVtGroupThreads) void vt_group_kernel(
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ dir, int low, int groups,
-    int tiles, int max_pts, int64_t n, uint32_t ncells, VtCells s, uint32_t* __restrict__ owner,
-    uint32_t* __restrict__ bitmap, int64_t bitmap_words) {
+    int tiles, int max_pts, uint32_t ncells, VtCells s, uint32_t* __restrict__ owner,
+    int* __restrict__ owner_npts, unsigned char* __restrict__ isfirst) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
   const int cpg = 1 << low;
-  const int lane = lane_id(), wave = wave_id();
-  const size_t per_wave = (size_t)cpg * 8 + (size_t)cpg * 4 + (size_t)(2 * tiles + 2) * 4;
-  unsigned char* my = vt_smem + (size_t)wave * ((per_wave + 15) / 16 * 16);
-  unsigned long long* mask = reinterpret_cast<unsigned long long*>(my);  // [cpg]
-  int* cnt = reinterpret_cast<int*>(mask + cpg);                          // [cpg]
-  int* tpre = cnt + cpg;         // [tiles + 1] exclusive prefix of this group's per-tile counts
+  unsigned long long* mask_all = reinterpret_cast<unsigned long long*>(vt_smem);   // [waves][cpg]
+  int* base_all = reinterpret_cast<int*>(mask_all + (size_t)kVtGroupWaves * cpg);  // [waves][cpg]
+  int* run = base_all + (size_t)kVtGroupWaves * cpg;                               // [cpg] points so far
+  int* first = run + cpg;                                                          // [cpg] first point idx
+  int* tpre = first + cpg;       // [tiles + 1] exclusive prefix of this group's per-tile counts
   int* toff = tpre + tiles + 1;  // [tiles] offset of the group's segment inside each tile
-  const int grp = blockIdx.x * kVtGroupWaves + wave, frame = blockIdx.y;
-  if (grp >= groups) return;  // whole wave
+  int* scan_tmp = toff + tiles;  // [waves + 1]
+  const int grp = blockIdx.x, frame = blockIdx.y;
+  const int lane = lane_id(), wave = wave_id();
+  unsigned long long* mask = mask_all + (size_t)wave * cpg;
+  int* base = base_all + (size_t)wave * cpg;
 
-  for (int c = lane; c < cpg; c += kWave) {
-    cnt[c] = 0;
-    mask[c] = 0ull;
+  for (int c = threadIdx.x; c < cpg; c += kVtGroupThreads) {
+    run[c] = 0;
+#pragma unroll
+    for (int w = 0; w < kVtGroupWaves; ++w) {
+      mask_all[(size_t)w * cpg + c] = 0ull;
+      base_all[(size_t)w * cpg + c] = 0;
+    }
   }
-  // directory column -> per-tile (offset, count), then an exclusive scan across the tiles
+  // directory column -> per-tile (offset, count); sequential chunks of tiles per thread for the scan
   const uint32_t* dcol = dir + (int64_t)frame * tiles * groups + grp;
-  int running = 0;
-  for (int t0 = 0; t0 < tiles; t0 += kWave) {
-    const int t = t0 + lane;
-    int c = 0;
+  const int per = (tiles + kVtGroupThreads - 1) / kVtGroupThreads;
+  const int t_lo = threadIdx.x * per;
+  int mysum = 0;
+  for (int j = 0; j < per; ++j) {
+    const int t = t_lo + j;
     if (t < tiles) {
       const uint32_t d = dcol[(int64_t)t * groups];
       toff[t] = (int)(d & 0xFFFFu);
-      c = (int)(d >> 16);
+      tpre[t] = (int)(d >> 16);  // count for now
+      mysum += (int)(d >> 16);
     }
-    const int inc = wave_inclusive_scan(c);
-    if (t < tiles) tpre[t] = running + inc - c;
-    running += __shfl(inc, kWave - 1, kWave);
   }
-  const int n_g = running;
-  if (lane == 0) tpre[tiles] = n_g;
-  vt_wave_sync();
-  if (n_g == 0) return;
+  int n_g;
+  int runp = block_exclusive_scan<kVtGroupThreads>(mysum, scan_tmp, n_g);
+  for (int j = 0; j < per; ++j) {
+    const int t = t_lo + j;
+    if (t < tiles) {
+      const int c = tpre[t];
+      tpre[t] = runp;
+      runp += c;
+    }
+  }
+  if (threadIdx.x == 0) tpre[tiles] = n_g;
+  __syncthreads();
+  if (n_g == 0) return;  // uniform
 
   const uint32_t* rf = recs + (int64_t)frame * tiles * kVtTile;
   const unsigned long long below_me = (1ull << lane) - 1ull;
   const uint32_t cell_mask = (uint32_t)cpg - 1u;
   const float inv_g = 1.0f / (float)groups;
   uint32_t* plist_f = s.plist + (int64_t)frame * ncells * max_pts;
+  const int64_t own_base = (int64_t)frame * tiles * kVtTile;
 
-  auto fetch = [&](int j) -> uint32_t {
-    // largest t with tpre[t] <= j  (tpre is non-decreasing, tpre[tiles] = n_g > j)
-    int lo = 0, hi = tiles;  // invariant: tpre[lo] <= j < tpre[hi]
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (tpre[mid] <= j) lo = mid; else hi = mid;
-    }
-    return rf[(int64_t)lo * kVtTile + toff[lo] + (j - tpre[lo])];
-  };
-
-  uint32_t rec_next = lane < n_g ? fetch(lane) : 0u;
-  for (int j0 = 0; j0 < n_g; j0 += kWave) {
-    const uint32_t rec = rec_next;
-    const bool valid = j0 + lane < n_g;
-    const int jn = j0 + kWave + lane;
-    rec_next = jn < n_g ? fetch(jn) : 0u;  // in flight while this step is ranked
-    const int cell = (int)(rec & cell_mask);
-    const uint32_t idx = rec >> low;
-    if (valid) atomicOr(&mask[cell], 1ull << lane);
-    vt_wave_sync();
-    int rank = 0, total = 0, base = 0;
-    if (valid) {
-      const unsigned long long m = mask[cell];
-      rank = __popcll(m & below_me);
-      total = __popcll(m);
-      base = cnt[cell];
-    }
-    vt_wave_sync();
-    if (valid) {
-      const int slot = base + rank;  // number of earlier points in this cell
-      const uint32_t key = vt_group_to_key((uint32_t)grp, (uint32_t)cell, (uint32_t)groups, inv_g);
-      if (slot < max_pts) plist_f[(int64_t)key * max_pts + slot] = idx;
-      if (slot == 0) {  // the cell's first point: its index orders the voxels
-        owner[(int64_t)frame * bitmap_words * 32 + idx] = key;
-        atomicOr(&bitmap[(int64_t)frame * bitmap_words + (idx >> 5)], 1u << (idx & 31));
-      }
-      if (rank == 0) {
-        cnt[cell] = base + total;
-        mask[cell] = 0ull;
+  for (int p0 = 0; p0 < n_g; p0 += kVtGroupPass) {
+    // ---- fetch this wave's quarter of the pass (independent loads) and count per cell
+    uint32_t rec[kVtGroupSteps];
+    bool valid[kVtGroupSteps];
+#pragma unroll
+    for (int u = 0; u < kVtGroupSteps; ++u) {
+      const int j = p0 + wave * (kVtGroupSteps * kWave) + u * kWave + lane;
+      valid[u] = j < n_g;
+      rec[u] = 0u;
+      if (valid[u]) {
+        int lo = 0, hi = tiles;  // largest t with tpre[t] <= j; invariant tpre[lo] <= j < tpre[hi]
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (tpre[mid] <= j) lo = mid; else hi = mid;
+        }
+        rec[u] = rf[(int64_t)lo * kVtTile + toff[lo] + (j - tpre[lo])];
       }
     }
-    vt_wave_sync();
+#pragma unroll
+    for (int u = 0; u < kVtGroupSteps; ++u)
+      if (valid[u]) atomicAdd(&base[rec[u] & cell_mask], 1);
+    __syncthreads();
+    // ---- per cell: turn the per-wave counts into per-wave start ranks, advance the running count
+    for (int c = threadIdx.x; c < cpg; c += kVtGroupThreads) {
+      int acc = run[c];
+#pragma unroll
+      for (int w = 0; w < kVtGroupWaves; ++w) {
+        const int t = base_all[(size_t)w * cpg + c];
+        base_all[(size_t)w * cpg + c] = acc;
+        acc += t;
+      }
+      run[c] = acc;
+    }
+    __syncthreads();
+    // ---- wave-synchronous exact ranking, 64 records a step
+#pragma unroll
+    for (int u = 0; u < kVtGroupSteps; ++u) {
+      const int cell = (int)(rec[u] & cell_mask);
+      const uint32_t idx = rec[u] >> low;
+      if (valid[u]) atomicOr(&mask[cell], 1ull << lane);
+      vt_wave_sync();
+      int rank = 0, total = 0, b0 = 0;
+      if (valid[u]) {
+        const unsigned long long m = mask[cell];
+        rank = __popcll(m & below_me);
+        total = __popcll(m);
+        b0 = base[cell];
+      }
+      vt_wave_sync();
+      if (valid[u]) {
+        const int slot = b0 + rank;  // number of earlier points in this cell
+        if (slot < max_pts) {
+          const uint32_t key = vt_group_to_key((uint32_t)grp, (uint32_t)cell, (uint32_t)groups, inv_g);
+          plist_f[(int64_t)key * max_pts + slot] = idx;
+          if (slot == 0) {  // the cell's first point: its index orders the voxels
+            first[cell] = (int)idx;
+            owner[own_base + idx] = key;
+            isfirst[own_base + idx] = 1;
+          }
+        }
+        if (rank == 0) {
+          base[cell] = b0 + total;
+          mask[cell] = 0ull;
+        }
+      }
+      vt_wave_sync();
+    }
+    __syncthreads();
+    if (p0 + kVtGroupPass < n_g) {  // another pass follows: the per-wave tables start from zero again
+      for (int c = threadIdx.x; c < cpg; c += kVtGroupThreads)
+#pragma unroll
+        for (int w = 0; w < kVtGroupWaves; ++w) base_all[(size_t)w * cpg + c] = 0;
+      __syncthreads();
+    }
   }
-  int* npts_f = s.npts + (int64_t)frame * ncells;
-  for (int c = lane; c < cpg; c += kWave) {
-    const int k = cnt[c];
-    if (k > 0) {
-      const uint32_t key = vt_group_to_key((uint32_t)grp, (uint32_t)c, (uint32_t)groups, inv_g);
-      if (key < ncells) npts_f[key] = min(k, max_pts);
-    }
+  // final per-cell counts, parked next to the cell's first point (read by the assign kernel)
+  for (int c = threadIdx.x; c < cpg; c += kVtGroupThreads) {
+    const int k = run[c];
+    if (k > 0) owner_npts[own_base + first[c]] = min(k, max_pts);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ C
-// voxel id = number of set bits before the cell's first point.  Two tiny kernels: per-block popcounts,
-// then every block sums the blocks before it and hands out ids.  One bitmap word per thread.
+// voxel id = number of first-point flags before the cell's first point.  Two tiny kernels: per-block
+// counts, then every block sums the blocks before it and hands out ids.  A thread owns 8 consecutive
+// points (one 64-bit load of their flags); the gathers of a voxel's (cell key, count) are independent.
 constexpr int kVtAssignThreads = 256;
+constexpr int kVtAssignPoints = kVtAssignThreads * 8;  // 2048 points per block (divides kVtTile)
 
-__global__ __launch_bounds__(kVtAssignThreads) void vt_count_kernel(const uint32_t* __restrict__ bitmap,
-                                                                    int64_t bitmap_words,
-                                                                    int* __restrict__ wsum) {
+__device__ __forceinline__ int vt_flag_count(unsigned long long x) {
+  return __popcll(x & 0x0101010101010101ull);
+}
+
+__global__ __launch_bounds__(kVtAssignThreads) void vt_count_kernel(
+    const unsigned char* __restrict__ isfirst, int64_t stride, int* __restrict__ wsum) {
   __shared__ int scan_tmp[kVtAssignThreads / kWave + 1];
   const int frame = blockIdx.y;
-  const int64_t w = (int64_t)blockIdx.x * kVtAssignThreads + threadIdx.x;
-  const int c = w < bitmap_words ? __popc(bitmap[(int64_t)frame * bitmap_words + w]) : 0;
+  const int64_t i = (int64_t)frame * stride + ((int64_t)blockIdx.x * kVtAssignThreads + threadIdx.x) * 8;
+  const unsigned long long x = *reinterpret_cast<const unsigned long long*>(isfirst + i);
   int total;
-  (void)block_exclusive_scan<kVtAssignThreads>(c, scan_tmp, total);
+  (void)block_exclusive_scan<kVtAssignThreads>(vt_flag_count(x), scan_tmp, total);
   if (threadIdx.x == 0) wsum[(int64_t)frame * gridDim.x + blockIdx.x] = total;
 }
 
 __global__ __launch_bounds__(kVtAssignThreads) void vt_assign_kernel(
-    const uint32_t* __restrict__ bitmap, int64_t bitmap_words, const uint32_t* __restrict__ owner,
-    const int* __restrict__ wsum, int64_t n, int max_voxels, uint32_t* __restrict__ vid2key,
-    int* __restrict__ totals) {
+    const unsigned char* __restrict__ isfirst, int64_t stride, const uint32_t* __restrict__ owner,
+    const int* __restrict__ owner_npts, const int* __restrict__ wsum, int max_voxels,
+    uint32_t* __restrict__ vid2key, int* __restrict__ vid_npts, int* __restrict__ totals) {
   __shared__ int scan_tmp[kVtAssignThreads / kWave + 1];
   const int frame = blockIdx.y, nblk = gridDim.x;
   // sum of the blocks before this one (and, for block 0, of all blocks -> totals)
@@ -352,81 +423,109 @@ __global__ __launch_bounds__(kVtAssignThreads) void vt_assign_kernel(
   }
   int tot_before, tot_all;
   (void)block_exclusive_scan<kVtAssignThreads>(before, scan_tmp, tot_before);
-  (void)block_exclusive_scan<kVtAssignThreads>(all, scan_tmp, tot_all);
-  if (blockIdx.x == 0 && threadIdx.x == 0) totals[frame] = tot_all;
-  const int64_t w = (int64_t)blockIdx.x * kVtAssignThreads + threadIdx.x;
-  uint32_t bits = w < bitmap_words ? bitmap[(int64_t)frame * bitmap_words + w] : 0u;
+  if (blockIdx.x == 0) {  // uniform
+    (void)block_exclusive_scan<kVtAssignThreads>(all, scan_tmp, tot_all);
+    if (threadIdx.x == 0) totals[frame] = tot_all;
+  }
+  const int64_t i = (int64_t)frame * stride + ((int64_t)blockIdx.x * kVtAssignThreads + threadIdx.x) * 8;
+  const unsigned long long x = *reinterpret_cast<const unsigned long long*>(isfirst + i);
   int blk_total;
-  int vid = tot_before + block_exclusive_scan<kVtAssignThreads>(__popc(bits), scan_tmp, blk_total);
-  const uint32_t* own = owner + (int64_t)frame * n + w * 32;
-  while (bits && vid < max_voxels) {
-    const int b = __ffs((int)bits) - 1;
-    bits &= bits - 1u;
-    vid2key[(int64_t)frame * max_voxels + vid] = own[b];
-    ++vid;
+  int vid = tot_before + block_exclusive_scan<kVtAssignThreads>(vt_flag_count(x), scan_tmp, blk_total);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    if ((x >> (8 * b)) & 1ull) {
+      if (vid < max_voxels) {
+        vid2key[(int64_t)frame * max_voxels + vid] = owner[i + b];
+        vid_npts[(int64_t)frame * max_voxels + vid] = owner_npts[i + b];
+      }
+      ++vid;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ D
-// VEC consecutive floats of one voxel row per thread.  rowq = P*D/VEC chunks per row.
+// Output writer.  Thread (x, y) of a 32 x 8 block owns chunk column x (VEC consecutive floats at a fixed
+// offset inside a voxel row) of kVtWriteIlp voxel rows; a wave therefore covers two adjacent rows, so its
+// stores are two contiguous row segments.  The column's (point k, channel c) split is computed once; per
+// row the dependent chain (voxel -> cell key -> point list -> point) is walked for all kVtWriteIlp rows
+// in lock step, so that many independent loads are in flight per level.  Rows >= num_voxels and slots
+// >= num_points are written as zeros by the same stores: no separate memset of the outputs.
+constexpr int kVtWriteIlp = 4;
+constexpr int kVtWriteRows = 8;  // blockDim.y
+
 template <int VEC, int DIM>
 __global__ __launch_bounds__(256) void vt_write_kernel(
     const float* __restrict__ points, VtCells s, const uint32_t* __restrict__ vid2key,
-    const int* __restrict__ totals, int64_t n, uint32_t ncells, int dim_rt, int max_pts,
-    int max_voxels, int rowq, float inv_rowq, VtGrid g, float* __restrict__ voxels,
+    const int* __restrict__ vid_npts, const int* __restrict__ totals, int64_t n, uint32_t ncells,
+    int dim_rt, int max_pts, int max_voxels, int rowq, VtGrid g, float* __restrict__ voxels,
     int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ num_voxels) {
   const int dim = DIM > 0 ? DIM : dim_rt;
   const int frame = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // chunk index inside the frame
   const int nv = min(totals[frame], max_voxels);
-  if (e == 0) num_voxels[frame] = nv;
-  if (e >= max_voxels * rowq) return;
-  int v = (int)((float)e * inv_rowq);
-  if (v * rowq > e) --v;
-  else if ((v + 1) * rowq <= e) ++v;
-  const int q = e - v * rowq;
-  float val[VEC];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) num_voxels[frame] = nv;
+  const float* pf = points + (int64_t)frame * n * dim;
+  const int vbase = blockIdx.x * (kVtWriteRows * kVtWriteIlp) + threadIdx.y;
+  for (int q = threadIdx.x; q < rowq; q += 32) {
+    const int k0 = (q * VEC) / dim, c0 = (q * VEC) - k0 * dim;
+    const bool two = VEC > 1 && c0 + VEC > dim;  // the chunk straddles points k0 and k0 + 1
+    int v[kVtWriteIlp], np[kVtWriteIlp];
+    uint32_t key[kVtWriteIlp], pa[kVtWriteIlp], pb[kVtWriteIlp];
 #pragma unroll
-  for (int u = 0; u < VEC; ++u) val[u] = 0.f;
-  int np = 0;
-  uint32_t key = 0;
-  if (v < nv) {
-    key = vid2key[(int64_t)frame * max_voxels + v];
-    np = s.npts[(int64_t)frame * ncells + key];
-    const uint32_t* pl = s.plist + ((int64_t)frame * ncells + key) * max_pts;
-    const float* pf = points + (int64_t)frame * n * dim;
-    int k = (q * VEC) / dim, c = (q * VEC) - k * dim;
-    uint32_t pi = k < np ? pl[k] : 0u;
-#pragma unroll
-    for (int u = 0; u < VEC; ++u) {
-      if (k < np) val[u] = pf[(int64_t)pi * dim + c];
-      if (++c == dim) {
-        c = 0;
-        ++k;
-        if (u + 1 < VEC) pi = k < np ? pl[k] : 0u;
+    for (int j = 0; j < kVtWriteIlp; ++j) {  // level 1: voxel -> (cell key, count)
+      v[j] = vbase + j * kVtWriteRows;
+      key[j] = 0;
+      np[j] = 0;
+      if (v[j] < nv) {
+        key[j] = vid2key[(int64_t)frame * max_voxels + v[j]];
+        np[j] = vid_npts[(int64_t)frame * max_voxels + v[j]];
       }
     }
-  }
-  float* dst = voxels + ((int64_t)frame * max_voxels + v) * ((int64_t)rowq * VEC) + (int64_t)q * VEC;
-  if (VEC == 4) {
-    *reinterpret_cast<float4*>(dst) = make_float4(val[0], val[1], val[2], val[3]);
-  } else {
 #pragma unroll
-    for (int u = 0; u < VEC; ++u) dst[u] = val[u];
-  }
-  if (q == 0) {  // voxel meta: coords (z, y, x) and count, zero padded
-    int cz = 0, cy = 0, cx = 0;
-    if (v < nv) {
-      cx = (int)(key % (uint32_t)g.gx);
-      const uint32_t t = key / (uint32_t)g.gx;
-      cy = (int)(t % (uint32_t)g.gy);
-      cz = (int)(t / (uint32_t)g.gy);
+    for (int j = 0; j < kVtWriteIlp; ++j) {  // level 2: the (<= 2) point-list entries of this chunk
+      const uint32_t* pl = s.plist + ((int64_t)frame * ncells + key[j]) * max_pts;
+      pa[j] = (k0 < np[j]) ? pl[k0] : 0u;
+      pb[j] = (two && k0 + 1 < np[j]) ? pl[k0 + 1] : 0u;
     }
-    int32_t* co = coords + ((int64_t)frame * max_voxels + v) * 3;
-    co[0] = cz;
-    co[1] = cy;
-    co[2] = cx;
-    num_pts[(int64_t)frame * max_voxels + v] = np;
+    float val[kVtWriteIlp][VEC];
+#pragma unroll
+    for (int j = 0; j < kVtWriteIlp; ++j) {  // level 3: the floats
+      int k = k0, c = c0;
+      uint32_t pi = pa[j];
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) {
+        val[j][u] = (k < np[j]) ? pf[(int64_t)pi * dim + c] : 0.f;
+        if (++c == dim) {
+          c = 0;
+          ++k;
+          pi = pb[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kVtWriteIlp; ++j) {
+      if (v[j] >= max_voxels) continue;
+      float* dst = voxels + ((int64_t)frame * max_voxels + v[j]) * ((int64_t)rowq * VEC) + (int64_t)q * VEC;
+      if (VEC == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(val[j][0], val[j][1], val[j][2], val[j][3]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) dst[u] = val[j][u];
+      }
+      if (q == 0) {  // voxel meta: coords (z, y, x) and count, zero padded
+        int cz = 0, cy = 0, cx = 0;
+        if (v[j] < nv) {
+          cx = (int)(key[j] % (uint32_t)g.gx);
+          const uint32_t t = key[j] / (uint32_t)g.gx;
+          cy = (int)(t % (uint32_t)g.gy);
+          cz = (int)(t / (uint32_t)g.gy);
+        }
+        int32_t* co = coords + ((int64_t)frame * max_voxels + v[j]) * 3;
+        co[0] = cz;
+        co[1] = cy;
+        co[2] = cx;
+        num_pts[(int64_t)frame * max_voxels + v[j]] = np[j];
+      }
+    }
   }
 }
 

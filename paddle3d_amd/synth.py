@@ -23,7 +23,12 @@ KITTI_PILLAR = (0.16, 0.16, 4.0)
 
 def nuscenes_sweep(seed: int, n_points: int = 300_000, dims: int = 5, sweeps: int = 10,
                    shuffle: bool = False, oob_frac: float = 0.03) -> np.ndarray:
-    """One multi-sweep frame of a 32-beam spinning LiDAR over a ground plane plus box obstacles."""
+    """One multi-sweep frame of a 32-beam spinning LiDAR over a ground plane plus box obstacles.
+
+    Points come in FIRING ORDER, like a real HDL-32E packet stream and like ``LoadPointCloud``'s
+    concatenation of sweeps (reader.py:126-164): sweep after sweep, inside a sweep azimuth step after
+    azimuth step, inside a step beam 0..31.  ``shuffle=True`` permutes the frame (the ``ShufflePoint``
+    training transform) -- the worst case for every gather on the path."""
     rng = np.random.default_rng(seed)
     per = n_points // sweeps
     beams = np.deg2rad(np.linspace(-30.0, 10.0, 32)).astype(np.float64)
@@ -37,8 +42,9 @@ def nuscenes_sweep(seed: int, n_points: int = 300_000, dims: int = 5, sweeps: in
     for s in range(sweeps):
         lo, hi = s * per, (s + 1) * per if s < sweeps - 1 else n_points
         m = hi - lo
-        az = rng.uniform(0.0, 2 * np.pi, m)
-        el = beams[rng.integers(0, 32, m)] + rng.normal(0, 0.0003, m)
+        step = np.arange(m) // 32
+        az = (step + rng.uniform(-0.3, 0.3, m)) * (2 * np.pi / max(1, (m + 31) // 32)) + rng.uniform(0, 2 * np.pi)
+        el = beams[np.arange(m) % 32] + rng.normal(0, 0.0003, m)
         # range of the ground hit for downward beams; free-space returns otherwise
         r_ground = np.where(el < -0.01, sensor_h / np.maximum(np.tan(-el), 1e-3), 1e9)
         r_free = 1.0 + 69.0 * rng.random(m) ** 2.5

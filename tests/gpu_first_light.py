@@ -49,6 +49,13 @@ for batch in (1, 8):
     out = torch.empty(batch, 64, 512, 512, device="cuda")
     dt = timeit(lambda: ps.pointpillars_scatter(f, c, batch, 512, 512, out=out))
     res[f"scatter_b{batch}"] = dict(ms=dt * 1e3, GBps=75268864 * batch / dt / 1e9)
+# write-only ceilings
+z = torch.empty(100 * 1024 * 1024 // 4, device="cuda")
+dt = timeit(lambda: z.zero_())
+res["fill_100MB_GBps"] = z.numel() * 4 / dt / 1e9
+z2 = torch.empty(12 * 1024 * 1024 // 4, device="cuda")
+dt = timeit(lambda: z2.zero_())
+res["fill_12MB_GBps"] = z2.numel() * 4 / dt / 1e9
 # plain device copy ceiling
 a = torch.empty(256 * 1024 * 1024 // 4, device="cuda")
 b = torch.empty_like(a)
