@@ -201,9 +201,10 @@ static VoxWorkspace carve(void* base, int batch, int64_t n, int max_voxels, cons
 // tiled fast path (voxelize_tiled.hpp)
 // ---------------------------------------------------------------------------------------------------
 struct VtWorkspace {
-  uint32_t *recs, *dir, *owner, *plist, *vid2key;
+  uint32_t *recs, *dir, *plist, *vid2key;
+  uint2* owner;
   unsigned char* isfirst;
-  int *owner_npts, *wsum, *totals, *vid_npts;
+  int *wsum, *totals, *vid_npts;
   int64_t stride;  // tiles * kVtTile: per-frame length of the per-point arrays
   int assign_blocks;
   size_t bytes;
@@ -219,8 +220,7 @@ static VtWorkspace vt_carve(void* base, int batch, int64_t n, int max_pts, int m
   w.isfirst = c.take<unsigned char>((size_t)batch * w.stride);
   w.recs = c.take<uint32_t>((size_t)batch * w.stride);
   w.dir = c.take<uint32_t>((size_t)batch * p.tiles * p.groups);
-  w.owner = c.take<uint32_t>((size_t)batch * w.stride);
-  w.owner_npts = c.take<int>((size_t)batch * w.stride);
+  w.owner = c.take<uint2>((size_t)batch * w.stride);
   w.plist = c.take<uint32_t>((size_t)batch * ncells * max_pts);
   w.vid2key = c.take<uint32_t>((size_t)batch * max_voxels);
   w.vid_npts = c.take<int>((size_t)batch * max_voxels);
@@ -294,12 +294,11 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
   dim3 bgrid(plan.groups, batch);
   vt_group_kernel<<<bgrid, kVtGroupThreads, lds_b, s>>>(w.recs, w.dir, plan.low, plan.groups,
                                                         plan.tiles, max_pts, g.ncells, cells, w.owner,
-                                                        w.owner_npts, w.isfirst);
+                                                        w.isfirst);
   dim3 cgrid(w.assign_blocks, batch);
   vt_count_kernel<<<cgrid, kVtAssignThreads, 0, s>>>(w.isfirst, w.stride, w.wsum);
-  vt_assign_kernel<<<cgrid, kVtAssignThreads, 0, s>>>(w.isfirst, w.stride, w.owner, w.owner_npts,
-                                                      w.wsum, max_voxels, w.vid2key, w.vid_npts,
-                                                      w.totals);
+  vt_assign_kernel<<<cgrid, kVtAssignThreads, 0, s>>>(w.isfirst, w.stride, w.owner, w.wsum,
+                                                      max_voxels, w.vid2key, w.vid_npts, w.totals);
   const int64_t row = (int64_t)max_pts * dim;
   const bool vec4 = (row % 4 == 0) && (reinterpret_cast<uintptr_t>(voxels) % 16 == 0);
   const int rowq = (int)(vec4 ? row / 4 : row);

@@ -174,9 +174,11 @@ __global__ __launch_bounds__(kVtRouteThreads) void vt_route_kernel(
       for (int w = 0; w < kVtRouteWaves; ++w) c1 += run_all[(size_t)w * groups + d0 + 1];
     int total;
     const int ex = block_exclusive_scan<kVtRouteThreads>(c0 + c1, scan_tmp, total);
-    uint32_t* drow = dir + ((int64_t)frame * tiles + tile) * groups;
+    // directory is stored group-major (dir[frame][group][tile]) so that the group kernel reads its column
+    // as one contiguous run; these strided 4-byte stores are fire-and-forget
+    uint32_t* dcol0 = dir + (int64_t)frame * groups * tiles + tile;
     if (d0 < groups) {
-      drow[d0] = (uint32_t)ex | ((uint32_t)c0 << 16);
+      dcol0[(int64_t)d0 * tiles] = (uint32_t)ex | ((uint32_t)c0 << 16);
       int acc = ex;
       for (int w = 0; w < kVtRouteWaves; ++w) {  // per-wave start of group d0 inside the tile
         const int c = run_all[(size_t)w * groups + d0];
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(kVtRouteThreads) void vt_route_kernel(
       }
     }
     if (d0 + 1 < groups) {
-      drow[d0 + 1] = (uint32_t)(ex + c0) | ((uint32_t)c1 << 16);
+      dcol0[(int64_t)(d0 + 1) * tiles] = (uint32_t)(ex + c0) | ((uint32_t)c1 << 16);
       int acc = ex + c0;
       for (int w = 0; w < kVtRouteWaves; ++w) {
         const int c = run_all[(size_t)w * groups + d0 + 1];
@@ -244,8 +246,8 @@ constexpr int kVtGroupPass = kVtGroupThreads * kVtGroupSteps;        // 1024 rec
 // independent loads up front, so a pass costs ONE global round trip.
 __global__ __launch_bounds__(kVtGroupThreads) void vt_group_kernel(
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ dir, int low, int groups,
-    int tiles, int max_pts, uint32_t ncells, VtCells s, uint32_t* __restrict__ owner,
-    int* __restrict__ owner_npts, unsigned char* __restrict__ isfirst) {
+    int tiles, int max_pts, uint32_t ncells, VtCells s, uint2* __restrict__ owner,
+    unsigned char* __restrict__ isfirst) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
   const int cpg = 1 << low;
   unsigned long long* mask_all = reinterpret_cast<unsigned long long*>(vt_smem);   // [waves][cpg]
@@ -269,14 +271,14 @@ __global__ __launch_bounds__(kVtGroupThreads) void vt_group_kernel(
     }
   }
   // directory column -> per-tile (offset, count); sequential chunks of tiles per thread for the scan
-  const uint32_t* dcol = dir + (int64_t)frame * tiles * groups + grp;
+  const uint32_t* dcol = dir + ((int64_t)frame * groups + grp) * tiles;
   const int per = (tiles + kVtGroupThreads - 1) / kVtGroupThreads;
   const int t_lo = threadIdx.x * per;
   int mysum = 0;
   for (int j = 0; j < per; ++j) {
     const int t = t_lo + j;
     if (t < tiles) {
-      const uint32_t d = dcol[(int64_t)t * groups];
+      const uint32_t d = dcol[t];
       toff[t] = (int)(d & 0xFFFFu);
       tpre[t] = (int)(d >> 16);  // count for now
       mysum += (int)(d >> 16);
@@ -357,11 +359,7 @@ __global__ __launch_bounds__(kVtGroupThreads) void vt_group_kernel(
         if (slot < max_pts) {
           const uint32_t key = vt_group_to_key((uint32_t)grp, (uint32_t)cell, (uint32_t)groups, inv_g);
           plist_f[(int64_t)key * max_pts + slot] = idx;
-          if (slot == 0) {  // the cell's first point: its index orders the voxels
-            first[cell] = (int)idx;
-            owner[own_base + idx] = key;
-            isfirst[own_base + idx] = 1;
-          }
+          if (slot == 0) first[cell] = (int)idx;  // the cell's first point: its index orders the voxels
         }
         if (rank == 0) {
           base[cell] = b0 + total;
@@ -378,10 +376,15 @@ __global__ __launch_bounds__(kVtGroupThreads) void vt_group_kernel(
       __syncthreads();
     }
   }
-  // final per-cell counts, parked next to the cell's first point (read by the assign kernel)
+  // per occupied cell: raise the flag of its first point and park (cell key, final count) there
   for (int c = threadIdx.x; c < cpg; c += kVtGroupThreads) {
     const int k = run[c];
-    if (k > 0) owner_npts[own_base + first[c]] = min(k, max_pts);
+    if (k > 0) {
+      const int64_t at = own_base + first[c];
+      const uint32_t key = vt_group_to_key((uint32_t)grp, (uint32_t)c, (uint32_t)groups, inv_g);
+      owner[at] = make_uint2(key, (uint32_t)min(k, max_pts));
+      isfirst[at] = 1;
+    }
   }
 }
 
@@ -408,9 +411,9 @@ __global__ __launch_bounds__(kVtAssignThreads) void vt_count_kernel(
 }
 
 __global__ __launch_bounds__(kVtAssignThreads) void vt_assign_kernel(
-    const unsigned char* __restrict__ isfirst, int64_t stride, const uint32_t* __restrict__ owner,
-    const int* __restrict__ owner_npts, const int* __restrict__ wsum, int max_voxels,
-    uint32_t* __restrict__ vid2key, int* __restrict__ vid_npts, int* __restrict__ totals) {
+    const unsigned char* __restrict__ isfirst, int64_t stride, const uint2* __restrict__ owner,
+    const int* __restrict__ wsum, int max_voxels, uint32_t* __restrict__ vid2key,
+    int* __restrict__ vid_npts, int* __restrict__ totals) {
   __shared__ int scan_tmp[kVtAssignThreads / kWave + 1];
   const int frame = blockIdx.y, nblk = gridDim.x;
   // sum of the blocks before this one (and, for block 0, of all blocks -> totals)
@@ -435,8 +438,9 @@ __global__ __launch_bounds__(kVtAssignThreads) void vt_assign_kernel(
   for (int b = 0; b < 8; ++b) {
     if ((x >> (8 * b)) & 1ull) {
       if (vid < max_voxels) {
-        vid2key[(int64_t)frame * max_voxels + vid] = owner[i + b];
-        vid_npts[(int64_t)frame * max_voxels + vid] = owner_npts[i + b];
+        const uint2 o = owner[i + b];
+        vid2key[(int64_t)frame * max_voxels + vid] = o.x;
+        vid_npts[(int64_t)frame * max_voxels + vid] = (int)o.y;
       }
       ++vid;
     }
