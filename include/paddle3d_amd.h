@@ -169,6 +169,39 @@ int pd3_bev_pool_v2_bkwd(const float *out_grad, const float *depth, const float 
                          int channels, int64_t depth_elems, int64_t feat_elems, float *depth_grad,
                          float *feat_grad, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * sparse_conv3d -- replaces the Paddle-core sparse ops the CenterPoint-Voxel middle encoder is built
+ * from: paddle.sparse.nn.SubmConv3D / Conv3D (+ BatchNorm, ReLU, sparse.add fused into the epilogue) and
+ * SparseCooTensor.to_dense (call sites paddle3d/models/middle_encoders/sparse_resnet.py:31-59, :115-206;
+ * sparsenet.py:31-64).  The reference arithmetic is in the paddlepaddle wheel (>= 2.4.0, not vendored):
+ * parity is pinned on the public definition against a dense conv3d oracle.
+ *
+ * A convolution = pd3_sparse_conv3d_indices (output coordinate set + neighbour table; reusable by every
+ * conv that shares the same input set, kernel, stride and padding -- the reference's `key=` hint) followed
+ * by pd3_sparse_conv3d_features (gather-GEMM with fused epilogue).
+ *   in_coords  [n_in, 4] int32 (batch, z, y, x); rows with batch < 0 are padding and ignored
+ *   spatial_shape host int[3] (D, H, W);  kernel_size / stride / padding host int[3]
+ *   subm != 0: output set = input set (same rows, same order); requires stride 1, padding = k/2
+ *   subm == 0: output set = every position reached by an active input, rows sorted by (b, z, y, x)
+ *   out_coords [out_cap, 4], nbr [out_cap, kd*kh*kw] int32 (input row or -1), n_out [1] int32 (device)
+ *   weight [kd, kh, kw, Cin, Cout] (Paddle layout); bias / scale+shift / residual may be NULL
+ *   out = relu?( (sum_k W[k].in[nbr[.,k]] + bias) * scale + shift + residual ),  Cout <= 128
+ */
+size_t pd3_sparse_conv3d_workspace(int n_in, const int *kernel_size, int subm, int out_cap);
+int pd3_sparse_conv3d_indices(const int32_t *in_coords, int n_in, int batch, const int *spatial_shape,
+                              const int *kernel_size, const int *stride, const int *padding, int subm,
+                              int32_t *out_coords, int32_t *nbr, int32_t *n_out, int out_cap,
+                              void *workspace, size_t workspace_bytes, void *stream);
+int pd3_sparse_conv3d_features(const float *in_feats, const int32_t *nbr, const int32_t *n_out,
+                               int n_out_cap, int kernel_volume, int cin, int cout,
+                               const float *weight, const float *bias, const float *scale,
+                               const float *shift, const float *residual, int relu, float *out,
+                               void *stream);
+/* values [n, C] at coords -> dense [batch, C*D, H, W] fp32 (to_dense + transpose + reshape of
+ * sparse_resnet.py:202-205); `dense` is fully written (zero where inactive). n may be NULL (= n_cap). */
+int pd3_sparse_to_dense(const float *feats, const int32_t *coords, const int32_t *n, int n_cap,
+                        int channels, int batch, const int *spatial_shape, float *dense, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

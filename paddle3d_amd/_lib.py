@@ -51,6 +51,15 @@ _SIGNATURES = {
                                                      C.c_void_p]),
     "pd3_bev_pool_v2_bkwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64,
                                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pd3_sparse_conv3d_workspace": (C.c_size_t, [C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "pd3_sparse_conv3d_indices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pd3_sparse_conv3d_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_sparse_to_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 SYMBOLS = tuple(_SIGNATURES)

@@ -1,0 +1,464 @@
+// Sparse 3-D convolution (submanifold + regular/strided) for gfx950.
+// Reference: the CenterPoint-Voxel middle encoder builds on Paddle-core `paddle.sparse.nn.SubmConv3D /
+// Conv3D / BatchNorm / ReLU` and `paddle.sparse.add` (call sites: paddle3d/models/middle_encoders/
+// sparse_resnet.py:31-59, :115-206; sparsenet.py:31-64).  The arithmetic lives in the paddlepaddle wheel
+// (>= 2.4.0, not vendored, not installable here), so parity is pinned on the PUBLIC definition instead:
+//   submanifold conv: output index set = input index set, out[p] = sum_k W[k] . in[p + k - pad]
+//   regular conv:     output index set = every q reached by some active input, out[q] = sum_k W[k] .
+//                     in[q * stride - pad + k]        (weight layout [kd, kh, kw, Cin, Cout])
+// and checked against torch.nn.functional.conv3d on densified inputs (tests/test_sparse_conv_gpu.py).
+//
+// Design: coordinates are linearised to uint32 keys ((b*D+z)*H+y)*W+x.  An open-addressing hash table in
+// global memory (atomicCAS insert, linear probing) answers "which row holds coordinate c".  A convolution
+// is (1) its output key set -- the input set itself (submanifold), or the radix-sorted unique set of
+// reachable outputs (regular; sorted => deterministic row order), (2) a neighbour table nbr[row][K] of
+// input rows (-1 = absent), (3) ONE gather-GEMM kernel that walks the K offsets in order for a tile of
+// output rows, staging W[k] and the gathered input rows in LDS -- a fixed summation order, so results are
+// run-to-run identical -- with bias / folded BatchNorm / residual add / ReLU fused into the epilogue.
+#include "../../include/paddle3d_amd.h"
+#include "common.hpp"
+#include "radix_sort.hpp"
+#include "scan.hpp"
+
+#include <algorithm>
+
+namespace pd3 {
+
+constexpr uint32_t kSpEmpty = 0xFFFFFFFFu;
+
+struct SpShape {
+  int batch, d, h, w;
+};
+
+__device__ __forceinline__ uint32_t sp_hash(uint32_t k) {
+  k ^= k >> 16;
+  k *= 0x7feb352dU;
+  k ^= k >> 15;
+  k *= 0x846ca68bU;
+  k ^= k >> 16;
+  return k;
+}
+
+__device__ __forceinline__ uint32_t sp_key(int b, int z, int y, int x, const SpShape& s) {
+  return (uint32_t)(((b * s.d + z) * s.h + y) * s.w + x);
+}
+
+// coords [n,4] (b,z,y,x) -> keys; rows with b < 0 (padding) get kSpEmpty
+__global__ __launch_bounds__(256) void sp_keys_kernel(const int32_t* __restrict__ coords, int n,
+                                                      SpShape s, uint32_t* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = coords[i * 4], z = coords[i * 4 + 1], y = coords[i * 4 + 2], x = coords[i * 4 + 3];
+  const bool ok = b >= 0 && b < s.batch && z >= 0 && z < s.d && y >= 0 && y < s.h && x >= 0 && x < s.w;
+  keys[i] = ok ? sp_key(b, z, y, x, s) : kSpEmpty;
+}
+
+__global__ __launch_bounds__(256) void sp_hash_insert_kernel(const uint32_t* __restrict__ keys, int n,
+                                                             uint32_t* __restrict__ tkeys,
+                                                             int* __restrict__ tvals, uint32_t mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = keys[i];
+  if (k == kSpEmpty) return;
+  uint32_t slot = sp_hash(k) & mask;
+  while (true) {
+    const uint32_t prev = atomicCAS(&tkeys[slot], kSpEmpty, k);
+    if (prev == kSpEmpty || prev == k) {
+      // duplicate coordinates (never produced by the voxelizer): the highest row wins, deterministically
+      atomicMax(&tvals[slot], i);
+      return;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ int sp_lookup(uint32_t k, const uint32_t* __restrict__ tkeys,
+                                         const int* __restrict__ tvals, uint32_t mask) {
+  uint32_t slot = sp_hash(k) & mask;
+  while (true) {
+    const uint32_t cur = tkeys[slot];
+    if (cur == k) return tvals[slot];
+    if (cur == kSpEmpty) return -1;
+    slot = (slot + 1) & mask;
+  }
+}
+
+struct SpConv {
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+};
+
+// neighbour table: thread per (output row, kernel offset).  out coordinates come from out_keys.
+__global__ __launch_bounds__(256) void sp_rulebook_kernel(const uint32_t* __restrict__ out_keys,
+                                                          const int* __restrict__ n_out_dev,
+                                                          int n_out_cap, SpShape in_s, SpShape out_s,
+                                                          SpConv c, const uint32_t* __restrict__ tkeys,
+                                                          const int* __restrict__ tvals, uint32_t mask,
+                                                          int32_t* __restrict__ nbr) {
+  const int K = c.kd * c.kh * c.kw;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_out = n_out_dev ? min(*n_out_dev, n_out_cap) : n_out_cap;
+  if (t >= (int64_t)n_out * K) return;
+  const int row = (int)(t / K), k = (int)(t - (int64_t)row * K);
+  const uint32_t key = out_keys[row];
+  int j = -1;
+  if (key != kSpEmpty) {
+    uint32_t r = key;
+    const int x = (int)(r % (uint32_t)out_s.w);
+    r /= (uint32_t)out_s.w;
+    const int y = (int)(r % (uint32_t)out_s.h);
+    r /= (uint32_t)out_s.h;
+    const int z = (int)(r % (uint32_t)out_s.d);
+    const int b = (int)(r / (uint32_t)out_s.d);
+    const int kz = k / (c.kh * c.kw), ky = (k / c.kw) % c.kh, kx = k % c.kw;
+    const int iz = z * c.sd - c.pd + kz, iy = y * c.sh - c.ph + ky, ix = x * c.sw - c.pw + kx;
+    if (iz >= 0 && iz < in_s.d && iy >= 0 && iy < in_s.h && ix >= 0 && ix < in_s.w)
+      j = sp_lookup(sp_key(b, iz, iy, ix, in_s), tkeys, tvals, mask);
+  }
+  nbr[t] = j;
+}
+
+// regular conv: every (input row, offset) proposes the output it contributes to (or kSpEmpty)
+__global__ __launch_bounds__(256) void sp_candidates_kernel(const uint32_t* __restrict__ in_keys, int n_in,
+                                                            SpShape in_s, SpShape out_s, SpConv c,
+                                                            uint32_t* __restrict__ cand) {
+  const int K = c.kd * c.kh * c.kw;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)n_in * K) return;
+  const int row = (int)(t / K), k = (int)(t - (int64_t)row * K);
+  const uint32_t key = in_keys[row];
+  uint32_t out = kSpEmpty;
+  if (key != kSpEmpty) {
+    uint32_t r = key;
+    const int x = (int)(r % (uint32_t)in_s.w);
+    r /= (uint32_t)in_s.w;
+    const int y = (int)(r % (uint32_t)in_s.h);
+    r /= (uint32_t)in_s.h;
+    const int z = (int)(r % (uint32_t)in_s.d);
+    const int b = (int)(r / (uint32_t)in_s.d);
+    const int kz = k / (c.kh * c.kw), ky = (k / c.kw) % c.kh, kx = k % c.kw;
+    const int nz = z + c.pd - kz, ny = y + c.ph - ky, nx = x + c.pw - kx;  // = q * stride
+    if (nz >= 0 && ny >= 0 && nx >= 0 && nz % c.sd == 0 && ny % c.sh == 0 && nx % c.sw == 0) {
+      const int qz = nz / c.sd, qy = ny / c.sh, qx = nx / c.sw;
+      if (qz < out_s.d && qy < out_s.h && qx < out_s.w) out = sp_key(b, qz, qy, qx, out_s);
+    }
+  }
+  cand[t] = out;
+}
+
+// sorted candidates -> head flags (first of each run of equal valid keys), as ints for the scan
+__global__ __launch_bounds__(256) void sp_heads_kernel(const uint32_t* __restrict__ sorted, int64_t n,
+                                                       int* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = sorted[i];
+  flags[i] = (k != kSpEmpty && (i == 0 || sorted[i - 1] != k)) ? 1 : 0;
+}
+
+struct EpiUniqueKeys {
+  const uint32_t* sorted;
+  uint32_t* out_keys;
+  int32_t* out_coords;
+  SpShape s;
+  int cap;
+  __device__ __forceinline__ void operator()(int, int64_t i, int flag, int prefix, int) const {
+    if (flag && prefix < cap) {
+      uint32_t r = sorted[i];
+      out_keys[prefix] = r;
+      const int x = (int)(r % (uint32_t)s.w);
+      r /= (uint32_t)s.w;
+      const int y = (int)(r % (uint32_t)s.h);
+      r /= (uint32_t)s.h;
+      out_coords[prefix * 4 + 3] = x;
+      out_coords[prefix * 4 + 2] = y;
+      out_coords[prefix * 4 + 1] = (int)(r % (uint32_t)s.d);
+      out_coords[prefix * 4 + 0] = (int)(r / (uint32_t)s.d);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// gather-GEMM: tile of kSpRows output rows per workgroup (4 waves x 8 rows), lanes = output channels.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSpRows = 32;
+constexpr int kSpRowsPerWave = 8;
+
+struct SpGemmArgs {
+  const float* in;       // [n_in, cin]
+  const int32_t* nbr;    // [n_out, K]
+  const float* weight;   // [K, cin, cout]
+  const float* bias;     // [cout] or null
+  const float* scale;    // [cout] or null (folded BatchNorm)
+  const float* shift;    // [cout] or null
+  const float* residual; // [n_out, cout] or null
+  float* out;            // [n_out, cout]
+  const int* n_out_dev;  // device row count or null
+  int n_out_cap, K, cin, cout, relu;
+};
+
+template <int COUT_PER_LANE>
+__global__ __launch_bounds__(256) void sp_gather_gemm_kernel(SpGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sp_smem[];
+  float* W = sp_smem;                       // [cin][cout]
+  float* xs = W + (size_t)a.cin * a.cout;   // [kSpRows][cin]
+  int* nb = reinterpret_cast<int*>(xs + (size_t)kSpRows * a.cin);  // [kSpRows]
+  const int lane = lane_id(), wave = wave_id();
+  const int n_out = a.n_out_dev ? min(*a.n_out_dev, a.n_out_cap) : a.n_out_cap;
+  const int row0 = blockIdx.x * kSpRows;
+  if (row0 >= n_out) return;
+  float acc[kSpRowsPerWave][COUT_PER_LANE];
+#pragma unroll
+  for (int r = 0; r < kSpRowsPerWave; ++r)
+#pragma unroll
+    for (int u = 0; u < COUT_PER_LANE; ++u) acc[r][u] = 0.f;
+
+  for (int k = 0; k < a.K; ++k) {
+    __syncthreads();  // previous offset's W / xs fully consumed
+    if (threadIdx.x < kSpRows) {
+      const int row = row0 + threadIdx.x;
+      nb[threadIdx.x] = row < n_out ? a.nbr[(int64_t)row * a.K + k] : -1;
+    }
+    __syncthreads();
+    // does any row of the tile have this neighbour?  (uniform: every thread reads the same 32 ints)
+    int any = 0;
+    for (int r = 0; r < kSpRows; ++r) any |= (nb[r] >= 0);
+    if (!any) continue;
+    const float* wk = a.weight + (int64_t)k * a.cin * a.cout;
+    for (int e = threadIdx.x; e < a.cin * a.cout; e += blockDim.x) W[e] = wk[e];
+    for (int e = threadIdx.x; e < kSpRows * a.cin; e += blockDim.x) {
+      const int r = e / a.cin, ci = e - r * a.cin;
+      const int j = nb[r];
+      xs[e] = j >= 0 ? a.in[(int64_t)j * a.cin + ci] : 0.f;
+    }
+    __syncthreads();
+    bool mine = false;
+#pragma unroll
+    for (int r = 0; r < kSpRowsPerWave; ++r) mine |= nb[wave * kSpRowsPerWave + r] >= 0;
+    if (!mine) continue;  // wave-uniform
+    for (int ci = 0; ci < a.cin; ++ci) {
+      float w[COUT_PER_LANE];
+#pragma unroll
+      for (int u = 0; u < COUT_PER_LANE; ++u) {
+        const int co = lane + u * kWave;
+        w[u] = co < a.cout ? W[ci * a.cout + co] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < kSpRowsPerWave; ++r) {
+        const float x = xs[(wave * kSpRowsPerWave + r) * a.cin + ci];
+#pragma unroll
+        for (int u = 0; u < COUT_PER_LANE; ++u) acc[r][u] = fmaf(x, w[u], acc[r][u]);
+      }
+    }
+  }
+  // epilogue: bias, folded BN, residual, ReLU
+#pragma unroll
+  for (int r = 0; r < kSpRowsPerWave; ++r) {
+    const int row = row0 + wave * kSpRowsPerWave + r;
+    if (row >= n_out) continue;
+#pragma unroll
+    for (int u = 0; u < COUT_PER_LANE; ++u) {
+      const int co = lane + u * kWave;
+      if (co >= a.cout) continue;
+      float v = acc[r][u];
+      if (a.bias) v += a.bias[co];
+      if (a.scale) v = fmaf(v, a.scale[co], a.shift[co]);
+      if (a.residual) v += a.residual[(int64_t)row * a.cout + co];
+      if (a.relu) v = fmaxf(v, 0.f);
+      a.out[(int64_t)row * a.cout + co] = v;
+    }
+  }
+}
+
+// values [n, c] at coords (b,z,y,x) -> dense [B, C*D, H, W]  (to_dense + transpose + reshape of
+// sparse_resnet.py:202-205 in one pass; the destination is zero-filled first)
+__global__ __launch_bounds__(256) void sp_to_dense_kernel(const float* __restrict__ feats,
+                                                          const int32_t* __restrict__ coords,
+                                                          const int* __restrict__ n_dev, int n_cap,
+                                                          int c, SpShape s, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = n_dev ? min(*n_dev, n_cap) : n_cap;
+  if (t >= (int64_t)n * c) return;
+  const int row = (int)(t / c), ch = (int)(t - (int64_t)row * c);
+  const int b = coords[row * 4], z = coords[row * 4 + 1], y = coords[row * 4 + 2], x = coords[row * 4 + 3];
+  if (b < 0 || b >= s.batch) return;
+  out[((((int64_t)b * c + ch) * s.d + z) * s.h + y) * s.w + x] = feats[t];
+}
+
+__global__ void sp_set_count_kernel(const int* __restrict__ total, int fixed, int cap,
+                                    int32_t* __restrict__ n_out) {
+  *n_out = total ? min(*total, cap) : min(fixed, cap);
+}
+
+static inline uint32_t table_size(int n) {
+  uint32_t t = 1024;
+  while (t < (uint32_t)n * 2u) t <<= 1;
+  return t;
+}
+
+struct SpWorkspace {
+  uint32_t *in_keys, *tkeys, *out_keys, *cand_a, *cand_b, *val_a, *val_b;
+  int *tvals, *flags, *hist, *partial, *total;
+  uint32_t tsize;
+  size_t bytes;
+};
+
+static SpWorkspace sp_carve(void* base, int n_in, int K, bool subm, int out_cap) {
+  Carver c(base);
+  SpWorkspace w{};
+  w.tsize = table_size(n_in);
+  w.in_keys = c.take<uint32_t>((size_t)n_in);
+  w.tkeys = c.take<uint32_t>(w.tsize);
+  w.tvals = c.take<int>(w.tsize);
+  w.total = c.take<int>(1);
+  if (!subm) {
+    const size_t nc = (size_t)n_in * K;
+    const RadixPlan plan = radix_plan(0xFFFFFFFFu, (int64_t)nc);
+    w.out_keys = c.take<uint32_t>((size_t)out_cap);
+    w.cand_a = c.take<uint32_t>(nc);
+    w.cand_b = c.take<uint32_t>(nc);
+    w.val_a = c.take<uint32_t>(nc);
+    w.val_b = c.take<uint32_t>(nc);
+    w.flags = c.take<int>(nc);
+    w.hist = c.take<int>(radix_hist_ints(plan));
+    w.partial = c.take<int>((size_t)std::max(scan_num_tiles((int64_t)radix_hist_ints(plan)),
+                                             scan_num_tiles((int64_t)nc)));
+  }
+  w.bytes = c.off;
+  return w;
+}
+
+static bool out_shape(const SpShape& in, const SpConv& c, SpShape& out) {
+  out.batch = in.batch;
+  out.d = (in.d + 2 * c.pd - c.kd) / c.sd + 1;
+  out.h = (in.h + 2 * c.ph - c.kh) / c.sh + 1;
+  out.w = (in.w + 2 * c.pw - c.kw) / c.sw + 1;
+  return out.d > 0 && out.h > 0 && out.w > 0 &&
+         (int64_t)out.batch * out.d * out.h * out.w < (int64_t)0xFFFFFFFF;
+}
+
+}  // namespace pd3
+
+using namespace pd3;
+
+extern "C" size_t pd3_sparse_conv3d_workspace(int n_in, const int* kernel_size, int subm,
+                                              int out_cap) {
+  if (n_in <= 0 || !kernel_size || out_cap <= 0) return 0;
+  const int K = kernel_size[0] * kernel_size[1] * kernel_size[2];
+  if (K <= 0 || (int64_t)n_in * K >= ((int64_t)1 << 31)) return 0;
+  return sp_carve(nullptr, n_in, K, subm != 0, out_cap).bytes;
+}
+
+extern "C" int pd3_sparse_conv3d_indices(const int32_t* in_coords, int n_in, int batch,
+                                         const int* spatial_shape, const int* kernel_size,
+                                         const int* stride, const int* padding, int subm,
+                                         int32_t* out_coords, int32_t* nbr, int32_t* n_out,
+                                         int out_cap, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  if (!in_coords || !spatial_shape || !kernel_size || !stride || !padding || !out_coords || !nbr ||
+      !n_out || !workspace || n_in <= 0 || batch <= 0 || out_cap <= 0)
+    return PD3_EINVAL;
+  SpShape in_s{batch, spatial_shape[0], spatial_shape[1], spatial_shape[2]};
+  SpConv c{kernel_size[0], kernel_size[1], kernel_size[2], stride[0], stride[1], stride[2],
+           padding[0], padding[1], padding[2]};
+  const int K = c.kd * c.kh * c.kw;
+  if (K <= 0 || c.sd <= 0 || c.sh <= 0 || c.sw <= 0 || in_s.d <= 0 || in_s.h <= 0 || in_s.w <= 0)
+    return PD3_EINVAL;
+  if ((int64_t)in_s.batch * in_s.d * in_s.h * in_s.w >= (int64_t)0xFFFFFFFF) return PD3_EUNSUPPORTED;
+  if ((int64_t)n_in * K >= ((int64_t)1 << 31)) return PD3_EUNSUPPORTED;
+  SpShape out_s = in_s;
+  if (subm) {
+    // submanifold: stride 1 and "same" padding, so that the centre tap sits on the output coordinate
+    if (c.sd != 1 || c.sh != 1 || c.sw != 1 || c.pd * 2 + 1 != c.kd || c.ph * 2 + 1 != c.kh ||
+        c.pw * 2 + 1 != c.kw)
+      return PD3_EUNSUPPORTED;
+    if (out_cap < n_in) return PD3_EINVAL;
+  } else if (!out_shape(in_s, c, out_s)) {
+    return PD3_EUNSUPPORTED;
+  }
+  SpWorkspace w = sp_carve(workspace, n_in, K, subm != 0, out_cap);
+  if (workspace_bytes < w.bytes) return PD3_EWORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(w.tkeys, 0xFF, sizeof(uint32_t) * w.tsize, s);  // kSpEmpty
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(w.tvals, 0xFF, sizeof(int) * w.tsize, s);  // -1
+  if (e != hipSuccess) return (int)e;
+  const unsigned gb = (unsigned)ceil_div(n_in, 256);
+  sp_keys_kernel<<<gb, 256, 0, s>>>(in_coords, n_in, in_s, w.in_keys);
+  sp_hash_insert_kernel<<<gb, 256, 0, s>>>(w.in_keys, n_in, w.tkeys, w.tvals, w.tsize - 1);
+  if (subm) {
+    if (out_coords != in_coords) {
+      e = hipMemcpyAsync(out_coords, in_coords, sizeof(int32_t) * 4 * (size_t)n_in,
+                         hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) return (int)e;
+    }
+    sp_set_count_kernel<<<1, 1, 0, s>>>(nullptr, n_in, out_cap, n_out);
+    sp_rulebook_kernel<<<(unsigned)ceil_div((int64_t)n_in * K, 256), 256, 0, s>>>(
+        w.in_keys, nullptr, n_in, in_s, out_s, c, w.tkeys, w.tvals, w.tsize - 1, nbr);
+    return launch_status();
+  }
+  const int64_t nc = (int64_t)n_in * K;
+  sp_candidates_kernel<<<(unsigned)ceil_div(nc, 256), 256, 0, s>>>(w.in_keys, n_in, in_s, out_s, c,
+                                                                   w.cand_a);
+  const uint32_t max_key = (uint32_t)((int64_t)out_s.batch * out_s.d * out_s.h * out_s.w);  // < kSpEmpty
+  (void)max_key;
+  const RadixPlan plan = radix_plan(0xFFFFFFFFu, nc);
+  const int where = enqueue_radix_sort(w.cand_a, w.val_a, w.cand_b, w.val_b, nc, nc, 1, plan,
+                                       /*identity_vals=*/true, w.hist, w.partial, s);
+  const uint32_t* sorted = where ? w.cand_b : w.cand_a;
+  sp_heads_kernel<<<(unsigned)ceil_div(nc, 256), 256, 0, s>>>(sorted, nc, w.flags);
+  EpiUniqueKeys epi{sorted, w.out_keys, out_coords, out_s, out_cap};
+  enqueue_exclusive_scan(w.flags, nc, nc, 1, w.partial, w.total, (int*)nullptr, LoadIdentity{}, epi, s);
+  sp_set_count_kernel<<<1, 1, 0, s>>>(w.total, 0, out_cap, n_out);
+  sp_rulebook_kernel<<<(unsigned)ceil_div((int64_t)out_cap * K, 256), 256, 0, s>>>(
+      w.out_keys, n_out, out_cap, in_s, out_s, c, w.tkeys, w.tvals, w.tsize - 1, nbr);
+  return launch_status();
+}
+
+extern "C" int pd3_sparse_conv3d_features(const float* in_feats, const int32_t* nbr,
+                                          const int32_t* n_out, int n_out_cap, int kernel_volume,
+                                          int cin, int cout, const float* weight, const float* bias,
+                                          const float* scale, const float* shift,
+                                          const float* residual, int relu, float* out, void* stream) {
+  if (!in_feats || !nbr || !weight || !out || n_out_cap <= 0 || kernel_volume <= 0 || cin <= 0 ||
+      cout <= 0)
+    return PD3_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr)) return PD3_EINVAL;
+  if (cout > 128) return PD3_EUNSUPPORTED;
+  SpGemmArgs a{in_feats, nbr, weight, bias, scale, shift, residual, out, n_out, n_out_cap,
+               kernel_volume, cin, cout, relu ? 1 : 0};
+  const size_t lds = ((size_t)cin * cout + (size_t)kSpRows * cin) * sizeof(float) + kSpRows * sizeof(int);
+  if (lds > 160 * 1024) return PD3_EUNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned grid = (unsigned)ceil_div(n_out_cap, kSpRows);
+  hipError_t e;
+  if (cout <= 64) {
+    if (lds > 48 * 1024) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gather_gemm_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    sp_gather_gemm_kernel<1><<<grid, 256, lds, s>>>(a);
+  } else {
+    if (lds > 48 * 1024) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gather_gemm_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    sp_gather_gemm_kernel<2><<<grid, 256, lds, s>>>(a);
+  }
+  return launch_status();
+}
+
+extern "C" int pd3_sparse_to_dense(const float* feats, const int32_t* coords, const int32_t* n,
+                                   int n_cap, int channels, int batch, const int* spatial_shape,
+                                   float* dense, void* stream) {
+  if (!feats || !coords || !spatial_shape || !dense || n_cap <= 0 || channels <= 0 || batch <= 0)
+    return PD3_EINVAL;
+  SpShape sh{batch, spatial_shape[0], spatial_shape[1], spatial_shape[2]};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t elems = (size_t)batch * channels * sh.d * sh.h * sh.w;
+  hipError_t e = hipMemsetAsync(dense, 0, elems * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  sp_to_dense_kernel<<<(unsigned)ceil_div((int64_t)n_cap * channels, 256), 256, 0, s>>>(
+      feats, coords, n, n_cap, channels, sh, dense);
+  return launch_status();
+}
