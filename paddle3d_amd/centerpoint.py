@@ -33,8 +33,9 @@ from .ops import pointpillars_scatter as _ps
 from .ops import voxel_encoder as _ve
 from .ops import voxelize as _vox
 
-__all__ = ["HardVoxelizer", "PillarFeatureNet", "PointPillarsScatter", "SecondBackbone", "SecondFPN",
-           "CenterHead", "CenterPoint", "centerpoint_pillars_nuscenes", "load_paddle_state_dict"]
+__all__ = ["HardVoxelizer", "PillarFeatureNet", "VoxelMean", "PointPillarsScatter", "SecondBackbone",
+           "SecondFPN", "CenterHead", "CenterPoint", "centerpoint_pillars_nuscenes",
+           "centerpoint_voxels_nuscenes", "load_paddle_state_dict"]
 
 
 def _grid(voxel_size, point_cloud_range):
@@ -120,6 +121,18 @@ class PillarFeatureNet(nn.Module):
             self._folded = self._fold()
         return _ve.pillar_feature_net(features, num_points_per_voxel, coors, self.vx, self.vy, self.x_offset,
                                       self.y_offset, *self._folded)
+
+
+class VoxelMean(nn.Module):
+    """voxel_encoder.py:44-57: mean of the points of a voxel."""
+
+    def __init__(self, in_channels=4):
+        super().__init__()
+        self.in_channels = in_channels
+
+    def forward(self, features, num_points_per_voxel, coors=None):
+        assert self.in_channels == features.shape[-1]
+        return _ve.voxel_mean(features, num_points_per_voxel)
 
 
 class PointPillarsScatter(nn.Module):
@@ -350,11 +363,17 @@ class CenterPoint(nn.Module):
         return out, lens
 
     def extract_pillars(self, points, num_points=None):
-        """voxelize -> PFN -> scatter: the LiDAR front half (BEV features [B, 64, ny, nx])."""
+        """voxelize -> voxel encoder -> middle encoder: the LiDAR front half (dense BEV features)."""
         voxels, coors, npv, nv = self.voxelizer(points, num_points)
         b, v, p, d = voxels.shape
-        feats = self.voxel_encoder(voxels.view(b * v, p, d), npv.view(b * v), coors.view(b * v, 4))
-        return self.middle_encoder(feats, coors.view(b * v, 4), b)
+        voxels, coors, npv = voxels.view(b * v, p, d), coors.view(b * v, 4), npv.view(b * v)
+        if not isinstance(self.middle_encoder, PointPillarsScatter):
+            # the sparse middle encoder works on the occupied voxels only (one host sync, like the
+            # reference's voxels[0:num_voxels] slice, voxelize.py:43)
+            keep = coors[:, 0] >= 0
+            voxels, coors, npv = voxels[keep], coors[keep].contiguous(), npv[keep]
+        feats = self.voxel_encoder(voxels, npv, coors)
+        return self.middle_encoder(feats, coors, b)
 
     def _dense_fold(self):
         """BatchNorm folded into the backbone / neck convolutions for inference."""
@@ -420,6 +439,24 @@ def centerpoint_pillars_nuscenes(max_num_voxels=(30000, 60000)) -> CenterPoint:
         backbone=SecondBackbone(64, (64, 128, 256), (3, 5, 5), (2, 2, 2)),
         neck=SecondFPN((64, 128, 256), (128, 128, 128), (0.5, 1, 2), use_conv_for_no_stride=True),
         bbox_head=CenterHead(384, NUSC_TASKS, dict(reg=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2))),
+        test_cfg=test_cfg, box_with_velocity=True)
+
+
+def centerpoint_voxels_nuscenes(max_num_voxels=(120000, 160000)) -> CenterPoint:
+    """configs/centerpoint/centerpoint_voxels_0075voxel_nuscenes_10sweep.yml:111-173, random init."""
+    from .sparse import SparseResNet3D
+
+    pcr, vs = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0], [0.075, 0.075, 0.2]
+    test_cfg = dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], max_per_img=500,
+                    nms=dict(nms_pre_max_size=1000, nms_post_max_size=83, nms_iou_threshold=0.2),
+                    score_threshold=0.1, point_cloud_range=[-54.0, -54.0], down_ratio=8, voxel_size=[0.075, 0.075])
+    return CenterPoint(
+        voxelizer=HardVoxelizer(vs, pcr, 10, list(max_num_voxels)),
+        voxel_encoder=VoxelMean(5),
+        middle_encoder=SparseResNet3D(5, vs, pcr),
+        backbone=SecondBackbone(256, (128, 256), (5, 5), (1, 2)),
+        neck=SecondFPN((128, 256), (256, 256), (1, 2), use_conv_for_no_stride=True),
+        bbox_head=CenterHead(512, NUSC_TASKS, dict(reg=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2))),
         test_cfg=test_cfg, box_with_velocity=True)
 
 

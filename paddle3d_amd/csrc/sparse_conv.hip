@@ -268,6 +268,121 @@ __global__ __launch_bounds__(256) void sp_gather_gemm_kernel(SpGemmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// gather-GEMM on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, one fma chain per output).
+// Tile = 64 output rows per workgroup, 16 per wave; a wave owns its rows for all NB = Cout/16 column
+// blocks (NB independent accumulators keep the 40-cycle dependent latency hidden).  Per kernel offset k:
+// the wave gathers ITS 16 input rows into LDS (wave-local, no workgroup barrier), the workgroup stages
+// W[k] in chunks of <= 32 input channels, and every lane feeds the MFMA one A and one B value from LDS:
+//   A[i = lane & 15][kk = lane >> 4] = x[row i][ci0 + kk],  B[kk][j = lane & 15] = W[k][ci0 + kk][nb*16 + j],
+//   D: col = lane & 15, row = (lane >> 4) * 4 + reg          (cdna_hip_programming.md section 3).
+// Offsets no row of the tile needs are skipped for the workgroup, offsets none of a wave's 16 rows needs
+// are skipped for that wave; the summation order over k is fixed => bit-reproducible results.
+// LDS strides: A rows are padded to stride == 2 (mod 16) floats and W rows to Cout + 16 floats so that
+// the 32-lane groups of a ds_read_b32 hit 32 distinct banks.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSpTile = 64;
+constexpr int kSpChunk = 32;  // input channels of W staged per step
+typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NB>
+__global__ __launch_bounds__(256) void sp_gemm_mfma_kernel(SpGemmArgs a, int cin_pad, int astride,
+                                                           int wstride) {
+  extern __shared__ __attribute__((aligned(16))) float sp_smem[];
+  float* As_all = sp_smem;                                      // [4][16][astride]
+  float* Ws = As_all + (size_t)4 * 16 * astride;                // [kSpChunk][wstride]
+  int* nb = reinterpret_cast<int*>(Ws + (size_t)kSpChunk * wstride);  // [kSpTile]
+  const int lane = lane_id(), wave = wave_id();
+  float* As = As_all + (size_t)wave * 16 * astride;
+  const int n_out = a.n_out_dev ? min(*a.n_out_dev, a.n_out_cap) : a.n_out_cap;
+  const int row0 = blockIdx.x * kSpTile;
+  if (row0 >= n_out) return;
+  const int cout = NB * 16;
+  sp_f32x4 acc[NB];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) acc[u] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ar = lane & 15, akk = lane >> 4;
+  const int nchunks = (cin_pad + kSpChunk - 1) / kSpChunk;
+  const bool vec_rows = (a.cin % 4) == 0;
+
+  for (int k = 0; k < a.K; ++k) {
+    int mine = -1;
+    if (threadIdx.x < kSpTile) {
+      const int row = row0 + threadIdx.x;
+      mine = row < n_out ? a.nbr[(int64_t)row * a.K + k] : -1;
+      nb[threadIdx.x] = mine;
+    }
+    // barrier: nb visible, previous offset's Ws consumed; OR-reduce "someone needs this offset"
+    if (!__syncthreads_or(mine >= 0)) continue;
+    const int myj = nb[wave * 16 + ar];
+    const bool wave_any = __ballot(myj >= 0) != 0ull;
+    if (wave_any) {
+      // gather this wave's 16 rows (zero rows where the neighbour is absent); float4 along channels
+      const int q4 = cin_pad / 4;
+      for (int e = lane; e < 16 * q4; e += kWave) {
+        const int r = e / q4, c4 = e - r * q4;
+        const int j = nb[wave * 16 + r];
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (j >= 0) {
+          const float* src = a.in + (int64_t)j * a.cin + c4 * 4;
+          if (vec_rows) {
+            const float4 t = *reinterpret_cast<const float4*>(src);
+            v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+          } else {
+            const int left = a.cin - c4 * 4;
+            if (left > 0) v0 = src[0];
+            if (left > 1) v1 = src[1];
+            if (left > 2) v2 = src[2];
+            if (left > 3) v3 = src[3];
+          }
+        }
+        float* dst = As + r * astride + c4 * 4;
+        dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+      }
+    }
+    const float* wk = a.weight + (int64_t)k * a.cin * cout;
+    for (int c = 0; c < nchunks; ++c) {
+      if (c > 0) __syncthreads();  // previous chunk of Ws consumed
+      const int ci0 = c * kSpChunk;
+      const int rows = min(kSpChunk, cin_pad - ci0);
+      for (int e = threadIdx.x; e < rows * (cout / 4); e += blockDim.x) {
+        const int r = e / (cout / 4), c4 = e - r * (cout / 4);
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ci0 + r < a.cin) t = *reinterpret_cast<const float4*>(wk + (int64_t)(ci0 + r) * cout + c4 * 4);
+        float* dst = Ws + r * wstride + c4 * 4;
+        dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+      }
+      __syncthreads();
+      if (wave_any) {
+        for (int s4 = 0; s4 < rows; s4 += 4) {
+          const float av = As[ar * astride + ci0 + s4 + akk];
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {
+            const float bv = Ws[(s4 + akk) * wstride + u * 16 + ar];
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[u], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // epilogue: D layout col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const int co = u * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + wave * 16 + (lane >> 4) * 4 + r;
+      if (row >= n_out) continue;
+      float v = acc[u][r];
+      if (a.bias) v += a.bias[co];
+      if (a.scale) v = fmaf(v, a.scale[co], a.shift[co]);
+      if (a.residual) v += a.residual[(int64_t)row * cout + co];
+      if (a.relu) v = fmaxf(v, 0.f);
+      a.out[(int64_t)row * cout + co] = v;
+    }
+  }
+}
+
 // values [n, c] at coords (b,z,y,x) -> dense [B, C*D, H, W]  (to_dense + transpose + reshape of
 // sparse_resnet.py:202-205 in one pass; the destination is zero-filled first)
 __global__ __launch_bounds__(256) void sp_to_dense_kernel(const float* __restrict__ feats,
@@ -425,25 +540,56 @@ extern "C" int pd3_sparse_conv3d_features(const float* in_feats, const int32_t* 
   if (cout > 128) return PD3_EUNSUPPORTED;
   SpGemmArgs a{in_feats, nbr, weight, bias, scale, shift, residual, out, n_out, n_out_cap,
                kernel_volume, cin, cout, relu ? 1 : 0};
-  const size_t lds = ((size_t)cin * cout + (size_t)kSpRows * cin) * sizeof(float) + kSpRows * sizeof(int);
-  if (lds > 160 * 1024) return PD3_EUNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const unsigned grid = (unsigned)ceil_div(n_out_cap, kSpRows);
   hipError_t e;
-  if (cout <= 64) {
-    if (lds > 48 * 1024) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gather_gemm_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
+  if (cout % 16 == 0 && (reinterpret_cast<uintptr_t>(weight) % 16 == 0) &&
+      (cin % 4 != 0 || reinterpret_cast<uintptr_t>(in_feats) % 16 == 0)) {
+    // matrix-core path
+    const int cin_pad = (cin + 3) / 4 * 4;
+    const int astride = ((cin_pad - 2 + 15) / 16) * 16 + 2;
+    const int wstride = cout == 16 ? 16 : cout + 16;
+    const size_t lds = ((size_t)4 * 16 * astride + (size_t)kSpChunk * wstride) * sizeof(float) +
+                       kSpTile * sizeof(int);
+    const unsigned grid = (unsigned)ceil_div(n_out_cap, kSpTile);
+#define PD3_SP_MFMA(NBV)                                                                          \
+  do {                                                                                            \
+    if (lds > 48 * 1024) {                                                                        \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gemm_mfma_kernel<NBV>),            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+      if (e != hipSuccess) return (int)e;                                                         \
+    }                                                                                             \
+    sp_gemm_mfma_kernel<NBV><<<grid, 256, lds, s>>>(a, cin_pad, astride, wstride);               \
+  } while (0)
+    switch (cout / 16) {
+      case 1: PD3_SP_MFMA(1); break;
+      case 2: PD3_SP_MFMA(2); break;
+      case 4: PD3_SP_MFMA(4); break;
+      case 8: PD3_SP_MFMA(8); break;
+      default: goto valu_path;
     }
-    sp_gather_gemm_kernel<1><<<grid, 256, lds, s>>>(a);
-  } else {
-    if (lds > 48 * 1024) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gather_gemm_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
+#undef PD3_SP_MFMA
+    return launch_status();
+  }
+valu_path:
+  {
+    const size_t lds = ((size_t)cin * cout + (size_t)kSpRows * cin) * sizeof(float) + kSpRows * sizeof(int);
+    if (lds > 160 * 1024) return PD3_EUNSUPPORTED;
+    const unsigned grid = (unsigned)ceil_div(n_out_cap, kSpRows);
+    if (cout <= 64) {
+      if (lds > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gather_gemm_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+      }
+      sp_gather_gemm_kernel<1><<<grid, 256, lds, s>>>(a);
+    } else {
+      if (lds > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gather_gemm_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+      }
+      sp_gather_gemm_kernel<2><<<grid, 256, lds, s>>>(a);
     }
-    sp_gather_gemm_kernel<2><<<grid, 256, lds, s>>>(a);
   }
   return launch_status();
 }

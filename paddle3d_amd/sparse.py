@@ -136,7 +136,14 @@ class SparseResNet3D(nn.Module):
 
     @torch.no_grad()
     def forward(self, voxel_features, coors, batch_size):
-        x = SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+        # rows in raster order: tiles of consecutive rows are then spatial neighbours, so a tile's kernel
+        # offsets are mostly all-present or all-absent (skipped) and its gathers share cache lines.  The
+        # final dense map does not depend on the row order.
+        d, h, w = self.sparse_shape
+        c64 = coors.long()
+        order = torch.argsort(((c64[:, 0] * d + c64[:, 1]) * h + c64[:, 2]) * w + c64[:, 3])
+        x = SparseConvTensor(voxel_features[order].contiguous(), coors[order].contiguous(), self.sparse_shape,
+                             batch_size)
         x = self.conv_input(x)
         x = self.conv1(x)
         x = self.conv2(self.conv2_down(x))

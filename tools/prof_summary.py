@@ -5,7 +5,8 @@ import sys
 src = sys.argv[1]
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dst = sys.argv[3] if len(sys.argv) > 3 else None
-rows = list(csv.DictReader(open(src)))
+flt = sys.argv[4] if len(sys.argv) > 4 else ""
+rows = [r for r in csv.DictReader(open(src)) if flt in r["Name"]]
 rows.sort(key=lambda r: -int(r["TotalDurationNs"]))
 lines = ["%-72s %6s %10s %10s %6s" % ("kernel", "calls", "avg_us", "total_ms", "pct")]
 for r in rows[:top]:
