@@ -82,19 +82,24 @@ int pd3_pointpillars_scatter(const float *voxel_features, const int32_t *coords,
  * over the points of a pillar; the non-last layer concatenates the max back).  BatchNorm is folded by
  * the caller: scale = gamma / sqrt(var + eps), shift = beta - mean * scale.
  *
+ * The same entry point covers HardVFE.forward with with_cluster_center = with_voxel_center = True
+ * (voxel_encoders/voxel_encoder.py:142-283, the BEVFusion LiDAR stream): voxel_center_dims = 3 adds the z
+ * offset z - (coor_z * vz + z_offset) and layer 1 keeps all its C1 units (w2 is [2*C1, C2] either way).
+ *
  *   voxels [M, P, D], num_points [M] int32, coors [M, 4] int32 (b, z, y, x)
- *   w1 [D+5, C1] (Paddle Linear layout [in, out]), scale1/shift1 [C1]
+ *   voxel_center_dims 2 (PillarFeatureNet: x, y) or 3 (HardVFE: x, y, z)
+ *   w1 [D+3+voxel_center_dims, C1] (Paddle Linear layout [in, out]), scale1/shift1 [C1]
  *   w2 [2*C1, C2], scale2/shift2 [C2]   (w2 == NULL: single-layer PFN, output [M, C1])
  *   out [M, C2]
  * legacy == 0 only (the nuScenes configs); with_distance unsupported (no config on the path uses it).
  * Rows with num_points <= 0 (padding of a fixed-shape batch) produce zeros.
  */
 int pd3_pillar_feature_net(const float *voxels, const int32_t *num_points, const int32_t *coors,
-                           int64_t num_pillars, int max_points, int num_point_dim, float vx,
-                           float vy, float x_offset, float y_offset, const float *w1,
-                           const float *scale1, const float *shift1, int c1, const float *w2,
-                           const float *scale2, const float *shift2, int c2, float *out,
-                           void *stream);
+                           int64_t num_pillars, int max_points, int num_point_dim,
+                           int voxel_center_dims, float vx, float vy, float vz, float x_offset,
+                           float y_offset, float z_offset, const float *w1, const float *scale1,
+                           const float *shift1, int c1, const float *w2, const float *scale2,
+                           const float *shift2, int c2, float *out, void *stream);
 
 /* VoxelMean.forward, paddle3d/models/voxel_encoders/voxel_encoder.py:44-57: sum over P / count. */
 int pd3_voxel_mean(const float *voxels, const int32_t *num_points, int64_t num_voxels,

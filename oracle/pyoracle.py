@@ -184,6 +184,58 @@ def pfn_forward_torch(voxels, num_points, coors, params, voxel_size, pc_range):
     return x.squeeze(1).numpy()
 
 
+def hard_vfe_forward_torch(voxels, num_points, coors, params, voxel_size, pc_range):
+    """HardVFE.forward in eval mode with cluster + voxel centre (voxel_encoder.py:220-283, VFELayer :94-138)."""
+    import torch
+
+    f = torch.as_tensor(voxels, dtype=torch.float32)
+    npv = torch.as_tensor(num_points).to(torch.float32).reshape(-1, 1, 1)
+    co = torch.as_tensor(coors).to(torch.float32)
+    P = f.shape[1]
+    vx, vy, vz = (float(v) for v in voxel_size)
+    offs = (vx / 2 + pc_range[0], vy / 2 + pc_range[1], vz / 2 + pc_range[2])
+    f_cluster = f[:, :, :3] - f[:, :, :3].sum(1, keepdim=True) / npv
+    f_center = torch.zeros(f.shape[0], P, 3)
+    f_center[:, :, 0] = f[:, :, 0] - (co[:, 3].unsqueeze(1) * vx + offs[0])
+    f_center[:, :, 1] = f[:, :, 1] - (co[:, 2].unsqueeze(1) * vy + offs[1])
+    f_center[:, :, 2] = f[:, :, 2] - (co[:, 1].unsqueeze(1) * vz + offs[2])
+    x = torch.cat([f, f_cluster, f_center], -1)
+    mask = (torch.as_tensor(num_points).reshape(-1, 1) > torch.arange(P).reshape(1, -1)).to(torch.float32)
+    x = x * mask.unsqueeze(-1)
+    for li, p in enumerate(params):
+        w, g, b, mu, var = (torch.as_tensor(np.asarray(p[k]), dtype=torch.float32)
+                            for k in ("weight", "gamma", "beta", "mean", "var"))
+        y = torch.relu(((x @ w) - mu) / torch.sqrt(var + 1e-3) * g + b)
+        ymax = y.max(dim=1, keepdim=True).values
+        x = ymax if li == len(params) - 1 else torch.cat([y, ymax.expand(-1, P, -1)], dim=2)
+    return x.squeeze(1).numpy()
+
+
+def lss_voxel_pooling_numpy(geom, x, dx, bx, nx):
+    """LiftSplatShoot.voxel_pooling with the cumsum trick (cam_stream_lss.py:111-121, :318-373), NumPy.
+    geom [B,N,D,H,W,3] metric coordinates, x [B,N,D,H,W,C] -> [B, C, Z, X, Y]."""
+    B = x.shape[0]
+    C = x.shape[-1]
+    nprime = int(np.prod(x.shape[:-1]))
+    xf = x.reshape(nprime, C).astype(np.float32)
+    g = ((geom - (bx - dx / 2.0)) / dx).astype(np.int64).reshape(nprime, 3)
+    batch_ix = np.repeat(np.arange(B), nprime // B).reshape(-1, 1)
+    g = np.concatenate([g, batch_ix], 1)
+    kept = (g[:, 0] >= 0) & (g[:, 0] < nx[0]) & (g[:, 1] >= 0) & (g[:, 1] < nx[1]) & (g[:, 2] >= 0) & (g[:, 2] < nx[2])
+    xf, g = xf[kept], g[kept]
+    ranks = g[:, 0] * (nx[1] * nx[2] * B) + g[:, 1] * (nx[2] * B) + g[:, 2] * B + g[:, 3]
+    order = np.argsort(ranks, kind="stable")
+    xf, g, ranks = xf[order], g[order], ranks[order]
+    cs = np.cumsum(xf, 0, dtype=np.float32)
+    keep = np.ones(len(xf), bool)
+    keep[:-1] = ranks[1:] != ranks[:-1]
+    cs, g = cs[keep], g[keep]
+    cs = np.concatenate([cs[:1], cs[1:] - cs[:-1]])
+    final = np.zeros((B * nx[2] * nx[0] * nx[1], C), np.float32)
+    final[g[:, 3] * (nx[2] * nx[0] * nx[1]) + g[:, 2] * (nx[0] * nx[1]) + g[:, 0] * nx[1] + g[:, 1]] = cs
+    return final.reshape(B, nx[2], nx[0], nx[1], C).transpose(0, 4, 1, 2, 3)
+
+
 # ------------------------------------------------------------------------------------------------
 # centerpoint_postprocess
 # ------------------------------------------------------------------------------------------------

@@ -28,7 +28,8 @@ _SIGNATURES = {
     "pd3_pointpillars_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pd3_pillar_feature_net": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
-                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                         C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                         C.c_float, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "pd3_voxel_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,

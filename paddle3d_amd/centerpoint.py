@@ -33,7 +33,7 @@ from .ops import pointpillars_scatter as _ps
 from .ops import voxel_encoder as _ve
 from .ops import voxelize as _vox
 
-__all__ = ["HardVoxelizer", "PillarFeatureNet", "VoxelMean", "PointPillarsScatter", "SecondBackbone",
+__all__ = ["HardVoxelizer", "PillarFeatureNet", "HardVFE", "VoxelMean", "PointPillarsScatter", "SecondBackbone",
            "SecondFPN", "CenterHead", "CenterPoint", "centerpoint_pillars_nuscenes",
            "centerpoint_voxels_nuscenes", "load_paddle_state_dict"]
 
@@ -121,6 +121,36 @@ class PillarFeatureNet(nn.Module):
             self._folded = self._fold()
         return _ve.pillar_feature_net(features, num_points_per_voxel, coors, self.vx, self.vy, self.x_offset,
                                       self.y_offset, *self._folded)
+
+
+class HardVFE(nn.Module):
+    """voxel_encoder.py:142-283 with with_cluster_center = with_voxel_center = True, two VFE layers (the
+    BEVFusion LiDAR stream, configs/bevfusion/bevf_pp_2x8_1x_nusc.yaml:93-101); parameters only, arithmetic
+    in the fused HIP op."""
+
+    def __init__(self, in_channels=4, feat_channels=(64, 64), with_distance=False, with_cluster_center=True,
+                 with_voxel_center=True, voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1)):
+        super().__init__()
+        if with_distance or not (with_cluster_center and with_voxel_center) or len(feat_channels) != 2:
+            raise NotImplementedError("HardVFE: only the BEVFusion configuration is on the hot path")
+        self.voxel_size, self.point_cloud_range = tuple(voxel_size), tuple(point_cloud_range)
+        chans = [in_channels + 6] + list(feat_channels)
+
+        class _VFE(nn.Module):
+            def __init__(self, cin, cout):
+                super().__init__()
+                self.linear = nn.Linear(cin, cout, bias=False)
+                self.norm = nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01)
+
+        self.vfe_layers = nn.ModuleList([_VFE(chans[0], chans[1]), _VFE(2 * chans[1], chans[2])])
+
+    def forward(self, features, num_points, coors):
+        args = []
+        for l in self.vfe_layers:
+            scale, shift = _ve.fold_batchnorm(l.norm.weight, l.norm.bias, l.norm.running_mean, l.norm.running_var,
+                                              l.norm.eps)
+            args += [l.linear.weight.t().contiguous().detach(), scale.detach(), shift.detach()]
+        return _ve.hard_vfe(features, num_points, coors, self.voxel_size, self.point_cloud_range, *args)
 
 
 class VoxelMean(nn.Module):

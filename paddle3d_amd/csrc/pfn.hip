@@ -25,7 +25,7 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-constexpr int kPfnWaves = 8;
+constexpr int kPfnMaxWaves = 8;
 constexpr int kPfnRowChunk = 8;
 
 struct PfnArgs {
@@ -34,7 +34,8 @@ struct PfnArgs {
   const int32_t* coors;
   int64_t m;
   int p, d;
-  float vx, vy, x_off, y_off;
+  float vx, vy, vz, x_off, y_off, z_off;
+  int center_dims;  // 2: PillarFeatureNet (x, y); 3: HardVFE (x, y, z)
   const float *w1, *scale1, *shift1;
   int c1;
   const float *w2, *scale2, *shift2;
@@ -43,7 +44,8 @@ struct PfnArgs {
   int in_dim, in_pad;
 };
 
-__global__ __launch_bounds__(kPfnWaves * 64) void pfn_kernel(PfnArgs a) {
+__global__ __launch_bounds__(kPfnMaxWaves * 64) void pfn_kernel(PfnArgs a) {
+  const int kPfnWaves = blockDim.x / kWave;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = lane_id(), wave = wave_id();
   const bool two = a.w2 != nullptr;
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(kPfnWaves * 64) void pfn_kernel(PfnArgs a) {
     const float mx = sx / cnt, my = sy / cnt, mz = sz / cnt;
     const float pcx = (float)a.coors[pil * 4 + 3] * a.vx + a.x_off;
     const float pcy = (float)a.coors[pil * 4 + 2] * a.vy + a.y_off;
+    const float pcz = (float)a.coors[pil * 4 + 1] * a.vz + a.z_off;  // HardVFE only (voxel_encoder.py:262-264)
     for (int e = lane; e < rows * a.in_pad; e += 64) {
       const int k = e / a.in_pad, i = e - k * a.in_pad;
       float v = 0.f;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(kPfnWaves * 64) void pfn_kernel(PfnArgs a) {
           v = vox[k * a.d + ax] - (ax == 0 ? mx : (ax == 1 ? my : mz));
         } else {
           const int ax = i - a.d - 3;
-          v = vox[k * a.d + ax] - (ax == 0 ? pcx : pcy);
+          v = vox[k * a.d + ax] - (ax == 0 ? pcx : (ax == 1 ? pcy : pcz));
         }
       }
       xs[e] = v;
@@ -198,12 +201,14 @@ using namespace pd3;
 
 extern "C" int pd3_pillar_feature_net(const float* voxels, const int32_t* num_points,
                                       const int32_t* coors, int64_t num_pillars, int max_points,
-                                      int num_point_dim, float vx, float vy, float x_offset,
-                                      float y_offset, const float* w1, const float* scale1,
+                                      int num_point_dim, int voxel_center_dims, float vx, float vy,
+                                      float vz, float x_offset, float y_offset, float z_offset,
+                                      const float* w1, const float* scale1,
                                       const float* shift1, int c1, const float* w2,
                                       const float* scale2, const float* shift2, int c2, float* out,
                                       void* stream) {
   if (num_pillars < 0 || max_points <= 0 || num_point_dim < 3) return PD3_EINVAL;
+  if (voxel_center_dims != 2 && voxel_center_dims != 3) return PD3_EINVAL;
   if (num_pillars == 0) return 0;
   if (!voxels || !num_points || !coors || !w1 || !scale1 || !shift1 || !out) return PD3_EINVAL;
   if (c1 <= 0 || c1 > 64 || (c1 % 4) != 0) return PD3_EUNSUPPORTED;
@@ -217,8 +222,11 @@ extern "C" int pd3_pillar_feature_net(const float* voxels, const int32_t* num_po
   a.d = num_point_dim;
   a.vx = vx;
   a.vy = vy;
+  a.vz = vz;
   a.x_off = x_offset;
   a.y_off = y_offset;
+  a.z_off = z_offset;
+  a.center_dims = voxel_center_dims;
   a.w1 = w1;
   a.scale1 = scale1;
   a.shift1 = shift1;
@@ -228,22 +236,24 @@ extern "C" int pd3_pillar_feature_net(const float* voxels, const int32_t* num_po
   a.shift2 = shift2;
   a.c2 = w2 ? c2 : 0;
   a.out = out;
-  a.in_dim = num_point_dim + 5;
+  a.in_dim = num_point_dim + 3 + voxel_center_dims;
   a.in_pad = (a.in_dim + 3) / 4 * 4;
   // xs must also be able to hold c1 maxima (see mx_store)
   if (max_points * a.in_pad < c1) return PD3_EUNSUPPORTED;
-  const size_t floats = (size_t)a.in_pad * c1 + (w2 ? (size_t)2 * c1 * c2 : 0) +
-                        (size_t)kPfnWaves * ((size_t)max_points * a.in_pad + (size_t)max_points * c1);
-  const size_t bytes = floats * sizeof(float);
+  const size_t w_floats = (size_t)a.in_pad * c1 + (w2 ? (size_t)2 * c1 * c2 : 0);
+  const size_t wave_floats = (size_t)max_points * a.in_pad + (size_t)max_points * c1;
+  int waves = kPfnMaxWaves;
+  while (waves > 1 && (w_floats + waves * wave_floats) * sizeof(float) > 160 * 1024) waves >>= 1;
+  const size_t bytes = (w_floats + waves * wave_floats) * sizeof(float);
   if (bytes > 160 * 1024) return PD3_EUNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (bytes > 64 * 1024) {
+  if (bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pfn_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
   }
-  const int64_t blocks = std::min<int64_t>(ceil_div(num_pillars, kPfnWaves), 256 * 8);
-  pfn_kernel<<<(unsigned)blocks, kPfnWaves * 64, bytes, s>>>(a);
+  const int64_t blocks = std::min<int64_t>(ceil_div(num_pillars, waves), 256 * 8);
+  pfn_kernel<<<(unsigned)blocks, waves * 64, bytes, s>>>(a);
   return launch_status();
 }
 

@@ -11,7 +11,7 @@ import torch
 
 from ._common import check, lib, ptr, require_gpu, stream_ptr
 
-__all__ = ["pillar_feature_net", "voxel_mean", "fold_batchnorm"]
+__all__ = ["pillar_feature_net", "hard_vfe", "voxel_mean", "fold_batchnorm"]
 
 
 def fold_batchnorm(gamma, beta, mean, var, eps):
@@ -20,16 +20,17 @@ def fold_batchnorm(gamma, beta, mean, var, eps):
 
 
 def pillar_feature_net(voxels, num_points, coors, vx, vy, x_offset, y_offset, w1, scale1, shift1,
-                       w2=None, scale2=None, shift2=None):
-    """voxels [M,P,D], num_points [M] i32, coors [M,4] i32 (b,z,y,x); w* in Paddle Linear layout [in,out]."""
+                       w2=None, scale2=None, shift2=None, vz=0.0, z_offset=0.0, voxel_center_dims=2):
+    """voxels [M,P,D], num_points [M] i32, coors [M,4] i32 (b,z,y,x); w* in Paddle Linear layout [in,out].
+    voxel_center_dims=3 (+ vz, z_offset) is the HardVFE decoration (voxel_encoder.py:252-266)."""
     v = require_gpu(voxels, "pillar_feature_net")
     n = require_gpu(num_points, "pillar_feature_net", torch.int32)
     c = require_gpu(coors, "pillar_feature_net", torch.int32)
     m, p, d = v.shape
     w1 = require_gpu(w1, "pillar_feature_net")
     c1 = w1.shape[1]
-    if w1.shape[0] != d + 5:
-        raise RuntimeError(f"pillar_feature_net: w1 must be [{d + 5}, C1]")
+    if w1.shape[0] != d + 3 + voxel_center_dims:
+        raise RuntimeError(f"pillar_feature_net: w1 must be [{d + 3 + voxel_center_dims}, C1]")
     two = w2 is not None
     if two:
         w2 = require_gpu(w2, "pillar_feature_net")
@@ -39,13 +40,22 @@ def pillar_feature_net(voxels, num_points, coors, vx, vy, x_offset, y_offset, w1
     else:
         c2 = 0
     out = torch.empty((m, c2 if two else c1), dtype=torch.float32, device=v.device)
-    check(lib().pd3_pillar_feature_net(ptr(v), ptr(n), ptr(c), m, p, d, C.c_float(vx), C.c_float(vy),
-                                       C.c_float(x_offset), C.c_float(y_offset), ptr(w1),
+    check(lib().pd3_pillar_feature_net(ptr(v), ptr(n), ptr(c), m, p, d, int(voxel_center_dims), C.c_float(vx),
+                                       C.c_float(vy), C.c_float(vz), C.c_float(x_offset),
+                                       C.c_float(y_offset), C.c_float(z_offset), ptr(w1),
                                        ptr(scale1.contiguous()), ptr(shift1.contiguous()), c1,
                                        ptr(w2), ptr(scale2.contiguous() if two else None),
                                        ptr(shift2.contiguous() if two else None), c2, ptr(out),
                                        stream_ptr(v.device)), "pillar_feature_net")
     return out
+
+
+def hard_vfe(voxels, num_points, coors, voxel_size, point_cloud_range, w1, scale1, shift1, w2, scale2, shift2):
+    """HardVFE.forward (eval, with_cluster_center + with_voxel_center, two VFE layers)."""
+    vx, vy, vz = (float(v) for v in voxel_size)
+    return pillar_feature_net(voxels, num_points, coors, vx, vy, vx / 2 + point_cloud_range[0],
+                              vy / 2 + point_cloud_range[1], w1, scale1, shift1, w2, scale2, shift2, vz=vz,
+                              z_offset=vz / 2 + point_cloud_range[2], voxel_center_dims=3)
 
 
 def voxel_mean(voxels, num_points):
