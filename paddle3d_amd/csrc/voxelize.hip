@@ -275,8 +275,7 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
   VtGrid vg{g.min_x, g.min_y, g.min_z, g.size_x, g.size_y, g.size_z, g.gx, g.gy, g.gz, g.ncells};
   hipError_t e = hipSuccess;
   const size_t lds_a = (size_t)kVtRouteWaves * plan.groups * 12 + (kVtRouteWaves + 2) * 4;
-  const size_t lds_b = (size_t)kVtGroupWaves * plan.cpg * 12 + (size_t)plan.cpg * 8 +
-                       (size_t)(2 * plan.tiles + 1) * 4 + (kVtGroupWaves + 2) * 4;
+  const size_t lds_b = (size_t)plan.cpg * 16 + (size_t)(2 * plan.tiles + 2) * 4 + (size_t)kVtGroupPass * 4;
   if (lds_a > 48 * 1024) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(vt_route_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
@@ -292,7 +291,7 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
                                                         plan.groups, plan.tiles, w.recs, w.dir, w.isfirst);
   VtCells cells{w.plist};
   dim3 bgrid(plan.groups, batch);
-  vt_group_kernel<<<bgrid, kVtGroupThreads, lds_b, s>>>(w.recs, w.dir, plan.low, plan.groups,
+  vt_group_kernel<<<bgrid, kWave, lds_b, s>>>(w.recs, w.dir, plan.low, plan.groups,
                                                         plan.tiles, max_pts, g.ncells, cells, w.owner,
                                                         w.isfirst);
   dim3 cgrid(w.assign_blocks, batch);

@@ -35,8 +35,6 @@ constexpr int kVtTile = 4096;
 constexpr int kVtRouteThreads = 512;
 constexpr int kVtRounds = kVtTile / kVtRouteThreads;  // 8
 constexpr int kVtRouteWaves = kVtRouteThreads / kWave;
-constexpr int kVtGroupThreads = 256;
-constexpr int kVtGroupWaves = kVtGroupThreads / kWave;
 constexpr int kVtMaxGroups = 1024;
 constexpr int kVtMaxTiles = 1024;
 
@@ -65,7 +63,7 @@ static inline VtPlan vt_plan(uint32_t ncells, int64_t n, int max_pts) {
   p.groups = (int)ceil_div((int64_t)ncells, p.cpg);
   p.tiles = (int)ceil_div(n, kVtTile);
   p.slots = 0;
-  p.ok = p.groups <= kVtMaxGroups && p.tiles <= kVtMaxTiles && n < ((int64_t)1 << (32 - low));
+  p.ok = p.groups <= kVtMaxGroups && p.tiles <= kVtMaxTiles && n < ((int64_t)1 << (32 - low)) - 1;
   return p;
 }
 
@@ -235,68 +233,54 @@ struct VtCells {
   uint32_t* plist;  // [frames][ncells][P]
 };
 
-constexpr int kVtGroupSteps = 4;                                    // 64-record steps per wave per pass
-constexpr int kVtGroupPass = kVtGroupThreads * kVtGroupSteps;        // 1024 records per pass
+constexpr int kVtGroupSteps = 16;                          // 64-record steps per pass
+constexpr int kVtGroupPass = kWave * kVtGroupSteps;        // 1024 records per pass
 
-// One workgroup per group.  The group's record stream (its points in input order) is cut into passes of
-// 1024 records; inside a pass wave w owns the w-th contiguous quarter, so the exact in-order rank of a
-// point is  (count of its cell in earlier passes) + (count in earlier waves of this pass) + (rank inside
-// its wave) -- the same three-phase scheme as the route kernel: per-wave counts, a per-cell prefix over
-// the waves, then wave-synchronous bitmask ranking.  All of a wave's records of a pass are fetched with
-// independent loads up front, so a pass costs ONE global round trip.
-__global__ __launch_bounds__(kVtGroupThreads) void vt_group_kernel(
+// One WAVE per group, one wave per workgroup: fully wave-synchronous (no barrier anywhere), ~9 KB of LDS,
+// so every group of a batch is resident at once and the kernel lasts as long as its slowest wave.  The
+// group's record stream (its points in input order) is cut into passes of 1024 records; ALL records of a
+// pass are fetched with independent loads up front (one global round trip per pass, and the diagonal
+// group assignment keeps almost every group within one pass), then ranked 64 at a time with the LDS
+// bitmask table: rank of a point = points of its cell seen so far + lower lanes of its step with the
+// same cell.
+__global__ __launch_bounds__(kWave) void vt_group_kernel(
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ dir, int low, int groups,
     int tiles, int max_pts, uint32_t ncells, VtCells s, uint2* __restrict__ owner,
     unsigned char* __restrict__ isfirst) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
   const int cpg = 1 << low;
-  unsigned long long* mask_all = reinterpret_cast<unsigned long long*>(vt_smem);   // [waves][cpg]
-  int* base_all = reinterpret_cast<int*>(mask_all + (size_t)kVtGroupWaves * cpg);  // [waves][cpg]
-  int* run = base_all + (size_t)kVtGroupWaves * cpg;                               // [cpg] points so far
-  int* first = run + cpg;                                                          // [cpg] first point idx
+  unsigned long long* mask = reinterpret_cast<unsigned long long*>(vt_smem);  // [cpg]
+  int* run = reinterpret_cast<int*>(mask + cpg);                               // [cpg] points so far
+  int* first = run + cpg;                                                      // [cpg] first point idx
   int* tpre = first + cpg;       // [tiles + 1] exclusive prefix of this group's per-tile counts
   int* toff = tpre + tiles + 1;  // [tiles] offset of the group's segment inside each tile
-  int* scan_tmp = toff + tiles;  // [waves + 1]
+  uint32_t* srcpos = reinterpret_cast<uint32_t*>(toff + tiles);  // [kVtGroupPass] routed position per record
   const int grp = blockIdx.x, frame = blockIdx.y;
-  const int lane = lane_id(), wave = wave_id();
-  unsigned long long* mask = mask_all + (size_t)wave * cpg;
-  int* base = base_all + (size_t)wave * cpg;
+  const int lane = threadIdx.x;
 
-  for (int c = threadIdx.x; c < cpg; c += kVtGroupThreads) {
-    run[c] = 0;
-#pragma unroll
-    for (int w = 0; w < kVtGroupWaves; ++w) {
-      mask_all[(size_t)w * cpg + c] = 0ull;
-      base_all[(size_t)w * cpg + c] = 0;
-    }
-  }
-  // directory column -> per-tile (offset, count); sequential chunks of tiles per thread for the scan
+  // directory row of this group (contiguous) -> per-tile (offset, count) and the exclusive scan
   const uint32_t* dcol = dir + ((int64_t)frame * groups + grp) * tiles;
-  const int per = (tiles + kVtGroupThreads - 1) / kVtGroupThreads;
-  const int t_lo = threadIdx.x * per;
-  int mysum = 0;
-  for (int j = 0; j < per; ++j) {
-    const int t = t_lo + j;
+  int running = 0;
+  for (int t0 = 0; t0 < tiles; t0 += kWave) {
+    const int t = t0 + lane;
+    int c = 0;
     if (t < tiles) {
       const uint32_t d = dcol[t];
       toff[t] = (int)(d & 0xFFFFu);
-      tpre[t] = (int)(d >> 16);  // count for now
-      mysum += (int)(d >> 16);
+      c = (int)(d >> 16);
     }
+    const int inc = wave_inclusive_scan(c);
+    if (t < tiles) tpre[t] = running + inc - c;
+    running += __shfl(inc, kWave - 1, kWave);
   }
-  int n_g;
-  int runp = block_exclusive_scan<kVtGroupThreads>(mysum, scan_tmp, n_g);
-  for (int j = 0; j < per; ++j) {
-    const int t = t_lo + j;
-    if (t < tiles) {
-      const int c = tpre[t];
-      tpre[t] = runp;
-      runp += c;
-    }
+  const int n_g = running;
+  if (lane == 0) tpre[tiles] = n_g;
+  for (int c = lane; c < cpg; c += kWave) {
+    run[c] = 0;
+    mask[c] = 0ull;
   }
-  if (threadIdx.x == 0) tpre[tiles] = n_g;
-  __syncthreads();
-  if (n_g == 0) return;  // uniform
+  vt_wave_sync();
+  if (n_g == 0) return;
 
   const uint32_t* rf = recs + (int64_t)frame * tiles * kVtTile;
   const unsigned long long below_me = (1ull << lane) - 1ull;
@@ -306,55 +290,39 @@ __global__ __launch_bounds__(kVtGroupThreads) void vt_group_kernel(
   const int64_t own_base = (int64_t)frame * tiles * kVtTile;
 
   for (int p0 = 0; p0 < n_g; p0 += kVtGroupPass) {
-    // ---- fetch this wave's quarter of the pass (independent loads) and count per cell
+    // source address of every record of this pass: lanes = tiles expand their segments into LDS
+    // (load-balanced "expand": ~n_g / tiles stores per lane instead of a binary search per record)
+    const int p1 = min(p0 + kVtGroupPass, n_g);
+    for (int t = lane; t < tiles; t += kWave) {
+      const int lo = max(tpre[t], p0), hi = min(tpre[t + 1], p1);
+      const uint32_t src = (uint32_t)t * kVtTile + (uint32_t)toff[t] - (uint32_t)tpre[t];
+      for (int j = lo; j < hi; ++j) srcpos[j - p0] = src + (uint32_t)j;
+    }
+    vt_wave_sync();
     uint32_t rec[kVtGroupSteps];
-    bool valid[kVtGroupSteps];
 #pragma unroll
     for (int u = 0; u < kVtGroupSteps; ++u) {
-      const int j = p0 + wave * (kVtGroupSteps * kWave) + u * kWave + lane;
-      valid[u] = j < n_g;
-      rec[u] = 0u;
-      if (valid[u]) {
-        int lo = 0, hi = tiles;  // largest t with tpre[t] <= j; invariant tpre[lo] <= j < tpre[hi]
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (tpre[mid] <= j) lo = mid; else hi = mid;
-        }
-        rec[u] = rf[(int64_t)lo * kVtTile + toff[lo] + (j - tpre[lo])];
-      }
+      const int j = p0 + u * kWave + lane;
+      rec[u] = 0xFFFFFFFFu;  // idx field all ones never occurs (N < 2^(32-low) - 1 is enforced by the plan)
+      if (j < p1) rec[u] = rf[srcpos[j - p0]];
     }
-#pragma unroll
-    for (int u = 0; u < kVtGroupSteps; ++u)
-      if (valid[u]) atomicAdd(&base[rec[u] & cell_mask], 1);
-    __syncthreads();
-    // ---- per cell: turn the per-wave counts into per-wave start ranks, advance the running count
-    for (int c = threadIdx.x; c < cpg; c += kVtGroupThreads) {
-      int acc = run[c];
-#pragma unroll
-      for (int w = 0; w < kVtGroupWaves; ++w) {
-        const int t = base_all[(size_t)w * cpg + c];
-        base_all[(size_t)w * cpg + c] = acc;
-        acc += t;
-      }
-      run[c] = acc;
-    }
-    __syncthreads();
-    // ---- wave-synchronous exact ranking, 64 records a step
 #pragma unroll
     for (int u = 0; u < kVtGroupSteps; ++u) {
+      if (p0 + u * kWave >= n_g) break;  // uniform
+      const bool valid = rec[u] != 0xFFFFFFFFu;
       const int cell = (int)(rec[u] & cell_mask);
       const uint32_t idx = rec[u] >> low;
-      if (valid[u]) atomicOr(&mask[cell], 1ull << lane);
+      if (valid) atomicOr(&mask[cell], 1ull << lane);
       vt_wave_sync();
       int rank = 0, total = 0, b0 = 0;
-      if (valid[u]) {
+      if (valid) {
         const unsigned long long m = mask[cell];
         rank = __popcll(m & below_me);
         total = __popcll(m);
-        b0 = base[cell];
+        b0 = run[cell];
       }
       vt_wave_sync();
-      if (valid[u]) {
+      if (valid) {
         const int slot = b0 + rank;  // number of earlier points in this cell
         if (slot < max_pts) {
           const uint32_t key = vt_group_to_key((uint32_t)grp, (uint32_t)cell, (uint32_t)groups, inv_g);
@@ -362,22 +330,15 @@ __global__ __launch_bounds__(kVtGroupThreads) void vt_group_kernel(
           if (slot == 0) first[cell] = (int)idx;  // the cell's first point: its index orders the voxels
         }
         if (rank == 0) {
-          base[cell] = b0 + total;
+          run[cell] = b0 + total;
           mask[cell] = 0ull;
         }
       }
       vt_wave_sync();
     }
-    __syncthreads();
-    if (p0 + kVtGroupPass < n_g) {  // another pass follows: the per-wave tables start from zero again
-      for (int c = threadIdx.x; c < cpg; c += kVtGroupThreads)
-#pragma unroll
-        for (int w = 0; w < kVtGroupWaves; ++w) base_all[(size_t)w * cpg + c] = 0;
-      __syncthreads();
-    }
   }
   // per occupied cell: raise the flag of its first point and park (cell key, final count) there
-  for (int c = threadIdx.x; c < cpg; c += kVtGroupThreads) {
+  for (int c = lane; c < cpg; c += kWave) {
     const int k = run[c];
     if (k > 0) {
       const int64_t at = own_base + first[c];
