@@ -44,7 +44,15 @@ static int run_nms(const float* boxes, int n, float thresh, int32_t* keep, int32
   unsigned long long* mask = static_cast<unsigned long long*>(workspace);
   dim3 grid(cb, cb, 1);
   nms_mask_kernel<NORMAL><<<grid, 64, 0, s>>>(boxes, nullptr, n, n, cb, thresh, mask);
-  nms_sweep_kernel<<<1, 64, 0, s>>>(mask, nullptr, n, n, cb, keep, num_to_keep);
+  {
+    const size_t lds = nms_sweep_lds(n);
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    nms_sweep_kernel<<<1, 256, lds, s>>>(mask, nullptr, n, n, cb, keep, num_to_keep);
+  }
   return launch_status();
 }
 

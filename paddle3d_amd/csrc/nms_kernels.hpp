@@ -14,6 +14,12 @@ constexpr int kNmsMaxWords = 1024;  // sweep supports up to 65536 boxes per set
 
 // grid (cb_cap, cb_cap, sets), 64 threads (one wave): tile (row block, col block) of the bit matrix.
 // Only tiles with col >= row are needed by the sweep; the others are skipped.
+//
+// Two phases per tile.  (1) every lane = one row walks the tile's columns with the cheap exact early-out
+// (disjoint circumscribed circles => the reference's overlap is exactly 0) and pushes the surviving
+// (row, col) pairs into an LDS list with a wave-aggregated append.  (2) the list is processed one pair per
+// lane: the expensive polygon clip only runs for the ~1-2 % of pairs that can overlap, with all lanes busy,
+// instead of diverging inside a 64-step column loop.  Same per-pair arithmetic as before => same bits.
 template <bool NORMAL>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes,
                                                       const int* __restrict__ counts, int n_fixed,
@@ -30,7 +36,11 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   const int lane = threadIdx.x;
 
   __shared__ BoxPre col_pre[64];
+  __shared__ BoxPre row_pre[64];
   __shared__ float col_raw[64 * 7];
+  __shared__ unsigned long long bits_s[64];
+  __shared__ unsigned short pairs[64 * 64];
+  bits_s[lane] = 0ull;
   if (lane < col_size) {
     const float* b = bx + (int64_t)(col_blk * 64 + lane) * 7;
     if (NORMAL) {
@@ -40,48 +50,89 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
       col_pre[lane] = box_prepare(b);
     }
   }
-  __syncthreads();
-  if (lane < row_size) {
-    const int row = row_blk * 64 + lane;
-    const float* b = bx + (int64_t)row * 7;
-    unsigned long long bits = 0ull;
-    const int start = (row_blk == col_blk) ? lane + 1 : 0;
-    if (NORMAL) {
+  if (NORMAL) {
+    __syncthreads();
+    if (lane < row_size) {
+      const float* b = bx + (int64_t)(row_blk * 64 + lane) * 7;
       float me[7];
 #pragma unroll
       for (int k = 0; k < 7; ++k) me[k] = b[k];
+      unsigned long long bits = 0ull;
+      const int start = (row_blk == col_blk) ? lane + 1 : 0;
       for (int i = start; i < col_size; ++i)
         if (iou_normal(me, col_raw + i * 7) > thresh) bits |= 1ull << i;
-    } else {
-      const BoxPre me = box_prepare(b);
-      for (int i = start; i < col_size; ++i)
-        if (iou_bev(me, col_pre[i]) > thresh) bits |= 1ull << i;
+      mask[((int64_t)set * cap + row_blk * 64 + lane) * cb_cap + col_blk] = bits;
     }
-    mask[((int64_t)set * cap + row) * cb_cap + col_blk] = bits;
+    return;
   }
+  if (lane < row_size) row_pre[lane] = box_prepare(bx + (int64_t)(row_blk * 64 + lane) * 7);
+  __syncthreads();
+  // phase 1: candidate pairs
+  int npairs = 0;
+  {
+    const bool live = lane < row_size;
+    const float mx = live ? row_pre[lane].cx : 0.f, my = live ? row_pre[lane].cy : 0.f;
+    const float mr = live ? row_pre[lane].rad : 0.f;
+    const int start = (row_blk == col_blk) ? lane + 1 : 0;
+    for (int i = 0; i < col_size; ++i) {
+      bool cand = false;
+      if (live && i >= start) {
+        const float dx = mx - col_pre[i].cx, dy = my - col_pre[i].cy, r = mr + col_pre[i].rad + 0.25f;
+        cand = !(dx * dx + dy * dy > r * r);  // the same test box_overlap starts with
+      }
+      const unsigned long long m = __ballot(cand);
+      if (cand) pairs[npairs + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((lane << 6) | i);
+      npairs += __popcll(m);
+    }
+  }
+  __syncthreads();
+  // phase 2: one candidate pair per lane
+  for (int p = lane; p < npairs; p += 64) {
+    const int r = pairs[p] >> 6, i = pairs[p] & 63;
+    if (iou_bev(row_pre[r], col_pre[i]) > thresh) atomicOr(&bits_s[r], 1ull << i);
+  }
+  __syncthreads();
+  if (lane < row_size) mask[((int64_t)set * cap + row_blk * 64 + lane) * cb_cap + col_blk] = bits_s[lane];
 }
 
-// One wave per set.  keep [set][cap] receives kept indices in order; num_keep[set] their number.
-static __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
-                                                       const int* __restrict__ counts, int n_fixed,
-                                                       int cap, int cb_cap,
-                                                       int32_t* __restrict__ keep,
-                                                       int32_t* __restrict__ num_keep) {
-  __shared__ unsigned long long remv[kNmsMaxWords];
+// One workgroup per set.  keep [set][cap] receives kept indices in order; num_keep[set] their number.
+// The greedy sweep is inherently serial over the boxes; what can be removed is the memory latency: for
+// sets of up to kNmsLdsBoxes boxes the needed half of the bit matrix is copied into LDS by all 256 threads
+// first (one bulk round trip), then wave 0 sweeps 64 boxes per step entirely out of LDS.
+constexpr int kNmsLdsBoxes = 1024;
+constexpr int kNmsLdsWords = kNmsLdsBoxes / 64;
+
+static __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
+                                                               const int* __restrict__ counts, int n_fixed,
+                                                               int cap, int cb_cap,
+                                                               int32_t* __restrict__ keep,
+                                                               int32_t* __restrict__ num_keep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long nms_smem[];
+  unsigned long long* remv = nms_smem;               // [kNmsMaxWords]
+  unsigned long long* mlds = nms_smem + kNmsMaxWords;  // [n][cbs] when the set fits
   const int set = blockIdx.x;
   const int n = counts ? min(counts[set], cap) : n_fixed;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int cbs = (n + 63) / 64;
   const unsigned long long* m = mask + (int64_t)set * cap * cb_cap;
   int32_t* kp = keep + (int64_t)set * cap;
-  for (int j = lane; j < cbs; j += 64) remv[j] = 0ull;
+  const bool in_lds = n <= kNmsLdsBoxes;
+  for (int j = threadIdx.x; j < cbs; j += blockDim.x) remv[j] = 0ull;
+  if (in_lds) {
+    for (int e = threadIdx.x; e < n * cbs; e += blockDim.x) {
+      const int i = e / cbs, j = e - i * cbs;
+      if (j >= (i >> 6)) mlds[e] = m[(int64_t)i * cb_cap + j];  // upper triangle only
+    }
+  }
   __syncthreads();
+  if (threadIdx.x >= 64) return;
   int kept_total = 0;
   for (int nb = 0; nb < cbs; ++nb) {
     const int rows = min(n - nb * 64, 64);
     // diagonal word of each row of this block
     unsigned long long diag = 0ull;
-    if (lane < rows) diag = m[(int64_t)(nb * 64 + lane) * cb_cap + nb];
+    if (lane < rows)
+      diag = in_lds ? mlds[(nb * 64 + lane) * cbs + nb] : m[(int64_t)(nb * 64 + lane) * cb_cap + nb];
     unsigned long long cur = remv[nb];  // uniform
     unsigned long long keepbits = 0ull;
     for (int t = 0; t < rows; ++t) {
@@ -103,13 +154,21 @@ static __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned lon
       while (kb) {
         const int t = __ffsll((long long)kb) - 1;
         kb &= kb - 1ull;
-        acc |= m[(int64_t)(nb * 64 + t) * cb_cap + j];
+        acc |= in_lds ? mlds[(nb * 64 + t) * cbs + j] : m[(int64_t)(nb * 64 + t) * cb_cap + j];
       }
       remv[j] = acc;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   if (lane == 0) num_keep[set] = kept_total;
+}
+
+// dynamic LDS bytes for nms_sweep_kernel given the largest set size
+static inline size_t nms_sweep_lds(int cap) {
+  size_t b = (size_t)kNmsMaxWords * 8;
+  if (cap <= kNmsLdsBoxes) b += (size_t)cap * ((cap + 63) / 64) * 8;
+  return b;
 }
 
 }  // namespace pd3

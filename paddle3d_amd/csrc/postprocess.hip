@@ -287,7 +287,15 @@ extern "C" int pd3_centerpoint_postprocess(
   dim3 mgrid(cb, cb, sets);
   nms_mask_kernel<false><<<mgrid, 64, 0, s>>>(w.nms_boxes, w.counts, 0, cap, cb, nms_iou_threshold,
                                               w.mask);
-  nms_sweep_kernel<<<sets, 64, 0, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);
+  {
+    const size_t lds = nms_sweep_lds(cap);
+    if (lds > 48 * 1024) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    nms_sweep_kernel<<<sets, 256, lds, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);
+  }
   cp_output_kernel<<<batch, 256, 0, s>>>(w.boxes, w.scores, w.labels, sidx, w.counts, w.keep, w.nkeep, h,
                                      num_tasks, hw, c.dims, cap, nms_post_max_size, out_bboxes,
                                      out_scores, out_labels, out_count);

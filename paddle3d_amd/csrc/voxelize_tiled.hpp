@@ -95,6 +95,12 @@ __device__ __forceinline__ uint32_t vt_group_to_key(uint32_t grp, uint32_t local
   return local * G + lo;
 }
 
+// x, y, z of a point as ONE 12-byte load (global_load_dwordx3 needs only dword alignment); the separate
+// p[0], p[1], p[2] loads cost three address-coalescing passes over the same cache lines.
+struct __attribute__((packed, aligned(4))) VtXyz {
+  float x, y, z;
+};
+
 __device__ __forceinline__ bool vt_axis_cell(float p, float lo, float size, int extent, int& c) {
   const float q = floorf((p - lo) / size);  // voxelize_op.cc:37-45; see axis_cell in voxelize.hip
   if (!(q >= 0.0f && q < (float)extent)) return false;
@@ -148,10 +154,10 @@ __global__ __launch_bounds__(kVtRouteThreads) void vt_route_kernel(
     const int64_t i = wave_base + r * kWave + lane;
     uint32_t k = 0xFFFFFFFFu;
     if (i < nf) {
-      const float* p = pf + i * dim;
+      const VtXyz p = *reinterpret_cast<const VtXyz*>(pf + i * dim);
       int cx, cy, cz;
-      if (vt_axis_cell(p[0], g.min_x, g.size_x, g.gx, cx) && vt_axis_cell(p[1], g.min_y, g.size_y, g.gy, cy) &&
-          vt_axis_cell(p[2], g.min_z, g.size_z, g.gz, cz)) {
+      if (vt_axis_cell(p.x, g.min_x, g.size_x, g.gx, cx) && vt_axis_cell(p.y, g.min_y, g.size_y, g.gy, cy) &&
+          vt_axis_cell(p.z, g.min_z, g.size_z, g.gz, cz)) {
         const uint32_t cellkey = ((uint32_t)cz * (uint32_t)g.gy + (uint32_t)cy) * (uint32_t)g.gx + (uint32_t)cx;
         uint32_t grp, local;
         vt_key_to_group(cellkey, (uint32_t)groups, inv_g, grp, local);
