@@ -207,6 +207,22 @@ int pd3_sparse_conv3d_features(const float *in_feats, const int32_t *nbr, const 
 int pd3_sparse_to_dense(const float *feats, const int32_t *coords, const int32_t *n, int n_cap,
                         int channels, int batch, const int *spatial_shape, float *dense, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * merge_sweeps -- the caller-side step right before hard_voxelize on the nuScenes path:
+ * LoadPointCloud.__call__'s multi-sweep merge, paddle3d/transforms/reader.py:118-164.
+ *   points         [sweep_offsets[num_sweeps], dim_in] fp32: key frame first, then the sweeps (device)
+ *   sweep_offsets  host int64[num_sweeps + 1]; sweep 0 is the key frame (kept untouched)
+ *   ref_from_curr  host double[num_sweeps][16] row-major 4x4 (NULL: no transform); time_lag host
+ *                  float[num_sweeps] (NULL: zeros); remove_radius = sweep_remove_radius
+ *   out            [<= total points, use_dim (+1 if use_time_lag)] fp32, rows in the reference's
+ *                  concatenation order (given the sweep order); num_out [1] int32 (device)
+ */
+size_t pd3_merge_sweeps_workspace(int64_t num_points);
+int pd3_merge_sweeps(const float *points, const int64_t *sweep_offsets, int num_sweeps, int dim_in,
+                     int use_dim, const double *ref_from_curr, const float *time_lag, int use_time_lag,
+                     float remove_radius, float *out, int32_t *num_out, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,6 +211,25 @@ def hard_vfe_forward_torch(voxels, num_points, coors, params, voxel_size, pc_ran
     return x.squeeze(1).numpy()
 
 
+def merge_sweeps_numpy(key_frame, sweeps, ref_from_curr, time_lags, use_dim=None, use_time_lag=True, radius=1.0):
+    """LoadPointCloud.__call__ multi-sweep merge (reader.py:118-164) for a GIVEN sweep order."""
+    data = key_frame if use_dim is None else key_frame[:, :use_dim]
+    if use_time_lag:
+        data = np.hstack([data, np.zeros((data.shape[0], 1), dtype=data.dtype)])
+    out = [data]
+    for sw, m, lag in zip(sweeps, ref_from_curr, time_lags):
+        sd = (sw if use_dim is None else sw[:, :use_dim]).T.copy()
+        not_close = np.logical_not(np.logical_and(np.abs(sd[0, :]) < radius, np.abs(sd[1, :]) < radius))
+        sd = sd[:, not_close]
+        if m is not None:
+            sd[:3, :] = np.asarray(m).dot(np.vstack((sd[:3, :], np.ones(sd.shape[1]))))[:3, :]
+        sd = sd.T
+        if use_time_lag:
+            sd = np.hstack([sd, lag * np.ones((sd.shape[0], 1)).astype(sd.dtype)])
+        out.append(sd)
+    return np.concatenate(out, axis=0)
+
+
 def lss_voxel_pooling_numpy(geom, x, dx, bx, nx):
     """LiftSplatShoot.voxel_pooling with the cumsum trick (cam_stream_lss.py:111-121, :318-373), NumPy.
     geom [B,N,D,H,W,3] metric coordinates, x [B,N,D,H,W,C] -> [B, C, Z, X, Y]."""
