@@ -223,6 +223,18 @@ int pd3_merge_sweeps(const float *points, const int64_t *sweep_offsets, int num_
                      float remove_radius, float *out, int32_t *num_out, void *workspace,
                      size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * conv3x3_bias_relu -- dense 3x3 / stride 1 / pad 1 convolution with fused bias and ReLU on the fp32
+ * matrix cores: the stride-1 convolutions of SecondBackbone (paddle3d/models/backbones/second_backbone.py:
+ * 72-120) and CenterHead / SeparateHead (detection/centerpoint/center_head.py:43-220) with BatchNorm folded
+ * into weight and bias (cuDNN convolutions in the reference).
+ *   x [batch, cin, h, w] fp32 NCHW;  out [batch, cout, h, w];  bias [cout] or NULL
+ *   w_packed: the [cout, cin, 3, 3] weight re-ordered to [cout/64][cin/8][72 = ci*9 + ky*3 + kx][64]
+ *   requires cin % 8 == 0, cout % 64 == 0 and (w % 128 == 0 | w % 64 == 0 & h % 2 == 0 | w % 32 == 0 & h % 4 == 0)
+ */
+int pd3_conv3x3_bias_relu(const float *x, const float *w_packed, const float *bias, int batch, int cin,
+                          int cout, int h, int w, int relu, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

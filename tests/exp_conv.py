@@ -1,0 +1,38 @@
+"""Experiment driver (not a test): conv3x3 MFMA kernel vs MIOpen on the dense-graph layer shapes."""
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from paddle3d_amd.ops import conv  # noqa: E402
+
+torch.backends.cudnn.benchmark = True
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / iters * 1e3
+
+
+for cin, cout, hw in [(64, 64, 256), (128, 128, 128), (256, 256, 64), (384, 64, 128), (64, 2304, 128)]:
+    x = torch.randn(B, cin, hw, hw, device="cuda")
+    w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
+    b = torch.randn(cout, device="cuda")
+    wp = conv.pack_conv3x3_weight(w)
+    out = torch.empty(B, cout, hw, hw, device="cuda")
+    t_mi = timeit(lambda: F.relu_(F.conv2d(x, w, b, padding=1)))
+    t_me = timeit(lambda: conv.conv3x3_bias_relu(x, wp, b, cout, True, out=out))
+    fl = 2 * cin * cout * 9 * hw * hw * B / 1e12
+    err = (out - F.relu(F.conv2d(x, w, b, padding=1))).abs().max().item()
+    print(f"cin {cin:4d} cout {cout:4d} hw {hw:3d}: miopen {t_mi:7.3f} ms ({fl / t_mi * 1e3:6.1f} TF)  "
+          f"mfma {t_me:7.3f} ms ({fl / t_me * 1e3:6.1f} TF)  max|diff| {err:.2e}")

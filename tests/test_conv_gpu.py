@@ -1,0 +1,44 @@
+"""conv3x3_bias_relu (fp32 MFMA) vs torch conv2d on the CPU (fp32)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(2, 64, 64, 32, 128), (1, 64, 128, 8, 64), (2, 8, 64, 4, 32), (1, 128, 128, 64, 64), (1, 384, 64, 16, 128)]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", CASES)
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv3x3_matches_torch(n, cin, cout, h, w, relu):
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, b, padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    out = conv.conv3x3_bias_relu(x.cuda(), conv.pack_conv3x3_weight(wt.cuda()), b.cuda(), cout, relu).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 2e-4, (out - ref).abs().max().item()
+
+
+def test_asymmetric_identity():
+    """A = I against an asymmetric input catches a transposed / mis-rowed accumulator layout."""
+    from paddle3d_amd.ops import conv
+
+    cin = cout = 64
+    wt = torch.zeros(cout, cin, 3, 3)
+    wt[torch.arange(64), torch.arange(64), 1, 1] = 1.0  # identity, centre tap
+    x = torch.arange(1 * 64 * 4 * 128, dtype=torch.float32).reshape(1, 64, 4, 128) / 1000.0
+    out = conv.conv3x3_bias_relu(x.cuda(), conv.pack_conv3x3_weight(wt.cuda()), None, cout, False).cpu()
+    assert torch.equal(out, x)
+    # shift taps: output = input shifted by one pixel in x (zero padding at the border)
+    wt2 = torch.zeros(cout, cin, 3, 3)
+    wt2[torch.arange(64), torch.arange(64), 1, 0] = 1.0
+    out2 = conv.conv3x3_bias_relu(x.cuda(), conv.pack_conv3x3_weight(wt2.cuda()), None, cout, False).cpu()
+    want = torch.zeros_like(x)
+    want[..., 1:] = x[..., :-1]
+    assert torch.equal(out2, want)
