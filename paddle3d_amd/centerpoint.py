@@ -21,6 +21,7 @@ torch is plumbing here (device memory, streams, MIOpen); the LiDAR-specific work
 from __future__ import annotations
 
 import math
+import os
 from typing import Sequence
 
 import numpy as np
@@ -29,6 +30,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .ops import centerpoint_postprocess as _cp
+from .ops import conv as _conv
 from .ops import pointpillars_scatter as _ps
 from .ops import voxel_encoder as _ve
 from .ops import voxelize as _vox
@@ -380,6 +382,10 @@ class CenterPoint(nn.Module):
         self.test_cfg = test_cfg
         self.box_with_velocity = box_with_velocity
         self._dense = None
+        # "miopen": PyTorch-ROCm convolutions (default, currently the faster one); "hip": the hand-written
+        # fp32-MFMA kernel (ops/conv.py) for the stride-1 3x3 backbone convolutions
+        self.dense_backend = os.environ.get("PD3_DENSE_BACKEND", "miopen")
+        self._packed = {}
 
     def _pack(self, points):
         if isinstance(points, torch.Tensor):
@@ -419,9 +425,15 @@ class CenterPoint(nn.Module):
         nb = len(self.backbone.blocks)
         self._dense = (seqs[:nb], seqs[nb:])
 
-    @staticmethod
-    def _run(layers, x):
+    def _run(self, layers, x):
         for tr, w, b, stride, padding in layers:
+            if (self.dense_backend == "hip" and not tr and tuple(w.shape[2:]) == (3, 3) and tuple(stride) == (1, 1)
+                    and tuple(padding) == (1, 1) and _conv.supported(w.shape[1], w.shape[0], x.shape[2], x.shape[3])):
+                key = w.data_ptr()
+                if key not in self._packed:
+                    self._packed[key] = _conv.pack_conv3x3_weight(w)
+                x = _conv.conv3x3_bias_relu(x, self._packed[key], b, w.shape[0], relu=True)
+                continue
             x = F.conv_transpose2d(x, w, b, stride=stride, padding=padding) if tr else \
                 F.conv2d(x, w, b, stride=stride, padding=padding)
             x = F.relu_(x)
