@@ -194,10 +194,24 @@ def main():
                                                     for k in range(args.steps)]))
         alg = algorithmic_bytes(V)
 
+        # HBM traffic per launch from the PMC passes (tools/gpu_traffic.sh -> profiles/*_traffic.json), when a
+        # profile of this exact configuration is committed; collected offline because rocprofv3 --pmc cannot
+        # wrap the timed run itself
+        traffic = {}
+        try:
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+                t = json.load(open(path))
+                if t.get("batch") == B and t.get("max_voxels") == V:
+                    traffic = t
+        except Exception:  # noqa: BLE001
+            traffic = {}
+
         def hbm(name, key):
             a = alg[key] * B / (per_op_ms[name] * 1e-3) / 1e9
+            tr = traffic.get(key, {}).get("bytes_per_launch")
             return dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBPS, unit="GB/s", frac=a / HBM_PEAK_GBPS,
-                        traffic=None, ms_per_launch=per_op_ms[name], units_per_launch=B,
+                        traffic=tr, ms_per_launch=per_op_ms[name], units_per_launch=B,
                         algorithmic_bytes_per_unit=alg[key])
 
         tf = dense_flops() * B / (per_op_ms["dense"] * 1e-3) / 1e12

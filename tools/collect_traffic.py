@@ -1,0 +1,53 @@
+"""Aggregate the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a bench.py run into per-op HBM
+traffic per launch -> profiles/<tag>_traffic.json (read back by bench.py to fill `roofline.traffic`).
+
+    usage: collect_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps> <out.json> <batch> <max_voxels>
+
+Units / corrections (MI355X_MICROARCH.md section HBM): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports exactly half of a streamed read -- calibrated here on vt_route_kernel, whose only HBM
+reads are the points (batch * 6.0 MB): the x2 factor reproduces that byte count to 2 %; WRITE_SIZE of
+vt_write_kernel matches its known 100.4 MB per 8 scenes to 3 % without correction.
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+OPS = {
+    "hard_voxelize": ("vt_route", "vt_group", "vt_count", "vt_assign", "vt_write", "cell_key", "seg_head",
+                      "gather_voxels", "voxel_meta", "EpiVoxelStart", "LoadNonNegative"),
+    "pillar_feature_net": ("pfn_kernel",),
+    "pointpillars_scatter": ("fill_i32", "inverse_map", "canvas_write"),
+    "centerpoint_postprocess": ("cp_decode", "cp_nms_boxes", "cp_output", "nms_mask", "nms_sweep"),
+}
+# the radix sort / scan kernels are shared: with the tiled voxelizer active they belong to the postprocess
+SHARED = ("rs_hist", "rs_scatter", "scan_reduce", "scan_partials", "scan_apply")
+
+
+def load(path):
+    acc = defaultdict(float)
+    for r in csv.DictReader(open(path)):
+        acc[r["Kernel_Name"]] += float(r["Counter_Value"])
+    return acc
+
+
+def main():
+    fetch, write = load(sys.argv[1]), load(sys.argv[2])
+    launches = int(sys.argv[3])  # steps + warmup of the profiled bench run
+    out = {"batch": int(sys.argv[5]), "max_voxels": int(sys.argv[6]), "launches_profiled": launches,
+           "note": "bytes per launch (= per bench step) ; fetch corrected x2 (gfx950 FETCH_SIZE), write uncorrected"}
+    tiled = any("vt_route" in k for k in fetch)
+    ops = dict(OPS)
+    owner = "centerpoint_postprocess" if tiled else "hard_voxelize"
+    ops[owner] = ops[owner] + SHARED
+    for op, pats in ops.items():
+        f = sum(v for k, v in fetch.items() if any(p in k for p in pats))
+        w = sum(v for k, v in write.items() if any(p in k for p in pats))
+        out[op] = {"fetch_size_kib_raw": f / launches, "write_size_kib": w / launches,
+                   "bytes_per_launch": (2.0 * f + w) * 1024.0 / launches}
+    json.dump(out, open(sys.argv[4], "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
