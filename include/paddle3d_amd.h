@@ -48,6 +48,9 @@ const char *pd3_target_arch(void);
  *   coords            [batch, max_voxels, 3] int32 (z, y, x), zero padded
  *   num_points_per_voxel [batch, max_voxels] int32, zero padded
  *   num_voxels        [batch] int32
+ *   coors_batched     optional (NULL to skip) [batch, max_voxels, 4] int32 (batch, z, y, x) with batch = -1 on
+ *                     padding rows: the `coors_pad` HardVoxelizer.single_forward builds with cast + F.pad
+ *                     (voxelize.py:51-57), written by the same pass
  * batch = 1 is exactly the reference op; batch > 1 is the reference's HardVoxelizer python loop
  * (paddle3d/models/voxelizers/voxelize.py:60-82) in one launch sequence.
  */
@@ -57,8 +60,8 @@ size_t pd3_hard_voxelize_workspace(int batch, int64_t max_points, int num_point_
 int pd3_hard_voxelize(const float *points, const int32_t *num_points, int batch, int64_t max_points,
                       int num_point_dim, const float *voxel_size, const float *point_cloud_range,
                       int max_num_points_in_voxel, int max_voxels, float *voxels, int32_t *coords,
-                      int32_t *num_points_per_voxel, int32_t *num_voxels, void *workspace,
-                      size_t workspace_bytes, void *stream);
+                      int32_t *num_points_per_voxel, int32_t *num_voxels, int32_t *coors_batched,
+                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * pointpillars_scatter -- replaces PointPillarsScatter.forward_batch,

@@ -23,7 +23,7 @@ _SIGNATURES = {
                                                  C.c_int, C.c_int]),
     "pd3_hard_voxelize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pd3_pointpillars_scatter_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "pd3_pointpillars_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -62,14 +62,11 @@ class HardVoxelizer(nn.Module):
 
     def forward(self, points: torch.Tensor, num_points: torch.Tensor | None = None):
         v = self.max_num_voxels[0] if self.training else self.max_num_voxels[1]
-        voxels, coords, npv, nv = _vox.hard_voxelize_batch(points, self.voxel_size, self.point_cloud_range,
-                                                           self.max_num_points_in_voxel, v, num_points)
-        b = points.shape[0]
-        # batch column (voxelize.py:51-57 does this through a float cast + F.pad); -1 marks padding rows
-        ar = torch.arange(v, device=points.device, dtype=torch.int32).unsqueeze(0)
-        bcol = torch.arange(b, device=points.device, dtype=torch.int32).unsqueeze(1).expand(b, v)
-        bcol = torch.where(ar < nv.unsqueeze(1), bcol, torch.full_like(bcol, -1))
-        coors = torch.cat([bcol.unsqueeze(-1), coords], dim=-1)
+        # the batch column (voxelize.py:51-57 builds it through a float cast + F.pad) is written by the op
+        # itself; -1 marks padding rows
+        voxels, _, npv, nv, coors = _vox.hard_voxelize_batch(points, self.voxel_size, self.point_cloud_range,
+                                                             self.max_num_points_in_voxel, v, num_points,
+                                                             with_batch_coors=True)
         return voxels, coors, npv, nv
 
 

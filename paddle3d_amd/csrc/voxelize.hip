@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void gather_voxels_kernel(
 __global__ __launch_bounds__(256) void voxel_meta_kernel(
     const uint32_t* __restrict__ skey, const int* __restrict__ vox_start,
     const int* __restrict__ totals, int64_t n, int max_pts, int max_voxels, VoxGrid g,
-    int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ num_voxels) {
+    int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ num_voxels,
+    int32_t* __restrict__ coors4) {
   const int frame = blockIdx.y;
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   const int nv = min(totals[frame], max_voxels);
@@ -151,6 +152,13 @@ __global__ __launch_bounds__(256) void voxel_meta_kernel(
   co[1] = cy;
   co[2] = cx;
   num_pts[(int64_t)frame * max_voxels + v] = cnt;
+  if (coors4) {
+    int32_t* c4 = coors4 + ((int64_t)frame * max_voxels + v) * 4;
+    c4[0] = v < nv ? frame : -1;
+    c4[1] = cz;
+    c4[2] = cy;
+    c4[3] = cx;
+  }
 }
 
 static bool make_grid(const float* voxel_size, const float* range, VoxGrid& g) {
@@ -252,11 +260,11 @@ static void launch_write(int dim, dim3 grid, hipStream_t s, const float* points,
                          const uint32_t* vid2key, const int* vid_npts, const int* totals, int64_t n,
                          uint32_t ncells,
                          int max_pts, int max_voxels, int rowq, VtGrid vg, float* voxels,
-                         int32_t* coords, int32_t* num_pts, int32_t* num_voxels) {
+                         int32_t* coords, int32_t* num_pts, int32_t* num_voxels, int32_t* coors4) {
 #define PD3_VT_WRITE(D)                                                                           \
   vt_write_kernel<VEC, D><<<grid, dim3(32, kVtWriteRows), 0, s>>>(                                  \
       points, cells, vid2key, vid_npts, totals, n, ncells, dim, max_pts, max_voxels, rowq, vg, voxels,   \
-      coords, num_pts, num_voxels)
+      coords, num_pts, num_voxels, coors4)
   switch (dim) {
     case 3: PD3_VT_WRITE(3); break;
     case 4: PD3_VT_WRITE(4); break;
@@ -270,7 +278,7 @@ static void launch_write(int dim, dim3 grid, hipStream_t s, const float* points,
 static int run_tiled(const float* points, const int32_t* num_points, int batch, int64_t n, int dim,
                      const VoxGrid& g, int max_pts, int max_voxels, const VtPlan& plan,
                      float* voxels, int32_t* coords, int32_t* num_pts, int32_t* num_voxels,
-                     void* workspace, hipStream_t s) {
+                     int32_t* coors4, void* workspace, hipStream_t s) {
   VtWorkspace w = vt_carve(workspace, batch, n, max_pts, max_voxels, g.ncells, plan);
   VtGrid vg{g.min_x, g.min_y, g.min_z, g.size_x, g.size_y, g.size_z, g.gx, g.gy, g.gz, g.ncells};
   hipError_t e = hipSuccess;
@@ -304,10 +312,10 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
   dim3 dgrid((unsigned)ceil_div(max_voxels, kVtWriteRows * kVtWriteIlp), batch);
   if (vec4)
     launch_write<4>(dim, dgrid, s, points, cells, w.vid2key, w.vid_npts, w.totals, n, g.ncells, max_pts,
-                    max_voxels, rowq, vg, voxels, coords, num_pts, num_voxels);
+                    max_voxels, rowq, vg, voxels, coords, num_pts, num_voxels, coors4);
   else
     launch_write<1>(dim, dgrid, s, points, cells, w.vid2key, w.vid_npts, w.totals, n, g.ncells, max_pts,
-                    max_voxels, rowq, vg, voxels, coords, num_pts, num_voxels);
+                    max_voxels, rowq, vg, voxels, coords, num_pts, num_voxels, coors4);
   return launch_status();
 }
 
@@ -335,7 +343,8 @@ extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points,
                                  const float* point_cloud_range, int max_num_points_in_voxel,
                                  int max_voxels, float* voxels, int32_t* coords,
                                  int32_t* num_points_per_voxel, int32_t* num_voxels,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+                                 int32_t* coors_batched, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
   VoxGrid g;
   if (!points || !voxels || !coords || !num_points_per_voxel || !num_voxels || !workspace)
     return PD3_EINVAL;
@@ -356,7 +365,8 @@ extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points,
     if (ov == 2 && !can) return PD3_EUNSUPPORTED;
     if (can && ov != 1)
       return run_tiled(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel,
-                       max_voxels, vp, voxels, coords, num_points_per_voxel, num_voxels, workspace, s);
+                       max_voxels, vp, voxels, coords, num_points_per_voxel, num_voxels, coors_batched,
+                       workspace, s);
   }
   const RadixPlan plan = radix_plan(g.ncells, max_points);
   VoxWorkspace w = carve(workspace, batch, max_points, max_voxels, plan);
@@ -378,7 +388,7 @@ extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points,
                                              voxels);
   dim3 mgrid((unsigned)ceil_div(max_voxels, 256), batch);
   voxel_meta_kernel<<<mgrid, 256, 0, s>>>(skey, w.vox_start, w.totals, n, max_num_points_in_voxel,
-                                          max_voxels, g, coords, num_points_per_voxel, num_voxels);
+                                          max_voxels, g, coords, num_points_per_voxel, num_voxels, coors_batched);
   return launch_status();
 }
 

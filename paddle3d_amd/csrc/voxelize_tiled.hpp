@@ -429,7 +429,8 @@ __global__ __launch_bounds__(256) void vt_write_kernel(
     const float* __restrict__ points, VtCells s, const uint32_t* __restrict__ vid2key,
     const int* __restrict__ vid_npts, const int* __restrict__ totals, int64_t n, uint32_t ncells,
     int dim_rt, int max_pts, int max_voxels, int rowq, VtGrid g, float* __restrict__ voxels,
-    int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ num_voxels) {
+    int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ num_voxels,
+    int32_t* __restrict__ coors4) {
   const int dim = DIM > 0 ? DIM : dim_rt;
   const int frame = blockIdx.y;
   const int nv = min(totals[frame], max_voxels);
@@ -495,6 +496,10 @@ __global__ __launch_bounds__(256) void vt_write_kernel(
         co[1] = cy;
         co[2] = cx;
         num_pts[(int64_t)frame * max_voxels + v[j]] = np[j];
+        if (coors4) {  // (batch, z, y, x), batch = -1 on padding rows (HardVoxelizer's coors_pad)
+          *reinterpret_cast<int4*>(coors4 + ((int64_t)frame * max_voxels + v[j]) * 4) =
+              make_int4(v[j] < nv ? frame : -1, cz, cy, cx);
+        }
       }
     }
   }

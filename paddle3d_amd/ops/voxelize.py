@@ -17,11 +17,12 @@ __all__ = ["hard_voxelize", "hard_voxelize_batch"]
 
 
 def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max_num_points_in_voxel: int,
-                        max_voxels: int, num_points: torch.Tensor | None = None):
+                        max_voxels: int, num_points: torch.Tensor | None = None, with_batch_coors: bool = False):
     """points [B, N, D] fp32 on the GPU; num_points optional int32 [B] (valid rows per frame).
 
     Returns voxels [B,V,P,D], coords [B,V,3], num_points_per_voxel [B,V], num_voxels [B] -- the
     reference's per-sample op results stacked (HardVoxelizer's python loop, voxelize.py:60-82).
+    with_batch_coors=True additionally returns coors [B,V,4] = (batch, z, y, x), batch -1 on padding rows.
     """
     pts = require_gpu(points, "hard_voxelize")
     if pts.dim() != 3:
@@ -34,6 +35,7 @@ def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max
     coords = torch.empty((b, v, 3), dtype=torch.int32, device=dev)
     npv = torch.empty((b, v), dtype=torch.int32, device=dev)
     nv = torch.empty((b,), dtype=torch.int32, device=dev)
+    coors4 = torch.empty((b, v, 4), dtype=torch.int32, device=dev) if with_batch_coors else None
     if num_points is not None:
         num_points = require_gpu(num_points, "hard_voxelize", torch.int32)
     L = lib()
@@ -42,8 +44,10 @@ def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max
         raise RuntimeError("hard_voxelize: invalid voxel_size / point_cloud_range / sizes")
     ws = workspace(ws_bytes, dev)
     check(L.pd3_hard_voxelize(ptr(pts), ptr(num_points), b, n, d, ptr(vs), ptr(pr), p, v, ptr(voxels),
-                              ptr(coords), ptr(npv), ptr(nv), ptr(ws), ws.numel(), stream_ptr(dev)),
+                              ptr(coords), ptr(npv), ptr(nv), ptr(coors4), ptr(ws), ws.numel(), stream_ptr(dev)),
           "hard_voxelize")
+    if with_batch_coors:
+        return voxels, coords, npv, nv, coors4
     return voxels, coords, npv, nv
 
 

@@ -140,3 +140,17 @@ def test_properties_full_size():
     assert int(nv2.item()) == n
     np.testing.assert_array_equal(co2.cpu().numpy()[:n], co[:n])
     np.testing.assert_array_equal(npv2.cpu().numpy()[:n], npv[:n])
+
+
+def test_batched_coors_output(oracle):
+    """coors_batched = (batch, z, y, x) with -1 on padding rows, from both paths."""
+    from paddle3d_amd.ops import voxelize
+
+    frames = np.stack([synth.nuscenes_sweep(30 + i, n_points=40000) for i in range(2)])
+    out = voxelize.hard_voxelize_batch(torch.from_numpy(frames).cuda(), list(synth.NUSC_PILLAR),
+                                       list(synth.NUSC_RANGE), 20, 12000, with_batch_coors=True)
+    vox, co, npv, nv, c4 = [o.cpu().numpy() for o in out]
+    for b in range(2):
+        n = int(nv[b])
+        np.testing.assert_array_equal(c4[b, :, 1:], co[b])
+        assert (c4[b, :n, 0] == b).all() and (c4[b, n:, 0] == -1).all()
