@@ -154,7 +154,8 @@ __global__ __launch_bounds__(kVtRouteThreads) void vt_route_kernel(
     const int64_t i = wave_base + r * kWave + lane;
     uint32_t k = 0xFFFFFFFFu;
     if (i < nf) {
-      const VtXyz p = *reinterpret_cast<const VtXyz*>(pf + i * dim);
+      VtXyz p;
+      __builtin_memcpy(&p, pf + i * dim, sizeof(VtXyz));  // 4-byte aligned 12-byte load
       int cx, cy, cz;
       if (vt_axis_cell(p.x, g.min_x, g.size_x, g.gx, cx) && vt_axis_cell(p.y, g.min_y, g.size_y, g.gy, cy) &&
           vt_axis_cell(p.z, g.min_z, g.size_z, g.gz, cz)) {
