@@ -5,25 +5,30 @@
 //
 // Implicit GEMM, D[co][pixel] = sum_k W[co][k] * X[k][pixel], k = (ci, ky, kx), on
 // v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 157 TFLOP/s peak -- there is no TF32 on gfx950).
-// Workgroup tile: 64 output channels x 128 pixels (R rows x WT columns of one image, R * WT = 128), four
-// waves, wave w owns pixel columns [32w, 32w+32) for both 32-channel row blocks (2 accumulators of 16
-// registers).  K is walked 8 input channels (72 taps) at a time:
-//   X chunk  -> LDS as [8][R+2][WT+2] (halo included, zero outside the image): for tap (ky,kx) the 32 pixels
-//               of a wave are consecutive floats => conflict-free ds_read_b32 for the B operand;
-//   W chunk  -> LDS as [72][64], pre-packed on the host in exactly this order so the copy is linear and the
-//               A operand (lane = output channel) is conflict-free.
-// Several workgroups per CU (30 KB of LDS each) overlap one another's staging with MFMA issue; the
-// epilogue adds the bias, applies ReLU and writes 128-byte row segments.
+// Workgroup tile: 64 output channels x (R rows x WT columns) pixels of one image, R * WT = 128 or 256; four
+// waves, wave w owns NB = R*WT/128 blocks of 32 pixels for both 32-channel row blocks (2*NB accumulators of
+// 16 registers).  K is walked 8 input channels (72 taps) at a time, as 36 MFMA steps (channel pair cp, tap):
+// the two K lanes of the instruction (lane >> 5) take channels 2cp and 2cp+1 of the SAME tap, so every LDS
+// address of the step is a per-lane base plus a compile-time constant -- the unrolled loop is ds_read with
+// immediate offsets and MFMA only, no integer VALU work.
+//   X chunk  -> LDS as [8][R+2][WT+8] (staged with aligned float4 loads from column x0-4, zero outside the
+//               image): for tap (ky,kx) the 32 pixels of a block are consecutive floats => conflict-free
+//               ds_read_b32 for the B operand;
+//   W chunk  -> LDS as [36 steps][2 K lanes][64], pre-packed on the host in exactly this order so the copy
+//               is linear and the A operand (lane = output channel) is conflict-free.
+// Software pipeline: chunk c+1 travels global -> registers while the matrix cores work on chunk c out of LDS
+// buffer c & 1; the registers are parked in the other buffer after the MFMA loop (one barrier per chunk).
+// The epilogue adds the bias, applies ReLU and writes 128-byte row segments.
 #include "../../include/paddle3d_amd.h"
 #include "common.hpp"
 
 namespace pd3 {
 
 typedef float cv_f32x16 __attribute__((ext_vector_type(16)));
+typedef float cv_f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kCvCo = 64;    // output channels per tile
-constexpr int kCvPix = 128;  // pixels per tile
-constexpr int kCvCi = 8;     // input channels per K chunk
+constexpr int kCvCo = 64;  // output channels per tile
+constexpr int kCvCi = 8;   // input channels per K chunk
 constexpr int kCvK = kCvCi * 9;
 
 template <int R, int WT>
@@ -32,75 +37,157 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
                                                            const float* __restrict__ bias,
                                                            float* __restrict__ out, int cin, int cout,
                                                            int h, int w, int relu) {
-  static_assert(R * WT == kCvPix, "tile must hold 128 pixels");
-  constexpr int XR = R + 2, XW = WT + 2;
-  __shared__ float Xs[kCvCi * XR * XW];
-  __shared__ __attribute__((aligned(16))) float Ws[kCvK * kCvCo];
-  __shared__ int koff[kCvK];
+  static_assert(R * WT == 128 || R * WT == 256, "tile must hold 128 or 256 pixels");
+  constexpr int NB = R * WT / 128;           // 32-pixel blocks per wave
+  constexpr int XR = R + 2, XW = WT + 8;     // staged columns x0-4 .. x0+WT+3
+  constexpr int XQ = XW / 4;                 // float4 per staged row
+  constexpr int XPL = XR * XW;               // floats per staged channel plane
+  constexpr int XN4 = kCvCi * XR * XQ;       // float4 of one X chunk
+  constexpr int XPT = (XN4 + 255) / 256;
+  constexpr int WN4 = kCvK * kCvCo / 4;      // 1152 float4 of one W chunk
+  constexpr int WPT = (WN4 + 255) / 256;
+  constexpr int XSZ = kCvCi * XPL;           // floats per X buffer
+  constexpr int WSZ = kCvK * kCvCo;          // floats per W buffer
+  extern __shared__ __attribute__((aligned(16))) float cv_smem[];  // X[2][XSZ] then W[2][WSZ]
   const int lane = lane_id(), wave = wave_id();
   const int tiles_x = w / WT, tiles_y = h / R;
   const int pt = blockIdx.x;
   const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
   const int ct = blockIdx.y;
   const int y0 = ty * R, x0 = tx * WT;
-  if (threadIdx.x < kCvK) {
-    const int cil = threadIdx.x / 9, tap = threadIdx.x % 9;
-    koff[threadIdx.x] = cil * (XR * XW) + (tap / 3) * XW + (tap % 3);
-  }
-  const int pj = wave * 32 + (lane & 31);
-  const int pr = pj / WT, px = pj % WT;
-  const int pbase = pr * XW + px;
   const int kk = lane >> 5;
-  cv_f32x16 acc0, acc1;
+  // per-lane LDS bases (floats): B operand of pixel block t, A operand of channel block 0
+  int xb[NB];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    acc0[i] = 0.f;
-    acc1[i] = 0.f;
+  for (int t = 0; t < NB; ++t) {
+    const int pj = (wave * NB + t) * 32 + (lane & 31);
+    xb[t] = kk * XPL + (pj / WT) * XW + (pj % WT) + 3;
   }
+  const int wb = 2 * XSZ + kk * kCvCo + (lane & 31);
+  cv_f32x16 acc[2][NB];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
   const int chunks = cin / kCvCi;
-  const float* xin = x + (int64_t)n * cin * h * w;
-  const float4* wsrc = reinterpret_cast<const float4*>(wp + (int64_t)ct * chunks * (kCvK * kCvCo));
-  for (int cc = 0; cc < chunks; ++cc) {
-    __syncthreads();  // previous chunk fully consumed (also publishes koff on the first trip)
-    for (int e = threadIdx.x; e < kCvCi * XR * XW; e += 256) {
-      const int ci = e / (XR * XW), rem = e - ci * (XR * XW);
-      const int r = rem / XW, c = rem - r * XW;
-      const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-      float v = 0.f;
-      if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = xin[((int64_t)(cc * kCvCi + ci) * h + gy) * w + gx];
-      Xs[e] = v;
-    }
-    float4* wdst = reinterpret_cast<float4*>(Ws);
-    for (int e = threadIdx.x; e < kCvK * kCvCo / 4; e += 256) wdst[e] = wsrc[(int64_t)cc * (kCvK * kCvCo / 4) + e];
-    __syncthreads();
-#pragma unroll 4
-    for (int k2 = 0; k2 < kCvK / 2; ++k2) {
-      const int k = 2 * k2 + kk;
-      const float b = Xs[koff[k] + pbase];
-      const float a0 = Ws[k * kCvCo + (lane & 31)];
-      const float a1 = Ws[k * kCvCo + 32 + (lane & 31)];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
-    }
-  }
-  // epilogue: D layout col = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  float* obase = out + (int64_t)n * cout * h * w + (int64_t)(y0 + pr) * w + x0 + px;
+  const int64_t plane = (int64_t)h * w;
+  const float* xin = x + (int64_t)n * cin * plane;
+  // staging pattern, identical for every chunk: float4 e of the LDS image <- global offset inside the chunk
+  // (clamped to a valid address; `live` bit i says whether the value or zero is kept).  Threads past the end
+  // of the image repeat its last float4 (same value to the same address).
+  int gofs[XPT], ldst[XPT];
+  unsigned live = 0;
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kk;
-    {
-      const int co = ct * kCvCo + row;
-      float v = acc0[reg] + (bias ? bias[co] : 0.f);
-      if (relu) v = fmaxf(v, 0.f);
-      obase[(int64_t)co * h * w] = v;
-    }
-    {
-      const int co = ct * kCvCo + 32 + row;
-      float v = acc1[reg] + (bias ? bias[co] : 0.f);
-      if (relu) v = fmaxf(v, 0.f);
-      obase[(int64_t)co * h * w] = v;
-    }
+  for (int i = 0; i < XPT; ++i) {
+    const int e = min((int)threadIdx.x + i * 256, XN4 - 1);
+    const int ci = e / (XR * XQ), rem = e - ci * (XR * XQ);
+    const int r = rem / XQ, c4 = rem - r * XQ;
+    const int gy = y0 - 1 + r, gx = x0 - 4 + c4 * 4;  // a float4 is entirely inside or outside (w % 4 == 0)
+    const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
+    gofs[i] = ok ? (int)(ci * plane + (int64_t)gy * w + gx) : 0;
+    live |= ok ? (1u << i) : 0u;
+    ldst[i] = e * 4;
   }
+  int wofs[WPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) wofs[i] = min((int)threadIdx.x + i * 256, WN4 - 1);
+  const cv_f32x4* wsrc = reinterpret_cast<const cv_f32x4*>(wp) + (int64_t)ct * chunks * WN4;
+  cv_f32x4 xr[XPT], wr[WPT];
+
+#define CV_FETCH(cc)                                                                     \
+  {                                                                                      \
+    const float* xc_ = xin + (int64_t)(cc) * kCvCi * plane;                              \
+    _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                      \
+        xr[i] = *reinterpret_cast<const cv_f32x4*>(xc_ + gofs[i]);                         \
+    const cv_f32x4* wc_ = wsrc + (int64_t)(cc) * WN4;                                      \
+    _Pragma("unroll") for (int i = 0; i < WPT; ++i) wr[i] = wc_[wofs[i]];                \
+  }
+#define CV_STASH(buf)                                                                    \
+  {                                                                                      \
+    float* xd_ = cv_smem + (buf) * XSZ;                                                  \
+    float* wd_ = cv_smem + 2 * XSZ + (buf) * WSZ;                                        \
+    _Pragma("unroll") for (int i = 0; i < XPT; ++i) {                                    \
+      const bool on_ = (live >> i) & 1u;                                                 \
+      const cv_f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                          \
+      *reinterpret_cast<cv_f32x4*>(xd_ + ldst[i]) = on_ ? xr[i] : z_;                    \
+    }                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < WPT; ++i)                                      \
+        *reinterpret_cast<cv_f32x4*>(wd_ + wofs[i] * 4) = wr[i];                         \
+  }
+
+  CV_FETCH(0)
+  CV_STASH(0)
+  __syncthreads();
+  for (int cc = 0; cc < chunks; ++cc) {
+    // the last trip re-fetches its own chunk into the idle buffer: no control flow around the pipeline
+    const int nx = min(cc + 1, chunks - 1);
+    CV_FETCH(nx)
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads in flight ahead of the MFMA block
+    const float* Xs = cv_smem + (cc & 1) * XSZ;
+    const float* Ws = cv_smem + (cc & 1) * WSZ + wb;
+#pragma unroll
+    for (int s = 0; s < kCvK / 2; ++s) {
+      const int cp = s / 9, tap = s % 9;
+      const int xo = 2 * cp * XPL + (tap / 3) * XW + (tap % 3);
+      const float a0 = Ws[s * 2 * kCvCo], a1 = Ws[s * 2 * kCvCo + 32];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const float b = Xs[xb[t] + xo];
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    CV_STASH((cc + 1) & 1)
+    __syncthreads();
+  }
+#undef CV_FETCH
+#undef CV_STASH
+  // epilogue: D layout col = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float bv[2][16];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) bv[m][reg] = 0.f;
+  if (bias) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        bv[m][reg] = bias[ct * kCvCo + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk];
+  }
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    const int pj = (wave * NB + t) * 32 + (lane & 31);
+    float* obase = out + (int64_t)n * cout * plane + (int64_t)(y0 + pj / WT) * w + x0 + (pj % WT);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int co = ct * kCvCo + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+        float v = acc[m][t][reg] + bv[m][reg];
+        if (relu) v = fmaxf(v, 0.f);
+        obase[(int64_t)co * plane] = v;
+      }
+  }
+}
+
+template <int R, int WT>
+static int launch_conv3x3(int64_t tiles, hipStream_t s, const float* x, const float* wp, const float* bias,
+                          float* out, int cin, int cout, int h, int w, int relu) {
+  constexpr size_t lds = (size_t)(2 * kCvCi * (R + 2) * (WT + 8) + 2 * kCvK * kCvCo) * sizeof(float);
+  static bool configured = false;  // raise the dynamic-LDS cap once per instantiation
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<R, WT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  dim3 grid((unsigned)tiles, (unsigned)(cout / kCvCo));
+  conv3x3_mfma_kernel<R, WT><<<grid, 256, lds, s>>>(x, wp, bias, out, cin, cout, h, w, relu);
+  return launch_status();
 }
 
 }  // namespace pd3
@@ -113,20 +200,15 @@ extern "C" int pd3_conv3x3_bias_relu(const float* x, const float* w_packed, cons
   if (!x || !w_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0)
     return PD3_EINVAL;
   if (cin % kCvCi != 0 || cout % kCvCo != 0) return PD3_EUNSUPPORTED;
-  if (reinterpret_cast<uintptr_t>(w_packed) % 16 != 0) return PD3_EINVAL;
+  if (reinterpret_cast<uintptr_t>(w_packed) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0)
+    return PD3_EINVAL;
+  if ((int64_t)cin * h * w >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
   hipStream_t s = static_cast<hipStream_t>(stream);
-  dim3 grid(0, cout / kCvCo);
-  if (w % 128 == 0) {
-    grid.x = (unsigned)((int64_t)batch * h * (w / 128));
-    conv3x3_mfma_kernel<1, 128><<<grid, 256, 0, s>>>(x, w_packed, bias, out, cin, cout, h, w, relu);
-  } else if (w % 64 == 0 && h % 2 == 0) {
-    grid.x = (unsigned)((int64_t)batch * (h / 2) * (w / 64));
-    conv3x3_mfma_kernel<2, 64><<<grid, 256, 0, s>>>(x, w_packed, bias, out, cin, cout, h, w, relu);
-  } else if (w % 32 == 0 && h % 4 == 0) {
-    grid.x = (unsigned)((int64_t)batch * (h / 4) * (w / 32));
-    conv3x3_mfma_kernel<4, 32><<<grid, 256, 0, s>>>(x, w_packed, bias, out, cin, cout, h, w, relu);
-  } else {
-    return PD3_EUNSUPPORTED;
-  }
-  return launch_status();
+  const int64_t px = (int64_t)batch * h * w;
+  if (w % 128 == 0 && h % 2 == 0) return launch_conv3x3<2, 128>(px / 256, s, x, w_packed, bias, out, cin, cout, h, w, relu);
+  if (w % 64 == 0 && h % 4 == 0) return launch_conv3x3<4, 64>(px / 256, s, x, w_packed, bias, out, cin, cout, h, w, relu);
+  if (w % 128 == 0) return launch_conv3x3<1, 128>(px / 128, s, x, w_packed, bias, out, cin, cout, h, w, relu);
+  if (w % 64 == 0 && h % 2 == 0) return launch_conv3x3<2, 64>(px / 128, s, x, w_packed, bias, out, cin, cout, h, w, relu);
+  if (w % 32 == 0 && h % 4 == 0) return launch_conv3x3<4, 32>(px / 128, s, x, w_packed, bias, out, cin, cout, h, w, relu);
+  return PD3_EUNSUPPORTED;
 }

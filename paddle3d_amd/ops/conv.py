@@ -15,10 +15,11 @@ def supported(cin: int, cout: int, h: int, w: int) -> bool:
 
 
 def pack_conv3x3_weight(weight: torch.Tensor) -> torch.Tensor:
-    """[Cout, Cin, 3, 3] -> [Cout/64][Cin/8][72][64] (the order the kernel stages into LDS)."""
+    """[Cout, Cin, 3, 3] -> [Cout/64][Cin/8][4 channel pairs][9 taps][2 channels of the pair][64]
+    (the order the kernel stages into LDS: one MFMA K step = one tap of one channel pair)."""
     cout, cin = weight.shape[:2]
     assert weight.shape[2:] == (3, 3) and cout % 64 == 0 and cin % 8 == 0
-    w = weight.reshape(cout // 64, 64, cin // 8, 8, 9).permute(0, 2, 3, 4, 1)
+    w = weight.reshape(cout // 64, 64, cin // 8, 4, 2, 9).permute(0, 2, 3, 5, 4, 1)
     return w.reshape(cout // 64, cin // 8, 72, 64).contiguous()
 
 
