@@ -227,16 +227,31 @@ int pd3_merge_sweeps(const float *points, const int64_t *sweep_offsets, int num_
                      size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
- * conv3x3_bias_relu -- dense 3x3 / stride 1 / pad 1 convolution with fused bias and ReLU on the fp32
- * matrix cores: the stride-1 convolutions of SecondBackbone (paddle3d/models/backbones/second_backbone.py:
- * 72-120) and CenterHead / SeparateHead (detection/centerpoint/center_head.py:43-220) with BatchNorm folded
- * into weight and bias (cuDNN convolutions in the reference).
- *   x [batch, cin, h, w] fp32 NCHW;  out [batch, cout, h, w];  bias [cout] or NULL
- *   w_packed: the [cout, cin, 3, 3] weight re-ordered to [cout/64][cin/8][72 = ci*9 + ky*3 + kx][64]
- *   requires cin % 8 == 0, cout % 64 == 0 and (w % 128 == 0 | w % 64 == 0 & h % 2 == 0 | w % 32 == 0 & h % 4 == 0)
+ * conv3x3_bias_relu -- dense 3x3 / pad 1 convolution, stride 1 or 2, with fused bias and ReLU on the fp32
+ * matrix cores: the convolutions of SecondBackbone (paddle3d/models/backbones/second_backbone.py:72-120)
+ * and CenterHead / SeparateHead (detection/centerpoint/center_head.py:43-220) with BatchNorm folded into
+ * weight and bias (cuDNN convolutions in the reference).
+ *   x [batch, cin, h, w] fp32 NCHW (16-byte aligned);  out [batch, cout, h/stride, w/stride];  bias [cout] or NULL
+ *   w_packed: the [cout, cin, 3, 3] weight re-ordered to [cout/64][cin/8][4 channel pairs][9 taps][2][64]
+ *             (row = (pair*9 + ky*3 + kx)*2 + channel-of-pair; see paddle3d_amd/ops/conv.py)
+ *   requires cin % 8 == 0, cout % 64 == 0, h and w multiples of stride, and for the OUTPUT size (ho, wo):
+ *   stride 1: wo % 128 == 0 | wo % 64 == 0 & ho % 2 == 0 | wo % 32 == 0 & ho % 4 == 0
+ *   stride 2: wo % 64 == 0 & ho % 2 == 0 | wo % 32 == 0 & ho % 4 == 0;   otherwise PD3_EUNSUPPORTED
  */
 int pd3_conv3x3_bias_relu(const float *x, const float *w_packed, const float *bias, int batch, int cin,
-                          int cout, int h, int w, int relu, float *out, void *stream);
+                          int cout, int h, int w, int stride, int relu, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * grouped_conv3x3_small -- grouped 3x3 / stride 1 / pad 1 convolution with 1..4 output channels per group and
+ * bias, no activation: the final convolutions of all SeparateHead branches (center_head.py:99-118) as one
+ * launch over the concatenated first-stage maps.
+ *   x [batch, groups*cin_per_group, h, w];  out [batch, groups*cout_per_group, h, w];  bias [groups*cout_per_group] or NULL
+ *   w_grouped: [groups][cin_per_group][cout_per_group][9] (the [groups*cout, cin, 3, 3] weight with the two
+ *              channel axes swapped inside each group)
+ *   requires cin_per_group % 4 == 0, h % 8 == 0, w % 128 == 0
+ */
+int pd3_grouped_conv3x3_small(const float *x, const float *w_grouped, const float *bias, int batch, int groups,
+                              int cin_per_group, int cout_per_group, int h, int w, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -66,7 +66,9 @@ _SIGNATURES = {
                                    C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.c_void_p]),
     "pd3_conv3x3_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_grouped_conv3x3_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }
 
 SYMBOLS = tuple(_SIGNATURES)

@@ -287,6 +287,7 @@ class CenterHead(nn.Module):
             heads.update(hm=(ncls, num_hm_conv))
             self.tasks.append(SeparateHead(share_conv_channel, heads, final_kernel=3, init_bias=init_bias))
         self._fused = None
+        self.dense_backend = os.environ.get("PD3_DENSE_BACKEND", "hip")
 
     # -- reference-shaped forward: list of per-task dicts -------------------------------------------
     def forward(self, x):
@@ -330,9 +331,22 @@ class CenterHead(nn.Module):
         if self._fused is None:
             self._build_fused()
         f = self._fused
-        x = F.relu(F.conv2d(x, f["w0"], f["b0"], padding=1))
-        y = F.relu(F.conv2d(x, f["w1"], f["b1"], padding=1))
-        z = F.conv2d(y, f["wf"], f["bf"], padding=1, groups=f["groups"])
+        if self.dense_backend == "hip" and x.is_cuda and _conv.supported(x.shape[1], f["w0"].shape[0], x.shape[2],
+                                                                         x.shape[3]):
+            if "p0" not in f:
+                f["p0"], f["p1"] = _conv.pack_conv3x3_weight(f["w0"]), _conv.pack_conv3x3_weight(f["w1"])
+            x = _conv.conv3x3_bias_relu(x, f["p0"], f["b0"], f["w0"].shape[0], relu=True)
+            y = _conv.conv3x3_bias_relu(x, f["p1"], f["b1"], f["w1"].shape[0], relu=True)
+        else:
+            x = F.relu(F.conv2d(x, f["w0"], f["b0"], padding=1))
+            y = F.relu(F.conv2d(x, f["w1"], f["b1"], padding=1))
+        if (self.dense_backend == "hip" and y.is_cuda
+                and _conv.grouped_small_supported(f["wf"].shape[1], f["cmax"], y.shape[2], y.shape[3])):
+            if "pf" not in f:
+                f["pf"] = _conv.pack_grouped_weight(f["wf"], f["groups"])
+            z = _conv.grouped_conv3x3_small(y, f["pf"], f["bf"], f["groups"])
+        else:
+            z = F.conv2d(y, f["wf"], f["bf"], padding=1, groups=f["groups"])
         rets = [dict() for _ in self.tasks]
         for g, (t, head) in enumerate(f["plan"]):
             rets[t][head] = z[:, g * f["cmax"]:g * f["cmax"] + f["ncls"][g]].contiguous()
@@ -379,9 +393,9 @@ class CenterPoint(nn.Module):
         self.test_cfg = test_cfg
         self.box_with_velocity = box_with_velocity
         self._dense = None
-        # "miopen": PyTorch-ROCm convolutions (default, currently the faster one); "hip": the hand-written
-        # fp32-MFMA kernel (ops/conv.py) for the stride-1 3x3 backbone convolutions
-        self.dense_backend = os.environ.get("PD3_DENSE_BACKEND", "miopen")
+        # "hip" (default): the hand-written fp32-MFMA kernel (ops/conv.py) for every 3x3 convolution of the
+        # backbone; "miopen": PyTorch-ROCm convolutions (also what the 1x1 / 2x2 FPN layers use)
+        self.dense_backend = os.environ.get("PD3_DENSE_BACKEND", "hip")
         self._packed = {}
 
     def _pack(self, points):
@@ -424,12 +438,13 @@ class CenterPoint(nn.Module):
 
     def _run(self, layers, x):
         for tr, w, b, stride, padding in layers:
-            if (self.dense_backend == "hip" and not tr and tuple(w.shape[2:]) == (3, 3) and tuple(stride) == (1, 1)
-                    and tuple(padding) == (1, 1) and _conv.supported(w.shape[1], w.shape[0], x.shape[2], x.shape[3])):
+            if (self.dense_backend == "hip" and x.is_cuda and not tr and tuple(w.shape[2:]) == (3, 3)
+                    and tuple(stride) in ((1, 1), (2, 2)) and tuple(padding) == (1, 1)
+                    and _conv.supported(w.shape[1], w.shape[0], x.shape[2], x.shape[3], stride[0])):
                 key = w.data_ptr()
                 if key not in self._packed:
                     self._packed[key] = _conv.pack_conv3x3_weight(w)
-                x = _conv.conv3x3_bias_relu(x, self._packed[key], b, w.shape[0], relu=True)
+                x = _conv.conv3x3_bias_relu(x, self._packed[key], b, w.shape[0], relu=True, stride=stride[0])
                 continue
             x = F.conv_transpose2d(x, w, b, stride=stride, padding=padding) if tr else \
                 F.conv2d(x, w, b, stride=stride, padding=padding)

@@ -31,15 +31,16 @@ constexpr int kCvCo = 64;  // output channels per tile
 constexpr int kCvCi = 8;   // input channels per K chunk
 constexpr int kCvK = kCvCi * 9;
 
-template <int R, int WT>
+template <int R, int WT, int S>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ wp,
                                                            const float* __restrict__ bias,
                                                            float* __restrict__ out, int cin, int cout,
                                                            int h, int w, int relu) {
+  // h, w: OUTPUT size; the input map is (S*h) x (S*w), S = stride (1 or 2), padding 1
   static_assert(R * WT == 128 || R * WT == 256, "tile must hold 128 or 256 pixels");
   constexpr int NB = R * WT / 128;           // 32-pixel blocks per wave
-  constexpr int XR = R + 2, XW = WT + 8;     // staged columns x0-4 .. x0+WT+3
+  constexpr int XR = (R - 1) * S + 3, XW = S * WT + 8;  // staged input columns S*x0-4 .. S*x0+S*WT+3
   constexpr int XQ = XW / 4;                 // float4 per staged row
   constexpr int XPL = XR * XW;               // floats per staged channel plane
   constexpr int XN4 = kCvCi * XR * XQ;       // float4 of one X chunk
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
     const int pj = (wave * NB + t) * 32 + (lane & 31);
-    xb[t] = kk * XPL + (pj / WT) * XW + (pj % WT) + 3;
+    xb[t] = kk * XPL + (pj / WT) * S * XW + (pj % WT) * S + 3;
   }
   const int wb = 2 * XSZ + kk * kCvCo + (lane & 31);
   cv_f32x16 acc[2][NB];
@@ -72,8 +73,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
   const int chunks = cin / kCvCi;
-  const int64_t plane = (int64_t)h * w;
-  const float* xin = x + (int64_t)n * cin * plane;
+  const int64_t plane = (int64_t)h * w;           // output plane
+  const int hi = S * h, wi = S * w;
+  const int64_t iplane = (int64_t)hi * wi;        // input plane
+  const float* xin = x + (int64_t)n * cin * iplane;
   // staging pattern, identical for every chunk: float4 e of the LDS image <- global offset inside the chunk
   // (clamped to a valid address; `live` bit i says whether the value or zero is kept).  Threads past the end
   // of the image repeat its last float4 (same value to the same address).
@@ -84,9 +87,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
     const int e = min((int)threadIdx.x + i * 256, XN4 - 1);
     const int ci = e / (XR * XQ), rem = e - ci * (XR * XQ);
     const int r = rem / XQ, c4 = rem - r * XQ;
-    const int gy = y0 - 1 + r, gx = x0 - 4 + c4 * 4;  // a float4 is entirely inside or outside (w % 4 == 0)
-    const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
-    gofs[i] = ok ? (int)(ci * plane + (int64_t)gy * w + gx) : 0;
+    const int gy = S * y0 - 1 + r, gx = S * x0 - 4 + c4 * 4;  // a float4 is entirely inside or outside (w % 4 == 0)
+    const bool ok = gy >= 0 && gy < hi && gx >= 0 && gx < wi;
+    gofs[i] = ok ? (int)(ci * iplane + (int64_t)gy * wi + gx) : 0;
     live |= ok ? (1u << i) : 0u;
     ldst[i] = e * 4;
   }
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
 
 #define CV_FETCH(cc)                                                                     \
   {                                                                                      \
-    const float* xc_ = xin + (int64_t)(cc) * kCvCi * plane;                              \
+    const float* xc_ = xin + (int64_t)(cc) * kCvCi * iplane;                             \
     _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                      \
         xr[i] = *reinterpret_cast<const cv_f32x4*>(xc_ + gofs[i]);                         \
     const cv_f32x4* wc_ = wsrc + (int64_t)(cc) * WN4;                                      \
@@ -174,20 +177,99 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
   }
 }
 
-template <int R, int WT>
+template <int R, int WT, int S>
 static int launch_conv3x3(int64_t tiles, hipStream_t s, const float* x, const float* wp, const float* bias,
                           float* out, int cin, int cout, int h, int w, int relu) {
-  constexpr size_t lds = (size_t)(2 * kCvCi * (R + 2) * (WT + 8) + 2 * kCvK * kCvCo) * sizeof(float);
+  constexpr size_t lds = (size_t)(2 * kCvCi * ((R - 1) * S + 3) * (S * WT + 8) + 2 * kCvK * kCvCo) * sizeof(float);
   static bool configured = false;  // raise the dynamic-LDS cap once per instantiation
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<R, WT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<R, WT, S>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
   dim3 grid((unsigned)tiles, (unsigned)(cout / kCvCo));
-  conv3x3_mfma_kernel<R, WT><<<grid, 256, lds, s>>>(x, wp, bias, out, cin, cout, h, w, relu);
+  conv3x3_mfma_kernel<R, WT, S><<<grid, 256, lds, s>>>(x, wp, bias, out, cin, cout, h, w, relu);
   return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Grouped 3x3 / stride 1 / pad 1 convolution with very few output channels per group: the 36 final
+// SeparateHead convolutions 64 -> {1,2,3} of CenterHead run as one launch on the [B, 36*64, H, W] first-stage
+// map (center_head.py:99-118).  1.4 GFLOP but 1.2 GB of input per 8 scenes: HBM-bound, so plain VALU FMAs
+// fed from LDS.  Workgroup = (image, group, 8 x 128 pixel tile); thread = 4 adjacent pixels x CO channels;
+// the weights of the group are wave-uniform and come in through scalar loads.
+constexpr int kGcCi = 4;              // input channels staged per trip
+constexpr int kGcR = 8, kGcW = 128;   // pixel tile
+constexpr int kGcXR = kGcR + 2, kGcXW = kGcW + 8;
+
+template <int CO>
+__global__ __launch_bounds__(256) void grouped_conv3x3_small_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ wg,
+                                                                    const float* __restrict__ bias,
+                                                                    float* __restrict__ out, int groups,
+                                                                    int cg, int h, int w) {
+  __shared__ __attribute__((aligned(16))) float Xs[kGcCi * kGcXR * kGcXW];
+  const int tiles_x = w / kGcW, tiles_y = h / kGcR;
+  const int pt = blockIdx.x;
+  const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
+  const int g = blockIdx.y;
+  const int y0 = ty * kGcR, x0 = tx * kGcW;
+  const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;  // pixel row, first pixel column of the thread
+  const int64_t plane = (int64_t)h * w;
+  const float* xin = x + ((int64_t)n * groups + g) * cg * plane;
+  const float* wgp = wg + (int64_t)g * cg * CO * 9;  // [cg][CO][9]
+  float acc[CO][4];
+#pragma unroll
+  for (int c = 0; c < CO; ++c)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[c][p] = 0.f;
+  constexpr int XQ = kGcXW / 4, XN4 = kGcCi * kGcXR * XQ;  // 1360 float4 per trip
+  for (int c0 = 0; c0 < cg; c0 += kGcCi) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < XN4; e += 256) {
+      const int ci = e / (kGcXR * XQ), rem = e - ci * (kGcXR * XQ);
+      const int r = rem / XQ, c4 = rem - r * XQ;
+      const int gy = y0 - 1 + r, gx = x0 - 4 + c4 * 4;
+      cv_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < h && gx >= 0 && gx < w)
+        v = *reinterpret_cast<const cv_f32x4*>(xin + (int64_t)(c0 + ci) * plane + (int64_t)gy * w + gx);
+      *reinterpret_cast<cv_f32x4*>(Xs + e * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ci = 0; ci < kGcCi; ++ci) {
+      const float* wc = wgp + (int64_t)(c0 + ci) * CO * 9;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        // input columns tc-1 .. tc+4 of row tr+ky live at LDS columns tc+3 .. tc+8
+        const float* row = Xs + (ci * kGcXR + tr + ky) * kGcXW + tc;
+        float in[6];
+        in[0] = row[3];
+        const cv_f32x4 mid = *reinterpret_cast<const cv_f32x4*>(row + 4);
+        in[1] = mid[0];
+        in[2] = mid[1];
+        in[3] = mid[2];
+        in[4] = mid[3];
+        in[5] = row[8];
+#pragma unroll
+        for (int c = 0; c < CO; ++c)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float wv = wc[c * 9 + ky * 3 + kx];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[c][p] = __builtin_fmaf(wv, in[p + kx], acc[c][p]);
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const float b = bias ? bias[g * CO + c] : 0.f;
+    cv_f32x4 v = {acc[c][0] + b, acc[c][1] + b, acc[c][2] + b, acc[c][3] + b};
+    *reinterpret_cast<cv_f32x4*>(out + ((int64_t)n * groups * CO + g * CO + c) * plane + (int64_t)(y0 + tr) * w +
+                                 x0 + tc) = v;
+  }
 }
 
 }  // namespace pd3
@@ -195,20 +277,48 @@ static int launch_conv3x3(int64_t tiles, hipStream_t s, const float* x, const fl
 using namespace pd3;
 
 extern "C" int pd3_conv3x3_bias_relu(const float* x, const float* w_packed, const float* bias,
-                                     int batch, int cin, int cout, int h, int w, int relu, float* out,
-                                     void* stream) {
+                                     int batch, int cin, int cout, int h, int w, int stride, int relu,
+                                     float* out, void* stream) {
   if (!x || !w_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0)
     return PD3_EINVAL;
-  if (cin % kCvCi != 0 || cout % kCvCo != 0) return PD3_EUNSUPPORTED;
+  if (stride != 1 && stride != 2) return PD3_EUNSUPPORTED;
+  if (cin % kCvCi != 0 || cout % kCvCo != 0 || h % stride != 0 || w % stride != 0) return PD3_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(w_packed) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0)
     return PD3_EINVAL;
   if ((int64_t)cin * h * w >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int64_t px = (int64_t)batch * h * w;
-  if (w % 128 == 0 && h % 2 == 0) return launch_conv3x3<2, 128>(px / 256, s, x, w_packed, bias, out, cin, cout, h, w, relu);
-  if (w % 64 == 0 && h % 4 == 0) return launch_conv3x3<4, 64>(px / 256, s, x, w_packed, bias, out, cin, cout, h, w, relu);
-  if (w % 128 == 0) return launch_conv3x3<1, 128>(px / 128, s, x, w_packed, bias, out, cin, cout, h, w, relu);
-  if (w % 64 == 0 && h % 2 == 0) return launch_conv3x3<2, 64>(px / 128, s, x, w_packed, bias, out, cin, cout, h, w, relu);
-  if (w % 32 == 0 && h % 4 == 0) return launch_conv3x3<4, 32>(px / 128, s, x, w_packed, bias, out, cin, cout, h, w, relu);
+  const int ho = h / stride, wo = w / stride;  // (h + 2 - 3) / stride + 1 for even h
+  const int64_t px = (int64_t)batch * ho * wo;
+#define PD3_CV(R, WT, S) launch_conv3x3<R, WT, S>(px / ((R) * (WT)), s, x, w_packed, bias, out, cin, cout, ho, wo, relu)
+  if (stride == 1) {
+    if (wo % 128 == 0 && ho % 2 == 0) return PD3_CV(2, 128, 1);
+    if (wo % 64 == 0 && ho % 4 == 0) return PD3_CV(4, 64, 1);
+    if (wo % 128 == 0) return PD3_CV(1, 128, 1);
+    if (wo % 64 == 0 && ho % 2 == 0) return PD3_CV(2, 64, 1);
+    if (wo % 32 == 0 && ho % 4 == 0) return PD3_CV(4, 32, 1);
+  } else {  // the staged input tile is 4x larger: 128-pixel tiles keep two workgroups per CU
+    if (wo % 64 == 0 && ho % 2 == 0) return PD3_CV(2, 64, 2);
+    if (wo % 32 == 0 && ho % 4 == 0) return PD3_CV(4, 32, 2);
+  }
+#undef PD3_CV
   return PD3_EUNSUPPORTED;
+}
+
+extern "C" int pd3_grouped_conv3x3_small(const float* x, const float* w_grouped, const float* bias, int batch,
+                                         int groups, int cin_per_group, int cout_per_group, int h, int w,
+                                         float* out, void* stream) {
+  if (!x || !w_grouped || !out || batch <= 0 || groups <= 0 || cin_per_group <= 0 || h <= 0 || w <= 0)
+    return PD3_EINVAL;
+  if (cout_per_group < 1 || cout_per_group > 4 || cin_per_group % kGcCi != 0 || h % kGcR != 0 || w % kGcW != 0)
+    return PD3_EUNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return PD3_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)((int64_t)batch * (h / kGcR) * (w / kGcW)), (unsigned)groups);
+  switch (cout_per_group) {
+    case 1: grouped_conv3x3_small_kernel<1><<<grid, 256, 0, s>>>(x, w_grouped, bias, out, groups, cin_per_group, h, w); break;
+    case 2: grouped_conv3x3_small_kernel<2><<<grid, 256, 0, s>>>(x, w_grouped, bias, out, groups, cin_per_group, h, w); break;
+    case 3: grouped_conv3x3_small_kernel<3><<<grid, 256, 0, s>>>(x, w_grouped, bias, out, groups, cin_per_group, h, w); break;
+    default: grouped_conv3x3_small_kernel<4><<<grid, 256, 0, s>>>(x, w_grouped, bias, out, groups, cin_per_group, h, w); break;
+  }
+  return launch_status();
 }

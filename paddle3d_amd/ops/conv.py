@@ -6,12 +6,18 @@ import torch
 
 from ._common import check, lib, ptr, require_gpu, stream_ptr
 
-__all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported"]
+__all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pack_grouped_weight", "grouped_conv3x3_small",
+           "grouped_small_supported"]
 
 
-def supported(cin: int, cout: int, h: int, w: int) -> bool:
-    return cin % 8 == 0 and cout % 64 == 0 and (w % 128 == 0 or (w % 64 == 0 and h % 2 == 0) or
-                                                 (w % 32 == 0 and h % 4 == 0))
+def supported(cin: int, cout: int, h: int, w: int, stride: int = 1) -> bool:
+    """Shapes pd3_conv3x3_bias_relu takes ([h, w] = input size)."""
+    if stride not in (1, 2) or cin % 8 or cout % 64 or h % stride or w % stride:
+        return False
+    ho, wo = h // stride, w // stride
+    if stride == 1:
+        return wo % 128 == 0 or (wo % 64 == 0 and ho % 2 == 0) or (wo % 32 == 0 and ho % 4 == 0)
+    return (wo % 64 == 0 and ho % 2 == 0) or (wo % 32 == 0 and ho % 4 == 0)
 
 
 def pack_conv3x3_weight(weight: torch.Tensor) -> torch.Tensor:
@@ -24,11 +30,36 @@ def pack_conv3x3_weight(weight: torch.Tensor) -> torch.Tensor:
 
 
 def conv3x3_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, relu: bool = True,
-                      out: torch.Tensor | None = None) -> torch.Tensor:
+                      stride: int = 1, out: torch.Tensor | None = None) -> torch.Tensor:
     xx = require_gpu(x, "conv3x3_bias_relu")
     n, cin, h, w = xx.shape
     if out is None:
-        out = torch.empty((n, cout, h, w), dtype=torch.float32, device=xx.device)
-    check(lib().pd3_conv3x3_bias_relu(ptr(xx), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
-                                      ptr(out), stream_ptr(xx.device)), "conv3x3_bias_relu")
+        out = torch.empty((n, cout, h // stride, w // stride), dtype=torch.float32, device=xx.device)
+    check(lib().pd3_conv3x3_bias_relu(ptr(xx), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(stride),
+                                      int(bool(relu)), ptr(out), stream_ptr(xx.device)), "conv3x3_bias_relu")
+    return out
+
+
+def grouped_small_supported(cin_per_group: int, cout_per_group: int, h: int, w: int) -> bool:
+    return 1 <= cout_per_group <= 4 and cin_per_group % 4 == 0 and h % 8 == 0 and w % 128 == 0
+
+
+def pack_grouped_weight(weight: torch.Tensor, groups: int) -> torch.Tensor:
+    """[groups*co, cg, 3, 3] -> [groups][cg][co][9]."""
+    gco, cg = weight.shape[:2]
+    co = gco // groups
+    return weight.reshape(groups, co, cg, 9).permute(0, 2, 1, 3).contiguous()
+
+
+def grouped_conv3x3_small(x: torch.Tensor, w_grouped: torch.Tensor, bias, groups: int,
+                          out: torch.Tensor | None = None) -> torch.Tensor:
+    """Grouped 3x3 convolution + bias with 1..4 output channels per group (the final SeparateHead convolutions)."""
+    xx = require_gpu(x, "grouped_conv3x3_small")
+    n, c, h, w = xx.shape
+    cg, co = w_grouped.shape[1], w_grouped.shape[2]
+    assert c == groups * cg
+    if out is None:
+        out = torch.empty((n, groups * co, h, w), dtype=torch.float32, device=xx.device)
+    check(lib().pd3_grouped_conv3x3_small(ptr(xx), ptr(w_grouped), ptr(bias), n, groups, cg, co, h, w, ptr(out),
+                                          stream_ptr(xx.device)), "grouped_conv3x3_small")
     return out

@@ -1,0 +1,63 @@
+"""Profiling driver (not a test): the dense BEV graph (SECOND + FPN + CenterHead) of CenterPoint-Pillars on a
+batch of random pseudo-images, timed per section with HIP events.  PD3_DENSE_BACKEND selects miopen / hip."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from paddle3d_amd import centerpoint as cpm  # noqa: E402
+
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+torch.manual_seed(0)
+model = cpm.centerpoint_pillars_nuscenes().cuda().eval()
+x = torch.randn(batch, 64, 512, 512, device="cuda")
+
+
+def timed(fn, *a):
+    for _ in range(2):
+        out = fn(*a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        out = fn(*a)
+    e1.record()
+    torch.cuda.synchronize()
+    return out, e0.elapsed_time(e1) / iters
+
+
+with torch.no_grad():
+    _, total = timed(lambda t: model.bbox_head(model.dense_forward(t)), x)
+    print(f"dense backend={model.dense_backend} batch={batch}: {total:.3f} ms  ({127.2e9 * batch / total / 1e9:.1f} TFLOP/s)")
+    outs, cur = [], x
+    for i, blk in enumerate(model._dense[0]):
+        for j, layer in enumerate(blk):
+            nxt, ms = timed(lambda t: model._run([layer], t), cur)
+            fl = 2 * layer[1].numel() * nxt.shape[2] * nxt.shape[3] * batch
+            print(f"  block{i} conv{j} {tuple(cur.shape[1:])}->{tuple(nxt.shape[1:])} stride {layer[3]}: {ms:.3f} ms {fl / ms / 1e9:.1f} TF")
+            cur = nxt
+        outs.append(cur)
+    ups = []
+    for i, (d, o) in enumerate(zip(model._dense[1], outs)):
+        u, ms = timed(lambda t: model._run(d, t), o)
+        print(f"  neck{i} {tuple(o.shape[1:])}->{tuple(u.shape[1:])}: {ms:.3f} ms")
+        ups.append(u)
+    cat, ms = timed(lambda: torch.cat(ups, dim=1))
+    print(f"  concat: {ms:.3f} ms")
+    head = model.bbox_head
+    f = head._fused
+    from paddle3d_amd.ops import conv as _conv
+    import torch.nn.functional as F
+    if head.dense_backend == "hip":
+        s, ms0 = timed(lambda t: _conv.conv3x3_bias_relu(t, f["p0"], f["b0"], 64, relu=True), cat)
+        y, ms1 = timed(lambda t: _conv.conv3x3_bias_relu(t, f["p1"], f["b1"], f["w1"].shape[0], relu=True), s)
+        z, ms2 = timed(lambda t: _conv.grouped_conv3x3_small(t, f["pf"], f["bf"], f["groups"]), y)
+    else:
+        s, ms0 = timed(lambda t: F.relu(F.conv2d(t, f["w0"], f["b0"], padding=1)), cat)
+        y, ms1 = timed(lambda t: F.relu(F.conv2d(t, f["w1"], f["b1"], padding=1)), s)
+        z, ms2 = timed(lambda t: F.conv2d(t, f["wf"], f["bf"], padding=1, groups=f["groups"]), y)
+    print(f"  head shared 384->64: {ms0:.3f} ms; first stage 64->{f['w1'].shape[0]}: {ms1:.3f} ms; final grouped: {ms2:.3f} ms")
+    _, ms3 = timed(lambda t: head(t), cat)
+    print(f"  head total (incl. slicing): {ms3:.3f} ms")

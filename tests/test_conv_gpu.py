@@ -42,3 +42,45 @@ def test_asymmetric_identity():
     want = torch.zeros_like(x)
     want[..., 1:] = x[..., :-1]
     assert torch.equal(out2, want)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 8, 128), (1, 64, 128, 16, 64), (1, 128, 256, 64, 128),
+                                            (1, 8, 64, 4, 256)])
+def test_conv3x3_stride2_matches_torch(n, cin, cout, h, w):
+    """Stride-2 variant (the first convolution of every SECOND block, second_backbone.py:90-97)."""
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator().manual_seed(cin * 3 + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = torch.relu(F.conv2d(x, wt, b, stride=2, padding=1))
+    assert conv.supported(cin, cout, h, w, 2)
+    out = conv.conv3x3_bias_relu(x.cuda(), conv.pack_conv3x3_weight(wt.cuda()), b.cuda(), cout, True, stride=2).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 2e-4, (out - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("co", [1, 2, 3, 4])
+def test_grouped_conv3x3_small_matches_torch(co):
+    from paddle3d_amd.ops import conv
+
+    groups, cg, n, h, w = 5, 64, 2, 16, 128
+    g = torch.Generator().manual_seed(co)
+    x = torch.randn(n, groups * cg, h, w, generator=g)
+    wt = torch.randn(groups * co, cg, 3, 3, generator=g) / (cg * 9) ** 0.5
+    b = torch.randn(groups * co, generator=g)
+    ref = F.conv2d(x, wt, b, padding=1, groups=groups)
+    assert conv.grouped_small_supported(cg, co, h, w)
+    out = conv.grouped_conv3x3_small(x.cuda(), conv.pack_grouped_weight(wt.cuda(), groups), b.cuda(), groups).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 2e-4, (out - ref).abs().max().item()
+
+
+def test_unsupported_shapes_are_refused():
+    from paddle3d_amd.ops import conv
+
+    x = torch.randn(1, 8, 6, 48).cuda()
+    wp = torch.zeros(1, 1, 72, 64).cuda()
+    with pytest.raises(RuntimeError):
+        conv.conv3x3_bias_relu(x, wp, None, 64, True)

@@ -140,3 +140,23 @@ def test_hip_dense_backend_matches_miopen(monkeypatch):
     out = a.dense_forward(x)
     assert out.shape == ref.shape == (1, 384, 128, 128)
     assert (out - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_hip_dense_backend_head_matches_miopen():
+    """CenterHead with the shared / first-stage convolutions on the hand-written MFMA kernel."""
+    from paddle3d_amd import centerpoint as cpm
+
+    torch.manual_seed(5)
+    a = cpm.centerpoint_pillars_nuscenes().cuda().eval()
+    _randomise_bn(a)
+    x = torch.randn(2, 384, 128, 128, device="cuda")
+    head = a.bbox_head
+    head.dense_backend = "miopen"
+    ref, shared_ref = head(x)
+    head.dense_backend = "hip"
+    out, shared = head(x)
+    assert (shared - shared_ref).abs().max().item() < 1e-3 * max(1.0, shared_ref.abs().max().item())
+    for r, o in zip(ref, out):
+        for k in r:
+            assert o[k].shape == r[k].shape
+            assert (o[k] - r[k]).abs().max().item() < 1e-3 * max(1.0, r[k].abs().max().item()), k
