@@ -67,6 +67,8 @@ _SIGNATURES = {
                                    C.c_void_p]),
     "pd3_conv3x3_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_conv3x3_winograd_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                 C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pd3_grouped_conv3x3_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }

@@ -7,7 +7,7 @@ import torch
 from ._common import check, lib, ptr, require_gpu, stream_ptr
 
 __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pack_grouped_weight", "grouped_conv3x3_small",
-           "grouped_small_supported"]
+           "grouped_small_supported", "winograd_supported", "pack_winograd_weight", "conv3x3_winograd_bias_relu"]
 
 
 def supported(cin: int, cout: int, h: int, w: int, stride: int = 1) -> bool:
@@ -37,6 +37,33 @@ def conv3x3_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, 
         out = torch.empty((n, cout, h // stride, w // stride), dtype=torch.float32, device=xx.device)
     check(lib().pd3_conv3x3_bias_relu(ptr(xx), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(stride),
                                       int(bool(relu)), ptr(out), stream_ptr(xx.device)), "conv3x3_bias_relu")
+    return out
+
+
+def winograd_supported(cin: int, cout: int, h: int, w: int) -> bool:
+    return cin % 8 == 0 and cout % 32 == 0 and h % 8 == 0 and w % 32 == 0
+
+
+def pack_winograd_weight(weight: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> U = G g G^T packed [Cout/32][Cin/8][16 components][2 blocks][8 ci][16 co]."""
+    cout, cin = weight.shape[:2]
+    assert weight.shape[2:] == (3, 3) and cout % 32 == 0 and cin % 8 == 0
+    g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64,
+                     device=weight.device)
+    u = torch.einsum("ij,ocjk,lk->ocil", g, weight.double(), g).float()  # [cout, cin, 4, 4]
+    u = u.reshape(cout // 32, 2, 16, cin // 8, 8, 16).permute(0, 3, 5, 1, 4, 2)
+    return u.contiguous()
+
+
+def conv3x3_winograd_bias_relu(x: torch.Tensor, u_packed: torch.Tensor, bias, cout: int, relu: bool = True,
+                               out: torch.Tensor | None = None) -> torch.Tensor:
+    xx = require_gpu(x, "conv3x3_winograd_bias_relu")
+    n, cin, h, w = xx.shape
+    if out is None:
+        out = torch.empty((n, cout, h, w), dtype=torch.float32, device=xx.device)
+    check(lib().pd3_conv3x3_winograd_bias_relu(ptr(xx), ptr(u_packed), ptr(bias), n, cin, cout, h, w,
+                                               int(bool(relu)), ptr(out), stream_ptr(xx.device)),
+          "conv3x3_winograd_bias_relu")
     return out
 
 

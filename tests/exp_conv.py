@@ -30,9 +30,13 @@ for cin, cout, hw in [(64, 64, 256), (128, 128, 128), (256, 256, 64), (384, 64, 
     b = torch.randn(cout, device="cuda")
     wp = conv.pack_conv3x3_weight(w)
     out = torch.empty(B, cout, hw, hw, device="cuda")
-    t_mi = timeit(lambda: F.relu_(F.conv2d(x, w, b, padding=1)))
+    up = conv.pack_winograd_weight(w)
+    out2 = torch.empty(B, cout, hw, hw, device="cuda")
+    t_mi = timeit(lambda: F.relu_(F.conv2d(x, w, b, padding=1))) if os.environ.get("EXP_MIOPEN", "1") == "1" else float("nan")
     t_me = timeit(lambda: conv.conv3x3_bias_relu(x, wp, b, cout, True, out=out))
+    t_wg = timeit(lambda: conv.conv3x3_winograd_bias_relu(x, up, b, cout, True, out=out2))
     fl = 2 * cin * cout * 9 * hw * hw * B / 1e12
-    err = (out - F.relu(F.conv2d(x, w, b, padding=1))).abs().max().item()
+    err = (out2 - out).abs().max().item()
     print(f"cin {cin:4d} cout {cout:4d} hw {hw:3d}: miopen {t_mi:7.3f} ms ({fl / t_mi * 1e3:6.1f} TF)  "
-          f"mfma {t_me:7.3f} ms ({fl / t_me * 1e3:6.1f} TF)  max|diff| {err:.2e}")
+          f"direct {t_me:7.3f} ms ({fl / t_me * 1e3:6.1f} TF)  winograd {t_wg:7.3f} ms ({fl / t_wg * 1e3:6.1f} TF eff)  "
+          f"max|wino-direct| {err:.2e}")

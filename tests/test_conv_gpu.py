@@ -84,3 +84,38 @@ def test_unsupported_shapes_are_refused():
     wp = torch.zeros(1, 1, 72, 64).cuda()
     with pytest.raises(RuntimeError):
         conv.conv3x3_bias_relu(x, wp, None, 64, True)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 128), (1, 8, 32, 8, 32), (1, 128, 96, 16, 64),
+                                            (1, 384, 64, 24, 96), (3, 16, 32, 8, 32)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv3x3_winograd_matches_torch(n, cin, cout, h, w, relu):
+    """Winograd F(2x2,3x3) on the fp32 matrix cores vs torch conv2d on the CPU."""
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator().manual_seed(cin * 11 + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, b, padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    assert conv.winograd_supported(cin, cout, h, w)
+    out = conv.conv3x3_winograd_bias_relu(x.cuda(), conv.pack_winograd_weight(wt.cuda()), b.cuda(), cout, relu).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 2e-4, (out - ref).abs().max().item()
+
+
+def test_winograd_shift_taps():
+    """Single-tap weights against an asymmetric input: catches transposed transforms / tile mis-addressing."""
+    from paddle3d_amd.ops import conv
+
+    cin = cout = 32
+    x = torch.arange(1 * cin * 8 * 64, dtype=torch.float32).reshape(1, cin, 8, 64) / 512.0
+    for ky in range(3):
+        for kx in range(3):
+            wt = torch.zeros(cout, cin, 3, 3)
+            wt[torch.arange(cout), torch.arange(cin), ky, kx] = 1.0
+            out = conv.conv3x3_winograd_bias_relu(x.cuda(), conv.pack_winograd_weight(wt.cuda()), None, cout, False).cpu()
+            want = F.conv2d(x, wt, None, padding=1)
+            assert (out - want).abs().max().item() < 1e-3, (ky, kx)
