@@ -270,6 +270,26 @@ def _fold_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
     return w.detach().contiguous(), ((b - bn.running_mean) * scale + bn.bias).detach().contiguous()
 
 
+def _hip_conv3x3(x, w, b, stride, cache):
+    """3x3 / pad 1 convolution + bias + ReLU on the hand-written kernels: Winograd F(2x2,3x3) for stride 1 where
+    the shape allows (PD3_CONV_ALGO=direct turns it off), the direct implicit-GEMM kernel otherwise; None if
+    neither takes the shape.  `cache` keeps the packed weights."""
+    cout, cin = w.shape[:2]
+    h, wd = x.shape[2], x.shape[3]
+    if (stride == 1 and os.environ.get("PD3_CONV_ALGO", "winograd") == "winograd"
+            and _conv.winograd_supported(cin, cout, h, wd)):
+        key = ("wino", w.data_ptr())
+        if key not in cache:
+            cache[key] = _conv.pack_winograd_weight(w)
+        return _conv.conv3x3_winograd_bias_relu(x, cache[key], b, cout, relu=True)
+    if _conv.supported(cin, cout, h, wd, stride):
+        key = ("direct", w.data_ptr())
+        if key not in cache:
+            cache[key] = _conv.pack_conv3x3_weight(w)
+        return _conv.conv3x3_bias_relu(x, cache[key], b, cout, relu=True, stride=stride)
+    return None
+
+
 class CenterHead(nn.Module):
     """center_head.py:156-220 forward + :294-339 predict_by_custom_op (inference only)."""
 
@@ -333,10 +353,9 @@ class CenterHead(nn.Module):
         f = self._fused
         if self.dense_backend == "hip" and x.is_cuda and _conv.supported(x.shape[1], f["w0"].shape[0], x.shape[2],
                                                                          x.shape[3]):
-            if "p0" not in f:
-                f["p0"], f["p1"] = _conv.pack_conv3x3_weight(f["w0"]), _conv.pack_conv3x3_weight(f["w1"])
-            x = _conv.conv3x3_bias_relu(x, f["p0"], f["b0"], f["w0"].shape[0], relu=True)
-            y = _conv.conv3x3_bias_relu(x, f["p1"], f["b1"], f["w1"].shape[0], relu=True)
+            pk = f.setdefault("packed", {})
+            x = _hip_conv3x3(x, f["w0"], f["b0"], 1, pk)
+            y = _hip_conv3x3(x, f["w1"], f["b1"], 1, pk)
         else:
             x = F.relu(F.conv2d(x, f["w0"], f["b0"], padding=1))
             y = F.relu(F.conv2d(x, f["w1"], f["b1"], padding=1))
@@ -439,13 +458,11 @@ class CenterPoint(nn.Module):
     def _run(self, layers, x):
         for tr, w, b, stride, padding in layers:
             if (self.dense_backend == "hip" and x.is_cuda and not tr and tuple(w.shape[2:]) == (3, 3)
-                    and tuple(stride) in ((1, 1), (2, 2)) and tuple(padding) == (1, 1)
-                    and _conv.supported(w.shape[1], w.shape[0], x.shape[2], x.shape[3], stride[0])):
-                key = w.data_ptr()
-                if key not in self._packed:
-                    self._packed[key] = _conv.pack_conv3x3_weight(w)
-                x = _conv.conv3x3_bias_relu(x, self._packed[key], b, w.shape[0], relu=True, stride=stride[0])
-                continue
+                    and tuple(stride) in ((1, 1), (2, 2)) and tuple(padding) == (1, 1)):
+                y = _hip_conv3x3(x, w, b, stride[0], self._packed)
+                if y is not None:
+                    x = y
+                    continue
             x = F.conv_transpose2d(x, w, b, stride=stride, padding=padding) if tr else \
                 F.conv2d(x, w, b, stride=stride, padding=padding)
             x = F.relu_(x)

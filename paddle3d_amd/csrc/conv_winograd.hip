@@ -10,17 +10,19 @@
 //
 // Workgroup = 32 output channels x 64 tiles (4 tile rows x 16 tile columns = 8 x 32 output pixels) x all 16
 // components; K walks 8 input channels per trip:
-//   U trip   : pre-transformed on the host and packed [16 xi][2 co blocks][8 ci][16 co] -> linear copy to LDS;
+//   U trip   : pre-transformed on the host and packed [2 co blocks][8 ci][16 co][16 xi + 4 pad] -> linear copy
+//              to LDS;
 //   raw X    : [8 ci][10 rows][40 cols] (aligned float4 loads from column x0-4, zero outside the image);
 //   V trip   : each thread transforms two (ci, tile) patches B^T d B out of the raw buffer and scatters the 16
-//              components to LDS as [16 xi][4 tile rows][8 ci][16 tile cols];
+//              components to LDS as [4 tile rows][8 ci][16 tile cols][16 xi + 4 pad] (four b128 writes);
 //   MFMA     : wave w owns co block (w & 1) and tile rows 2(w >> 1), 2(w >> 1) + 1 for ALL 16 components
-//              (32 accumulator quads): A = U (row = co), B = V (col = tile); both operand layouts put the two
-//              K lanes of one LDS cycle on disjoint bank halves, and every address is base + constant.
+//              (32 accumulator quads): A = U (row = co), B = V (col = tile); a lane reads four components of
+//              its (k, co) / (k, tile) element with one ds_read_b128 (stride 20 floats: conflict-free), every
+//              address is base + constant.
 //   epilogue : one lane holds all 16 components of its (co, tile) -> A^T M A in registers, + bias, ReLU,
 //              float2 stores (16 lanes = one 128-byte row segment).
 // The next trip's global loads are issued before the MFMA block and parked in LDS after it; two workgroups
-// per CU (62 KB of LDS, 128 accumulator registers) overlap one's transform phase with the other's MFMAs.
+// per CU (73 KB of LDS, 128 accumulator registers) overlap one's transform phase with the other's MFMAs.
 #include "../../include/paddle3d_amd.h"
 #include "common.hpp"
 
@@ -35,10 +37,13 @@ constexpr int kWgTR = 4, kWgTC = 16;     // tile rows / columns per workgroup (2
 constexpr int kWgRawR = 2 * kWgTR + 2;   // 10 staged input rows
 constexpr int kWgRawW = 2 * kWgTC + 8;   // 40 staged input columns: x0-4 .. x0+35
 constexpr int kWgRawPl = kWgRawR * kWgRawW;
-constexpr int kWgUsz = 16 * kWgCo * kWgCi;                // 4096 floats
+constexpr int kWgCs = 20;                                 // 16 components + 4 pad: conflict-free b128 access
+constexpr int kWgUsz = kWgCo * kWgCi * kWgCs;             // 5120 floats  [2 co blocks][8 ci][16 co][20]
 constexpr int kWgRawSz = kWgCi * kWgRawPl;                // 3200 floats
-constexpr int kWgVsz = 16 * kWgTR * kWgCi * kWgTC;        // 8192 floats
-constexpr int kWgUN4 = kWgUsz / 4;                        // 1024 float4 = 4 per thread
+constexpr int kWgVsz = kWgTR * kWgCi * kWgTC * kWgCs;     // 10240 floats [4 tile rows][8 ci][16 tile cols][20]
+constexpr int kWgUN4 = kWgUsz / 4;                        // 1280 float4 = 5 per thread
+constexpr int kWgUPT = kWgUN4 / 256;
+constexpr size_t kWgLds = (size_t)(kWgUsz + kWgRawSz + kWgVsz) * sizeof(float);  // 74240 B: two workgroups per CU
 constexpr int kWgXN4 = kWgRawSz / 4;                      // 800 float4
 constexpr int kWgXPT = (kWgXN4 + 255) / 256;              // 4 (the tail repeats element 799)
 
@@ -47,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const float* _
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ out, int cin, int cout,
                                                                   int h, int w, int relu) {
-  __shared__ __attribute__((aligned(16))) float smem[kWgUsz + kWgRawSz + kWgVsz];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Us = smem;
   float* Raw = smem + kWgUsz;
   float* Vs = smem + kWgUsz + kWgRawSz;
@@ -85,12 +90,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const float* _
     const int idx = q + 8 * it;
     const int tb = idx & 3, ci = (idx >> 2) * 2 + ((lane >> 4) & 1);
     rsrc[it] = ci * kWgRawPl + (2 * tb) * kWgRawW + 2 * t16 + 3;
-    vdst[it] = tb * (kWgCi * kWgTC) + ci * kWgTC + t16;
+    vdst[it] = ((tb * kWgCi + ci) * kWgTC + t16) * kWgCs;
   }
   // MFMA operand bases
   const int cb = wave & 1, tb0 = 2 * (wave >> 1);
-  const int abase = cb * (kWgCi * 16) + (lane >> 4) * 16 + (lane & 15);
-  const int bbase = tb0 * (kWgCi * kWgTC) + (lane >> 4) * kWgTC + (lane & 15);
+  const int abase = ((cb * kWgCi + (lane >> 4)) * 16 + (lane & 15)) * kWgCs;
+  const int bbase = ((tb0 * kWgCi + (lane >> 4)) * kWgTC + (lane & 15)) * kWgCs;
 
   wg_f32x4 acc[16][2];
 #pragma unroll
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const float* _
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[c][b] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
 
-  wg_f32x4 xr[kWgXPT], ur[4];
+  wg_f32x4 xr[kWgXPT], ur[kWgUPT];
 
 #define WG_FETCH(cc)                                                                     \
   {                                                                                      \
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const float* _
     _Pragma("unroll") for (int i = 0; i < kWgXPT; ++i)                                   \
         xr[i] = *reinterpret_cast<const wg_f32x4*>(xc_ + gofs[i]);                       \
     const wg_f32x4* uc_ = usrc + (int64_t)(cc) * kWgUN4;                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) ur[i] = uc_[threadIdx.x + i * 256];    \
+    _Pragma("unroll") for (int i = 0; i < kWgUPT; ++i) ur[i] = uc_[threadIdx.x + i * 256]; \
   }
 #define WG_STASH()                                                                       \
   {                                                                                      \
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const float* _
       const wg_f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                          \
       *reinterpret_cast<wg_f32x4*>(Raw + ldst[i]) = on_ ? xr[i] : z_;                    \
     }                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+    _Pragma("unroll") for (int i = 0; i < kWgUPT; ++i)                                   \
         *reinterpret_cast<wg_f32x4*>(Us + (threadIdx.x + i * 256) * 4) = ur[i];          \
   }
   // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
@@ -133,32 +138,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const float* _
         t_[3][j] = d1 - d3;                                                              \
       }                                                                                  \
       float* v_ = Vs + vdst[it];                                                         \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                    \
-        v_[(i * 4 + 0) * (kWgVsz / 16)] = t_[i][0] - t_[i][2];                           \
-        v_[(i * 4 + 1) * (kWgVsz / 16)] = t_[i][1] + t_[i][2];                           \
-        v_[(i * 4 + 2) * (kWgVsz / 16)] = t_[i][2] - t_[i][1];                           \
-        v_[(i * 4 + 3) * (kWgVsz / 16)] = t_[i][1] - t_[i][3];                           \
-      }                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                      \
+          *reinterpret_cast<wg_f32x4*>(v_ + i * 4) =                                     \
+              (wg_f32x4){t_[i][0] - t_[i][2], t_[i][1] + t_[i][2], t_[i][2] - t_[i][1],  \
+                         t_[i][1] - t_[i][3]};                                           \
     }                                                                                    \
   }
 
-  // 32 steps (k half, component), software-pipelined by hand: the operands of step s+1 are read while the two
-  // MFMAs of step s issue; the scheduling fences keep the compiler from hoisting all 96 LDS reads (registers)
+  // 8 groups (k half, 4 components): three b128 reads feed eight MFMAs; the reads of group g+1 are issued
+  // while group g runs (the scheduling fences keep the compiler from hoisting every read: registers)
+#define WG_LOAD(g_, a_, b0_, b1_)                                                        \
+  {                                                                                      \
+    const int o_ = ((g_) >> 2) * (4 * 16 * kWgCs) + ((g_) & 3) * 4;                      \
+    a_ = *reinterpret_cast<const wg_f32x4*>(Us + abase + o_);                            \
+    b0_ = *reinterpret_cast<const wg_f32x4*>(Vs + bbase + o_);                           \
+    b1_ = *reinterpret_cast<const wg_f32x4*>(Vs + bbase + o_ + kWgCi * kWgTC * kWgCs);   \
+  }
 #define WG_MFMA()                                                                        \
   {                                                                                      \
-    float a_ = Us[abase], b0_ = Vs[bbase], b1_ = Vs[bbase + kWgCi * kWgTC];              \
-    _Pragma("unroll") for (int s_ = 0; s_ < 32; ++s_) {                                  \
-      const int c_ = s_ & 15;                                                            \
-      float an_ = 0.f, b0n_ = 0.f, b1n_ = 0.f;                                           \
-      if (s_ + 1 < 32) {                                                                 \
-        const int o_ = ((s_ + 1) >> 4) * 64;                                             \
-        const int cn_ = (s_ + 1) & 15;                                                   \
-        an_ = Us[abase + cn_ * (kWgCo * kWgCi) + o_];                                    \
-        b0n_ = Vs[bbase + cn_ * (kWgVsz / 16) + o_];                                     \
-        b1n_ = Vs[bbase + cn_ * (kWgVsz / 16) + o_ + kWgCi * kWgTC];                     \
+    wg_f32x4 a_, b0_, b1_;                                                               \
+    WG_LOAD(0, a_, b0_, b1_)                                                             \
+    _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                   \
+      wg_f32x4 an_ = a_, b0n_ = b0_, b1n_ = b1_;                                         \
+      if (g_ + 1 < 8) WG_LOAD(g_ + 1, an_, b0n_, b1n_)                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                 \
+      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                 \
+        const int c_ = (g_ & 3) * 4 + j_;                                                \
+        acc[c_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[j_], b0_[j_], acc[c_][0], 0, 0, 0); \
+        acc[c_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[j_], b1_[j_], acc[c_][1], 0, 0, 0); \
       }                                                                                  \
-      acc[c_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b0_, acc[c_][0], 0, 0, 0);   \
-      acc[c_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b1_, acc[c_][1], 0, 0, 0);   \
       __builtin_amdgcn_sched_barrier(0);                                                 \
       a_ = an_;                                                                          \
       b0_ = b0n_;                                                                        \
@@ -185,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const float* _
   }
   WG_MFMA()
 #undef WG_MFMA
+#undef WG_LOAD
 #undef WG_FETCH
 #undef WG_STASH
 #undef WG_TRANSFORM
@@ -239,7 +248,14 @@ extern "C" int pd3_conv3x3_winograd_bias_relu(const float* x, const float* u_pac
     return PD3_EINVAL;
   if ((int64_t)cin * h * w >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
   dim3 grid((unsigned)((int64_t)batch * (h / (2 * kWgTR)) * (w / (2 * kWgTC))), (unsigned)(cout / kWgCo));
-  conv3x3_winograd_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(x, u_packed, bias, out, cin, cout,
-                                                                              h, w, relu);
+  static bool configured = false;  // raise the dynamic-LDS cap once
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_winograd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgLds);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  conv3x3_winograd_kernel<<<grid, 256, kWgLds, static_cast<hipStream_t>(stream)>>>(x, u_packed, bias, out, cin,
+                                                                                   cout, h, w, relu);
   return launch_status();
 }

@@ -51,8 +51,8 @@ with torch.no_grad():
     from paddle3d_amd.ops import conv as _conv
     import torch.nn.functional as F
     if head.dense_backend == "hip":
-        s, ms0 = timed(lambda t: _conv.conv3x3_bias_relu(t, f["p0"], f["b0"], 64, relu=True), cat)
-        y, ms1 = timed(lambda t: _conv.conv3x3_bias_relu(t, f["p1"], f["b1"], f["w1"].shape[0], relu=True), s)
+        s, ms0 = timed(lambda t: cpm._hip_conv3x3(t, f["w0"], f["b0"], 1, f["packed"]), cat)
+        y, ms1 = timed(lambda t: cpm._hip_conv3x3(t, f["w1"], f["b1"], 1, f["packed"]), s)
         z, ms2 = timed(lambda t: _conv.grouped_conv3x3_small(t, f["pf"], f["bf"], f["groups"]), y)
     else:
         s, ms0 = timed(lambda t: F.relu(F.conv2d(t, f["w0"], f["b0"], padding=1)), cat)
