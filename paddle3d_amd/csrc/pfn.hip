@@ -25,6 +25,15 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Same ordering point without the fence: a wavefront-scope fence also drains vmcnt, i.e. it would wait for the
+// next pillar's prefetch loads at every LDS hand-off.  The LDS queue of a wave is in order, so a compiler-level
+// barrier is all the streaming kernels need.
+__device__ __forceinline__ void wave_lds_order() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
 constexpr int kPfnMaxWaves = 8;
 constexpr int kPfnRowChunk = 8;
 
@@ -181,6 +190,276 @@ __global__ __launch_bounds__(kPfnMaxWaves * 64) void pfn_kernel(PfnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fast path for the single-layer, 64-channel PillarFeatureNet of PointPillars / CenterPoint-Pillars
+// (pillar_encoder.py:156-210 with feat_channels (64,)): lane = output channel with its column of W in
+// registers; a wave streams pillars: the pillar's <= 128 raw floats arrive with one coalesced load per lane
+// (prefetched one pillar ahead), are parked in a wave-private LDS line and read back as broadcasts, and
+// only the real points are evaluated (+ the one representative padded row, see the header comment).  The
+// arithmetic is the same fmaf chain, in the same order, as pfn_kernel.
+template <int D, int CD>
+__global__ __launch_bounds__(256) void pfn_single64_kernel(PfnArgs a) {
+  constexpr int IN = D + 3 + CD;
+  __shared__ float line[4][128];
+  const int lane = lane_id(), wave = wave_id();
+  float w[IN];
+#pragma unroll
+  for (int i = 0; i < IN; ++i) w[i] = a.w1[i * 64 + lane];
+  const float sc = a.scale1[lane], sh = a.shift1[lane];
+  const float ypad = fmaxf(sh, 0.f);  // a zero input row: relu(bn(0))
+  const int pd = a.p * D;             // <= 128 floats per pillar
+  float* ln = line[wave];
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t pil = (int64_t)blockIdx.x * 4 + wave;
+  if (pil >= a.m) return;
+  // prefetch registers for the pillar about to be processed
+  float v0 = 0.f, v1 = 0.f;
+  int npn = a.num_points[pil];
+  int c1 = a.coors[pil * 4 + 1], c2 = a.coors[pil * 4 + 2], c3 = a.coors[pil * 4 + 3];
+  if (lane < pd) v0 = a.voxels[pil * pd + lane];
+  if (lane + 64 < pd) v1 = a.voxels[pil * pd + 64 + lane];
+  for (; pil < a.m; pil += stride) {
+    const int np_raw = npn;
+    const float pcx = (float)c3 * a.vx + a.x_off, pcy = (float)c2 * a.vy + a.y_off;
+    const float pcz = (float)c1 * a.vz + a.z_off;
+    ln[lane] = v0;
+    ln[64 + lane] = v1;
+    wave_lds_order();
+    const int64_t nxt = pil + stride;
+    if (nxt < a.m) {  // next pillar's loads fly while this one is evaluated
+      npn = a.num_points[nxt];
+      c1 = a.coors[nxt * 4 + 1];
+      c2 = a.coors[nxt * 4 + 2];
+      c3 = a.coors[nxt * 4 + 3];
+      v0 = lane < pd ? a.voxels[nxt * pd + lane] : 0.f;
+      v1 = lane + 64 < pd ? a.voxels[nxt * pd + 64 + lane] : 0.f;
+    }
+    if (np_raw <= 0) {  // padding row of a fixed-shape [B*V] batch: no pillar here
+      a.out[pil * 64 + lane] = 0.f;
+      wave_lds_order();
+      continue;
+    }
+    const int np = min(np_raw, a.p);
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int k = 0; k < np; ++k) {
+      sx += ln[k * D + 0];
+      sy += ln[k * D + 1];
+      sz += ln[k * D + 2];
+    }
+    const float cnt = (float)np_raw;
+    const float mx = sx / cnt, my = sy / cnt, mz = sz / cnt;
+    float m1 = np < a.p ? ypad : -INFINITY;
+    for (int k = 0; k < np; ++k) {
+      float f[IN];
+#pragma unroll
+      for (int i = 0; i < D; ++i) f[i] = ln[k * D + i];
+      f[D + 0] = f[0] - mx;
+      f[D + 1] = f[1] - my;
+      f[D + 2] = f[2] - mz;
+      f[D + 3] = f[0] - pcx;
+      f[D + 4] = f[1] - pcy;
+      if (CD == 3) f[D + 3 + CD - 1] = f[2] - pcz;
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < IN; ++i) acc = fmaf(f[i], w[i], acc);
+      m1 = fmaxf(m1, fmaxf(fmaf(acc, sc, sh), 0.f));
+    }
+    a.out[pil * 64 + lane] = m1;
+    wave_lds_order();  // the next trip overwrites the line
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fast path for the two-layer PillarFeatureNet of CenterPoint-Pillars (feat_channels (64, 64): PFNLayer 1 is
+// Linear(in, 32), layer 2 Linear([y1 | max y1] = 64, 64); pillar_encoder.py:81-105, :156-210) on the fp32
+// matrix cores.  One wave per pillar, streaming pillars; the pillar's rows (its real points + the one
+// representative padded row) form one or two 16-row MFMA blocks:
+//   layer 1:  Y1[16 x 32] = X[16 x 12] W1       3 k-steps x 2 column blocks of v_mfma_f32_16x16x4_f32
+//   layer 2:  Y2[16 x 64] = Y1 W2[0:32] + base   8 k-steps x 4 column blocks, accumulator preset to
+//             base = max_rows(Y1) W2[32:64] (the row-independent half of the concat, VALU, lane = channel)
+// Both weight matrices live in registers as MFMA B operands for the whole kernel.  Lane (row, k) builds its
+// three decorated features of layer 1's A operand in registers from the wave-private copy of the pillar; Y1
+// passes through a wave-private LDS tile (row stride 34 floats: conflict-free A-operand reads); rows past the
+// pillar's last one repeat point 0, so no row masks are needed in the two max reductions.  The only global
+// traffic is the pillar's raw floats (one coalesced load, prefetched a pillar ahead) and its 64 outputs.
+typedef float pfn_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPfYs = 34;
+constexpr int kPfWaveFloats = 128 + 32 * kPfYs + 32 + 64 + 4 * 64;  // line, y1s, m1, base, part
+
+template <int D, int CD>
+__global__ __launch_bounds__(256, 3) void pfn_two_mfma_kernel(PfnArgs a) {
+  constexpr int IN = D + 3 + CD;
+  static_assert(IN <= 12, "layer-1 K is padded to 12");
+  __shared__ __attribute__((aligned(16))) float smem[4 * kPfWaveFloats];
+  const int lane = lane_id(), wave = wave_id();
+  const int r16 = lane & 15, g = lane >> 4;
+  float* ln = smem + wave * kPfWaveFloats;  // raw pillar, [k][D]
+  float* y1s = ln + 128;                    // [32 rows][34]
+  float* m1s = y1s + 32 * kPfYs;            // [32]
+  float* bases = m1s + 32;                  // [64]
+  float* part = bases + 64;                 // [4][64]
+  // ---- weights and folded BatchNorm in registers ------------------------------------------------
+  float w1r[3][2], w2a[8][4], w2b[32];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int k = ks * 4 + g;
+      w1r[ks][cb] = k < IN ? a.w1[k * 32 + cb * 16 + r16] : 0.f;
+    }
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) w2a[ks][cb] = a.w2[(ks * 4 + g) * 64 + cb * 16 + r16];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) w2b[i] = a.w2[(32 + i) * 64 + lane];
+  float sc1[2], sh1[2], sc2[4], sh2[4];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    sc1[cb] = a.scale1[cb * 16 + r16];
+    sh1[cb] = a.shift1[cb * 16 + r16];
+  }
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    sc2[cb] = a.scale2[cb * 16 + r16];
+    sh2[cb] = a.shift2[cb * 16 + r16];
+  }
+  // this lane's A-operand features: k-step ks carries decorated feature i = 4 ks + g of point lane & 15
+  int fsrc[3], fkind[3];  // source coordinate; 0 raw, 1 minus cluster mean, 2 minus pillar centre, 3 padding (zero)
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    const int i = ks * 4 + g;
+    fkind[ks] = i >= IN ? 3 : (i < D ? 0 : (i < D + 3 ? 1 : 2));
+    fsrc[ks] = i >= IN ? 0 : (i < D ? i : (i < D + 3 ? i - D : i - D - 3));
+  }
+  const int pd = a.p * D;  // <= 128 floats per pillar
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t pil = (int64_t)blockIdx.x * 4 + wave;
+  if (pil >= a.m) return;
+  float v0 = 0.f, v1 = 0.f;
+  int npn = a.num_points[pil];
+  int c1 = a.coors[pil * 4 + 1], c2 = a.coors[pil * 4 + 2], c3 = a.coors[pil * 4 + 3];
+  if (lane < pd) v0 = a.voxels[pil * pd + lane];
+  if (lane + 64 < pd) v1 = a.voxels[pil * pd + 64 + lane];
+  for (; pil < a.m; pil += stride) {
+    const int np_raw = npn;
+    float pc[3];
+    pc[0] = (float)c3 * a.vx + a.x_off;
+    pc[1] = (float)c2 * a.vy + a.y_off;
+    pc[2] = (float)c1 * a.vz + a.z_off;
+    ln[lane] = v0;
+    ln[64 + lane] = v1;
+    wave_lds_order();
+    const int64_t nxt = pil + stride;
+    if (nxt < a.m) {  // next pillar's loads fly while this one is evaluated
+      npn = a.num_points[nxt];
+      c1 = a.coors[nxt * 4 + 1];
+      c2 = a.coors[nxt * 4 + 2];
+      c3 = a.coors[nxt * 4 + 3];
+      v0 = lane < pd ? a.voxels[nxt * pd + lane] : 0.f;
+      v1 = lane + 64 < pd ? a.voxels[nxt * pd + 64 + lane] : 0.f;
+    }
+    if (np_raw <= 0) {  // padding row of a fixed-shape [B*V] batch: no pillar here
+      a.out[pil * 64 + lane] = 0.f;
+      wave_lds_order();
+      continue;
+    }
+    const int np = min(np_raw, a.p);
+    const int rows = np + (np < a.p ? 1 : 0);  // + one representative padded (all-zero) row
+    const int nblk = rows > 16 ? 2 : 1;
+    // ---- decorate (pillar_encoder.py:166-199) straight into the layer-1 A operand ------------------
+    float mean[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < np; ++k) {
+      mean[0] += ln[k * D + 0];
+      mean[1] += ln[k * D + 1];
+      mean[2] += ln[k * D + 2];
+    }
+    const float cnt = (float)np_raw;
+    mean[0] = mean[0] / cnt;
+    mean[1] = mean[1] / cnt;
+    mean[2] = mean[2] / cnt;
+    float sub[3];  // what this lane's three features subtract: 0, a cluster mean or a pillar centre
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      const float mv = fsrc[ks] == 0 ? mean[0] : (fsrc[ks] == 1 ? mean[1] : mean[2]);
+      const float pv = fsrc[ks] == 0 ? pc[0] : (fsrc[ks] == 1 ? pc[1] : pc[2]);
+      sub[ks] = fkind[ks] == 1 ? mv : (fkind[ks] == 2 ? pv : 0.f);
+    }
+    // ---- layer 1 on the matrix cores; Y1 = relu(bn1(X W1)) -> y1s ---------------------------------
+    // rows >= `rows` repeat point 0, so every row of a block is a legitimate member of the max below
+    float pm1[2] = {-INFINITY, -INFINITY};
+    for (int b = 0; b < nblk; ++b) {
+      const int k = b * 16 + r16;
+      const bool real = k < np, zero_row = (k == np) && (np < a.p);
+      const int kk = real ? k : 0;
+      pfn_f32x4 acc1[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) acc1[cb] = (pfn_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        float av = ln[kk * D + fsrc[ks]] - sub[ks];
+        av = (zero_row || fkind[ks] == 3) ? 0.f : av;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1r[ks][cb], acc1[cb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y = fmaxf(fmaf(acc1[cb][r], sc1[cb], sh1[cb]), 0.f);
+          y1s[(b * 16 + 4 * g + r) * kPfYs + cb * 16 + r16] = y;
+          pm1[cb] = fmaxf(pm1[cb], y);
+        }
+    }
+    // ---- max over the rows of Y1 (the concat half of PFNLayer :100-104), base = m1 W2[32:64] --------
+    part[g * 64 + r16] = pm1[0];
+    part[g * 64 + 16 + r16] = pm1[1];
+    wave_lds_order();
+    if (lane < 32)
+      m1s[lane] = fmaxf(fmaxf(part[lane], part[64 + lane]), fmaxf(part[128 + lane], part[192 + lane]));
+    wave_lds_order();
+    float base = 0.f;
+#pragma unroll
+    for (int i4 = 0; i4 < 32; i4 += 4) {
+      const pfn_f32x4 mv = *reinterpret_cast<const pfn_f32x4*>(m1s + i4);
+      base = fmaf(mv[0], w2b[i4 + 0], base);
+      base = fmaf(mv[1], w2b[i4 + 1], base);
+      base = fmaf(mv[2], w2b[i4 + 2], base);
+      base = fmaf(mv[3], w2b[i4 + 3], base);
+    }
+    bases[lane] = base;
+    wave_lds_order();
+    // ---- layer 2 on the matrix cores, accumulators preset to the base; max over the rows --------------
+    float pm[4], bs[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      pm[cb] = -INFINITY;
+      bs[cb] = bases[cb * 16 + r16];
+    }
+    for (int b = 0; b < nblk; ++b) {
+      pfn_f32x4 acc2[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc2[cb] = (pfn_f32x4){bs[cb], bs[cb], bs[cb], bs[cb]};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const float av = y1s[(b * 16 + r16) * kPfYs + ks * 4 + g];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2a[ks][cb], acc2[cb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          pm[cb] = fmaxf(pm[cb], fmaxf(fmaf(acc2[cb][r], sc2[cb], sh2[cb]), 0.f));
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) part[g * 64 + cb * 16 + r16] = pm[cb];
+    wave_lds_order();
+    a.out[pil * 64 + lane] = fmaxf(fmaxf(part[lane], part[64 + lane]), fmaxf(part[128 + lane], part[192 + lane]));
+    wave_lds_order();  // the next trip overwrites the tile
+  }
+}
+
 __global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict__ voxels,
                                                          const int32_t* __restrict__ num_points,
                                                          int64_t m, int p, int d,
@@ -240,13 +519,30 @@ extern "C" int pd3_pillar_feature_net(const float* voxels, const int32_t* num_po
   a.in_pad = (a.in_dim + 3) / 4 * 4;
   // xs must also be able to hold c1 maxima (see mx_store)
   if (max_points * a.in_pad < c1) return PD3_EUNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!w2 && c1 == 64 && max_points * num_point_dim <= 128 && (num_point_dim == 4 || num_point_dim == 5)) {
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(num_pillars, 4), 256 * 16);
+    if (num_point_dim == 4 && voxel_center_dims == 2) pfn_single64_kernel<4, 2><<<blocks, 256, 0, s>>>(a);
+    else if (num_point_dim == 4) pfn_single64_kernel<4, 3><<<blocks, 256, 0, s>>>(a);
+    else if (voxel_center_dims == 2) pfn_single64_kernel<5, 2><<<blocks, 256, 0, s>>>(a);
+    else pfn_single64_kernel<5, 3><<<blocks, 256, 0, s>>>(a);
+    return launch_status();
+  }
+  if (w2 && c1 == 32 && c2 == 64 && max_points * num_point_dim <= 128 && max_points <= 32 &&
+      (num_point_dim == 4 || num_point_dim == 5) && a.in_dim <= 12) {
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(num_pillars, 4), 256 * 8);
+    if (num_point_dim == 4 && voxel_center_dims == 2) pfn_two_mfma_kernel<4, 2><<<blocks, 256, 0, s>>>(a);
+    else if (num_point_dim == 4) pfn_two_mfma_kernel<4, 3><<<blocks, 256, 0, s>>>(a);
+    else if (voxel_center_dims == 2) pfn_two_mfma_kernel<5, 2><<<blocks, 256, 0, s>>>(a);
+    else pfn_two_mfma_kernel<5, 3><<<blocks, 256, 0, s>>>(a);
+    return launch_status();
+  }
   const size_t w_floats = (size_t)a.in_pad * c1 + (w2 ? (size_t)2 * c1 * c2 : 0);
   const size_t wave_floats = (size_t)max_points * a.in_pad + (size_t)max_points * c1;
   int waves = kPfnMaxWaves;
   while (waves > 1 && (w_floats + waves * wave_floats) * sizeof(float) > 160 * 1024) waves >>= 1;
   const size_t bytes = (w_floats + waves * wave_floats) * sizeof(float);
   if (bytes > 160 * 1024) return PD3_EUNSUPPORTED;
-  hipStream_t s = static_cast<hipStream_t>(stream);
   if (bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pfn_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);

@@ -87,6 +87,38 @@ def test_pfn(oracle, two_layers):
     assert np.abs(out - ref).max() < 1e-3, np.abs(out - ref).max()
 
 
+@pytest.mark.parametrize("two_layers", [True, False])
+@pytest.mark.parametrize("p,d", [(32, 4), (20, 5), (7, 4)])
+def test_pfn_random_pillars(oracle, two_layers, p, d):
+    """Random pillars with every fill level 0..P (empty, partial, full) through the fast PFN kernels."""
+    from paddle3d_amd.ops import voxel_encoder as ve
+
+    rng = np.random.default_rng(p * 10 + d)
+    m = 500
+    npv = rng.integers(0, p + 1, m).astype(np.int32)
+    npv[:3] = [0, p, 1]
+    vox = rng.uniform(-3, 3, (m, p, d)).astype(np.float32)
+    vox *= (np.arange(p)[None, :, None] < npv[:, None, None])
+    c4 = np.concatenate([np.zeros((m, 2), np.int32), rng.integers(0, 400, (m, 2)).astype(np.int32)], 1)
+    c1, c2 = (32, 64) if two_layers else (64, 0)
+    params = _pfn_params(rng, d, c1, c2)
+    keep = npv > 0
+    ref = oracle.pfn_forward_torch(vox[keep], npv[keep], c4[keep], params, synth.NUSC_PILLAR, synth.NUSC_RANGE)
+    dev = torch.device("cuda")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    folded = []
+    for q in params:
+        s, sh = ve.fold_batchnorm(t(q["gamma"]), t(q["beta"]), t(q["mean"]), t(q["var"]), 1e-3)
+        folded.append((t(q["weight"]), s, sh))
+    vx, vy = synth.NUSC_PILLAR[0], synth.NUSC_PILLAR[1]
+    args = [t(vox), t(npv), t(c4), vx, vy, vx / 2 + synth.NUSC_RANGE[0], vy / 2 + synth.NUSC_RANGE[1], *folded[0]]
+    if two_layers:
+        args += list(folded[1])
+    out = ve.pillar_feature_net(*args).cpu().numpy()
+    assert np.all(out[~keep] == 0)
+    assert np.abs(out[keep] - ref).max() < 1e-3, np.abs(out[keep] - ref).max()
+
+
 def test_voxel_mean(oracle):
     from paddle3d_amd.ops import voxel_encoder as ve
 
