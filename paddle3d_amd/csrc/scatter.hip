@@ -27,34 +27,30 @@ __global__ __launch_bounds__(256) void inverse_map_kernel(const int32_t* __restr
   atomicMax(&inv[((int64_t)b * ny + y) * nx + x], (int)i);
 }
 
-// 4 consecutive cells per lane; loops over channels 4 at a time (4x4 register transpose).
+// 4 consecutive cells per lane x 4 channels per workgroup row (4x4 register transpose).  grid.x runs along
+// the cell axis, grid.y over channel groups: workgroups that are resident together write neighbouring 4 KB
+// pieces of the same few channel planes (long sequential HBM streams) instead of 64 planes each; the inverse
+// map (1 MB per frame) is re-read per channel group out of L2.
 __global__ __launch_bounds__(256) void canvas_write_vec4_kernel(const float* __restrict__ feats,
                                                                 const int* __restrict__ inv,
                                                                 int channels, int64_t plane,
                                                                 float* __restrict__ canvas) {
-  const int b = blockIdx.y;
+  const int b = blockIdx.z;
+  const int c = blockIdx.y * 4;
   const int64_t cell0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (cell0 >= plane) return;
   const int4 src = *reinterpret_cast<const int4*>(inv + (int64_t)b * plane + cell0);
   const int id[4] = {src.x, src.y, src.z, src.w};
-  float* out = canvas + (int64_t)b * channels * plane + cell0;
-  const bool any = src.x >= 0 || src.y >= 0 || src.z >= 0 || src.w >= 0;
-  if (!any) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < channels; ++c) *reinterpret_cast<float4*>(out + (int64_t)c * plane) = z;
-    return;
-  }
-  for (int c = 0; c < channels; c += 4) {
-    float4 r[4];
+  float* out = canvas + ((int64_t)b * channels + c) * plane + cell0;
+  float4 r[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      r[k] = id[k] >= 0 ? *reinterpret_cast<const float4*>(feats + (int64_t)id[k] * channels + c)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(out + (int64_t)(c + 0) * plane) = make_float4(r[0].x, r[1].x, r[2].x, r[3].x);
-    *reinterpret_cast<float4*>(out + (int64_t)(c + 1) * plane) = make_float4(r[0].y, r[1].y, r[2].y, r[3].y);
-    *reinterpret_cast<float4*>(out + (int64_t)(c + 2) * plane) = make_float4(r[0].z, r[1].z, r[2].z, r[3].z);
-    *reinterpret_cast<float4*>(out + (int64_t)(c + 3) * plane) = make_float4(r[0].w, r[1].w, r[2].w, r[3].w);
-  }
+  for (int k = 0; k < 4; ++k)
+    r[k] = id[k] >= 0 ? *reinterpret_cast<const float4*>(feats + (int64_t)id[k] * channels + c)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+  *reinterpret_cast<float4*>(out + 0 * plane) = make_float4(r[0].x, r[1].x, r[2].x, r[3].x);
+  *reinterpret_cast<float4*>(out + 1 * plane) = make_float4(r[0].y, r[1].y, r[2].y, r[3].y);
+  *reinterpret_cast<float4*>(out + 2 * plane) = make_float4(r[0].z, r[1].z, r[2].z, r[3].z);
+  *reinterpret_cast<float4*>(out + 3 * plane) = make_float4(r[0].w, r[1].w, r[2].w, r[3].w);
 }
 
 // Generic shape fallback: one thread per (channel, cell).
@@ -97,11 +93,11 @@ extern "C" int pd3_pointpillars_scatter(const float* voxel_features, const int32
   if (num_pillars > 0)
     inverse_map_kernel<<<(unsigned)ceil_div(num_pillars, 256), 256, 0, s>>>(coords, num_pillars,
                                                                             batch, ny, nx, inv);
-  const bool vec = (plane % 4 == 0) && (channels % 4 == 0) &&
+  const bool vec = (plane % 4 == 0) && (channels % 4 == 0) && (channels / 4 <= 65535) && (batch <= 65535) &&
                    (reinterpret_cast<uintptr_t>(canvas) % 16 == 0) &&
                    (reinterpret_cast<uintptr_t>(voxel_features) % 16 == 0);
   if (vec) {
-    dim3 grid((unsigned)ceil_div(plane / 4, 256), batch);
+    dim3 grid((unsigned)ceil_div(plane / 4, 256), (unsigned)(channels / 4), (unsigned)batch);
     canvas_write_vec4_kernel<<<grid, 256, 0, s>>>(voxel_features, inv, channels, plane, canvas);
   } else {
     dim3 grid((unsigned)ceil_div((int64_t)channels * plane, 256), batch);
