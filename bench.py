@@ -223,7 +223,9 @@ def main():
             dense_backbone_fpn_head=dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                                          frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=None,
                                          ms_per_launch=per_op_ms["dense"], units_per_launch=B,
-                                         flops_per_unit=dense_flops()))
+                                         flops_per_unit=dense_flops(),
+                                         note="direct-form flops of the graph / time; the stride-1 3x3 layers run "
+                                              "Winograd F(2x2,3x3) (2.25x fewer MFMA flops), all fp32"))
         line = {
             "metric": "scenes/sec CenterPoint-Pillars nuScenes 300k-pt sweeps",
             "value": world * B * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
@@ -234,8 +236,10 @@ def main():
                                    "full graph voxelize->PFN->scatter->SECOND+FPN->CenterHead->postprocess"
                                    + ("->RCCL all-gather" if world > 1 else ""),
                        "frames_per_gpu_per_step": B, "max_voxels": V, "parallelism": f"dp{world} (frames)"},
-            "roofline": dict(rooflines["hard_voxelize"], kernel="hard_voxelize launch sequence "
-                                                                 "(cell_key + radix sort + seg_head + scan + gather)"),
+            "roofline": dict(rooflines["hard_voxelize"], kernel=(
+                "hard_voxelize launch sequence (vt_route + vt_group + vt_count + vt_assign + vt_write)"
+                if os.environ.get("PD3_VOXELIZE_PATH", "tiled") != "sort" else
+                "hard_voxelize launch sequence (cell_key + radix sort + seg_head + scan + gather)")),
             "rooflines": rooflines,
             "per_op_ms": per_op_ms,
             "detections_first_frame": int(out[1][0].item()),

@@ -16,7 +16,7 @@ from collections import defaultdict
 OPS = {
     "hard_voxelize": ("vt_route", "vt_group", "vt_count", "vt_assign", "vt_write", "cell_key", "seg_head",
                       "gather_voxels", "voxel_meta", "EpiVoxelStart", "LoadNonNegative"),
-    "pillar_feature_net": ("pfn_kernel",),
+    "pillar_feature_net": ("pfn_",),
     "pointpillars_scatter": ("fill_i32", "inverse_map", "canvas_write"),
     "centerpoint_postprocess": ("cp_decode", "cp_nms_boxes", "cp_output", "nms_mask", "nms_sweep"),
 }
