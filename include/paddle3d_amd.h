@@ -258,9 +258,8 @@ int pd3_grouped_conv3x3_small(const float *x, const float *w_grouped, const floa
  * F(2x2, 3x3) on the fp32 matrix cores (2.25x fewer multiplies, all fp32; results differ from the direct
  * form by fp32 rounding only, ~1e-6 relative).  One fused kernel: input transform, 16 GEMMs, output transform.
  *   x [batch, cin, h, w] fp32 NCHW (16-byte aligned);  out [batch, cout, h, w];  bias [cout] or NULL
- *   u_packed: U = G g G^T of the [cout, cin, 3, 3] weight, packed [cout/32][cin/8][2][8][16][20]
- *             (16-channel block, input channel, channel, component xi*4+nu padded 16 -> 20;
- *             see paddle3d_amd/ops/conv.py)
+ *   u_packed: U = G g G^T of the [cout, cin, 3, 3] weight, packed [cout/32][cin/8][2][8][16][16]
+ *             (16-channel block, input channel, channel, component xi*4+nu; see paddle3d_amd/ops/conv.py)
  *   requires cin % 8 == 0, cout % 32 == 0, h % 8 == 0, w % 32 == 0
  */
 int pd3_conv3x3_winograd_bias_relu(const float *x, const float *u_packed, const float *bias, int batch,

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
                                                            const float* __restrict__ wp,
                                                            const float* __restrict__ bias,
                                                            float* __restrict__ out, int cin, int cout,
-                                                           int h, int w, int relu) {
+                                                           int h, int w, int relu, int ptiles) {
   // h, w: OUTPUT size; the input map is (S*h) x (S*w), S = stride (1 or 2), padding 1
   static_assert(R * WT == 128 || R * WT == 256, "tile must hold 128 or 256 pixels");
   constexpr int NB = R * WT / 128;           // 32-pixel blocks per wave
@@ -52,9 +52,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
   extern __shared__ __attribute__((aligned(16))) float cv_smem[];  // X[2][XSZ] then W[2][WSZ]
   const int lane = lane_id(), wave = wave_id();
   const int tiles_x = w / WT, tiles_y = h / R;
-  const int pt = blockIdx.x;
+  // XCD-aware tile order (workgroups are dealt round-robin over the 8 XCDs): pixel tile pt lives on XCD
+  // pt % 8 and its channel tiles follow each other there -> the input tile is fetched from HBM once per XCD
+  const int nct = cout / kCvCo;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ct = slot % nct, pt = (slot / nct) * 8 + xcd;
+  if (pt >= ptiles) return;
   const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
-  const int ct = blockIdx.y;
   const int y0 = ty * R, x0 = tx * WT;
   const int kk = lane >> 5;
   // per-lane LDS bases (floats): B operand of pixel block t, A operand of channel block 0
@@ -188,8 +192,9 @@ static int launch_conv3x3(int64_t tiles, hipStream_t s, const float* x, const fl
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  dim3 grid((unsigned)tiles, (unsigned)(cout / kCvCo));
-  conv3x3_mfma_kernel<R, WT, S><<<grid, 256, lds, s>>>(x, wp, bias, out, cin, cout, h, w, relu);
+  const int64_t nwg = (tiles + 7) / 8 * 8 * (cout / kCvCo);
+  if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
+  conv3x3_mfma_kernel<R, WT, S><<<(unsigned)nwg, 256, lds, s>>>(x, wp, bias, out, cin, cout, h, w, relu, (int)tiles);
   return launch_status();
 }
 

@@ -10,8 +10,8 @@
 //
 // Workgroup = 32 output channels x 64 tiles (4 tile rows x 16 tile columns = 8 x 32 output pixels) x all 16
 // components; K walks 8 input channels per trip:
-//   U trip   : pre-transformed on the host and packed [2 co blocks][8 ci][16 co][16 xi + 4 pad] -> linear copy
-//              to LDS;
+//   U trip   : pre-transformed on the host and packed [2 co blocks][8 ci][16 co][16 xi]; copied to LDS with
+//              the component axis padded 16 -> 20 floats;
 //   raw X    : [8 ci][10 rows][40 cols] (aligned float4 loads from column x0-4, zero outside the image);
 //   V trip   : each thread transforms two (ci, tile) patches B^T d B out of the raw buffer and scatters the 16
 //              components to LDS as [4 tile rows][8 ci][16 tile cols][16 xi + 4 pad] (four b128 writes);
@@ -41,8 +41,8 @@ constexpr int kWgCs = 20;                                 // 16 components + 4 p
 constexpr int kWgUsz = kWgCo * kWgCi * kWgCs;             // 5120 floats  [2 co blocks][8 ci][16 co][20]
 constexpr int kWgRawSz = kWgCi * kWgRawPl;                // 3200 floats
 constexpr int kWgVsz = kWgTR * kWgCi * kWgTC * kWgCs;     // 10240 floats [4 tile rows][8 ci][16 tile cols][20]
-constexpr int kWgUN4 = kWgUsz / 4;                        // 1280 float4 = 5 per thread
-constexpr int kWgUPT = kWgUN4 / 256;
+constexpr int kWgUN4 = kWgCo * kWgCi * 16 / 4;             // 1024 float4 of U per trip in global memory (no pad)
+constexpr int kWgUPT = kWgUN4 / 256;                      // 4 per thread
 constexpr size_t kWgLds = (size_t)(kWgUsz + kWgRawSz + kWgVsz) * sizeof(float);  // 74240 B: two workgroups per CU
 constexpr int kWgXN4 = kWgRawSz / 4;                      // 800 float4
 constexpr int kWgXPT = (kWgXN4 + 255) / 256;              // 4 (the tail repeats element 799)
@@ -51,16 +51,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const float* _
                                                                   const float* __restrict__ up,
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ out, int cin, int cout,
-                                                                  int h, int w, int relu) {
+                                                                  int h, int w, int relu, int ptiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Us = smem;
   float* Raw = smem + kWgUsz;
   float* Vs = smem + kWgUsz + kWgRawSz;
   const int lane = lane_id(), wave = wave_id();
   const int tiles_x = w / (2 * kWgTC), tiles_y = h / (2 * kWgTR);
-  const int pt = blockIdx.x;
+  // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs (private
+  // L2s).  Pixel tile pt lives on XCD pt % 8 and its channel tiles follow each other there, so the input
+  // patch is fetched from HBM once per XCD and each L2 only sees 1/8 of the image.
+  const int nct = cout / kWgCo;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ct = slot % nct, pt = (slot / nct) * 8 + xcd;
+  if (pt >= ptiles) return;
   const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
-  const int ct = blockIdx.y;
   const int y0 = ty * 2 * kWgTR, x0 = tx * 2 * kWgTC;
   const int chunks = cin / kWgCi;
   const int64_t plane = (int64_t)h * w;
@@ -104,6 +109,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const float* _
     for (int b = 0; b < 2; ++b) acc[c][b] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
 
   wg_f32x4 xr[kWgXPT], ur[kWgUPT];
+  // U float4 e = threadIdx.x + 256 i of the trip: element e / 4 (16 components each), quarter e % 4
+  const int udst = (threadIdx.x >> 2) * kWgCs + (threadIdx.x & 3) * 4;
 
 #define WG_FETCH(cc)                                                                     \
   {                                                                                      \
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const float* _
       *reinterpret_cast<wg_f32x4*>(Raw + ldst[i]) = on_ ? xr[i] : z_;                    \
     }                                                                                    \
     _Pragma("unroll") for (int i = 0; i < kWgUPT; ++i)                                   \
-        *reinterpret_cast<wg_f32x4*>(Us + (threadIdx.x + i * 256) * 4) = ur[i];          \
+        *reinterpret_cast<wg_f32x4*>(Us + udst + i * 64 * kWgCs) = ur[i];                \
   }
   // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
 #define WG_TRANSFORM()                                                                   \
@@ -247,7 +254,10 @@ extern "C" int pd3_conv3x3_winograd_bias_relu(const float* x, const float* u_pac
       reinterpret_cast<uintptr_t>(out) % 8 != 0)
     return PD3_EINVAL;
   if ((int64_t)cin * h * w >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
-  dim3 grid((unsigned)((int64_t)batch * (h / (2 * kWgTR)) * (w / (2 * kWgTC))), (unsigned)(cout / kWgCo));
+  const int64_t ptiles = (int64_t)batch * (h / (2 * kWgTR)) * (w / (2 * kWgTC));
+  const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / kWgCo);
+  if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
+  dim3 grid((unsigned)nwg);
   static bool configured = false;  // raise the dynamic-LDS cap once
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_winograd_kernel),
@@ -256,6 +266,6 @@ extern "C" int pd3_conv3x3_winograd_bias_relu(const float* x, const float* u_pac
     configured = true;
   }
   conv3x3_winograd_kernel<<<grid, 256, kWgLds, static_cast<hipStream_t>(stream)>>>(x, u_packed, bias, out, cin,
-                                                                                   cout, h, w, relu);
+                                                                                   cout, h, w, relu, (int)ptiles);
   return launch_status();
 }

@@ -45,14 +45,14 @@ def winograd_supported(cin: int, cout: int, h: int, w: int) -> bool:
 
 
 def pack_winograd_weight(weight: torch.Tensor) -> torch.Tensor:
-    """[Cout, Cin, 3, 3] -> U = G g G^T packed [Cout/32][Cin/8][2 blocks][8 ci][16 co][16 components + 4 pad]."""
+    """[Cout, Cin, 3, 3] -> U = G g G^T packed [Cout/32][Cin/8][2 blocks][8 ci][16 co][16 components]."""
     cout, cin = weight.shape[:2]
     assert weight.shape[2:] == (3, 3) and cout % 32 == 0 and cin % 8 == 0
     g = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64,
                      device=weight.device)
     u = torch.einsum("ij,ocjk,lk->ocil", g, weight.double(), g).float()  # [cout, cin, 4, 4]
     u = u.reshape(cout // 32, 2, 16, cin // 8, 8, 16).permute(0, 3, 1, 4, 2, 5)
-    return torch.nn.functional.pad(u, (0, 4)).contiguous()
+    return u.contiguous()
 
 
 def conv3x3_winograd_bias_relu(x: torch.Tensor, u_packed: torch.Tensor, bias, cout: int, relu: bool = True,
