@@ -265,6 +265,21 @@ int pd3_grouped_conv3x3_small(const float *x, const float *w_grouped, const floa
 int pd3_conv3x3_winograd_bias_relu(const float *x, const float *u_packed, const float *bias, int batch,
                                    int cin, int cout, int h, int w, int relu, float *out, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * patch_conv_bias_relu -- the non-overlapping-patch convolutions of SecondFPN (paddle3d/models/necks/
+ * second_fpn.py:99-157; Conv2D / Conv2DTranspose with kernel = stride, BatchNorm folded) as one fp32-MFMA
+ * GEMM with bias + ReLU, written at a channel offset of a wider output tensor (the concat of the FPN levels).
+ *   mode 0: Conv2D kernel 2 stride 2      x [batch, cin, h, w] -> out[:, off:off+cout] of [batch, ctot, h/2, w/2]
+ *           w_packed = A[co][ci*4 + py*2 + px] from the [cout, cin, 2, 2] weight; needs h % 4 == 0, w % 256 == 0
+ *   mode 1: 1x1 convolution               -> [batch, ctot, h, w];  A[co][ci]; needs (h*w) % 256 == 0
+ *   mode 2: Conv2DTranspose kernel 2 stride 2 -> [batch, ctot, 2h, 2w];  A[co*4 + dy*2 + dx][ci] from the
+ *           [cin, cout, 2, 2] weight; needs (h*w) % 256 == 0
+ *   A is packed [M/64][K/16][16][64] (paddle3d_amd/ops/conv.py:pack_patch_weight); K % 16 == 0, M % 64 == 0
+ */
+int pd3_patch_conv_bias_relu(const float *x, const float *w_packed, const float *bias, int mode, int batch,
+                             int cin, int cout, int h, int w, int relu, float *out, int out_channels_total,
+                             int out_channel_offset, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -468,6 +468,36 @@ class CenterPoint(nn.Module):
             x = F.relu_(x)
         return x
 
+    def _neck_fused(self, outs):
+        """The FPN levels on the patch-GEMM kernel, each writing its channel slice of the concatenated map."""
+        if self.dense_backend != "hip" or not outs[0].is_cuda:
+            return None
+        plan, hw, ctot = [], None, 0
+        for layers, o in zip(self._dense[1], outs):
+            if len(layers) != 1:
+                return None
+            tr, w, b, stride, padding = layers[0]
+            mode = _conv.patch_mode(w, stride[0], tr)
+            cout = w.shape[1] if tr else w.shape[0]
+            cin = w.shape[0] if tr else w.shape[1]
+            if (mode is None or tuple(padding) != (0, 0) or stride[0] != stride[1]
+                    or not _conv.patch_supported(mode, cin, cout, o.shape[2], o.shape[3])):
+                return None
+            scale = {0: 0.5, 1: 1, 2: 2}[mode]
+            size = (int(o.shape[2] * scale), int(o.shape[3] * scale))
+            if hw is not None and size != hw:
+                return None
+            hw = size
+            plan.append((mode, w, b, tr, cout, ctot))
+            ctot += cout
+        out = torch.empty((outs[0].shape[0], ctot, hw[0], hw[1]), dtype=torch.float32, device=outs[0].device)
+        for (mode, w, b, tr, cout, off), o in zip(plan, outs):
+            key = ("patch", w.data_ptr())
+            if key not in self._packed:
+                self._packed[key] = _conv.pack_patch_weight(w, mode, tr)
+            _conv.patch_conv_bias_relu(o, self._packed[key], b, mode, cout, out, off, relu=True)
+        return out
+
     def dense_forward(self, x):
         if self.training:
             return self.neck(self.backbone(x))
@@ -477,6 +507,9 @@ class CenterPoint(nn.Module):
         for blk in self._dense[0]:
             x = self._run(blk, x)
             outs.append(x)
+        fused = self._neck_fused(outs)
+        if fused is not None:
+            return fused
         ups = [self._run(d, o) for d, o in zip(self._dense[1], outs)]
         return torch.cat(ups, dim=1)
 

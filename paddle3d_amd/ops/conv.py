@@ -7,7 +7,8 @@ import torch
 from ._common import check, lib, ptr, require_gpu, stream_ptr
 
 __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pack_grouped_weight", "grouped_conv3x3_small",
-           "grouped_small_supported", "winograd_supported", "pack_winograd_weight", "conv3x3_winograd_bias_relu"]
+           "grouped_small_supported", "winograd_supported", "pack_winograd_weight", "conv3x3_winograd_bias_relu",
+           "patch_mode", "patch_supported", "pack_patch_weight", "patch_conv_bias_relu"]
 
 
 def supported(cin: int, cout: int, h: int, w: int, stride: int = 1) -> bool:
@@ -64,6 +65,51 @@ def conv3x3_winograd_bias_relu(x: torch.Tensor, u_packed: torch.Tensor, bias, co
     check(lib().pd3_conv3x3_winograd_bias_relu(ptr(xx), ptr(u_packed), ptr(bias), n, cin, cout, h, w,
                                                int(bool(relu)), ptr(out), stream_ptr(xx.device)),
           "conv3x3_winograd_bias_relu")
+    return out
+
+
+def patch_mode(weight: torch.Tensor, stride: int, transpose: bool):
+    """Which pd3_patch_conv_bias_relu mode computes this FPN layer (None if it is not a patch convolution)."""
+    k = weight.shape[2]
+    if weight.shape[2] != weight.shape[3] or k != stride:
+        return None
+    if k == 1:
+        return 1
+    if k == 2:
+        return 2 if transpose else 0
+    return None
+
+
+def patch_supported(mode: int, cin: int, cout: int, h: int, w: int) -> bool:
+    if mode == 0:
+        return h % 4 == 0 and w % 256 == 0 and (cin * 4) % 16 == 0 and cout % 64 == 0
+    if (h * w) % 256 or cin % 16:
+        return False
+    return cout % 64 == 0 if mode == 1 else (cout * 4) % 64 == 0
+
+
+def pack_patch_weight(weight: torch.Tensor, mode: int, transpose: bool) -> torch.Tensor:
+    """GEMM A matrix [M, K] of the layer, packed [M/64][K/16][16][64].
+    Conv2D weights are [cout, cin, k, k], Conv2DTranspose weights [cin, cout, k, k]."""
+    if mode == 0:
+        a = weight.reshape(weight.shape[0], -1)                       # [co][ci*4 + py*2 + px]
+    elif mode == 1:
+        a = weight[:, :, 0, 0].t() if transpose else weight[:, :, 0, 0]  # [co][ci]
+    else:
+        a = weight.permute(1, 2, 3, 0).reshape(-1, weight.shape[0])   # [co*4 + dy*2 + dx][ci]
+    m, k = a.shape
+    assert m % 64 == 0 and k % 16 == 0
+    return a.reshape(m // 64, 64, k // 16, 16).permute(0, 2, 3, 1).contiguous()
+
+
+def patch_conv_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, mode: int, cout: int, out: torch.Tensor,
+                         channel_offset: int = 0, relu: bool = True) -> torch.Tensor:
+    """Writes relu(conv(x) + bias) into out[:, channel_offset:channel_offset + cout]."""
+    xx = require_gpu(x, "patch_conv_bias_relu")
+    n, cin, h, w = xx.shape
+    check(lib().pd3_patch_conv_bias_relu(ptr(xx), ptr(w_packed), ptr(bias), int(mode), n, cin, cout, h, w,
+                                         int(bool(relu)), ptr(out), out.shape[1], int(channel_offset),
+                                         stream_ptr(xx.device)), "patch_conv_bias_relu")
     return out
 
 

@@ -119,3 +119,40 @@ def test_winograd_shift_taps():
             out = conv.conv3x3_winograd_bias_relu(x.cuda(), conv.pack_winograd_weight(wt.cuda()), None, cout, False).cpu()
             want = F.conv2d(x, wt, None, padding=1)
             assert (out - want).abs().max().item() < 1e-3, (ky, kx)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_patch_conv_matches_torch(mode):
+    """FPN patch convolutions (second_fpn.py:99-157) written at a channel offset of a wider tensor."""
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator().manual_seed(mode)
+    n, off, ctot = 2, 64, 256
+    if mode == 0:
+        cin, cout, h, w = 16, 128, 8, 256
+        wt = torch.randn(cout, cin, 2, 2, generator=g) / (cin * 4) ** 0.5
+        x = torch.randn(n, cin, h, w, generator=g)
+        b = torch.randn(cout, generator=g)
+        ref = torch.relu(F.conv2d(x, wt, b, stride=2))
+        tr = False
+    elif mode == 1:
+        cin, cout, h, w = 32, 64, 16, 32
+        wt = torch.randn(cin, cout, 1, 1, generator=g) / cin ** 0.5
+        x = torch.randn(n, cin, h, w, generator=g)
+        b = torch.randn(cout, generator=g)
+        ref = torch.relu(F.conv_transpose2d(x, wt, b, stride=1))
+        tr = True
+    else:
+        cin, cout, h, w = 48, 128, 16, 16
+        wt = torch.randn(cin, cout, 2, 2, generator=g) / cin ** 0.5
+        x = torch.randn(n, cin, h, w, generator=g)
+        b = torch.randn(cout, generator=g)
+        ref = torch.relu(F.conv_transpose2d(x, wt, b, stride=2))
+        tr = True
+    assert conv.patch_mode(wt, 1 if mode == 1 else 2, tr) == mode
+    assert conv.patch_supported(mode, cin, cout, h, w)
+    out = torch.full((n, ctot, ref.shape[2], ref.shape[3]), -7.0, device="cuda")
+    conv.patch_conv_bias_relu(x.cuda(), conv.pack_patch_weight(wt.cuda(), mode, tr), b.cuda(), mode, cout, out, off)
+    got = out.cpu()
+    assert (got[:, off:off + cout] - ref).abs().max().item() < 2e-4
+    assert (got[:, :off] == -7.0).all() and (got[:, off + cout:] == -7.0).all()
