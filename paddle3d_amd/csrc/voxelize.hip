@@ -306,6 +306,19 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
   vt_count_kernel<<<cgrid, kVtAssignThreads, 0, s>>>(w.isfirst, w.stride, w.wsum);
   vt_assign_kernel<<<cgrid, kVtAssignThreads, 0, s>>>(w.isfirst, w.stride, w.owner, w.wsum,
                                                       max_voxels, w.vid2key, w.vid_npts, w.totals);
+  if ((dim == 4 || dim == 5) && max_pts <= 256 && !std::getenv("PD3_VOXELIZE_WRITER_V1")) {
+    const int rpb = 256 / max_pts;  // voxel rows per workgroup: one lane per (row, point slot)
+    dim3 pgrid((unsigned)ceil_div(max_voxels, rpb), batch);
+    if (dim == 4)
+      vt_write_points_kernel<4><<<pgrid, 256, 0, s>>>(points, cells, w.vid2key, w.vid_npts, w.totals, n, g.ncells,
+                                                      max_pts, max_voxels, rpb, vg, voxels, coords, num_pts,
+                                                      num_voxels, coors4);
+    else
+      vt_write_points_kernel<5><<<pgrid, 256, 0, s>>>(points, cells, w.vid2key, w.vid_npts, w.totals, n, g.ncells,
+                                                      max_pts, max_voxels, rpb, vg, voxels, coords, num_pts,
+                                                      num_voxels, coors4);
+    return launch_status();
+  }
   const int64_t row = (int64_t)max_pts * dim;
   const bool vec4 = (row % 4 == 0) && (reinterpret_cast<uintptr_t>(voxels) % 16 == 0);
   const int rowq = (int)(vec4 ? row / 4 : row);

@@ -506,4 +506,59 @@ __global__ __launch_bounds__(256) void vt_write_kernel(
   }
 }
 
+// Output writer, second form: one LANE per (voxel row, point slot).  The lane copies its point as one 16-byte
+// (+ one 4-byte for D = 5) load / store pair -- consecutive lanes write consecutive D*4-byte slots, so a wave's
+// stores are one contiguous run across adjacent voxel rows -- or writes the slot's zero padding.  A fifth of
+// the instructions of the chunk-column form (whose 4-byte gathers cost ~370 instructions per wave trip).
+typedef float vt_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int DIM>
+__global__ __launch_bounds__(256) void vt_write_points_kernel(
+    const float* __restrict__ points, VtCells s, const uint32_t* __restrict__ vid2key,
+    const int* __restrict__ vid_npts, const int* __restrict__ totals, int64_t n, uint32_t ncells, int max_pts,
+    int max_voxels, int rows_per_block, VtGrid g, float* __restrict__ voxels, int32_t* __restrict__ coords,
+    int32_t* __restrict__ num_pts, int32_t* __restrict__ num_voxels, int32_t* __restrict__ coors4) {
+  static_assert(DIM == 4 || DIM == 5, "point rows of 4 or 5 floats");
+  const int frame = blockIdx.y;
+  const int nv = min(totals[frame], max_voxels);
+  if (blockIdx.x == 0 && threadIdx.x == 0) num_voxels[frame] = nv;
+  const int r = (int)threadIdx.x / max_pts, k = (int)threadIdx.x - r * max_pts;
+  const int v = blockIdx.x * rows_per_block + r;
+  if (r >= rows_per_block || v >= max_voxels) return;
+  uint32_t key = 0;
+  int np = 0;
+  if (v < nv) {
+    key = vid2key[(int64_t)frame * max_voxels + v];
+    np = vid_npts[(int64_t)frame * max_voxels + v];
+  }
+  vt_f32x4u a = {0.f, 0.f, 0.f, 0.f};
+  float b = 0.f;
+  if (k < np) {
+    const uint32_t pi = s.plist[((int64_t)frame * ncells + key) * max_pts + k];
+    const float* src = points + ((int64_t)frame * n + pi) * DIM;
+    a = *reinterpret_cast<const vt_f32x4u*>(src);
+    if (DIM == 5) b = src[4];
+  }
+  float* dst = voxels + (((int64_t)frame * max_voxels + v) * max_pts + k) * DIM;
+  *reinterpret_cast<vt_f32x4u*>(dst) = a;
+  if (DIM == 5) dst[4] = b;
+  if (k == 0) {  // voxel meta: coords (z, y, x) and count, zero padded
+    int cz = 0, cy = 0, cx = 0;
+    if (v < nv) {
+      cx = (int)(key % (uint32_t)g.gx);
+      const uint32_t t = key / (uint32_t)g.gx;
+      cy = (int)(t % (uint32_t)g.gy);
+      cz = (int)(t / (uint32_t)g.gy);
+    }
+    int32_t* co = coords + ((int64_t)frame * max_voxels + v) * 3;
+    co[0] = cz;
+    co[1] = cy;
+    co[2] = cx;
+    num_pts[(int64_t)frame * max_voxels + v] = np;
+    if (coors4)  // (batch, z, y, x), batch = -1 on padding rows (HardVoxelizer's coors_pad)
+      *reinterpret_cast<int4*>(coors4 + ((int64_t)frame * max_voxels + v) * 4) =
+          make_int4(v < nv ? frame : -1, cz, cy, cx);
+  }
+}
+
 }  // namespace pd3
