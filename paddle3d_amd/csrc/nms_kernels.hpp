@@ -119,9 +119,15 @@ static __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned lo
   const bool in_lds = n <= kNmsLdsBoxes;
   for (int j = threadIdx.x; j < cbs; j += blockDim.x) remv[j] = 0ull;
   if (in_lds) {
-    for (int e = threadIdx.x; e < n * cbs; e += blockDim.x) {
-      const int i = e / cbs, j = e - i * cbs;
-      if (j >= (i >> 6)) mlds[e] = m[(int64_t)i * cb_cap + j];  // upper triangle only
+    if (cbs == cb_cap) {  // full-width rows: one linear copy, four loads in flight per thread
+      const int total = n * cbs;
+#pragma unroll 4
+      for (int e = threadIdx.x; e < total; e += blockDim.x) mlds[e] = m[e];
+    } else {
+      for (int e = threadIdx.x; e < n * cbs; e += blockDim.x) {
+        const int i = e / cbs, j = e - i * cbs;
+        if (j >= (i >> 6)) mlds[e] = m[(int64_t)i * cb_cap + j];  // upper triangle only
+      }
     }
   }
   __syncthreads();
@@ -150,11 +156,19 @@ static __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned lo
     // OR the kept rows' words into the later column blocks
     for (int j = nb + 1 + lane; j < cbs; j += 64) {
       unsigned long long acc = remv[j];
-      unsigned long long kb = keepbits;
-      while (kb) {
-        const int t = __ffsll((long long)kb) - 1;
-        kb &= kb - 1ull;
-        acc |= in_lds ? mlds[(nb * 64 + t) * cbs + j] : m[(int64_t)(nb * 64 + t) * cb_cap + j];
+      if (in_lds) {  // every row of the block is read (independent LDS loads, pipelined); kept rows are OR-ed in
+#pragma unroll 8
+        for (int t = 0; t < rows; ++t) {
+          const unsigned long long v = mlds[(nb * 64 + t) * cbs + j];
+          acc |= ((keepbits >> t) & 1ull) ? v : 0ull;
+        }
+      } else {
+        unsigned long long kb = keepbits;
+        while (kb) {
+          const int t = __ffsll((long long)kb) - 1;
+          kb &= kb - 1ull;
+          acc |= m[(int64_t)(nb * 64 + t) * cb_cap + j];
+        }
       }
       remv[j] = acc;
     }
