@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
     ap.add_argument("--max-voxels", type=int, default=30000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -19,6 +19,7 @@
 #include "radix_sort.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace pd3 {
 
@@ -112,6 +113,118 @@ __global__ __launch_bounds__(256) void cp_decode_kernel(CpHeads h, CpCfg c, floa
     const int s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     if (s) atomicAdd(&counts[set], s);
   }
+}
+
+// Top-K selection instead of a full sort of the score keys: only the first min(count, nms_pre_max_size) cells of
+// the stable ascending-key order are ever used (postprocess.cu:176-206 sorts the masked scores and slices
+// [:nms_pre_max_size]).  One workgroup per set, everything in LDS: the hw keys are loaded once; a 3-pass radix
+// SELECT (10-bit LDS histograms) finds the exact cut-off key and how many cells with that key still fit; the
+// selected cells are compacted in cell order and sorted as (key, cell) pairs by a bitonic network -- the same
+// total order a stable key sort gives.  Writes sidx[set][0 .. K).
+constexpr int kTopkThreads = 256;
+constexpr int kTopkMaxHw = 16384;   // keys held in LDS
+constexpr int kTopkMaxK = 1024;     // bitonic list
+
+__global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(const uint32_t* __restrict__ keys,
+                                                               const int* __restrict__ counts, int hw,
+                                                               int cap, uint32_t* __restrict__ sidx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char topk_smem[];
+  uint32_t* ks = reinterpret_cast<uint32_t*>(topk_smem);                       // [hw]
+  unsigned long long* list = reinterpret_cast<unsigned long long*>(ks + hw);   // [kTopkMaxK]
+  int* hist = reinterpret_cast<int*>(list + kTopkMaxK);                        // [1024]
+  int* scr = hist + 1024;                                                      // [8]
+  const int set = blockIdx.x;
+  const int count = counts[set];
+  const int K = min(count, cap);
+  if (K <= 0) return;
+  const uint32_t* kg = keys + (int64_t)set * hw;
+  for (int i = threadIdx.x; i < hw; i += kTopkThreads) ks[i] = kg[i];
+  for (int i = threadIdx.x; i < kTopkMaxK; i += kTopkThreads) list[i] = ~0ull;
+  __syncthreads();
+  // ---- cut-off key kc and the number r of cells with key == kc that are taken (0: take every key < kc) -----
+  uint32_t kc = kKeyOut;
+  int r = 0;
+  if (count > K) {
+    uint32_t prefix = 0;  // decided high bits
+    int need = K;         // rank of the cut-off inside the still-undecided set (1-based)
+    for (int pass = 0; pass < 3; ++pass) {
+      const int shift = 20 - 10 * pass;
+      for (int i = threadIdx.x; i < 1024; i += kTopkThreads) hist[i] = 0;
+      __syncthreads();
+      for (int i = threadIdx.x; i < hw; i += kTopkThreads) {
+        const uint32_t k = ks[i];
+        if (pass == 0 || (k >> (shift + 10)) == prefix) atomicAdd(&hist[(k >> shift) & 1023u], 1);
+      }
+      __syncthreads();
+      // thread t owns bins 4t .. 4t+3: exclusive prefix over bins, find the bin holding rank `need`
+      const int b0 = threadIdx.x * 4;
+      const int h0 = hist[b0], h1 = hist[b0 + 1], h2 = hist[b0 + 2], h3 = hist[b0 + 3];
+      int total;
+      const int base = block_exclusive_scan<kTopkThreads>(h0 + h1 + h2 + h3, scr, total);
+      int cum = base;
+      const int hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (need > cum && need <= cum + hh[j]) {  // exactly one (thread, j) satisfies this
+          scr[6] = b0 + j;
+          scr[7] = need - cum;
+        }
+        cum += hh[j];
+      }
+      __syncthreads();
+      prefix = (prefix << 10) | (uint32_t)scr[6];
+      need = scr[7];
+      __syncthreads();
+    }
+    kc = prefix;
+    r = need;
+  }
+  // ---- compaction in cell order: thread t owns the contiguous cells [t*ept, (t+1)*ept) ------------------------
+  const int ept = (hw + kTopkThreads - 1) / kTopkThreads;
+  const int c0 = threadIdx.x * ept, c1 = min(c0 + ept, hw);
+  int nless = 0, neq = 0;
+  for (int i = c0; i < c1; ++i) {
+    const uint32_t k = ks[i];
+    nless += k < kc ? 1 : 0;
+    neq += k == kc ? 1 : 0;
+  }
+  int tot_less, tot_eq;
+  int pos_less = block_exclusive_scan<kTopkThreads>(nless, scr, tot_less);
+  int pos_eq = block_exclusive_scan<kTopkThreads>(neq, scr, tot_eq);
+  for (int i = c0; i < c1; ++i) {
+    const uint32_t k = ks[i];
+    if (k < kc) {
+      list[pos_less++] = ((unsigned long long)k << 32) | (uint32_t)i;
+    } else if (k == kc) {
+      if (pos_eq < r) list[tot_less + pos_eq] = ((unsigned long long)k << 32) | (uint32_t)i;
+      ++pos_eq;
+    }
+  }
+  __syncthreads();
+  // ---- bitonic sort of the (key, cell) pairs, padded with ~0 -------------------------------------------------
+  int n2 = 64;
+  while (n2 < K) n2 <<= 1;  // uniform
+  for (int size = 2; size <= n2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (n2 >> 1); t += kTopkThreads) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = list[lo], b = list[hi];
+        if ((a > b) == up) {
+          list[lo] = b;
+          list[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  uint32_t* so = sidx + (int64_t)set * hw;
+  for (int i = threadIdx.x; i < K; i += kTopkThreads) so[i] = (uint32_t)(list[i] & 0xffffffffull);
+}
+
+static inline size_t cp_topk_lds(int hw) {
+  return (size_t)hw * 4 + (size_t)kTopkMaxK * 8 + 1024 * 4 + 8 * 4;
 }
 
 // iou3d_nms_kernel.cu:294-308 remap of the top-n boxes (sorted order) into NMS layout
@@ -279,9 +392,23 @@ extern "C" int pd3_centerpoint_postprocess(
   if (e != hipSuccess) return (int)e;
   dim3 dgrid((hw + 255) / 256, sets);
   cp_decode_kernel<<<dgrid, 256, 0, s>>>(h, c, w.boxes, w.scores, w.labels, w.keys_a, w.counts);
-  const int where = enqueue_radix_sort(w.keys_a, w.vals_a, w.keys_b, w.vals_b, hw, hw, sets,
-                                       plan, /*identity_vals=*/true, w.hist, w.partial, s);
-  const uint32_t* sidx = where ? w.vals_b : w.vals_a;
+  const uint32_t* sidx;
+  if (hw <= kTopkMaxHw && hw % 2 == 0 && cap <= kTopkMaxK && !std::getenv("PD3_POSTPROCESS_FULL_SORT")) {
+    const size_t lds = cp_topk_lds(hw);
+    static bool configured = false;
+    if (!configured) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(cp_topk_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp_topk_lds(kTopkMaxHw));
+      if (e != hipSuccess) return (int)e;
+      configured = true;
+    }
+    cp_topk_kernel<<<sets, kTopkThreads, lds, s>>>(w.keys_a, w.counts, hw, cap, w.vals_a);
+    sidx = w.vals_a;
+  } else {
+    const int where = enqueue_radix_sort(w.keys_a, w.vals_a, w.keys_b, w.vals_b, hw, hw, sets,
+                                         plan, /*identity_vals=*/true, w.hist, w.partial, s);
+    sidx = where ? w.vals_b : w.vals_a;
+  }
   dim3 bgrid((cap + 255) / 256, sets);
   cp_nms_boxes_kernel<<<bgrid, 256, 0, s>>>(w.boxes, sidx, w.counts, hw, c.dims, cap, w.nms_boxes);
   dim3 mgrid(cb, cb, sets);

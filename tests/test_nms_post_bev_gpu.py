@@ -106,6 +106,27 @@ def test_centerpoint_postprocess_edges(oracle):
     np.testing.assert_allclose(b, rb, rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("pre", [37, 100, 1000])
+def test_postprocess_topk_select_equals_full_sort(oracle, monkeypatch, pre):
+    """The LDS top-K selection (cut-off key + ties in cell order) gives exactly the full stable sort's result,
+    also when many cells share one score: quantised heat maps put hundreds of ties at the cut-off."""
+    tasks = synth.center_head_outputs(7, feat_h=128, feat_w=128, n_peaks=50)
+    for t in tasks:
+        t["hm"] = (np.round(t["hm"] * 2.0) / 2.0 + 3.0).astype(np.float32)  # few distinct values, all selected
+    monkeypatch.delenv("PD3_POSTPROCESS_FULL_SORT", raising=False)
+    (b, s, l), (rb, rs, rl), _ = _post(oracle, tasks, nms_pre_max_size=pre, nms_post_max_size=83)
+    monkeypatch.setenv("PD3_POSTPROCESS_FULL_SORT", "1")
+    (b2, s2, l2), _, _ = _post(oracle, tasks, nms_pre_max_size=pre, nms_post_max_size=83)
+    assert b.shape == b2.shape
+    np.testing.assert_array_equal(l, l2)
+    np.testing.assert_array_equal(s, s2)
+    np.testing.assert_array_equal(b, b2)
+    # and the oracle (stable descending sort, ties in cell order) agrees
+    assert b.shape == rb.shape
+    np.testing.assert_array_equal(l, rl)
+    np.testing.assert_allclose(b, rb, rtol=2e-6, atol=2e-6)
+
+
 def test_postprocess_batch_check():
     from paddle3d_amd.ops import centerpoint_postprocess as cp
 
