@@ -63,6 +63,14 @@ int pd3_hard_voxelize(const float *points, const int32_t *num_points, int batch,
                       int32_t *num_points_per_voxel, int32_t *num_voxels, int32_t *coors_batched,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* dynamic_voxelize -- per-point voxel coordinates without the per-voxel cap.  The reference has no such
+ * operator (only a "dynamic voxelization" comment at transforms/ for num_points == -1);
+ * BASELINE.json's north star names it, so it is provided with hard_voxelize's own cell rule
+ * (voxelize_op.cc:37-45): coors[i] = (z, y, x) of point i, (-1, -1, -1) outside point_cloud_range.
+ *   points [num_points, num_point_dim] fp32 device;  coors [num_points, 3] int32 device */
+int pd3_dynamic_voxelize(const float *points, int64_t num_points, int num_point_dim, const float *voxel_size,
+                         const float *point_cloud_range, int32_t *coors, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * pointpillars_scatter -- replaces PointPillarsScatter.forward_batch,
  * paddle3d/models/middle_encoders/pillar_scatter.py:57-93 (zeros canvas + paddle.scatter(overwrite) +

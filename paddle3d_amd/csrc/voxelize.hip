@@ -70,6 +70,21 @@ __global__ __launch_bounds__(256) void cell_key_kernel(const float* __restrict__
   keys[(int64_t)frame * max_points + i] = key;
 }
 
+// dynamic_voxelize: the per-point half of voxelization (no per-voxel cap): coors[i] = (z, y, x) cell of point i by
+// the same rule as hard_voxelize (voxelize_op.cc:37-45), (-1, -1, -1) if the point falls outside the range.
+__global__ __launch_bounds__(256) void dynamic_voxelize_kernel(const float* __restrict__ points, int64_t n,
+                                                               int dim, VoxGrid g, int32_t* __restrict__ coors) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = points + i * dim;
+  int cx = 0, cy = 0, cz = 0;
+  const bool in = axis_cell(p[0], g.min_x, g.size_x, g.gx, cx) && axis_cell(p[1], g.min_y, g.size_y, g.gy, cy) &&
+                  axis_cell(p[2], g.min_z, g.size_z, g.gz, cz);
+  coors[i * 3 + 0] = in ? cz : -1;
+  coors[i * 3 + 1] = in ? cy : -1;
+  coors[i * 3 + 2] = in ? cx : -1;
+}
+
 __global__ __launch_bounds__(256) void seg_head_kernel(const uint32_t* __restrict__ skey,
                                                        const uint32_t* __restrict__ sidx,
                                                        int64_t n, uint32_t ncells,
@@ -407,3 +422,16 @@ extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points,
 
 extern "C" int pd3_version(void) { return 100; }
 extern "C" const char* pd3_target_arch(void) { return "gfx950"; }
+
+extern "C" int pd3_dynamic_voxelize(const float* points, int64_t num_points, int num_point_dim,
+                                    const float* voxel_size, const float* point_cloud_range, int32_t* coors,
+                                    void* stream) {
+  if (num_points < 0 || num_point_dim < 3 || !voxel_size || !point_cloud_range) return PD3_EINVAL;
+  if (num_points == 0) return 0;
+  if (!points || !coors) return PD3_EINVAL;
+  VoxGrid g;
+  if (!make_grid(voxel_size, point_cloud_range, g)) return PD3_EINVAL;
+  dynamic_voxelize_kernel<<<(unsigned)ceil_div(num_points, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      points, num_points, num_point_dim, g, coors);
+  return launch_status();
+}

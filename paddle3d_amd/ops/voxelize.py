@@ -13,7 +13,7 @@ import torch
 
 from ._common import check, host_f32, lib, ptr, require_gpu, stream_ptr, workspace
 
-__all__ = ["hard_voxelize", "hard_voxelize_batch"]
+__all__ = ["dynamic_voxelize", "hard_voxelize", "hard_voxelize_batch"]
 
 
 def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max_num_points_in_voxel: int,
@@ -59,3 +59,16 @@ def hard_voxelize(points: torch.Tensor, voxel_size, point_cloud_range, max_num_p
     voxels, coords, npv, nv = hard_voxelize_batch(pts.unsqueeze(0), voxel_size, point_cloud_range,
                                                   max_num_points_in_voxel, max_voxels)
     return voxels[0], coords[0], npv[0], nv
+
+
+def dynamic_voxelize(points: torch.Tensor, voxel_size, point_cloud_range) -> torch.Tensor:
+    """Per-point voxel coordinates [N, 3] int32 = (z, y, x), -1 outside the range; hard_voxelize's cell rule."""
+    pts = require_gpu(points, "dynamic_voxelize")
+    if pts.dim() != 2:
+        raise RuntimeError("dynamic_voxelize expects points of shape [N, D]")
+    n, d = pts.shape
+    vs, pr = host_f32(voxel_size, 3), host_f32(point_cloud_range, 6)
+    coors = torch.empty((n, 3), dtype=torch.int32, device=pts.device)
+    check(lib().pd3_dynamic_voxelize(ptr(pts), n, d, ptr(vs), ptr(pr), ptr(coors), stream_ptr(pts.device)),
+          "dynamic_voxelize")
+    return coors

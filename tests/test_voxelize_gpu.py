@@ -154,3 +154,20 @@ def test_batched_coors_output(oracle):
         n = int(nv[b])
         np.testing.assert_array_equal(c4[b, :, 1:], co[b])
         assert (c4[b, :n, 0] == b).all() and (c4[b, n:, 0] == -1).all()
+
+
+def test_dynamic_voxelize_agrees_with_hard_voxelize(oracle):
+    """dynamic_voxelize's per-point cells = the cells hard_voxelize (and the reference CPU kernel) assigns."""
+    from paddle3d_amd.ops import voxelize as V
+
+    pts = synth.nuscenes_sweep(11, n_points=50_000)
+    co = V.dynamic_voxelize(torch.from_numpy(pts).cuda(), list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE)).cpu().numpy()
+    vs, pr = np.asarray(synth.NUSC_PILLAR, np.float32), np.asarray(synth.NUSC_RANGE, np.float32)
+    grid = np.round((pr[3:] - pr[:3]) / vs).astype(np.int64)
+    c = np.floor((pts[:, :3] - pr[:3]) / vs)  # fp32 subtract / divide / floor, as voxelize_op.cc:37-45
+    inside = np.all((c >= 0) & (c < grid), axis=1)
+    want = np.where(inside[:, None], c[:, ::-1], -1).astype(np.int32)
+    assert np.array_equal(co, want)
+    # and the set of occupied cells equals the coords hard_voxelize reports when nothing is capped
+    rv, rc, rn, rnv = oracle.hard_voxelize(pts, synth.NUSC_PILLAR, synth.NUSC_RANGE, 20, 200_000)
+    assert set(map(tuple, co[inside])) == set(map(tuple, rc[:rnv]))
