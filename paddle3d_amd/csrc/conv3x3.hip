@@ -134,18 +134,31 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
     __builtin_amdgcn_sched_barrier(0);  // keep the loads in flight ahead of the MFMA block
     const float* Xs = cv_smem + (cc & 1) * XSZ;
     const float* Ws = cv_smem + (cc & 1) * WSZ + wb;
+    // 36 steps, operands read two steps ahead of their MFMAs through a ring of three register sets (the
+    // scheduling fences pin that order: the compiler would otherwise issue each read right before its use)
+    float a0_[3], a1_[3], b_[3][NB];
+#define CV_OPERANDS(s_, slot_)                                                           \
+  {                                                                                      \
+    const int cp_ = (s_) / 9, tap_ = (s_) % 9;                                           \
+    const int xo_ = 2 * cp_ * XPL + (tap_ / 3) * XW + (tap_ % 3);                        \
+    a0_[slot_] = Ws[(s_) * 2 * kCvCo];                                                   \
+    a1_[slot_] = Ws[(s_) * 2 * kCvCo + 32];                                              \
+    _Pragma("unroll") for (int t = 0; t < NB; ++t) b_[slot_][t] = Xs[xb[t] + xo_];       \
+  }
+    CV_OPERANDS(0, 0)
+    CV_OPERANDS(1, 1)
 #pragma unroll
     for (int s = 0; s < kCvK / 2; ++s) {
-      const int cp = s / 9, tap = s % 9;
-      const int xo = 2 * cp * XPL + (tap / 3) * XW + (tap % 3);
-      const float a0 = Ws[s * 2 * kCvCo], a1 = Ws[s * 2 * kCvCo + 32];
+      if (s + 2 < kCvK / 2) CV_OPERANDS(s + 2, (s + 2) % 3)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
-        const float b = Xs[xb[t] + xo];
-        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][t], 0, 0, 0);
-        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][t], 0, 0, 0);
+        acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_[s % 3], b_[s % 3][t], acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_[s % 3], b_[s % 3][t], acc[1][t], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
+#undef CV_OPERANDS
     __builtin_amdgcn_sched_barrier(0);
     CV_STASH((cc + 1) & 1)
     __syncthreads();
