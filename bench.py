@@ -73,7 +73,7 @@ def make_batch(batch, seed0, device):
     return torch.from_numpy(arr).to(device)
 
 
-def cpu_baseline(model_cpu, max_voxels, frames=2):
+def cpu_baseline(model_cpu, max_voxels, frames=8):
     """Oracle pipeline on the host cores (bounded sample)."""
     from oracle import pyoracle as O
     from paddle3d_amd import synth
@@ -241,6 +241,9 @@ def main():
                 if os.environ.get("PD3_VOXELIZE_PATH", "tiled") != "sort" else
                 "hard_voxelize launch sequence (cell_key + radix sort + seg_head + scan + gather)")),
             "rooflines": rooflines,
+            # `roofline` is the kernel the north star puts the HBM target on; by time the step is dominated by
+            # the dense graph (rooflines["dense_backbone_fpn_head"], MFMA bound)
+            "dominant_by_time": "dense_backbone_fpn_head",
             "per_op_ms": per_op_ms,
             "detections_first_frame": int(out[1][0].item()),
         }
