@@ -268,7 +268,7 @@ int pd3_grouped_conv3x3_small(const float *x, const float *w_grouped, const floa
  *   x [batch, cin, h, w] fp32 NCHW (16-byte aligned);  out [batch, cout, h, w];  bias [cout] or NULL
  *   u_packed: U = G g G^T of the [cout, cin, 3, 3] weight, packed [cout/32][cin/8][2][8][16][16]
  *             (16-channel block, input channel, channel, component xi*4+nu; see paddle3d_amd/ops/conv.py)
- *   requires cin % 8 == 0, cout % 32 == 0, h % 8 == 0, w % 32 == 0
+ *   requires cin % 8 == 0, cout % 32 == 0, w % 4 == 0 (any h; partial 8 x 32 tiles at the border are masked)
  */
 int pd3_conv3x3_winograd_bias_relu(const float *x, const float *u_packed, const float *bias, int batch,
                                    int cin, int cout, int h, int w, int relu, float *out, void *stream);

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const float* _
   float* Raw = smem + kWgUsz;
   float* Vs = smem + kWgUsz + kWgRawSz;
   const int lane = lane_id(), wave = wave_id();
-  const int tiles_x = w / (2 * kWgTC), tiles_y = h / (2 * kWgTR);
+  const int tiles_x = (w + 2 * kWgTC - 1) / (2 * kWgTC), tiles_y = (h + 2 * kWgTR - 1) / (2 * kWgTR);
   // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs (private
   // L2s).  Pixel tile pt lives on XCD pt % 8 and its channel tiles follow each other there, so the input
   // patch is fetched from HBM once per XCD and each L2 only sees 1/8 of the image.
@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd_kernel(const float* _
           v0 = fmaxf(v0, 0.f);
           v1 = fmaxf(v1, 0.f);
         }
-        *reinterpret_cast<wg_f32x2*>(o + (int64_t)i * w) = (wg_f32x2){v0, v1};
+        if (oy + i < h && ox < w)  // partial tiles at the bottom / right border (w is even: a pair is in or out)
+          *reinterpret_cast<wg_f32x2*>(o + (int64_t)i * w) = (wg_f32x2){v0, v1};
       }
     }
   }
@@ -248,13 +249,13 @@ extern "C" int pd3_conv3x3_winograd_bias_relu(const float* x, const float* u_pac
                                               int batch, int cin, int cout, int h, int w, int relu, float* out,
                                               void* stream) {
   if (!x || !u_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return PD3_EINVAL;
-  if (cin % kWgCi != 0 || cout % kWgCo != 0 || h % (2 * kWgTR) != 0 || w % (2 * kWgTC) != 0)
+  if (cin % kWgCi != 0 || cout % kWgCo != 0 || w % 4 != 0)  // float4 staging: a quad is inside or outside a row
     return PD3_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(u_packed) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0 ||
       reinterpret_cast<uintptr_t>(out) % 8 != 0)
     return PD3_EINVAL;
   if ((int64_t)cin * h * w >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
-  const int64_t ptiles = (int64_t)batch * (h / (2 * kWgTR)) * (w / (2 * kWgTC));
+  const int64_t ptiles = (int64_t)batch * ceil_div(h, 2 * kWgTR) * ceil_div(w, 2 * kWgTC);
   const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / kWgCo);
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
   dim3 grid((unsigned)nwg);

@@ -42,7 +42,7 @@ def conv3x3_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, 
 
 
 def winograd_supported(cin: int, cout: int, h: int, w: int) -> bool:
-    return cin % 8 == 0 and cout % 32 == 0 and h % 8 == 0 and w % 32 == 0
+    return cin % 8 == 0 and cout % 32 == 0 and w % 4 == 0
 
 
 def pack_winograd_weight(weight: torch.Tensor) -> torch.Tensor:

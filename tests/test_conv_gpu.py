@@ -87,7 +87,8 @@ def test_unsupported_shapes_are_refused():
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 128), (1, 8, 32, 8, 32), (1, 128, 96, 16, 64),
-                                            (1, 384, 64, 24, 96), (3, 16, 32, 8, 32)])
+                                            (1, 384, 64, 24, 96), (3, 16, 32, 8, 32), (1, 24, 32, 8, 64), (2, 16, 64, 45, 180),
+                                            (1, 8, 32, 5, 12), (1, 40, 32, 62, 124)])
 @pytest.mark.parametrize("relu", [True, False])
 def test_conv3x3_winograd_matches_torch(n, cin, cout, h, w, relu):
     """Winograd F(2x2,3x3) on the fp32 matrix cores vs torch conv2d on the CPU."""
