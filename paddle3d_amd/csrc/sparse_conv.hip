@@ -341,17 +341,38 @@ __global__ __launch_bounds__(256) void sp_gemm_mfma_kernel(SpGemmArgs a, int cin
       }
     }
     const float* wk = a.weight + (int64_t)k * a.cin * cout;
+    // W[k] travels global -> registers one chunk ahead of its use (the loads of chunk c+1 are in flight while the
+    // matrix cores work on chunk c), then registers -> LDS between the two barriers of the chunk
+    constexpr int WPT = kSpChunk * NB * 16 / 4 / 256;  // float4 of a full chunk per thread (NB >= 2)
+    sp_f32x4 wreg[WPT > 0 ? WPT : 1];
+    const int cq = cout / 4;
+    auto fetch_w = [&](int c) {
+      const int ci0 = c * kSpChunk;
+      const int rows = min(kSpChunk, cin_pad - ci0);
+#pragma unroll
+      for (int i = 0; i < (WPT > 0 ? WPT : 1); ++i) {
+        const int e = threadIdx.x + i * 256;
+        const int r = e / cq, c4 = e - r * cq;
+        sp_f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (e < rows * cq && ci0 + r < a.cin) t = *reinterpret_cast<const sp_f32x4*>(wk + (int64_t)(ci0 + r) * cout + c4 * 4);
+        wreg[i] = t;
+      }
+    };
+    fetch_w(0);
     for (int c = 0; c < nchunks; ++c) {
       if (c > 0) __syncthreads();  // previous chunk of Ws consumed
       const int ci0 = c * kSpChunk;
       const int rows = min(kSpChunk, cin_pad - ci0);
-      for (int e = threadIdx.x; e < rows * (cout / 4); e += blockDim.x) {
-        const int r = e / (cout / 4), c4 = e - r * (cout / 4);
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ci0 + r < a.cin) t = *reinterpret_cast<const float4*>(wk + (int64_t)(ci0 + r) * cout + c4 * 4);
-        float* dst = Ws + r * wstride + c4 * 4;
-        dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+#pragma unroll
+      for (int i = 0; i < (WPT > 0 ? WPT : 1); ++i) {
+        const int e = threadIdx.x + i * 256;
+        const int r = e / cq, c4 = e - r * cq;
+        if (e < rows * cq) {
+          float* dst = Ws + r * wstride + c4 * 4;
+          dst[0] = wreg[i][0]; dst[1] = wreg[i][1]; dst[2] = wreg[i][2]; dst[3] = wreg[i][3];
+        }
       }
+      if (c + 1 < nchunks) fetch_w(c + 1);
       __syncthreads();
       if (wave_any) {
         for (int s4 = 0; s4 < rows; s4 += 4) {
