@@ -256,7 +256,7 @@ int pd3_conv3x3_bias_relu(const float *x, const float *w_packed, const float *bi
  *   x [batch, groups*cin_per_group, h, w];  out [batch, groups*cout_per_group, h, w];  bias [groups*cout_per_group] or NULL
  *   w_grouped: [groups][cin_per_group][cout_per_group][9] (the [groups*cout, cin, 3, 3] weight with the two
  *              channel axes swapped inside each group)
- *   requires cin_per_group % 4 == 0, h % 8 == 0, w % 128 == 0
+ *   requires cin_per_group % 4 == 0, w % 4 == 0 (any h; partial 8 x 128 tiles at the border are masked)
  */
 int pd3_grouped_conv3x3_small(const float *x, const float *w_grouped, const float *bias, int batch, int groups,
                               int cin_per_group, int cout_per_group, int h, int w, float *out, void *stream);

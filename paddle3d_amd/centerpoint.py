@@ -351,12 +351,15 @@ class CenterHead(nn.Module):
         if self._fused is None:
             self._build_fused()
         f = self._fused
-        if self.dense_backend == "hip" and x.is_cuda and _conv.supported(x.shape[1], f["w0"].shape[0], x.shape[2],
-                                                                         x.shape[3]):
+        y = None
+        if self.dense_backend == "hip" and x.is_cuda:
             pk = f.setdefault("packed", {})
-            x = _hip_conv3x3(x, f["w0"], f["b0"], 1, pk)
-            y = _hip_conv3x3(x, f["w1"], f["b1"], 1, pk)
-        else:
+            x1 = _hip_conv3x3(x, f["w0"], f["b0"], 1, pk)
+            if x1 is not None:
+                y = _hip_conv3x3(x1, f["w1"], f["b1"], 1, pk)
+                if y is not None:
+                    x = x1
+        if y is None:
             x = F.relu(F.conv2d(x, f["w0"], f["b0"], padding=1))
             y = F.relu(F.conv2d(x, f["w1"], f["b1"], padding=1))
         if (self.dense_backend == "hip" and y.is_cuda

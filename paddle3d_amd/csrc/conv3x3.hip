@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_kernel(const float*
                                                                     float* __restrict__ out, int groups,
                                                                     int cg, int h, int w) {
   __shared__ __attribute__((aligned(16))) float Xs[kGcCi * kGcXR * kGcXW];
-  const int tiles_x = w / kGcW, tiles_y = h / kGcR;
+  const int tiles_x = (w + kGcW - 1) / kGcW, tiles_y = (h + kGcR - 1) / kGcR;
   const int pt = blockIdx.x;
   const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
   const int g = blockIdx.y;
@@ -285,8 +285,9 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_kernel(const float*
   for (int c = 0; c < CO; ++c) {
     const float b = bias ? bias[g * CO + c] : 0.f;
     cv_f32x4 v = {acc[c][0] + b, acc[c][1] + b, acc[c][2] + b, acc[c][3] + b};
-    *reinterpret_cast<cv_f32x4*>(out + ((int64_t)n * groups * CO + g * CO + c) * plane + (int64_t)(y0 + tr) * w +
-                                 x0 + tc) = v;
+    if (y0 + tr < h && x0 + tc < w)  // partial tiles at the border (w % 4 == 0: a quad is in or out)
+      *reinterpret_cast<cv_f32x4*>(out + ((int64_t)n * groups * CO + g * CO + c) * plane +
+                                   (int64_t)(y0 + tr) * w + x0 + tc) = v;
   }
 }
 
@@ -327,11 +328,11 @@ extern "C" int pd3_grouped_conv3x3_small(const float* x, const float* w_grouped,
                                          float* out, void* stream) {
   if (!x || !w_grouped || !out || batch <= 0 || groups <= 0 || cin_per_group <= 0 || h <= 0 || w <= 0)
     return PD3_EINVAL;
-  if (cout_per_group < 1 || cout_per_group > 4 || cin_per_group % kGcCi != 0 || h % kGcR != 0 || w % kGcW != 0)
+  if (cout_per_group < 1 || cout_per_group > 4 || cin_per_group % kGcCi != 0 || w % 4 != 0)
     return PD3_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return PD3_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  dim3 grid((unsigned)((int64_t)batch * (h / kGcR) * (w / kGcW)), (unsigned)groups);
+  dim3 grid((unsigned)((int64_t)batch * ceil_div(h, kGcR) * ceil_div(w, kGcW)), (unsigned)groups);
   switch (cout_per_group) {
     case 1: grouped_conv3x3_small_kernel<1><<<grid, 256, 0, s>>>(x, w_grouped, bias, out, groups, cin_per_group, h, w); break;
     case 2: grouped_conv3x3_small_kernel<2><<<grid, 256, 0, s>>>(x, w_grouped, bias, out, groups, cin_per_group, h, w); break;

@@ -114,7 +114,7 @@ def patch_conv_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, mode: in
 
 
 def grouped_small_supported(cin_per_group: int, cout_per_group: int, h: int, w: int) -> bool:
-    return 1 <= cout_per_group <= 4 and cin_per_group % 4 == 0 and h % 8 == 0 and w % 128 == 0
+    return 1 <= cout_per_group <= 4 and cin_per_group % 4 == 0 and w % 4 == 0
 
 
 def pack_grouped_weight(weight: torch.Tensor, groups: int) -> torch.Tensor:
