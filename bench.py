@@ -130,7 +130,7 @@ def main():
     lib()  # fail loudly if libpaddle3d_amd.so is missing
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    torch.backends.cudnn.benchmark = True  # MIOpen find mode for the dense convolutions
+    torch.backends.cudnn.benchmark = True  # only matters for PD3_DENSE_BACKEND=miopen (MIOpen find mode)
     torch.manual_seed(0)
     V, B = args.max_voxels, args.batch
 

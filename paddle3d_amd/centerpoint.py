@@ -14,9 +14,13 @@ What differs from the reference, by design:
     loops over samples in Python and syncs on num_voxels per sample, voxelize.py:43);
   * padded rows beyond num_voxels are never sliced off on the host: fixed-shape [B, V, ...] tensors flow
     through PFN and scatter, which ignore rows >= num_voxels through the batch column -1;
-  * dense 2-D convolutions stay in PyTorch-ROCm (MIOpen -> MFMA), BatchNorm folded for inference, and the
-    36 first-stage head convolutions that read the same shared feature map are issued as ONE convolution.
-torch is plumbing here (device memory, streams, MIOpen); the LiDAR-specific work is in libpaddle3d_amd.so.
+  * the dense 2-D convolutions run on the library's own fp32-MFMA kernels in eval mode (Winograd F(2x2,3x3)
+    for the stride-1 3x3 layers, an implicit-GEMM kernel for the stride-2 ones, a patch-GEMM kernel for the
+    FPN levels writing into the concatenated map, a grouped kernel for the final head convolutions), with
+    BatchNorm folded; the 36 first-stage head convolutions that read the same shared feature map are issued
+    as ONE convolution.  PD3_DENSE_BACKEND=miopen routes them through PyTorch-ROCm instead (also the fallback
+    for shapes the kernels do not take, and the training-mode path).
+torch is plumbing here (device memory, streams); the work is in libpaddle3d_amd.so.
 """
 from __future__ import annotations
 
@@ -416,7 +420,7 @@ class CenterPoint(nn.Module):
         self.box_with_velocity = box_with_velocity
         self._dense = None
         # "hip" (default): the hand-written fp32-MFMA kernel (ops/conv.py) for every 3x3 convolution of the
-        # backbone; "miopen": PyTorch-ROCm convolutions (also what the 1x1 / 2x2 FPN layers use)
+        # backbone and the FPN levels; "miopen": PyTorch-ROCm convolutions
         self.dense_backend = os.environ.get("PD3_DENSE_BACKEND", "hip")
         self._packed = {}
 

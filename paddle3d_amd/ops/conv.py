@@ -1,5 +1,7 @@
-"""conv3x3_bias_relu: hand-written fp32-MFMA 3x3/stride-1 convolution for the dense BEV graph
-(SecondBackbone / CenterHead convolutions, BatchNorm folded)."""
+"""The dense BEV graph's convolutions on the library's fp32-MFMA kernels (SecondBackbone / SecondFPN / CenterHead
+with BatchNorm folded): conv3x3_winograd_bias_relu (stride 1), conv3x3_bias_relu (stride 1 / 2, implicit GEMM),
+patch_conv_bias_relu (kernel = stride FPN levels, written at a channel offset), grouped_conv3x3_small (the final
+SeparateHead convolutions), plus the host-side weight packers each kernel expects."""
 from __future__ import annotations
 
 import torch
