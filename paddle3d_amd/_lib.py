@@ -70,6 +70,8 @@ _SIGNATURES = {
                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pd3_conv3x3_winograd_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_conv3x3_winograd43_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                   C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pd3_patch_conv_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pd3_grouped_conv3x3_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -1,0 +1,279 @@
+// 3x3 / stride 1 / pad 1 convolution + bias + ReLU by Winograd F(4x4, 3x3) on the fp32 matrix cores, NCHW in
+// and out, fully fused (same layers as conv_winograd.hip; reference: second_backbone.py:72-120 and
+// center_head.py:43-220, cuDNN in the reference).
+//
+//   Y(4x4) = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A,   d = the 6x6 input patch of a 4x4 output tile
+// 36 independent GEMMs M[xi] = U[xi] V[xi]: 4x fewer multiplies than the direct form (F(2x2,3x3): 2.25x) for
+// 1.5x the transform work per pixel.  fp32 throughout; the transform constants (4, 5, 8, 1/24 ...) cost about one
+// decimal digit against the direct form (measured ~1e-5 absolute for |y| ~ 1.5), far inside the 1e-3 contract.
+//
+// Workgroup = 32 output channels x 32 tiles (2 tile rows x 16 tile columns = 8 x 64 output pixels) x all 36
+// components; K walks 4 input channels per trip = one K step of v_mfma_f32_16x16x4_f32:
+//   U trip : pre-transformed on the host, packed [2 co blocks][4 ci][16 co][36 xi] -> linear copy to LDS;
+//   raw X  : [4 ci][10 rows][72 cols], aligned float4 loads from column x0-4, zero outside the image;
+//   V trip : a PAIR of lanes transforms one (channel, tile) patch: lane h takes columns 3h..3h+2 through the
+//            row pass, the halves are swapped with one DPP quad_perm per value, lane h then runs the column
+//            pass for rows 3h..3h+2 and writes its 18 components to LDS as [2 tile rows][4 ci][16 tile cols][36];
+//   MFMA   : wave w owns co block (w & 1) and tile row (w >> 1) for all 36 components (36 accumulator quads);
+//            the 36-float component axis is read with conflict-free ds_read_b128 (36 l mod 64 are 16 distinct
+//            multiples of 4), 9 + 9 reads for 36 MFMAs, reads running two groups ahead of their MFMAs;
+//   epilogue: one lane holds all 36 components of its (co, tile): A^T M A in registers, + bias, ReLU, one float4
+//            store per output row (16 lanes = 256 contiguous bytes).
+// Two workgroups per CU (47 KB LDS); the next trip's global loads are issued before the MFMA block.
+#include "../../include/paddle3d_amd.h"
+#include "common.hpp"
+
+namespace pd3 {
+
+typedef float w4_f32x4 __attribute__((ext_vector_type(4)));
+typedef float w4_f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kW4Ci = 4;                  // input channels per trip (= MFMA K)
+constexpr int kW4Co = 32;                 // output channels per workgroup
+constexpr int kW4TR = 2, kW4TC = 16;      // tile rows / columns per workgroup (4x4 outputs each)
+constexpr int kW4Cs = 36;                 // components per element
+constexpr int kW4RawR = 4 * kW4TR + 2;    // 10 staged input rows
+constexpr int kW4RawW = 4 * kW4TC + 8;    // 72 staged input columns: x0-4 .. x0+67
+constexpr int kW4RawPl = kW4RawR * kW4RawW;                  // 720
+constexpr int kW4Usz = 2 * kW4Ci * 16 * kW4Cs;               // 4608 floats
+constexpr int kW4Vsz = kW4TR * kW4Ci * kW4TC * kW4Cs;        // 4608 floats
+constexpr int kW4RawSz = kW4Ci * kW4RawPl;                   // 2880 floats
+constexpr int kW4UN4 = kW4Usz / 4;                           // 1152 float4 (4.5 per thread)
+constexpr int kW4UPT = (kW4UN4 + 255) / 256;                 // 5 (the tail repeats the last one)
+constexpr int kW4XN4 = kW4RawSz / 4;                         // 720 float4
+constexpr int kW4XPT = (kW4XN4 + 255) / 256;                 // 3
+
+// B^T applied to six values (one column or one row of the patch)
+__device__ __forceinline__ void w4_in(const float d0, const float d1, const float d2, const float d3, const float d4,
+                                      const float d5, float (&t)[6]) {
+  const float a = __builtin_fmaf(-4.f, d2, d4), b = __builtin_fmaf(-4.f, d1, d3);
+  const float c = d4 - d2, e = d3 - d1;
+  t[0] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+  t[1] = a + b;
+  t[2] = a - b;
+  t[3] = __builtin_fmaf(2.f, e, c);
+  t[4] = __builtin_fmaf(-2.f, e, c);
+  t[5] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+}
+
+// A^T applied to six values -> four
+__device__ __forceinline__ void w4_out(const float m0, const float m1, const float m2, const float m3, const float m4,
+                                       const float m5, float (&s)[4]) {
+  const float p = m1 + m2, q = m1 - m2, r = m3 + m4, u = m3 - m4;
+  s[0] = m0 + p + r;
+  s[1] = __builtin_fmaf(2.f, u, q);
+  s[2] = __builtin_fmaf(4.f, r, p);
+  s[3] = __builtin_fmaf(8.f, u, q) + m5;
+}
+
+__device__ __forceinline__ float w4_swap_pair(float v) {  // value of the neighbouring lane (lane ^ 1)
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_winograd43_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ up,
+                                                                    const float* __restrict__ bias,
+                                                                    float* __restrict__ out, int cin, int cout,
+                                                                    int h, int w, int relu, int ptiles) {
+  __shared__ __attribute__((aligned(16))) float smem[kW4Usz + kW4Vsz + kW4RawSz];
+  float* Us = smem;
+  float* Vs = smem + kW4Usz;
+  float* Raw = smem + kW4Usz + kW4Vsz;
+  const int lane = lane_id(), wave = wave_id();
+  const int tiles_x = (w + 4 * kW4TC - 1) / (4 * kW4TC), tiles_y = (h + 4 * kW4TR - 1) / (4 * kW4TR);
+  // XCD-aware tile order (see conv_winograd.hip): pixel tile pt lives on XCD pt % 8 with all its channel tiles
+  const int nct = cout / kW4Co;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ct = slot % nct, pt = (slot / nct) * 8 + xcd;
+  if (pt >= ptiles) return;
+  const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
+  const int y0 = ty * 4 * kW4TR, x0 = tx * 4 * kW4TC;
+  const int chunks = cin / kW4Ci;
+  const int64_t plane = (int64_t)h * w;
+  const float* xin = x + (int64_t)n * cin * plane;
+  const w4_f32x4* usrc = reinterpret_cast<const w4_f32x4*>(up) + (int64_t)ct * chunks * kW4UN4;
+
+  // staging pattern of the raw patch (identical for every trip)
+  int gofs[kW4XPT], ldst[kW4XPT];
+  unsigned live = 0;
+#pragma unroll
+  for (int i = 0; i < kW4XPT; ++i) {
+    const int e = min((int)threadIdx.x + i * 256, kW4XN4 - 1);
+    const int ci = e / (kW4RawR * (kW4RawW / 4)), rem = e - ci * (kW4RawR * (kW4RawW / 4));
+    const int r = rem / (kW4RawW / 4), c4 = rem - r * (kW4RawW / 4);
+    const int gy = y0 - 1 + r, gx = x0 - 4 + c4 * 4;  // a float4 is entirely inside or outside (w % 4 == 0)
+    const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
+    gofs[i] = ok ? (int)(ci * plane + (int64_t)gy * w + gx) : 0;
+    live |= ok ? (1u << i) : 0u;
+    ldst[i] = e * 4;
+  }
+  int uofs[kW4UPT];
+#pragma unroll
+  for (int i = 0; i < kW4UPT; ++i) uofs[i] = min((int)threadIdx.x + i * 256, kW4UN4 - 1);
+  // transform assignment: thread pair (2p, 2p+1) owns patch p = (ci, tile); half hf = columns / rows 3hf..3hf+2
+  const int pidx = threadIdx.x >> 1, hf = threadIdx.x & 1;
+  const int pci = pidx >> 5, ptile = pidx & 31;
+  const int rsrc = pci * kW4RawPl + (4 * (ptile >> 4)) * kW4RawW + 4 * (ptile & 15) + 3 + 3 * hf;
+  const int vdst = (((ptile >> 4) * kW4Ci + pci) * kW4TC + (ptile & 15)) * kW4Cs + 18 * hf;
+  // MFMA operand bases
+  const int cb = wave & 1, tb = wave >> 1;
+  const int abase = ((cb * kW4Ci + (lane >> 4)) * 16 + (lane & 15)) * kW4Cs;
+  const int bbase = ((tb * kW4Ci + (lane >> 4)) * kW4TC + (lane & 15)) * kW4Cs;
+
+  w4_f32x4 acc[36];
+#pragma unroll
+  for (int c = 0; c < 36; ++c) acc[c] = (w4_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  w4_f32x4 xr[kW4XPT], ur[kW4UPT];
+
+#define W4_FETCH(cc)                                                                     \
+  {                                                                                      \
+    const float* xc_ = xin + (int64_t)(cc) * kW4Ci * plane;                              \
+    _Pragma("unroll") for (int i = 0; i < kW4XPT; ++i)                                   \
+        xr[i] = *reinterpret_cast<const w4_f32x4*>(xc_ + gofs[i]);                       \
+    const w4_f32x4* uc_ = usrc + (int64_t)(cc) * kW4UN4;                                 \
+    _Pragma("unroll") for (int i = 0; i < kW4UPT; ++i) ur[i] = uc_[uofs[i]];             \
+  }
+#define W4_STASH()                                                                       \
+  {                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < kW4XPT; ++i) {                                 \
+      const bool on_ = (live >> i) & 1u;                                                 \
+      const w4_f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                          \
+      *reinterpret_cast<w4_f32x4*>(Raw + ldst[i]) = on_ ? xr[i] : z_;                    \
+    }                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < kW4UPT; ++i)                                   \
+        *reinterpret_cast<w4_f32x4*>(Us + uofs[i] * 4) = ur[i];                          \
+  }
+  // V = B^T d B.  Row pass on this lane's three columns, halves swapped between the pair, column pass on this
+  // lane's three rows; components (row, nu) -> 6 row + nu.
+#define W4_TRANSFORM()                                                                   \
+  {                                                                                      \
+    float lo_[3][3], hi_[3][3]; /* (B^T d)[row a or 3 + a][my column b] */               \
+    _Pragma("unroll") for (int b = 0; b < 3; ++b) {                                      \
+      const float* d_ = Raw + rsrc + b;                                                  \
+      float t_[6];                                                                       \
+      w4_in(d_[0], d_[kW4RawW], d_[2 * kW4RawW], d_[3 * kW4RawW], d_[4 * kW4RawW], d_[5 * kW4RawW], t_); \
+      _Pragma("unroll") for (int a = 0; a < 3; ++a) {                                    \
+        lo_[a][b] = t_[a];                                                               \
+        hi_[a][b] = t_[3 + a];                                                           \
+      }                                                                                  \
+    }                                                                                    \
+    /* lane 0 of the pair keeps rows 0..2 and sends rows 3..5; lane 1 the other way round */ \
+    float own_[3][3], got_[3][3];                                                        \
+    _Pragma("unroll") for (int a = 0; a < 3; ++a)                                        \
+    _Pragma("unroll") for (int b = 0; b < 3; ++b) {                                      \
+      own_[a][b] = hf ? hi_[a][b] : lo_[a][b];                                           \
+      got_[a][b] = w4_swap_pair(hf ? lo_[a][b] : hi_[a][b]);                             \
+    }                                                                                    \
+    float* v_ = Vs + vdst;                                                               \
+    _Pragma("unroll") for (int a = 0; a < 3; ++a) {                                      \
+      /* row 3 hf + a of B^T d: columns 0..2 belong to the even lane, 3..5 to the odd lane */ \
+      float o_[6];                                                                       \
+      w4_in(hf ? got_[a][0] : own_[a][0], hf ? got_[a][1] : own_[a][1], hf ? got_[a][2] : own_[a][2],    \
+            hf ? own_[a][0] : got_[a][0], hf ? own_[a][1] : got_[a][1], hf ? own_[a][2] : got_[a][2], o_); \
+      *reinterpret_cast<w4_f32x2*>(v_ + a * 6 + 0) = (w4_f32x2){o_[0], o_[1]};           \
+      *reinterpret_cast<w4_f32x2*>(v_ + a * 6 + 2) = (w4_f32x2){o_[2], o_[3]};           \
+      *reinterpret_cast<w4_f32x2*>(v_ + a * 6 + 4) = (w4_f32x2){o_[4], o_[5]};           \
+    }                                                                                    \
+  }
+  // 9 groups of 4 components: two b128 reads feed four MFMAs; reads run two groups ahead (ring of three)
+#define W4_LOAD(g_, slot_)                                                               \
+  {                                                                                      \
+    a_[slot_] = *reinterpret_cast<const w4_f32x4*>(Us + abase + (g_) * 4);               \
+    b_[slot_] = *reinterpret_cast<const w4_f32x4*>(Vs + bbase + (g_) * 4);               \
+  }
+#define W4_MFMA()                                                                        \
+  {                                                                                      \
+    w4_f32x4 a_[3], b_[3];                                                               \
+    W4_LOAD(0, 0)                                                                        \
+    W4_LOAD(1, 1)                                                                        \
+    _Pragma("unroll") for (int g_ = 0; g_ < 9; ++g_) {                                   \
+      if (g_ + 2 < 9) W4_LOAD(g_ + 2, (g_ + 2) % 3)                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                 \
+      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                   \
+          acc[g_ * 4 + j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[g_ % 3][j_], b_[g_ % 3][j_], acc[g_ * 4 + j_], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                 \
+    }                                                                                    \
+  }
+
+  W4_FETCH(0)
+  W4_STASH()
+  __syncthreads();
+  W4_TRANSFORM()
+  __syncthreads();
+  // steady state (no conditionals around the loads); last trip peeled
+  for (int cc = 0; cc + 1 < chunks; ++cc) {
+    W4_FETCH(cc + 1)
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads in flight ahead of the MFMA block
+    W4_MFMA()
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // every wave is done with U and V of this trip
+    W4_STASH()
+    __syncthreads();
+    W4_TRANSFORM()
+    __syncthreads();
+  }
+  W4_MFMA()
+#undef W4_MFMA
+#undef W4_LOAD
+#undef W4_FETCH
+#undef W4_STASH
+#undef W4_TRANSFORM
+
+  // epilogue: Y = A^T M A; lane: tile column lane & 15, channels 4 (lane >> 4) + r of the co block
+  float bv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bv[r] = 0.f;
+  const int co0 = ct * kW4Co + cb * 16 + 4 * (lane >> 4);
+  if (bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = bias[co0 + r];
+  }
+  const int oy = y0 + 4 * tb, ox = x0 + 4 * (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float s[4][6];  // A^T M: column j of M through the row pass
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float c4[4];
+      w4_out(acc[0 * 6 + j][r], acc[1 * 6 + j][r], acc[2 * 6 + j][r], acc[3 * 6 + j][r], acc[4 * 6 + j][r],
+             acc[5 * 6 + j][r], c4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[k][j] = c4[k];
+    }
+    float* o = out + ((int64_t)n * cout + co0 + r) * plane + (int64_t)oy * w + ox;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float y4[4];
+      w4_out(s[k][0], s[k][1], s[k][2], s[k][3], s[k][4], s[k][5], y4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y4[j] += bv[r];
+        if (relu) y4[j] = fmaxf(y4[j], 0.f);
+      }
+      if (oy + k < h && ox < w)  // partial tiles at the border (w % 4 == 0: a quad is in or out)
+        *reinterpret_cast<w4_f32x4*>(o + (int64_t)k * w) = (w4_f32x4){y4[0], y4[1], y4[2], y4[3]};
+    }
+  }
+}
+
+}  // namespace pd3
+
+using namespace pd3;
+
+extern "C" int pd3_conv3x3_winograd43_bias_relu(const float* x, const float* u_packed, const float* bias,
+                                                int batch, int cin, int cout, int h, int w, int relu,
+                                                float* out, void* stream) {
+  if (!x || !u_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return PD3_EINVAL;
+  if (cin % kW4Ci != 0 || cout % kW4Co != 0 || w % 4 != 0) return PD3_EUNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(u_packed) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0 ||
+      reinterpret_cast<uintptr_t>(out) % 16 != 0)
+    return PD3_EINVAL;
+  if ((int64_t)cin * h * w >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
+  const int64_t ptiles = (int64_t)batch * ceil_div(h, 4 * kW4TR) * ceil_div(w, 4 * kW4TC);
+  const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / kW4Co);
+  if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
+  conv3x3_winograd43_kernel<<<(unsigned)nwg, 256, 0, static_cast<hipStream_t>(stream)>>>(
+      x, u_packed, bias, out, cin, cout, h, w, relu, (int)ptiles);
+  return launch_status();
+}

@@ -35,7 +35,12 @@ for cin, cout, hw in [(64, 64, 256), (128, 128, 128), (256, 256, 64), (384, 64, 
     t_mi = timeit(lambda: F.relu_(F.conv2d(x, w, b, padding=1))) if os.environ.get("EXP_MIOPEN", "1") == "1" else float("nan")
     t_me = timeit(lambda: conv.conv3x3_bias_relu(x, wp, b, cout, True, out=out))
     t_wg = timeit(lambda: conv.conv3x3_winograd_bias_relu(x, up, b, cout, True, out=out2))
+    u43 = conv.pack_winograd43_weight(w)
+    out3 = torch.empty(B, cout, hw, hw, device="cuda")
+    t_43 = timeit(lambda: conv.conv3x3_winograd43_bias_relu(x, u43, b, cout, True, out=out3))
+    e43 = (out3 - out).abs().max().item()
     fl = 2 * cin * cout * 9 * hw * hw * B / 1e12
+    print(f"   F(4x4,3x3) {t_43:7.3f} ms ({fl / t_43 * 1e3:6.1f} TF eff)  max|diff vs direct| {e43:.2e}")
     err = (out2 - out).abs().max().item()
     print(f"cin {cin:4d} cout {cout:4d} hw {hw:3d}: miopen {t_mi:7.3f} ms ({fl / t_mi * 1e3:6.1f} TF)  "
           f"direct {t_me:7.3f} ms ({fl / t_me * 1e3:6.1f} TF)  winograd {t_wg:7.3f} ms ({fl / t_wg * 1e3:6.1f} TF eff)  "

@@ -157,3 +157,39 @@ def test_patch_conv_matches_torch(mode):
     got = out.cpu()
     assert (got[:, off:off + cout] - ref).abs().max().item() < 2e-4
     assert (got[:, :off] == -7.0).all() and (got[:, off + cout:] == -7.0).all()
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 128), (1, 4, 32, 8, 64), (1, 128, 96, 16, 64),
+                                            (1, 384, 64, 24, 96), (3, 16, 32, 8, 32), (1, 24, 32, 8, 64),
+                                            (2, 16, 64, 45, 180), (1, 8, 32, 5, 12), (1, 40, 32, 62, 124)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv3x3_winograd43_matches_torch(n, cin, cout, h, w, relu):
+    """Winograd F(4x4,3x3) on the fp32 matrix cores vs torch conv2d on the CPU (looser: ~1e-5 from the transforms)."""
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator().manual_seed(cin * 13 + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, b, padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    assert conv.winograd43_supported(cin, cout, h, w)
+    out = conv.conv3x3_winograd43_bias_relu(x.cuda(), conv.pack_winograd43_weight(wt.cuda()), b.cuda(), cout, relu).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 5e-4, (out - ref).abs().max().item()
+
+
+def test_winograd43_shift_taps():
+    """Single-tap weights against an asymmetric input: catches transposed transforms / tile mis-addressing."""
+    from paddle3d_amd.ops import conv
+
+    cin = cout = 32
+    x = torch.arange(1 * cin * 8 * 64, dtype=torch.float32).reshape(1, cin, 8, 64) / 512.0
+    for ky in range(3):
+        for kx in range(3):
+            wt = torch.zeros(cout, cin, 3, 3)
+            wt[torch.arange(cout), torch.arange(cin), ky, kx] = 1.0
+            out = conv.conv3x3_winograd43_bias_relu(x.cuda(), conv.pack_winograd43_weight(wt.cuda()), None, cout, False).cpu()
+            want = F.conv2d(x, wt, None, padding=1)
+            assert (out - want).abs().max().item() < 5e-3, (ky, kx, (out - want).abs().max().item())
