@@ -275,13 +275,18 @@ def _fold_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
 
 
 def _hip_conv3x3(x, w, b, stride, cache):
-    """3x3 / pad 1 convolution + bias + ReLU on the hand-written kernels: Winograd F(2x2,3x3) for stride 1 where
-    the shape allows (PD3_CONV_ALGO=direct turns it off), the direct implicit-GEMM kernel otherwise; None if
-    neither takes the shape.  `cache` keeps the packed weights."""
+    """3x3 / pad 1 convolution + bias + ReLU on the hand-written kernels: stride 1 by Winograd F(4x4,3x3)
+    (PD3_CONV_ALGO=winograd selects F(2x2,3x3), =direct turns Winograd off), the direct implicit-GEMM kernel
+    otherwise; None if no kernel takes the shape.  `cache` keeps the packed weights."""
     cout, cin = w.shape[:2]
     h, wd = x.shape[2], x.shape[3]
-    if (stride == 1 and os.environ.get("PD3_CONV_ALGO", "winograd") == "winograd"
-            and _conv.winograd_supported(cin, cout, h, wd)):
+    algo = os.environ.get("PD3_CONV_ALGO", "winograd43")
+    if stride == 1 and algo == "winograd43" and _conv.winograd43_supported(cin, cout, h, wd):
+        key = ("wino43", w.data_ptr())
+        if key not in cache:
+            cache[key] = _conv.pack_winograd43_weight(w)
+        return _conv.conv3x3_winograd43_bias_relu(x, cache[key], b, cout, relu=True)
+    if stride == 1 and algo in ("winograd", "winograd43") and _conv.winograd_supported(cin, cout, h, wd):
         key = ("wino", w.data_ptr())
         if key not in cache:
             cache[key] = _conv.pack_winograd_weight(w)
