@@ -158,19 +158,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd43_kernel(const float*
         hi_[a][b] = t_[3 + a];                                                           \
       }                                                                                  \
     }                                                                                    \
-    /* lane 0 of the pair keeps rows 0..2 and sends rows 3..5; lane 1 the other way round */ \
-    float own_[3][3], got_[3][3];                                                        \
-    _Pragma("unroll") for (int a = 0; a < 3; ++a)                                        \
-    _Pragma("unroll") for (int b = 0; b < 3; ++b) {                                      \
-      own_[a][b] = hf ? hi_[a][b] : lo_[a][b];                                           \
-      got_[a][b] = w4_swap_pair(hf ? lo_[a][b] : hi_[a][b]);                             \
-    }                                                                                    \
+    /* the even lane runs the column pass for rows 0..2, the odd lane for rows 3..5; what a lane lacks are \
+       the other three columns of its rows, i.e. the partner's lo_ (even lane) or hi_ (odd lane): one      \
+       select with a DPP-swapped operand per value */                                    \
     float* v_ = Vs + vdst;                                                               \
     _Pragma("unroll") for (int a = 0; a < 3; ++a) {                                      \
-      /* row 3 hf + a of B^T d: columns 0..2 belong to the even lane, 3..5 to the odd lane */ \
+      float f_[3], l_[3]; /* columns 0..2 / 3..5 of row 3 hf + a of B^T d */             \
+      _Pragma("unroll") for (int b = 0; b < 3; ++b) {                                    \
+        const float ph_ = w4_swap_pair(hi_[a][b]), pl_ = w4_swap_pair(lo_[a][b]);        \
+        f_[b] = hf ? ph_ : lo_[a][b];                                                    \
+        l_[b] = hf ? hi_[a][b] : pl_;                                                    \
+      }                                                                                  \
       float o_[6];                                                                       \
-      w4_in(hf ? got_[a][0] : own_[a][0], hf ? got_[a][1] : own_[a][1], hf ? got_[a][2] : own_[a][2],    \
-            hf ? own_[a][0] : got_[a][0], hf ? own_[a][1] : got_[a][1], hf ? own_[a][2] : got_[a][2], o_); \
+      w4_in(f_[0], f_[1], f_[2], l_[0], l_[1], l_[2], o_);                               \
       *reinterpret_cast<w4_f32x2*>(v_ + a * 6 + 0) = (w4_f32x2){o_[0], o_[1]};           \
       *reinterpret_cast<w4_f32x2*>(v_ + a * 6 + 2) = (w4_f32x2){o_[2], o_[3]};           \
       *reinterpret_cast<w4_f32x2*>(v_ + a * 6 + 4) = (w4_f32x2){o_[4], o_[5]};           \

@@ -12,9 +12,15 @@ iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
 x = torch.randn(B, cin, hw, hw, device="cuda")
 w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
 b = torch.randn(cout, device="cuda")
-up = conv.pack_winograd_weight(w)
+algo = os.environ.get("PROF_ALGO", "43")
 out = torch.empty(B, cout, hw, hw, device="cuda")
+if algo == "43":
+    up = conv.pack_winograd43_weight(w)
+    fn = conv.conv3x3_winograd43_bias_relu
+else:
+    up = conv.pack_winograd_weight(w)
+    fn = conv.conv3x3_winograd_bias_relu
 for _ in range(iters):
-    conv.conv3x3_winograd_bias_relu(x, up, b, cout, True, out=out)
+    fn(x, up, b, cout, True, out=out)
 torch.cuda.synchronize()
 print("done")
