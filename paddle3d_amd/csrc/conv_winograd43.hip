@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd43_kernel(const float*
   for (int cc = 0; cc + 1 < chunks; ++cc) {
     W4_FETCH(cc + 1)
     __builtin_amdgcn_sched_barrier(0);  // keep the loads in flight ahead of the MFMA block
+    __builtin_amdgcn_s_setprio(1);  // the matrix phase outranks the co-resident workgroup's transform VALU
     W4_MFMA()
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // every wave is done with U and V of this trip
     W4_STASH()
