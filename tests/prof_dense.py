@@ -64,3 +64,17 @@ with torch.no_grad():
     print(f"  head shared 384->64: {ms0:.3f} ms; first stage 64->{f['w1'].shape[0]}: {ms1:.3f} ms; final grouped: {ms2:.3f} ms")
     _, ms3 = timed(lambda t: head(t), cat)
     print(f"  head total (incl. slicing): {ms3:.3f} ms")
+    # end-to-end deviation of the hand-written dense graph from the PyTorch-ROCm (MIOpen) one
+    import copy
+    ref_model = cpm.centerpoint_pillars_nuscenes().cuda().eval()
+    ref_model.load_state_dict(model.state_dict())
+    ref_model.dense_backend = "miopen"
+    ref_model.bbox_head.dense_backend = "miopen"
+    xs = x[:2]
+    a = model.dense_forward(xs)
+    b = ref_model.dense_forward(xs)
+    pa, _ = model.bbox_head(a)
+    pb, _ = ref_model.bbox_head(b)
+    dmax = max(float((pa[t][k] - pb[t][k]).abs().max()) for t in range(len(pa)) for k in pa[t])
+    print(f"  neck output: max|hip - miopen| {float((a - b).abs().max()):.2e} (max|ref| {float(b.abs().max()):.2f}); "
+          f"head outputs: max|diff| {dmax:.2e}")
