@@ -253,12 +253,16 @@ int pd3_conv3x3_bias_relu(const float *x, const float *w_packed, const float *bi
  * conv3x3_winograd43_bias_relu -- the same stride-1 convolution by Winograd F(4x4, 3x3) (4x fewer multiplies;
  * all fp32; ~1e-5 absolute from the direct form for |y| ~ 1).  One fused kernel.
  *   x [batch, cin, h, w] fp32 NCHW (16-byte aligned);  out [batch, cout, h, w] (16-byte aligned);  bias or NULL
- *   u_packed: U = G g G^T (6x6) of the [cout, cin, 3, 3] weight, packed [cout/32][cin/4][2][4][16][36]
- *             (16-channel block, input channel, channel, component xi*6+nu; paddle3d_amd/ops/conv.py)
- *   requires cin % 4 == 0, cout % 32 == 0, w % 4 == 0 (any h; partial 8 x 64 tiles at the border are masked)
+ *   channels_per_tile: 32 or 64 output channels per workgroup (64: one 512-thread workgroup per CU, half the
+ *             patch-transform work per MFMA; 32: two 256-thread workgroups per CU, for cout % 64 != 0)
+ *   u_packed: U = G g G^T (6x6) of the [cout, cin, 3, 3] weight, packed [cout/T][cin/4][T/16][4][16][36] for
+ *             T = channels_per_tile (16-channel block, input channel, channel, component xi*6+nu;
+ *             paddle3d_amd/ops/conv.py:pack_winograd43_weight)
+ *   requires cin % 4 == 0, cout % T == 0, w % 4 == 0 (any h; partial 8 x 64 tiles at the border are masked)
  */
 int pd3_conv3x3_winograd43_bias_relu(const float *x, const float *u_packed, const float *bias, int batch,
-                                     int cin, int cout, int h, int w, int relu, float *out, void *stream);
+                                     int cin, int cout, int h, int w, int relu, float *out,
+                                     int channels_per_tile, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * grouped_conv3x3_small -- grouped 3x3 / stride 1 / pad 1 convolution with 1..4 output channels per group and

@@ -29,19 +29,14 @@ typedef float w4_f32x4 __attribute__((ext_vector_type(4)));
 typedef float w4_f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kW4Ci = 4;                  // input channels per trip (= MFMA K)
-constexpr int kW4Co = 32;                 // output channels per workgroup
 constexpr int kW4TR = 2, kW4TC = 16;      // tile rows / columns per workgroup (4x4 outputs each)
 constexpr int kW4Cs = 36;                 // components per element
 constexpr int kW4RawR = 4 * kW4TR + 2;    // 10 staged input rows
 constexpr int kW4RawW = 4 * kW4TC + 8;    // 72 staged input columns: x0-4 .. x0+67
 constexpr int kW4RawPl = kW4RawR * kW4RawW;                  // 720
-constexpr int kW4Usz = 2 * kW4Ci * 16 * kW4Cs;               // 4608 floats
 constexpr int kW4Vsz = kW4TR * kW4Ci * kW4TC * kW4Cs;        // 4608 floats
 constexpr int kW4RawSz = kW4Ci * kW4RawPl;                   // 2880 floats
-constexpr int kW4UN4 = kW4Usz / 4;                           // 1152 float4 (4.5 per thread)
-constexpr int kW4UPT = (kW4UN4 + 255) / 256;                 // 5 (the tail repeats the last one)
 constexpr int kW4XN4 = kW4RawSz / 4;                         // 720 float4
-constexpr int kW4XPT = (kW4XN4 + 255) / 256;                 // 3
 
 // B^T applied to six values (one column or one row of the patch)
 __device__ __forceinline__ void w4_in(const float d0, const float d1, const float d2, const float d3, const float d4,
@@ -70,19 +65,31 @@ __device__ __forceinline__ float w4_swap_pair(float v) {  // value of the neighb
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
 }
 
-__global__ __launch_bounds__(256, 2) void conv3x3_winograd43_kernel(const float* __restrict__ x,
+// CB = 16-channel blocks per workgroup.  CB = 2: 256 threads, two workgroups per CU.  CB = 4: 512 threads, one
+// workgroup per CU -- every transformed patch then feeds 64 output channels (half the transform work per
+// MFMA) and the two waves of a SIMD run their MFMA phases together, back to back on the matrix pipe; waves
+// 0-3 transform while waves 4-7 park the (twice as large) U slice.
+template <int CB>
+__global__ __launch_bounds__(128 * CB, CB == 2 ? 2 : 1) void conv3x3_winograd43_kernel(const float* __restrict__ x,
                                                                     const float* __restrict__ up,
                                                                     const float* __restrict__ bias,
                                                                     float* __restrict__ out, int cin, int cout,
                                                                     int h, int w, int relu, int ptiles) {
-  __shared__ __attribute__((aligned(16))) float smem[kW4Usz + kW4Vsz + kW4RawSz];
+  constexpr int THREADS = 128 * CB;
+  constexpr int CO = 16 * CB;                       // output channels per workgroup
+  constexpr int USZ = CB * kW4Ci * 16 * kW4Cs;      // floats of one U trip
+  constexpr int UN4 = USZ / 4;                      // CB = 2: 1152, CB = 4: 2304 float4
+  constexpr int UT0 = CB == 2 ? 0 : 256;            // first of the 256 threads that move U
+  constexpr int UPT = (UN4 + 255) / 256;            // 5 (tail repeats the last one) / 9
+  constexpr int XPT = (kW4XN4 + THREADS - 1) / THREADS;  // 3 / 2
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Us = smem;
-  float* Vs = smem + kW4Usz;
-  float* Raw = smem + kW4Usz + kW4Vsz;
+  float* Vs = smem + USZ;
+  float* Raw = smem + USZ + kW4Vsz;
   const int lane = lane_id(), wave = wave_id();
   const int tiles_x = (w + 4 * kW4TC - 1) / (4 * kW4TC), tiles_y = (h + 4 * kW4TR - 1) / (4 * kW4TR);
   // XCD-aware tile order (see conv_winograd.hip): pixel tile pt lives on XCD pt % 8 with all its channel tiles
-  const int nct = cout / kW4Co;
+  const int nct = cout / CO;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int ct = slot % nct, pt = (slot / nct) * 8 + xcd;
   if (pt >= ptiles) return;
@@ -91,14 +98,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd43_kernel(const float*
   const int chunks = cin / kW4Ci;
   const int64_t plane = (int64_t)h * w;
   const float* xin = x + (int64_t)n * cin * plane;
-  const w4_f32x4* usrc = reinterpret_cast<const w4_f32x4*>(up) + (int64_t)ct * chunks * kW4UN4;
+  const w4_f32x4* usrc = reinterpret_cast<const w4_f32x4*>(up) + (int64_t)ct * chunks * UN4;
 
   // staging pattern of the raw patch (identical for every trip)
-  int gofs[kW4XPT], ldst[kW4XPT];
+  int gofs[XPT], ldst[XPT];
   unsigned live = 0;
 #pragma unroll
-  for (int i = 0; i < kW4XPT; ++i) {
-    const int e = min((int)threadIdx.x + i * 256, kW4XN4 - 1);
+  for (int i = 0; i < XPT; ++i) {
+    const int e = min((int)threadIdx.x + i * THREADS, kW4XN4 - 1);
     const int ci = e / (kW4RawR * (kW4RawW / 4)), rem = e - ci * (kW4RawR * (kW4RawW / 4));
     const int r = rem / (kW4RawW / 4), c4 = rem - r * (kW4RawW / 4);
     const int gy = y0 - 1 + r, gx = x0 - 4 + c4 * 4;  // a float4 is entirely inside or outside (w % 4 == 0)
@@ -107,16 +114,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd43_kernel(const float*
     live |= ok ? (1u << i) : 0u;
     ldst[i] = e * 4;
   }
-  int uofs[kW4UPT];
+  const bool moves_u = (int)threadIdx.x >= UT0;  // wave-uniform
+  int uofs[UPT];
 #pragma unroll
-  for (int i = 0; i < kW4UPT; ++i) uofs[i] = min((int)threadIdx.x + i * 256, kW4UN4 - 1);
+  for (int i = 0; i < UPT; ++i) uofs[i] = min(max((int)threadIdx.x - UT0, 0) + i * 256, UN4 - 1);
+  const bool transforms = threadIdx.x < 256;     // wave-uniform
   // transform assignment: thread pair (2p, 2p+1) owns patch p = (ci, tile); half hf = columns / rows 3hf..3hf+2
   const int pidx = threadIdx.x >> 1, hf = threadIdx.x & 1;
   const int pci = pidx >> 5, ptile = pidx & 31;
   const int rsrc = pci * kW4RawPl + (4 * (ptile >> 4)) * kW4RawW + 4 * (ptile & 15) + 3 + 3 * hf;
   const int vdst = (((ptile >> 4) * kW4Ci + pci) * kW4TC + (ptile & 15)) * kW4Cs + 18 * hf;
   // MFMA operand bases
-  const int cb = wave & 1, tb = wave >> 1;
+  const int cb = wave % CB, tb = wave / CB;
   const int abase = ((cb * kW4Ci + (lane >> 4)) * 16 + (lane & 15)) * kW4Cs;
   const int bbase = ((tb * kW4Ci + (lane >> 4)) * kW4TC + (lane & 15)) * kW4Cs;
 
@@ -124,30 +133,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd43_kernel(const float*
 #pragma unroll
   for (int c = 0; c < 36; ++c) acc[c] = (w4_f32x4){0.f, 0.f, 0.f, 0.f};
 
-  w4_f32x4 xr[kW4XPT], ur[kW4UPT];
+  w4_f32x4 xr[XPT], ur[UPT];
 
 #define W4_FETCH(cc)                                                                     \
   {                                                                                      \
     const float* xc_ = xin + (int64_t)(cc) * kW4Ci * plane;                              \
-    _Pragma("unroll") for (int i = 0; i < kW4XPT; ++i)                                   \
+    _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                      \
         xr[i] = *reinterpret_cast<const w4_f32x4*>(xc_ + gofs[i]);                       \
-    const w4_f32x4* uc_ = usrc + (int64_t)(cc) * kW4UN4;                                 \
-    _Pragma("unroll") for (int i = 0; i < kW4UPT; ++i) ur[i] = uc_[uofs[i]];             \
+    const w4_f32x4* uc_ = usrc + (int64_t)(cc) * UN4;                                    \
+    if (CB == 2 || moves_u) {                                                            \
+      _Pragma("unroll") for (int i = 0; i < UPT; ++i) ur[i] = uc_[uofs[i]];              \
+    }                                                                                    \
   }
-#define W4_STASH()                                                                       \
+#define W4_STASH_X()                                                                     \
   {                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < kW4XPT; ++i) {                                 \
+    _Pragma("unroll") for (int i = 0; i < XPT; ++i) {                                    \
       const bool on_ = (live >> i) & 1u;                                                 \
       const w4_f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                          \
       *reinterpret_cast<w4_f32x4*>(Raw + ldst[i]) = on_ ? xr[i] : z_;                    \
     }                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < kW4UPT; ++i)                                   \
+  }
+#define W4_STASH_U()                                                                     \
+  if (CB == 2 || moves_u) {                                                              \
+    _Pragma("unroll") for (int i = 0; i < UPT; ++i)                                      \
         *reinterpret_cast<w4_f32x4*>(Us + uofs[i] * 4) = ur[i];                          \
   }
   // V = B^T d B.  Row pass on this lane's three columns, halves swapped between the pair, column pass on this
   // lane's three rows; components (row, nu) -> 6 row + nu.
 #define W4_TRANSFORM()                                                                   \
-  {                                                                                      \
+  if (CB == 2 || transforms) {                                                                                      \
     float lo_[3][3], hi_[3][3]; /* (B^T d)[row a or 3 + a][my column b] */               \
     _Pragma("unroll") for (int b = 0; b < 3; ++b) {                                      \
       const float* d_ = Raw + rsrc + b;                                                  \
@@ -197,36 +211,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd43_kernel(const float*
   }
 
   W4_FETCH(0)
-  W4_STASH()
+  W4_STASH_X()
   __syncthreads();
   W4_TRANSFORM()
+  W4_STASH_U()
   __syncthreads();
-  // steady state (no conditionals around the loads); last trip peeled
+  // steady state (no conditionals around the activation loads); last trip peeled
   for (int cc = 0; cc + 1 < chunks; ++cc) {
     W4_FETCH(cc + 1)
     __builtin_amdgcn_sched_barrier(0);  // keep the loads in flight ahead of the MFMA block
-    __builtin_amdgcn_s_setprio(1);  // the matrix phase outranks the co-resident workgroup's transform VALU
+    __builtin_amdgcn_s_setprio(1);  // the matrix phase outranks the co-resident waves' transform VALU
     W4_MFMA()
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // every wave is done with U and V of this trip
-    W4_STASH()
+    W4_STASH_X()
     __syncthreads();
-    W4_TRANSFORM()
+    W4_TRANSFORM()  // CB = 4: waves 0-3 transform while waves 4-7 park U
+    W4_STASH_U()
     __syncthreads();
   }
   W4_MFMA()
 #undef W4_MFMA
 #undef W4_LOAD
 #undef W4_FETCH
-#undef W4_STASH
+#undef W4_STASH_X
+#undef W4_STASH_U
 #undef W4_TRANSFORM
 
   // epilogue: Y = A^T M A; lane: tile column lane & 15, channels 4 (lane >> 4) + r of the co block
   float bv[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) bv[r] = 0.f;
-  const int co0 = ct * kW4Co + cb * 16 + 4 * (lane >> 4);
+  const int co0 = ct * CO + cb * 16 + 4 * (lane >> 4);
   if (bias) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[r] = bias[co0 + r];
@@ -263,19 +280,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_winograd43_kernel(const float*
 
 using namespace pd3;
 
+template <int CB>
+static int launch_wino43(const float* x, const float* u_packed, const float* bias, int batch, int cin, int cout,
+                         int h, int w, int relu, float* out, hipStream_t s) {
+  constexpr size_t lds = (size_t)(CB * kW4Ci * 16 * kW4Cs + kW4Vsz + kW4RawSz) * sizeof(float);
+  static bool configured = false;  // raise the dynamic-LDS cap once per instantiation
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_winograd43_kernel<CB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  const int64_t ptiles = (int64_t)batch * ceil_div(h, 4 * kW4TR) * ceil_div(w, 4 * kW4TC);
+  const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / (16 * CB));
+  if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
+  conv3x3_winograd43_kernel<CB><<<(unsigned)nwg, 128 * CB, lds, s>>>(x, u_packed, bias, out, cin, cout, h, w, relu,
+                                                                       (int)ptiles);
+  return launch_status();
+}
+
+// channels_per_tile selects the workgroup shape the weights were packed for: 32 (two workgroups per CU) or 64
 extern "C" int pd3_conv3x3_winograd43_bias_relu(const float* x, const float* u_packed, const float* bias,
                                                 int batch, int cin, int cout, int h, int w, int relu,
-                                                float* out, void* stream) {
+                                                float* out, int channels_per_tile, void* stream) {
   if (!x || !u_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return PD3_EINVAL;
-  if (cin % kW4Ci != 0 || cout % kW4Co != 0 || w % 4 != 0) return PD3_EUNSUPPORTED;
+  if (channels_per_tile != 32 && channels_per_tile != 64) return PD3_EINVAL;
+  if (cin % kW4Ci != 0 || cout % channels_per_tile != 0 || w % 4 != 0) return PD3_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(u_packed) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0 ||
       reinterpret_cast<uintptr_t>(out) % 16 != 0)
     return PD3_EINVAL;
   if ((int64_t)cin * h * w >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
-  const int64_t ptiles = (int64_t)batch * ceil_div(h, 4 * kW4TR) * ceil_div(w, 4 * kW4TC);
-  const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / kW4Co);
-  if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
-  conv3x3_winograd43_kernel<<<(unsigned)nwg, 256, 0, static_cast<hipStream_t>(stream)>>>(
-      x, u_packed, bias, out, cin, cout, h, w, relu, (int)ptiles);
-  return launch_status();
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return channels_per_tile == 64 ? launch_wino43<4>(x, u_packed, bias, batch, cin, cout, h, w, relu, out, s)
+                                 : launch_wino43<2>(x, u_packed, bias, batch, cin, cout, h, w, relu, out, s);
 }

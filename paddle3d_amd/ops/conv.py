@@ -11,7 +11,7 @@ from ._common import check, lib, ptr, require_gpu, stream_ptr
 __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pack_grouped_weight", "grouped_conv3x3_small",
            "grouped_small_supported", "winograd_supported", "pack_winograd_weight", "conv3x3_winograd_bias_relu",
            "patch_mode", "patch_supported", "pack_patch_weight", "patch_conv_bias_relu",
-           "winograd43_supported", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu"]
+           "winograd43_supported", "winograd43_tile", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu"]
 
 
 def supported(cin: int, cout: int, h: int, w: int, stride: int = 1) -> bool:
@@ -75,14 +75,21 @@ def winograd43_supported(cin: int, cout: int, h: int, w: int) -> bool:
     return cin % 4 == 0 and cout % 32 == 0 and w % 4 == 0
 
 
-def pack_winograd43_weight(weight: torch.Tensor) -> torch.Tensor:
-    """[Cout, Cin, 3, 3] -> U = G g G^T (6x6, F(4x4,3x3)) packed [Cout/32][Cin/4][2 blocks][4 ci][16 co][36]."""
+def winograd43_tile(cout: int) -> int:
+    """Output channels per workgroup the kernel is run with: 64 where the layer allows, else 32."""
+    return 64 if cout % 64 == 0 else 32
+
+
+def pack_winograd43_weight(weight: torch.Tensor, tile: int | None = None) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> U = G g G^T (6x6, F(4x4,3x3)) packed [Cout/T][Cin/4][T/16 blocks][4 ci][16 co][36],
+    T = channels per workgroup (winograd43_tile(Cout) by default)."""
     cout, cin = weight.shape[:2]
-    assert weight.shape[2:] == (3, 3) and cout % 32 == 0 and cin % 4 == 0
+    t = winograd43_tile(cout) if tile is None else tile
+    assert weight.shape[2:] == (3, 3) and cout % t == 0 and cin % 4 == 0 and t in (32, 64)
     g = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
                       [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64, device=weight.device)
     u = torch.einsum("ij,ocjk,lk->ocil", g, weight.double(), g).float()  # [cout, cin, 6, 6]
-    u = u.reshape(cout // 32, 2, 16, cin // 4, 4, 36).permute(0, 3, 1, 4, 2, 5)
+    u = u.reshape(cout // t, t // 16, 16, cin // 4, 4, 36).permute(0, 3, 1, 4, 2, 5)
     return u.contiguous()
 
 
@@ -90,10 +97,11 @@ def conv3x3_winograd43_bias_relu(x: torch.Tensor, u_packed: torch.Tensor, bias, 
                                  out: torch.Tensor | None = None) -> torch.Tensor:
     xx = require_gpu(x, "conv3x3_winograd43_bias_relu")
     n, cin, h, w = xx.shape
+    tile = 16 * u_packed.shape[2]  # the packing records the workgroup shape
     if out is None:
         out = torch.empty((n, cout, h, w), dtype=torch.float32, device=xx.device)
     check(lib().pd3_conv3x3_winograd43_bias_relu(ptr(xx), ptr(u_packed), ptr(bias), n, cin, cout, h, w,
-                                                 int(bool(relu)), ptr(out), stream_ptr(xx.device)),
+                                                 int(bool(relu)), ptr(out), tile, stream_ptr(xx.device)),
           "conv3x3_winograd43_bias_relu")
     return out
 
