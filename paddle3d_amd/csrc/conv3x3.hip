@@ -22,6 +22,8 @@
 #include "../../include/paddle3d_amd.h"
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace pd3 {
 
 typedef float cv_f32x16 __attribute__((ext_vector_type(16)));
@@ -31,7 +33,9 @@ constexpr int kCvCo = 64;  // output channels per tile
 constexpr int kCvCi = 8;   // input channels per K chunk
 constexpr int kCvK = kCvCi * 9;
 
-template <int R, int WT, int S>
+// XB = number of X buffers: 2 (one barrier per trip), or 1 for the 256-pixel stride-2 tile whose staged input
+// (42 KB) would not leave room for two workgroups per CU if doubled -- one more barrier per trip instead.
+template <int R, int WT, int S, int XB>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ wp,
                                                            const float* __restrict__ bias,
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
   constexpr int WPT = (WN4 + 255) / 256;
   constexpr int XSZ = kCvCi * XPL;           // floats per X buffer
   constexpr int WSZ = kCvK * kCvCo;          // floats per W buffer
-  extern __shared__ __attribute__((aligned(16))) float cv_smem[];  // X[2][XSZ] then W[2][WSZ]
+  extern __shared__ __attribute__((aligned(16))) float cv_smem[];  // X[XB][XSZ] then W[2][WSZ]
   const int lane = lane_id(), wave = wave_id();
   const int tiles_x = w / WT, tiles_y = h / R;
   // XCD-aware tile order (workgroups are dealt round-robin over the 8 XCDs): pixel tile pt lives on XCD
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
     const int pj = (wave * NB + t) * 32 + (lane & 31);
     xb[t] = kk * XPL + (pj / WT) * S * XW + (pj % WT) * S + 3;
   }
-  const int wb = 2 * XSZ + kk * kCvCo + (lane & 31);
+  const int wb = XB * XSZ + kk * kCvCo + (lane & 31);
   cv_f32x16 acc[2][NB];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -113,8 +117,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
   }
 #define CV_STASH(buf)                                                                    \
   {                                                                                      \
-    float* xd_ = cv_smem + (buf) * XSZ;                                                  \
-    float* wd_ = cv_smem + 2 * XSZ + (buf) * WSZ;                                        \
+    float* xd_ = cv_smem + (XB == 2 ? (buf) : 0) * XSZ;                                  \
+    float* wd_ = cv_smem + XB * XSZ + (buf) * WSZ;                                       \
     _Pragma("unroll") for (int i = 0; i < XPT; ++i) {                                    \
       const bool on_ = (live >> i) & 1u;                                                 \
       const cv_f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                          \
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
     const int nx = min(cc + 1, chunks - 1);
     CV_FETCH(nx)
     __builtin_amdgcn_sched_barrier(0);  // keep the loads in flight ahead of the MFMA block
-    const float* Xs = cv_smem + (cc & 1) * XSZ;
+    const float* Xs = cv_smem + (XB == 2 ? (cc & 1) : 0) * XSZ;
     const float* Ws = cv_smem + (cc & 1) * WSZ + wb;
     // 36 steps, operands read two steps ahead of their MFMAs through a ring of three register sets (the
     // scheduling fences pin that order: the compiler would otherwise issue each read right before its use)
@@ -160,6 +164,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
     }
 #undef CV_OPERANDS
     __builtin_amdgcn_sched_barrier(0);
+    if (XB == 1) __syncthreads();  // the single X buffer is still being read
     CV_STASH((cc + 1) & 1)
     __syncthreads();
   }
@@ -194,20 +199,20 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
   }
 }
 
-template <int R, int WT, int S>
+template <int R, int WT, int S, int XB = 2>
 static int launch_conv3x3(int64_t tiles, hipStream_t s, const float* x, const float* wp, const float* bias,
                           float* out, int cin, int cout, int h, int w, int relu) {
-  constexpr size_t lds = (size_t)(2 * kCvCi * ((R - 1) * S + 3) * (S * WT + 8) + 2 * kCvK * kCvCo) * sizeof(float);
+  constexpr size_t lds = (size_t)(XB * kCvCi * ((R - 1) * S + 3) * (S * WT + 8) + 2 * kCvK * kCvCo) * sizeof(float);
   static bool configured = false;  // raise the dynamic-LDS cap once per instantiation
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<R, WT, S>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<R, WT, S, XB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
   const int64_t nwg = (tiles + 7) / 8 * 8 * (cout / kCvCo);
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
-  conv3x3_mfma_kernel<R, WT, S><<<(unsigned)nwg, 256, lds, s>>>(x, wp, bias, out, cin, cout, h, w, relu, (int)tiles);
+  conv3x3_mfma_kernel<R, WT, S, XB><<<(unsigned)nwg, 256, lds, s>>>(x, wp, bias, out, cin, cout, h, w, relu, (int)tiles);
   return launch_status();
 }
 
@@ -315,7 +320,9 @@ extern "C" int pd3_conv3x3_bias_relu(const float* x, const float* w_packed, cons
     if (wo % 128 == 0) return PD3_CV(1, 128, 1);
     if (wo % 64 == 0 && ho % 2 == 0) return PD3_CV(2, 64, 1);
     if (wo % 32 == 0 && ho % 4 == 0) return PD3_CV(4, 32, 1);
-  } else {  // the staged input tile is 4x larger: 128-pixel tiles keep two workgroups per CU
+  } else {  // the staged input tile is 4x larger: a 256-pixel tile with ONE X buffer, or 128-pixel tiles
+    if (wo % 128 == 0 && ho % 2 == 0 && !std::getenv("PD3_CONV_S2_SMALL_TILE"))
+      return launch_conv3x3<2, 128, 2, 1>(px / 256, s, x, w_packed, bias, out, cin, cout, ho, wo, relu);
     if (wo % 64 == 0 && ho % 2 == 0) return PD3_CV(2, 64, 2);
     if (wo % 32 == 0 && ho % 4 == 0) return PD3_CV(4, 32, 2);
   }
