@@ -167,6 +167,21 @@ int pd3_centerpoint_postprocess(const float *const *hm, const float *const *reg,
                                 int32_t *out_count, void *workspace, size_t workspace_bytes,
                                 void *stream);
 
+/* Same, for head tensors that are channel slices (views) of one wider [batch, C, H, W] map: every head pointer
+ * addresses frame 0 of its slice and `head_batch_stride` (> 0, in elements, the same for all heads) leads to the
+ * next frame -- what a fused CenterHead produces; saves the per-head contiguous copies. */
+int pd3_centerpoint_postprocess_strided(const float *const *hm, const float *const *reg,
+                                const float *const *height, const float *const *dim,
+                                const float *const *vel, const float *const *rot, int64_t head_batch_stride, int batch,
+                                int num_tasks, const int *hm_channels, int feat_h, int feat_w,
+                                const float *voxel_size, const float *point_cloud_range,
+                                const float *post_center_range, const int *label_offsets,
+                                int down_ratio, float score_threshold, float nms_iou_threshold,
+                                int nms_pre_max_size, int nms_post_max_size, int with_velocity,
+                                float *out_bboxes, float *out_scores, int64_t *out_labels,
+                                int32_t *out_count, void *workspace, size_t workspace_bytes,
+                                void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * bev_pool_v2 / bev_pool_v2_bkwd -- replace PD_BUILD_OP(bev_pool_v2) (bev_pool_v2/bev_pool.cc:111-118,
  * kernel bev_pool_cuda.cu:18-44) and PD_BUILD_OP(bev_pool_v2_bkwd)

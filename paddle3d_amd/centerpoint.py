@@ -380,7 +380,8 @@ class CenterHead(nn.Module):
             z = F.conv2d(y, f["wf"], f["bf"], padding=1, groups=f["groups"])
         rets = [dict() for _ in self.tasks]
         for g, (t, head) in enumerate(f["plan"]):
-            rets[t][head] = z[:, g * f["cmax"]:g * f["cmax"] + f["ncls"][g]].contiguous()
+            # channel slices of z stay views: the postprocess op takes them with their common batch stride
+            rets[t][head] = z[:, g * f["cmax"]:g * f["cmax"] + f["ncls"][g]]
         return rets, x
 
     @torch.no_grad()

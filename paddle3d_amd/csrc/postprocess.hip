@@ -36,6 +36,7 @@ struct CpHeads {
   const float* rot[kMaxTasks];
   int ncls[kMaxTasks];
   int label_offset[kMaxTasks];
+  int64_t batch_stride;  // elements between two frames of EVERY head tensor (views into one map); 0 = contiguous
 };
 
 struct CpCfg {
@@ -58,12 +59,13 @@ __global__ __launch_bounds__(256) void cp_decode_kernel(CpHeads h, CpCfg c, floa
   int selected = 0;
   if (i < c.hw) {
     // postprocess.cu:145-149  sigmoid, then max / argmax over the class axis (first maximum wins)
-    const float* hm = h.hm[t] + (int64_t)frame * h.ncls[t] * c.hw;
-    const float* regp = h.reg[t] + (int64_t)frame * 2 * c.hw;
-    const float* heip = h.height[t] + (int64_t)frame * c.hw;
-    const float* dimp = h.dim[t] + (int64_t)frame * 3 * c.hw;
-    const float* velp = h.vel[t] + (int64_t)frame * 2 * c.hw;
-    const float* rotp = h.rot[t] + (int64_t)frame * 2 * c.hw;
+    const int64_t bs = h.batch_stride;
+    const float* hm = h.hm[t] + (int64_t)frame * (bs ? bs : (int64_t)h.ncls[t] * c.hw);
+    const float* regp = h.reg[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
+    const float* heip = h.height[t] + (int64_t)frame * (bs ? bs : (int64_t)c.hw);
+    const float* dimp = h.dim[t] + (int64_t)frame * (bs ? bs : (int64_t)3 * c.hw);
+    const float* velp = h.vel[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
+    const float* rotp = h.rot[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
     float best = 0.f;
     int arg = 0;
     for (int k = 0; k < h.ncls[t]; ++k) {
@@ -335,7 +337,8 @@ extern "C" size_t pd3_centerpoint_postprocess_workspace(int batch, int num_tasks
   return cp_carve(nullptr, batch * num_tasks, hw, nms_pre_max_size, radix_plan(kKeyOut, hw)).bytes;
 }
 
-extern "C" int pd3_centerpoint_postprocess(
+static int cp_postprocess_impl(
+    int64_t head_batch_stride,
     const float* const* hm, const float* const* reg, const float* const* height,
     const float* const* dim, const float* const* vel, const float* const* rot, int batch,
     int num_tasks, const int* hm_channels, int feat_h, int feat_w, const float* voxel_size,
@@ -362,6 +365,7 @@ extern "C" int pd3_centerpoint_postprocess(
   hipStream_t s = static_cast<hipStream_t>(stream);
 
   CpHeads h;
+  h.batch_stride = head_batch_stride;
   for (int t = 0; t < num_tasks; ++t) {
     h.hm[t] = hm[t];
     h.reg[t] = reg[t];
@@ -427,4 +431,37 @@ extern "C" int pd3_centerpoint_postprocess(
                                      num_tasks, hw, c.dims, cap, nms_post_max_size, out_bboxes,
                                      out_scores, out_labels, out_count);
   return launch_status();
+}
+
+extern "C" int pd3_centerpoint_postprocess(
+    const float* const* hm, const float* const* reg, const float* const* height,
+    const float* const* dim, const float* const* vel, const float* const* rot, int batch,
+    int num_tasks, const int* hm_channels, int feat_h, int feat_w, const float* voxel_size,
+    const float* point_cloud_range, const float* post_center_range, const int* label_offsets,
+    int down_ratio, float score_threshold, float nms_iou_threshold, int nms_pre_max_size,
+    int nms_post_max_size, int with_velocity, float* out_bboxes, float* out_scores,
+    int64_t* out_labels, int32_t* out_count, void* workspace, size_t workspace_bytes,
+    void* stream) {
+  return cp_postprocess_impl(0, hm, reg, height, dim, vel, rot, batch, num_tasks, hm_channels, feat_h, feat_w,
+                             voxel_size, point_cloud_range, post_center_range, label_offsets, down_ratio,
+                             score_threshold, nms_iou_threshold, nms_pre_max_size, nms_post_max_size,
+                             with_velocity, out_bboxes, out_scores, out_labels, out_count, workspace,
+                             workspace_bytes, stream);
+}
+
+extern "C" int pd3_centerpoint_postprocess_strided(
+    const float* const* hm, const float* const* reg, const float* const* height,
+    const float* const* dim, const float* const* vel, const float* const* rot, int64_t head_batch_stride,
+    int batch, int num_tasks, const int* hm_channels, int feat_h, int feat_w, const float* voxel_size,
+    const float* point_cloud_range, const float* post_center_range, const int* label_offsets,
+    int down_ratio, float score_threshold, float nms_iou_threshold, int nms_pre_max_size,
+    int nms_post_max_size, int with_velocity, float* out_bboxes, float* out_scores,
+    int64_t* out_labels, int32_t* out_count, void* workspace, size_t workspace_bytes,
+    void* stream) {
+  if (head_batch_stride <= 0) return PD3_EINVAL;
+  return cp_postprocess_impl(head_batch_stride, hm, reg, height, dim, vel, rot, batch, num_tasks, hm_channels,
+                             feat_h, feat_w, voxel_size, point_cloud_range, post_center_range, label_offsets,
+                             down_ratio, score_threshold, nms_iou_threshold, nms_pre_max_size,
+                             nms_post_max_size, with_velocity, out_bboxes, out_scores, out_labels, out_count,
+                             workspace, workspace_bytes, stream);
 }

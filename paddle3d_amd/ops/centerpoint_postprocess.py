@@ -27,6 +27,33 @@ def _ptr_array(tensors):
     return arr
 
 
+def _shared_batch_stride(tensors) -> int:
+    """Batch stride (elements) if every tensor is a [B, c, H, W] view whose frames are dense [c, H, W] blocks with
+    ONE common, non-trivial batch stride; 0 if they are ordinary contiguous tensors (or anything else)."""
+    bs = 0
+    for t in tensors:
+        if not isinstance(t, torch.Tensor) or t.dim() != 4 or not t.is_cuda or t.dtype != torch.float32:
+            return 0
+        b, c, h, w = t.shape
+        if t.stride(3) != 1 or t.stride(2) != w or t.stride(1) != h * w:
+            return 0
+        if b > 1 and t.stride(0) == c * h * w:
+            return 0  # plain contiguous
+        s0 = int(t.stride(0))
+        if bs and s0 != bs:
+            return 0
+        bs = s0
+    if tensors and int(tensors[0].shape[0]) == 1:
+        return 0
+    return bs
+
+
+def _require_view(t: torch.Tensor, op: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"Unsupported device type for {op} operator.")
+    return t
+
+
 def centerpoint_postprocess_device(hm, reg, height, dim, vel, rot, voxel_size, point_cloud_range,
                                    post_center_range, num_classes, down_ratio, score_threshold,
                                    nms_iou_threshold, nms_pre_max_size, nms_post_max_size, with_velocity,
@@ -36,11 +63,15 @@ def centerpoint_postprocess_device(hm, reg, height, dim, vel, rot, voxel_size, p
     processed independently in one launch sequence)."""
     op = "centerpoint postprocess"
     t_n = len(hm)
+    groups = (hm, reg, height, dim, vel, rot)
+    if any(len(g) != t_n for g in groups):
+        raise RuntimeError("centerpoint_postprocess: every head list needs one tensor per task")
+    # heads that are channel slices of ONE wider [B, C, H, W] map (a fused CenterHead) are passed as views with
+    # their common batch stride instead of being copied out
+    bstride = _shared_batch_stride([t for g in groups for t in g])
     lists = []
-    for group in (hm, reg, height, dim, vel, rot):
-        if len(group) != t_n:
-            raise RuntimeError("centerpoint_postprocess: every head list needs one tensor per task")
-        lists.append([require_gpu(t, op) for t in group])
+    for group in groups:
+        lists.append([_require_view(t, op) if bstride else require_gpu(t, op) for t in group])
     hm0 = lists[0][0]
     batch = int(hm0.shape[0])
     if batch != 1 and not allow_batch:
@@ -64,6 +95,13 @@ def centerpoint_postprocess_device(hm, reg, height, dim, vel, rot, voxel_size, p
     ws = workspace(L.pd3_centerpoint_postprocess_workspace(batch, t_n, h, w, int(nms_pre_max_size),
                                                            int(nms_post_max_size)), dev)
     arrays = [_ptr_array(g) for g in lists]
+    if bstride:
+        check(L.pd3_centerpoint_postprocess_strided(
+            *[C.cast(a, C.c_void_p) for a in arrays], C.c_int64(bstride), batch, t_n, ptr(ncls), h, w, ptr(vs),
+            ptr(pr), ptr(pcr), ptr(offs), int(down_ratio), C.c_float(score_threshold),
+            C.c_float(nms_iou_threshold), int(nms_pre_max_size), int(nms_post_max_size), int(bool(with_velocity)),
+            ptr(out_b), ptr(out_s), ptr(out_l), ptr(out_n), ptr(ws), ws.numel(), stream_ptr(dev)), op)
+        return out_b, out_s, out_l, out_n
     check(L.pd3_centerpoint_postprocess(*[C.cast(a, C.c_void_p) for a in arrays], batch, t_n, ptr(ncls), h, w,
                                         ptr(vs), ptr(pr), ptr(pcr), ptr(offs), int(down_ratio),
                                         C.c_float(score_threshold), C.c_float(nms_iou_threshold),
