@@ -62,6 +62,15 @@ int pd3_hard_voxelize(const float *points, const int32_t *num_points, int batch,
                       int max_num_points_in_voxel, int max_voxels, float *voxels, int32_t *coords,
                       int32_t *num_points_per_voxel, int32_t *num_voxels, int32_t *coors_batched,
                       void *workspace, size_t workspace_bytes, void *stream);
+/* Same operator with the implementation chosen by the caller (diagnostics and the parity tests, which run
+ * every case on both): path 0 = automatic (what pd3_hard_voxelize does), 1 = generic radix-sort path (any
+ * grid below 2^31 cells), 2 = tiled path (BEV-sized grids; PD3_EUNSUPPORTED when the shape does not qualify).
+ * Both paths produce identical bytes. */
+int pd3_hard_voxelize_path(const float *points, const int32_t *num_points, int batch, int64_t max_points,
+                           int num_point_dim, const float *voxel_size, const float *point_cloud_range,
+                           int max_num_points_in_voxel, int max_voxels, float *voxels, int32_t *coords,
+                           int32_t *num_points_per_voxel, int32_t *num_voxels, int32_t *coors_batched,
+                           void *workspace, size_t workspace_bytes, void *stream, int path);
 
 /* dynamic_voxelize -- per-point voxel coordinates without the per-voxel cap.  The reference has no such
  * operator (only a "dynamic voxelization" comment at transforms/ for num_points == -1);

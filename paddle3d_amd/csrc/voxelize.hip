@@ -224,42 +224,37 @@ static VoxWorkspace carve(void* base, int batch, int64_t n, int max_voxels, cons
 // tiled fast path (voxelize_tiled.hpp)
 // ---------------------------------------------------------------------------------------------------
 struct VtWorkspace {
-  uint32_t *recs, *dir, *plist, *vid2key;
-  uint2* owner;
-  unsigned char* isfirst;
-  int *wsum, *totals, *vid_npts;
+  uint32_t *recs, *dir, *cellbase;
+  uint2 *owner, *vinfo;
+  unsigned char *isfirst, *slot8;
+  unsigned long long* cnt64;
+  float* compact;
+  int* totals;
   int64_t stride;  // tiles * kVtTile: per-frame length of the per-point arrays
-  int assign_blocks;
+  int64_t cap;     // per-frame capacity of the compact payload array, in points
+  int nblk;        // scan blocks per frame
   size_t bytes;
 };
 
-static VtWorkspace vt_carve(void* base, int batch, int64_t n, int max_pts, int max_voxels,
+static VtWorkspace vt_carve(void* base, int batch, int64_t n, int dim, int max_pts, int max_voxels,
                             uint32_t ncells, const VtPlan& p) {
-  (void)n;
   Carver c(base);
   VtWorkspace w;
   w.stride = (int64_t)p.tiles * kVtTile;
-  w.assign_blocks = (int)(w.stride / kVtAssignPoints);
+  w.nblk = (int)(w.stride / kVtAssignPoints);
+  w.cap = std::min<int64_t>(n, (int64_t)max_voxels * max_pts);
   w.isfirst = c.take<unsigned char>((size_t)batch * w.stride);
+  w.slot8 = c.take<unsigned char>((size_t)batch * w.stride);
   w.recs = c.take<uint32_t>((size_t)batch * w.stride);
   w.dir = c.take<uint32_t>((size_t)batch * p.tiles * p.groups);
   w.owner = c.take<uint2>((size_t)batch * w.stride);
-  w.plist = c.take<uint32_t>((size_t)batch * ncells * max_pts);
-  w.vid2key = c.take<uint32_t>((size_t)batch * max_voxels);
-  w.vid_npts = c.take<int>((size_t)batch * max_voxels);
-  w.wsum = c.take<int>((size_t)batch * w.assign_blocks);
+  w.cellbase = c.take<uint32_t>((size_t)batch * ncells);
+  w.vinfo = c.take<uint2>((size_t)batch * max_voxels);
+  w.cnt64 = c.take<unsigned long long>((size_t)batch * (w.stride / kVtChunk));
+  w.compact = c.take<float>((size_t)batch * w.cap * dim + 4);
   w.totals = c.take<int>((size_t)batch);
   w.bytes = c.off;
   return w;
-}
-
-// 0 = automatic, 1 = force the generic sort path, 2 = force the tiled path (error if not applicable).
-static int path_override() {
-  const char* e = std::getenv("PD3_VOXELIZE_PATH");
-  if (!e) return 0;
-  if (!std::strcmp(e, "sort")) return 1;
-  if (!std::strcmp(e, "tiled")) return 2;
-  return 0;
 }
 
 static bool tiled_applicable(const VoxGrid& g, int64_t n, int dim, int max_pts, int max_voxels,
@@ -267,83 +262,50 @@ static bool tiled_applicable(const VoxGrid& g, int64_t n, int dim, int max_pts, 
   plan = vt_plan(g.ncells, n, max_pts);
   const int64_t row = (int64_t)max_pts * dim;
   const int64_t rowq = (row % 4 == 0) ? row / 4 : row;
-  return plan.ok && (int64_t)max_voxels * rowq < ((int64_t)1 << 24);
-}
-
-template <int VEC>
-static void launch_write(int dim, dim3 grid, hipStream_t s, const float* points, VtCells cells,
-                         const uint32_t* vid2key, const int* vid_npts, const int* totals, int64_t n,
-                         uint32_t ncells,
-                         int max_pts, int max_voxels, int rowq, VtGrid vg, float* voxels,
-                         int32_t* coords, int32_t* num_pts, int32_t* num_voxels, int32_t* coors4) {
-#define PD3_VT_WRITE(D)                                                                           \
-  vt_write_kernel<VEC, D><<<grid, dim3(32, kVtWriteRows), 0, s>>>(                                  \
-      points, cells, vid2key, vid_npts, totals, n, ncells, dim, max_pts, max_voxels, rowq, vg, voxels,   \
-      coords, num_pts, num_voxels, coors4)
-  switch (dim) {
-    case 3: PD3_VT_WRITE(3); break;
-    case 4: PD3_VT_WRITE(4); break;
-    case 5: PD3_VT_WRITE(5); break;
-    case 6: PD3_VT_WRITE(6); break;
-    default: PD3_VT_WRITE(0); break;
-  }
-#undef PD3_VT_WRITE
+  return plan.ok && (int64_t)max_voxels * rowq < ((int64_t)1 << 24) - 4096;
 }
 
 static int run_tiled(const float* points, const int32_t* num_points, int batch, int64_t n, int dim,
                      const VoxGrid& g, int max_pts, int max_voxels, const VtPlan& plan,
                      float* voxels, int32_t* coords, int32_t* num_pts, int32_t* num_voxels,
                      int32_t* coors4, void* workspace, hipStream_t s) {
-  VtWorkspace w = vt_carve(workspace, batch, n, max_pts, max_voxels, g.ncells, plan);
-  VtGrid vg{g.min_x, g.min_y, g.min_z, g.size_x, g.size_y, g.size_z, g.gx, g.gy, g.gz, g.ncells};
-  hipError_t e = hipSuccess;
-  const size_t lds_a = (size_t)kVtRouteWaves * plan.groups * 12 + (kVtRouteWaves + 2) * 4;
-  const size_t lds_b = (size_t)plan.cpg * 16 + (size_t)(2 * plan.tiles + 2) * 4 + (size_t)kVtGroupPass * 4;
-  if (lds_a > 48 * 1024) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(vt_route_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-    if (e != hipSuccess) return (int)e;
+  VtWorkspace w = vt_carve(workspace, batch, n, dim, max_pts, max_voxels, g.ncells, plan);
+  VtGrid vg{g.min_x, g.min_y, g.min_z, g.size_x, g.size_y, g.size_z,
+            (float)(1.0 / (double)g.size_x), (float)(1.0 / (double)g.size_y), (float)(1.0 / (double)g.size_z),
+            g.gx, g.gy, g.gz, g.ncells};
+  const size_t lds_a = (size_t)kVtRouteWaves * plan.groups * 4 + (kVtRouteWaves + 2) * 4;
+  const size_t lds_b = vt_group_lds(plan.cpg, plan.tiles);
+  const unsigned tile_grid = (unsigned)(plan.tiles * batch);
+  vt_route_kernel<<<tile_grid, kVtRouteThreads, lds_a, s>>>(points, num_points, n, dim, vg, plan.low, plan.gbits,
+                                                            plan.tiles, batch, w.recs, w.dir, w.isfirst, w.cnt64);
+  vt_group_kernel<<<(unsigned)(plan.groups * batch), kWave, lds_b, s>>>(w.recs, w.dir, plan.low, plan.gbits,
+                                                                        plan.tiles, batch, max_pts, w.slot8,
+                                                                        w.owner, w.isfirst, w.cnt64);
+  vt_assign_kernel<<<(unsigned)(w.nblk * batch), kVtAssignThreads, 0, s>>>(
+      w.isfirst, w.stride, w.owner, w.cnt64, w.nblk, batch, max_voxels, vg, w.vinfo, w.cellbase, w.totals, coords,
+      num_pts, coors4);
+#define PD3_VT_EMIT(D)                                                                                          \
+  vt_emit_kernel<D><<<tile_grid, kVtRouteThreads, 0, s>>>(points, num_points, n, dim, vg, plan.tiles, batch,     \
+                                                          max_pts, w.slot8, w.cellbase, w.cap, w.compact)
+  switch (dim) {
+    case 4: PD3_VT_EMIT(4); break;
+    case 5: PD3_VT_EMIT(5); break;
+    default: PD3_VT_EMIT(0); break;
   }
-  if (lds_b > 48 * 1024) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(vt_group_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-    if (e != hipSuccess) return (int)e;
-  }
-  dim3 agrid(plan.tiles, batch);
-  vt_route_kernel<<<agrid, kVtRouteThreads, lds_a, s>>>(points, num_points, n, dim, vg, plan.low,
-                                                        plan.groups, plan.tiles, w.recs, w.dir, w.isfirst);
-  VtCells cells{w.plist};
-  dim3 bgrid(plan.groups, batch);
-  vt_group_kernel<<<bgrid, kWave, lds_b, s>>>(w.recs, w.dir, plan.low, plan.groups,
-                                                        plan.tiles, max_pts, g.ncells, cells, w.owner,
-                                                        w.isfirst);
-  dim3 cgrid(w.assign_blocks, batch);
-  vt_count_kernel<<<cgrid, kVtAssignThreads, 0, s>>>(w.isfirst, w.stride, w.wsum);
-  vt_assign_kernel<<<cgrid, kVtAssignThreads, 0, s>>>(w.isfirst, w.stride, w.owner, w.wsum,
-                                                      max_voxels, w.vid2key, w.vid_npts, w.totals);
-  if ((dim == 4 || dim == 5) && max_pts <= 256 && !std::getenv("PD3_VOXELIZE_WRITER_V1")) {
-    const int rpb = 256 / max_pts;  // voxel rows per workgroup: one lane per (row, point slot)
-    dim3 pgrid((unsigned)ceil_div(max_voxels, rpb), batch);
-    if (dim == 4)
-      vt_write_points_kernel<4><<<pgrid, 256, 0, s>>>(points, cells, w.vid2key, w.vid_npts, w.totals, n, g.ncells,
-                                                      max_pts, max_voxels, rpb, vg, voxels, coords, num_pts,
-                                                      num_voxels, coors4);
-    else
-      vt_write_points_kernel<5><<<pgrid, 256, 0, s>>>(points, cells, w.vid2key, w.vid_npts, w.totals, n, g.ncells,
-                                                      max_pts, max_voxels, rpb, vg, voxels, coords, num_pts,
-                                                      num_voxels, coors4);
-    return launch_status();
-  }
+#undef PD3_VT_EMIT
   const int64_t row = (int64_t)max_pts * dim;
   const bool vec4 = (row % 4 == 0) && (reinterpret_cast<uintptr_t>(voxels) % 16 == 0);
   const int rowq = (int)(vec4 ? row / 4 : row);
-  dim3 dgrid((unsigned)ceil_div(max_voxels, kVtWriteRows * kVtWriteIlp), batch);
+  const int units = (int)ceil_div((int64_t)max_voxels * rowq, kVtRowsThreads * kVtRowsIlp);
+  const int step_v = kVtRowsThreads / rowq, step_j = kVtRowsThreads % rowq;
   if (vec4)
-    launch_write<4>(dim, dgrid, s, points, cells, w.vid2key, w.vid_npts, w.totals, n, g.ncells, max_pts,
-                    max_voxels, rowq, vg, voxels, coords, num_pts, num_voxels, coors4);
+    vt_rows_kernel<4><<<(unsigned)(units * batch), kVtRowsThreads, 0, s>>>(
+        w.compact, w.cap, w.vinfo, w.totals, batch, units, max_voxels, rowq, step_v, step_j, dim, voxels, coords,
+        num_pts, num_voxels, coors4);
   else
-    launch_write<1>(dim, dgrid, s, points, cells, w.vid2key, w.vid_npts, w.totals, n, g.ncells, max_pts,
-                    max_voxels, rowq, vg, voxels, coords, num_pts, num_voxels, coors4);
+    vt_rows_kernel<1><<<(unsigned)(units * batch), kVtRowsThreads, 0, s>>>(
+        w.compact, w.cap, w.vinfo, w.totals, batch, units, max_voxels, rowq, step_v, step_j, dim, voxels, coords,
+        num_pts, num_voxels, coors4);
   return launch_status();
 }
 
@@ -362,24 +324,25 @@ extern "C" size_t pd3_hard_voxelize_workspace(int batch, int64_t max_points, int
   size_t bytes = carve(nullptr, batch, max_points, max_voxels, plan).bytes;
   VtPlan vp;
   if (tiled_applicable(g, max_points, num_point_dim, max_num_points_in_voxel, max_voxels, vp))
-    bytes = std::max(bytes, vt_carve(nullptr, batch, max_points, max_num_points_in_voxel, max_voxels, g.ncells, vp).bytes);
+    bytes = std::max(bytes, vt_carve(nullptr, batch, max_points, num_point_dim, max_num_points_in_voxel, max_voxels,
+                                     g.ncells, vp).bytes);
   return bytes;
 }
 
-extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points, int batch,
-                                 int64_t max_points, int num_point_dim, const float* voxel_size,
-                                 const float* point_cloud_range, int max_num_points_in_voxel,
-                                 int max_voxels, float* voxels, int32_t* coords,
-                                 int32_t* num_points_per_voxel, int32_t* num_voxels,
-                                 int32_t* coors_batched, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
+extern "C" int pd3_hard_voxelize_path(const float* points, const int32_t* num_points, int batch,
+                                      int64_t max_points, int num_point_dim, const float* voxel_size,
+                                      const float* point_cloud_range, int max_num_points_in_voxel,
+                                      int max_voxels, float* voxels, int32_t* coords,
+                                      int32_t* num_points_per_voxel, int32_t* num_voxels,
+                                      int32_t* coors_batched, void* workspace, size_t workspace_bytes,
+                                      void* stream, int path) {
   VoxGrid g;
   if (!points || !voxels || !coords || !num_points_per_voxel || !num_voxels || !workspace)
     return PD3_EINVAL;
   if (batch <= 0 || max_points <= 0 || max_points >= ((int64_t)1 << 31) || num_point_dim < 3 ||
       max_num_points_in_voxel <= 0 || max_voxels <= 0)
     return PD3_EINVAL;
-  if (!make_grid(voxel_size, point_cloud_range, g)) return PD3_EINVAL;
+  if (!make_grid(voxel_size, point_cloud_range, g) || path < 0 || path > 2) return PD3_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t n = max_points;
   if (workspace_bytes < pd3_hard_voxelize_workspace(batch, max_points, num_point_dim, voxel_size,
@@ -389,9 +352,8 @@ extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points,
   {
     VtPlan vp;
     const bool can = tiled_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, vp);
-    const int ov = path_override();
-    if (ov == 2 && !can) return PD3_EUNSUPPORTED;
-    if (can && ov != 1)
+    if (path == 2 && !can) return PD3_EUNSUPPORTED;
+    if (can && path != 1)
       return run_tiled(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel,
                        max_voxels, vp, voxels, coords, num_points_per_voxel, num_voxels, coors_batched,
                        workspace, s);
@@ -420,7 +382,20 @@ extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points,
   return launch_status();
 }
 
-extern "C" int pd3_version(void) { return 100; }
+extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points, int batch,
+                                 int64_t max_points, int num_point_dim, const float* voxel_size,
+                                 const float* point_cloud_range, int max_num_points_in_voxel,
+                                 int max_voxels, float* voxels, int32_t* coords,
+                                 int32_t* num_points_per_voxel, int32_t* num_voxels,
+                                 int32_t* coors_batched, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  return pd3_hard_voxelize_path(points, num_points, batch, max_points, num_point_dim, voxel_size,
+                                point_cloud_range, max_num_points_in_voxel, max_voxels, voxels, coords,
+                                num_points_per_voxel, num_voxels, coors_batched, workspace, workspace_bytes,
+                                stream, 0);
+}
+
+extern "C" int pd3_version(void) { return 200; }
 extern "C" const char* pd3_target_arch(void) { return "gfx950"; }
 
 extern "C" int pd3_dynamic_voxelize(const float* points, int64_t num_points, int num_point_dim,

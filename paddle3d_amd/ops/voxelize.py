@@ -17,12 +17,14 @@ __all__ = ["dynamic_voxelize", "hard_voxelize", "hard_voxelize_batch"]
 
 
 def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max_num_points_in_voxel: int,
-                        max_voxels: int, num_points: torch.Tensor | None = None, with_batch_coors: bool = False):
+                        max_voxels: int, num_points: torch.Tensor | None = None, with_batch_coors: bool = False,
+                        path: int = 0):
     """points [B, N, D] fp32 on the GPU; num_points optional int32 [B] (valid rows per frame).
 
     Returns voxels [B,V,P,D], coords [B,V,3], num_points_per_voxel [B,V], num_voxels [B] -- the
     reference's per-sample op results stacked (HardVoxelizer's python loop, voxelize.py:60-82).
     with_batch_coors=True additionally returns coors [B,V,4] = (batch, z, y, x), batch -1 on padding rows.
+    path: 0 automatic, 1 generic sort path, 2 tiled path (pd3_hard_voxelize_path; the tests run both).
     """
     pts = require_gpu(points, "hard_voxelize")
     if pts.dim() != 3:
@@ -43,8 +45,9 @@ def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max
     if ws_bytes == 0:
         raise RuntimeError("hard_voxelize: invalid voxel_size / point_cloud_range / sizes")
     ws = workspace(ws_bytes, dev)
-    check(L.pd3_hard_voxelize(ptr(pts), ptr(num_points), b, n, d, ptr(vs), ptr(pr), p, v, ptr(voxels),
-                              ptr(coords), ptr(npv), ptr(nv), ptr(coors4), ptr(ws), ws.numel(), stream_ptr(dev)),
+    check(L.pd3_hard_voxelize_path(ptr(pts), ptr(num_points), b, n, d, ptr(vs), ptr(pr), p, v, ptr(voxels),
+                                   ptr(coords), ptr(npv), ptr(nv), ptr(coors4), ptr(ws), ws.numel(),
+                                   stream_ptr(dev), int(path)),
           "hard_voxelize")
     if with_batch_coors:
         return voxels, coords, npv, nv, coors4
@@ -52,12 +55,12 @@ def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max
 
 
 def hard_voxelize(points: torch.Tensor, voxel_size, point_cloud_range, max_num_points_in_voxel: int,
-                  max_voxels: int):
+                  max_voxels: int, path: int = 0):
     pts = require_gpu(points, "hard_voxelize")
     if pts.dim() != 2:
         raise RuntimeError("hard_voxelize expects points of shape [N, D]")
     voxels, coords, npv, nv = hard_voxelize_batch(pts.unsqueeze(0), voxel_size, point_cloud_range,
-                                                  max_num_points_in_voxel, max_voxels)
+                                                  max_num_points_in_voxel, max_voxels, path=path)
     return voxels[0], coords[0], npv[0], nv
 
 

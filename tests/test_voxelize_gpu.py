@@ -8,20 +8,24 @@ from paddle3d_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+PATH = 0  # pd3_hard_voxelize_path selector of the running parametrisation (0 automatic, 1 generic sort path)
+
+
 @pytest.fixture(params=["auto", "sort"], autouse=True)
-def vox_path(request, monkeypatch):
+def vox_path(request):
     """Every test runs on the automatic path choice (tiled fast path where applicable) and with the generic
-    sort path forced."""
-    if request.param != "auto":
-        monkeypatch.setenv("PD3_VOXELIZE_PATH", request.param)
-    return request.param
+    sort path forced (explicit `path` argument of the C ABI; no process-wide switches)."""
+    global PATH
+    PATH = {"auto": 0, "sort": 1}[request.param]
+    yield request.param
+    PATH = 0
 
 
 def _run(points, voxel_size, pc_range, p, v):
     from paddle3d_amd.ops import voxelize
 
     t = torch.from_numpy(points).cuda()
-    out = voxelize.hard_voxelize(t, list(voxel_size), list(pc_range), p, v)
+    out = voxelize.hard_voxelize(t, list(voxel_size), list(pc_range), p, v, path=PATH)
     torch.cuda.synchronize()
     return [o.cpu().numpy() for o in out]
 
@@ -99,7 +103,7 @@ def test_batch_and_ragged(oracle):
     pts = torch.from_numpy(np.stack(frames)).cuda()
     num = torch.tensor(lens, dtype=torch.int32).cuda()
     vox, co, npv, nv = voxelize.hard_voxelize_batch(pts, list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20,
-                                                    30000, num_points=num)
+                                                    30000, num_points=num, path=PATH)
     torch.cuda.synchronize()
     for b in range(3):
         rv, rc, rn, rnv = oracle.hard_voxelize(frames[b][: lens[b]], synth.NUSC_PILLAR, synth.NUSC_RANGE, 20,
@@ -116,7 +120,8 @@ def test_properties_full_size():
 
     pts_np = synth.nuscenes_sweep(42)
     pts = torch.from_numpy(pts_np).cuda()
-    vox, co, npv, nv = voxelize.hard_voxelize(pts, list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20, 60000)
+    vox, co, npv, nv = voxelize.hard_voxelize(pts, list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20, 60000,
+                                              path=PATH)
     n = int(nv.item())
     co, npv, vox = co.cpu().numpy(), npv.cpu().numpy(), vox.cpu().numpy()
     # coords unique and inside the grid, counts in [1, P], padding is zero
@@ -136,7 +141,7 @@ def test_properties_full_size():
     # idempotence: voxelising the stored points again reproduces the same voxel set and counts
     stored = torch.from_numpy(np.ascontiguousarray(vox[:n][k])).cuda()
     vox2, co2, npv2, nv2 = voxelize.hard_voxelize(stored, list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20,
-                                                  60000)
+                                                  60000, path=PATH)
     assert int(nv2.item()) == n
     np.testing.assert_array_equal(co2.cpu().numpy()[:n], co[:n])
     np.testing.assert_array_equal(npv2.cpu().numpy()[:n], npv[:n])
@@ -148,7 +153,7 @@ def test_batched_coors_output(oracle):
 
     frames = np.stack([synth.nuscenes_sweep(30 + i, n_points=40000) for i in range(2)])
     out = voxelize.hard_voxelize_batch(torch.from_numpy(frames).cuda(), list(synth.NUSC_PILLAR),
-                                       list(synth.NUSC_RANGE), 20, 12000, with_batch_coors=True)
+                                       list(synth.NUSC_RANGE), 20, 12000, with_batch_coors=True, path=PATH)
     vox, co, npv, nv, c4 = [o.cpu().numpy() for o in out]
     for b in range(2):
         n = int(nv[b])
