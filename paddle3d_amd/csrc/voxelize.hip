@@ -224,33 +224,34 @@ static VoxWorkspace carve(void* base, int batch, int64_t n, int max_voxels, cons
 // tiled fast path (voxelize_tiled.hpp)
 // ---------------------------------------------------------------------------------------------------
 struct VtWorkspace {
-  uint32_t *recs, *dir, *cellbase;
-  uint2 *owner, *vinfo;
-  unsigned char *isfirst, *slot8;
-  unsigned long long* cnt64;
+  uint32_t *recs, *dir, *cposr, *tilecnt;
+  unsigned short* pos16;
+  unsigned char* slotr;
+  uint4* owner;
+  uint2* vinfo;
   float* compact;
   int* totals;
   int64_t stride;  // tiles * kVtTile: per-frame length of the per-point arrays
   int64_t cap;     // per-frame capacity of the compact payload array, in points
-  int nblk;        // scan blocks per frame
   size_t bytes;
 };
 
 static VtWorkspace vt_carve(void* base, int batch, int64_t n, int dim, int max_pts, int max_voxels,
                             uint32_t ncells, const VtPlan& p) {
+  (void)max_pts;
+  (void)ncells;
   Carver c(base);
   VtWorkspace w;
   w.stride = (int64_t)p.tiles * kVtTile;
-  w.nblk = (int)(w.stride / kVtAssignPoints);
-  w.cap = std::min<int64_t>(n, (int64_t)max_voxels * max_pts);
-  w.isfirst = c.take<unsigned char>((size_t)batch * w.stride);
-  w.slot8 = c.take<unsigned char>((size_t)batch * w.stride);
+  w.cap = n;  // every in-range point of a frame at most once
   w.recs = c.take<uint32_t>((size_t)batch * w.stride);
+  w.cposr = c.take<uint32_t>((size_t)batch * w.stride);
+  w.pos16 = c.take<unsigned short>((size_t)batch * w.stride);
+  w.slotr = c.take<unsigned char>((size_t)batch * w.stride);
   w.dir = c.take<uint32_t>((size_t)batch * p.tiles * p.groups);
-  w.owner = c.take<uint2>((size_t)batch * w.stride);
-  w.cellbase = c.take<uint32_t>((size_t)batch * ncells);
+  w.owner = c.take<uint4>((size_t)batch * w.stride);
   w.vinfo = c.take<uint2>((size_t)batch * max_voxels);
-  w.cnt64 = c.take<unsigned long long>((size_t)batch * (w.stride / kVtChunk));
+  w.tilecnt = c.take<uint32_t>((size_t)batch * p.tiles);
   w.compact = c.take<float>((size_t)batch * w.cap * dim + 4);
   w.totals = c.take<int>((size_t)batch);
   w.bytes = c.off;
@@ -273,20 +274,19 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
   VtGrid vg{g.min_x, g.min_y, g.min_z, g.size_x, g.size_y, g.size_z,
             (float)(1.0 / (double)g.size_x), (float)(1.0 / (double)g.size_y), (float)(1.0 / (double)g.size_z),
             g.gx, g.gy, g.gz, g.ncells};
-  const size_t lds_a = (size_t)kVtRouteWaves * plan.groups * 4 + (kVtRouteWaves + 2) * 4;
+  const size_t lds_a = ((size_t)kVtTile + (size_t)kVtRouteWaves * plan.groups + kVtRouteWaves + 2) * 4;
   const size_t lds_b = vt_group_lds(plan.cpg, plan.tiles);
   const unsigned tile_grid = (unsigned)(plan.tiles * batch);
   vt_route_kernel<<<tile_grid, kVtRouteThreads, lds_a, s>>>(points, num_points, n, dim, vg, plan.low, plan.gbits,
-                                                            plan.tiles, batch, w.recs, w.dir, w.isfirst, w.cnt64);
+                                                            plan.tiles, batch, max_voxels, w.recs, w.dir, w.pos16,
+                                                            w.tilecnt, w.vinfo);
   vt_group_kernel<<<(unsigned)(plan.groups * batch), kWave, lds_b, s>>>(w.recs, w.dir, plan.low, plan.gbits,
-                                                                        plan.tiles, batch, max_pts, w.slot8,
-                                                                        w.owner, w.isfirst, w.cnt64);
-  vt_assign_kernel<<<(unsigned)(w.nblk * batch), kVtAssignThreads, 0, s>>>(
-      w.isfirst, w.stride, w.owner, w.cnt64, w.nblk, batch, max_voxels, vg, w.vinfo, w.cellbase, w.totals, coords,
-      num_pts, coors4);
-#define PD3_VT_EMIT(D)                                                                                          \
-  vt_emit_kernel<D><<<tile_grid, kVtRouteThreads, 0, s>>>(points, num_points, n, dim, vg, plan.tiles, batch,     \
-                                                          max_pts, w.slot8, w.cellbase, w.cap, w.compact)
+                                                                        plan.tiles, batch, max_pts, w.slotr, w.cposr,
+                                                                        w.owner, w.tilecnt);
+#define PD3_VT_EMIT(D)                                                                                         \
+  vt_assign_emit_kernel<D><<<2 * tile_grid, kVtRouteThreads, 0, s>>>(                                          \
+      points, n, dim, plan.tiles, batch, w.cposr, w.pos16, w.owner, w.tilecnt, max_voxels, vg, w.vinfo, w.totals, \
+      coords, num_pts, coors4, w.cap, w.compact)
   switch (dim) {
     case 4: PD3_VT_EMIT(4); break;
     case 5: PD3_VT_EMIT(5); break;

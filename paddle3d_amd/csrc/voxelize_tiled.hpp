@@ -2,36 +2,43 @@
 //
 // Same order-independent restatement of the reference's sequential scan as voxelize.hip
 // (voxel id of a cell = rank of its first point among all first points; slot of a point = number of earlier
-// points in its cell), organised so that every byte that crosses HBM moves in coalesced runs:
+// points in its cell).  What this machine charges for is memory TRANSACTIONS, not bytes (tools/hwcheck/
+// memrates.hip on MI355X: ~190 G scattered 4-byte stores/s and ~80 G scattered 20-byte stores/s chip-wide,
+// i.e. 25 / 60 us for one access per point of a 16-frame batch, against 15 us to stream the batch), so every
+// array is laid out such that it is read and written in coalesced runs; the only scattered accesses left are
+// one 16-byte record per occupied cell (B -> C) and the 20-byte payload store of the kept points (D).
 //
 //   A  route_kernel   (tile of 4096 consecutive points, 512 threads)
-//        point -> cell key -> (group, cell-in-group); a group is a diagonal set of 2^LOW cells (see kVtSkew).
-//        The tile's 4-byte records are written SORTED BY GROUP, stable in point order, into the tile's own
-//        16 KB slice, plus one directory entry dir[group][tile] = (offset, count).  The in-order rank of a
-//        point among the wave's points of the same group is the value a returning LDS atomic add hands back
-//        (lanes of one ds_add_rtn are served in ascending lane order, instructions of a wave in order --
-//        checked on gfx950 by tools/hwcheck/lds_atomic_order.hip and, implicitly, by every bit-exact test).
+//        point -> cell key -> (group, cell-in-group); a group is a diagonal set of 2^LOW (<= 512) cells
+//        (see kVtSkew).  The tile's 4-byte records are sorted BY GROUP, stable in point order, in LDS and
+//        written as one coalesced 16 KB slice, plus the directory row dir[tile][group] = (offset, count) and
+//        pos16[point] = the point's position in the slice.  The in-order rank of a point among the wave's
+//        points of the same group is the value a returning LDS atomic add hands back (lanes of one ds_add_rtn
+//        are served in ascending lane order, instructions of a wave in order -- checked on gfx950 by
+//        tools/hwcheck/lds_atomic_order.hip and, implicitly, by every bit-exact test).
 //   B  group_kernel   (one wave per group)
-//        walks the directory row of its group in tile order -> its points in INPUT ORDER; the in-cell slot
-//        of a point is again what a returning LDS atomic add on the cell's counter hands back.  Every in-range
-//        point gets slot8[point] = min(slot, 255); the cell's first point gets a flag, (cell key, kept count)
-//        is parked at that point's index, and the per-64-point chunk counters the next kernel sums are bumped.
-//   C  assign_kernel  prefix over the first-point flags in point order = voxel id (the reference's hand-out
-//        order) and, in the same scan, the prefix of the kept counts = the voxel's base in the compact
-//        payload array.  Writes vinfo[voxel] = (base, count), cellbase[cell key] = base (0xFFFFFFFF for cells
-//        past max_voxels) and the voxel's coords / count rows.
-//   D  emit_kernel    streams the points a second time (coalesced; they are still in the Infinity Cache),
-//        recomputes the cell, and stores each kept point at compact[cellbase[cell] + slot]: the payload in
-//        DESTINATION order, densely packed (2.7 MB per nuScenes frame; the 20-byte stores merge in L2).
+//        walks the directory column of its group in tile order -> its points in INPUT ORDER (contiguous runs
+//        of the routed slices).  Phase 1: slot of a point = what a returning LDS atomic add on its cell's
+//        counter hands back.  Then a scan over the group's cells of min(count, P) places every cell in the
+//        group's region of the compact payload array (the region is sized by the group's record count, so its
+//        start is the sum of the group's offsets inside the tiles' slices: no global counter).  Phase 2: every
+//        record gets cposr[routed position] = compact position (or "dropped"), bit 31 marking a cell's first
+//        point; the first point also parks (cell key, compact start, kept count) at its point index and bumps
+//        its tile's first-point counter.
+//   C  assign_kernel  (tile)  prefix over the first-point flags in point order = voxel id (the reference's
+//        hand-out order); writes vinfo[voxel] = (compact start, count) and the voxel's coords / count rows
+//        (staged in LDS, coalesced).
+//   D  emit_kernel    (tile)  streams the points a second time (coalesced; still in the Infinity Cache) and
+//        stores each kept point at compact[cposr[pos16[point]]]: the payload grouped by cell, densely packed
+//        (2.7 MB per nuScenes frame; the 20-byte stores merge in L2).  Independent of C.
 //   E  rows_kernel    voxel-parallel, one 16-byte store per lane: a row's valid floats are one contiguous run
-//        of the compact array; the complete fixed-shape outputs (rows, zero padding, coords, counts) are
-//        written exactly once.
+//        of the compact array; the complete fixed-shape voxels tensor (rows and zero padding) and the padding
+//        of the coords / count rows are written exactly once.
 //
 // HBM traffic per frame: points read (A) and re-read (D), outputs written once (E); everything between is a few
 // MB of scratch.  Workgroups are mapped XCD-aware (vt_unit): with batch % 8 == 0 every frame's workgroups of
-// every kernel run on one XCD, so the scattered small stores of a frame (records, directory, slots, compact
-// payload) merge in that XCD's L2 instead of leaving it as partial lines.
-// Preconditions (else the generic sort path of voxelize.hip runs): cells <= 2^20, N < 2^(32-LOW) - 1,
+// every kernel run on one XCD, so the small stores of a frame merge in that XCD's L2.
+// Preconditions (else the generic sort path of voxelize.hip runs): cells <= 2^19, N < 2^(32-LOW) - 1,
 // N <= 4096 * 1024, max points per voxel <= 254.
 #pragma once
 #include "common.hpp"
@@ -44,14 +51,12 @@ constexpr int kVtTile = 4096;
 constexpr int kVtRouteThreads = 512;
 constexpr int kVtRounds = kVtTile / kVtRouteThreads;  // 8
 constexpr int kVtRouteWaves = kVtRouteThreads / kWave;
-constexpr int kVtMaxGroups = 1024;
+constexpr int kVtMaxLow = 9;       // cells per group <= 512: short record streams, one wave per group
+constexpr int kVtMaxGbits = 10;    // groups <= 1024: two per thread in the route kernel's scan
 constexpr int kVtMaxTiles = 1024;
-constexpr int kVtMaxPts = 254;                         // slot8 keeps 255 for "dropped"
-constexpr int kVtAssignThreads = 256;
-constexpr int kVtAssignPoints = kVtAssignThreads * 8;  // 2048 points per scan block (divides kVtTile)
-constexpr int kVtChunk = 64;                           // points per first-flag counter
-constexpr int kVtChunksPerTile = kVtTile / kVtChunk;
-constexpr int kVtChunksPerBlock = kVtAssignPoints / kVtChunk;
+constexpr int kVtMaxPts = 254;
+constexpr uint32_t kVtDropped = 0x7FFFFFFFu;  // cposr: the point is not stored
+constexpr uint32_t kVtFirstBit = 0x80000000u;  // cposr: the point is the first of its cell
 
 struct VtGrid {  // mirror of VoxGrid (kept separate so this header stands alone)
   float min_x, min_y, min_z, size_x, size_y, size_z;
@@ -71,17 +76,15 @@ struct VtPlan {
 
 static inline VtPlan vt_plan(uint32_t ncells, int64_t n, int max_pts) {
   VtPlan p{};
-  int gbits = 10;  // as many groups (= waves of the group kernel) as the route kernel's LDS table allows
-  while (gbits > 4 && (int64_t)ncells < ((int64_t)64 << gbits)) --gbits;  // small grids: >= 64 cells per group
-  p.gbits = gbits;
-  p.groups = 1 << gbits;
-  const int64_t per = ceil_div((int64_t)ncells, (int64_t)p.groups);
-  int low = 0;
-  while (((int64_t)1 << low) < per) ++low;
-  p.low = low;
-  p.cpg = 1 << low;
+  int bits = 0;
+  while (((int64_t)1 << bits) < (int64_t)ncells) ++bits;
+  p.gbits = std::min(std::max(bits - kVtMaxLow, 2), kVtMaxGbits);
+  p.low = std::max(bits - p.gbits, 0);
+  p.groups = 1 << p.gbits;
+  p.cpg = 1 << p.low;
   p.tiles = (int)ceil_div(n, kVtTile);
-  p.ok = low <= 10 && p.tiles <= kVtMaxTiles && n < ((int64_t)1 << (32 - low)) - 1 && max_pts <= kVtMaxPts;
+  p.ok = p.low <= kVtMaxLow && p.tiles <= kVtMaxTiles && n < ((int64_t)1 << (32 - p.low)) - 1 &&
+         n < ((int64_t)1 << 31) - 1 && max_pts <= kVtMaxPts;
   return p;
 }
 
@@ -96,8 +99,7 @@ __device__ __forceinline__ uint32_t vt_div(uint32_t x, uint32_t d, float inv_d) 
 // Cells are dealt to groups DIAGONALLY: cell key = local * G + lo  ->  group = (lo + kVtSkew * local) mod G
 // (G a power of two).  A plain "consecutive cells" or "every G-th cell" assignment makes a group a BEV row or
 // column, and the rows/columns through the sensor carry ~16x the average number of points (LiDAR density
-// ~ 1/r); the skew spreads every dense neighbourhood over hundreds of groups.  (group, local) <-> key is a
-// bijection.
+// ~ 1/r); the skew spreads every dense neighbourhood over all groups.  (group, local) <-> key is a bijection.
 constexpr uint32_t kVtSkew = 7;
 
 __device__ __forceinline__ void vt_key_to_group(uint32_t key, int gbits, uint32_t& grp, uint32_t& local) {
@@ -114,6 +116,9 @@ __device__ __forceinline__ uint32_t vt_group_to_key(uint32_t grp, uint32_t local
 // x, y, z of a point as ONE 12-byte load (global_load_dwordx3 needs only dword alignment).
 struct __attribute__((packed, aligned(4))) VtXyz {
   float x, y, z;
+};
+struct __attribute__((packed, aligned(4))) VtInt3 {
+  int32_t a, b, c;
 };
 typedef float vt_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -173,16 +178,19 @@ __device__ __forceinline__ void vt_unit(uint32_t b, uint32_t units, uint32_t bat
 //   phase 1 (no barrier)  keys; ord = returning atomic add on the wave's private count of the point's group
 //                         = number of earlier points of this wave in that group
 //   barrier, phase 2      thread t: tile histogram of groups 2t, 2t+1, exclusive scan over groups, per-wave
-//                         start offsets; directory entries written
-//   barrier, phase 3 (no barrier)  record position = the wave's start offset of the group + ord
-__global__ __launch_bounds__(kVtRouteThreads) void vt_route_kernel(
+//                         start offsets; directory row written (coalesced)
+//   barrier, phase 3      record -> LDS slice at (wave's start offset of the group + ord); pos16 written
+//   barrier, phase 4      the slice leaves as one coalesced run
+// Side jobs: the tile's first-point counter and its share of vinfo start out clear.
+__global__ __launch_bounds__(kVtRouteThreads, 8) void vt_route_kernel(
     const float* __restrict__ points, const int32_t* __restrict__ num_points, int64_t n, int dim,
-    VtGrid g, int low, int gbits, int tiles, int batch, uint32_t* __restrict__ recs,
-    uint32_t* __restrict__ dir, unsigned char* __restrict__ isfirst,
-    unsigned long long* __restrict__ cnt64) {
+    VtGrid g, int low, int gbits, int tiles, int batch, int max_voxels, uint32_t* __restrict__ recs,
+    uint32_t* __restrict__ dir, unsigned short* __restrict__ pos16, uint32_t* __restrict__ tilecnt,
+    uint2* __restrict__ vinfo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
   const int groups = 1 << gbits;
-  uint32_t* cnt_all = reinterpret_cast<uint32_t*>(vt_smem);                  // [waves][groups]
+  uint32_t* stage = reinterpret_cast<uint32_t*>(vt_smem);                     // [kVtTile]
+  uint32_t* cnt_all = stage + kVtTile;                                        // [waves][groups]
   int* scan_tmp = reinterpret_cast<int*>(cnt_all + (size_t)kVtRouteWaves * groups);  // [waves + 1]
   int frame, tile;
   vt_unit(blockIdx.x, (uint32_t)tiles, (uint32_t)batch, frame, tile);
@@ -192,10 +200,13 @@ __global__ __launch_bounds__(kVtRouteThreads) void vt_route_kernel(
 
   for (int d = lane; d < groups; d += kWave) cnt[d] = 0u;
   vt_wave_sync();
-  // this tile's "is the first point of its cell" flags and chunk counters start out clear
-  reinterpret_cast<unsigned long long*>(isfirst + ((int64_t)frame * tiles + tile) * kVtTile)[threadIdx.x] = 0ull;
-  if (threadIdx.x < kVtChunksPerTile)
-    cnt64[((int64_t)frame * tiles + tile) * kVtChunksPerTile + threadIdx.x] = 0ull;
+  if (threadIdx.x == 0) tilecnt[(int64_t)frame * tiles + tile] = 0u;
+  {  // vinfo rows of voxels that never come to life must read (0, 0)
+    const int per = (int)ceil_div(max_voxels, tiles);
+    const int v1 = min((tile + 1) * per, max_voxels);
+    for (int v = tile * per + (int)threadIdx.x; v < v1; v += kVtRouteThreads)
+      vinfo[(int64_t)frame * max_voxels + v] = make_uint2(0u, 0u);
+  }
 
   // phase 1
   const float* pf = points + (int64_t)frame * n * dim;
@@ -222,6 +233,7 @@ __global__ __launch_bounds__(kVtRouteThreads) void vt_route_kernel(
   }
   __syncthreads();
   // phase 2: tile-level offsets.  Groups are spread over the threads, two per thread (groups <= 1024).
+  int tile_total;
   {
     const int d0 = threadIdx.x * 2;
     int c0 = 0, c1 = 0;
@@ -229,14 +241,11 @@ __global__ __launch_bounds__(kVtRouteThreads) void vt_route_kernel(
       for (int w = 0; w < kVtRouteWaves; ++w) c0 += (int)cnt_all[(size_t)w * groups + d0];
       for (int w = 0; w < kVtRouteWaves; ++w) c1 += (int)cnt_all[(size_t)w * groups + d0 + 1];
     }
-    int total;
-    const int ex = block_exclusive_scan<kVtRouteThreads>(c0 + c1, scan_tmp, total);
-    // directory is group-major (dir[frame][group][tile]) so that the group kernel reads its row as one
-    // contiguous run; these strided 4-byte stores are fire-and-forget and merge in L2
+    const int ex = block_exclusive_scan<kVtRouteThreads>(c0 + c1, scan_tmp, tile_total);
     if (d0 < groups) {
-      uint32_t* dcol0 = dir + ((int64_t)frame * groups + d0) * tiles + tile;
-      dcol0[0] = (uint32_t)ex | ((uint32_t)c0 << 16);
-      dcol0[tiles] = (uint32_t)(ex + c0) | ((uint32_t)c1 << 16);
+      // (offset, count) fit 13 + 13 bits; one 8-byte store per thread: the row leaves coalesced
+      *reinterpret_cast<uint2*>(dir + ((int64_t)frame * tiles + tile) * groups + d0) =
+          make_uint2((uint32_t)ex | ((uint32_t)c0 << 16), (uint32_t)(ex + c0) | ((uint32_t)c1 << 16));
       uint32_t acc = (uint32_t)ex;
       for (int w = 0; w < kVtRouteWaves; ++w) {  // per-wave start of group d0 inside the tile
         const uint32_t c = cnt_all[(size_t)w * groups + d0];
@@ -251,57 +260,66 @@ __global__ __launch_bounds__(kVtRouteThreads) void vt_route_kernel(
     }
   }
   __syncthreads();
-  // phase 3: records written grouped, stable
-  uint32_t* out = recs + ((int64_t)frame * tiles + tile) * kVtTile;
+  // phase 3: records into the LDS slice, grouped and stable; position of every point to pos16
+  unsigned short* pos_f = pos16 + (int64_t)frame * tiles * kVtTile;
   const uint32_t low_mask = (1u << low) - 1u;
 #pragma unroll
   for (int r = 0; r < kVtRounds; ++r) {
     const uint32_t k = key[r];
+    const int64_t i = wave_base + r * kWave + lane;
+    uint32_t pos = 0xFFFFu;
     if (k != 0xFFFFFFFFu) {
-      const uint32_t idx = (uint32_t)(wave_base + r * kWave + lane);
-      out[cnt[k >> low] + ord[r]] = (idx << low) | (k & low_mask);
+      pos = cnt[k >> low] + ord[r];
+      stage[pos] = ((uint32_t)i << low) | (k & low_mask);
     }
+    pos_f[i] = (unsigned short)pos;
   }
+  __syncthreads();
+  // phase 4
+  uint32_t* out = recs + ((int64_t)frame * tiles + tile) * kVtTile;
+  for (int j = threadIdx.x; j < tile_total; j += kVtRouteThreads) out[j] = stage[j];
 }
 
 // ------------------------------------------------------------------------------------------------ B
-constexpr int kVtGroupSteps = 8;                           // 64-record steps per pass
-constexpr int kVtGroupPass = kWave * kVtGroupSteps;        // 512 records per pass
+constexpr int kVtGroupSteps = 24;                          // 64-record steps per pass
+constexpr int kVtGroupPass = kWave * kVtGroupSteps;        // 1536 records per pass
 
 static inline size_t vt_group_lds(int cpg, int tiles) {
-  return (size_t)cpg * 8 + (size_t)(tiles + 1) * 4 + (size_t)tiles * 4 + (size_t)kVtGroupPass * 4;
+  return (size_t)cpg * 4 + (size_t)kVtGroupPass * 4 + (size_t)(tiles + 1) * 4 + (size_t)tiles * 4 * 2;
 }
 
-// One WAVE per group, one wave per workgroup: fully wave-synchronous (no barrier anywhere), ~4 KB of LDS, so
-// all groups of a batch are resident at once.  The group's record stream (its points in input order) is cut
-// into passes of 512 records; ALL records of a pass are fetched with independent loads up front, then handed
-// 64 at a time to the cell counters: slot of a point = what the returning LDS atomic add on its cell's counter
-// hands back = number of earlier points of the cell (lanes in ascending order, steps in order).
-__global__ __launch_bounds__(kWave) void vt_group_kernel(
+// One WAVE per group, one wave per workgroup: fully wave-synchronous (no barrier anywhere).  The group's
+// record stream (its points in input order) is cut into passes of 1536 records (a nuScenes group has ~530;
+// a group that fits one pass never leaves the registers); ALL records of a pass are fetched with independent
+// loads up front.
+__global__ __launch_bounds__(kWave, 4) void vt_group_kernel(
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ dir, int low, int gbits, int tiles,
-    int batch, int max_pts, unsigned char* __restrict__ slot8, uint2* __restrict__ owner,
-    unsigned char* __restrict__ isfirst, unsigned long long* __restrict__ cnt64) {
+    int batch, int max_pts, unsigned char* __restrict__ slotr, uint32_t* __restrict__ cposr,
+    uint4* __restrict__ owner, uint32_t* __restrict__ tilecnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
   const int cpg = 1 << low, groups = 1 << gbits;
-  uint32_t* first = reinterpret_cast<uint32_t*>(vt_smem);      // [cpg] first point of the cell
-  uint32_t* run = first + cpg;                                 // [cpg] points of the cell so far
-  int* tpre = reinterpret_cast<int*>(run + cpg);               // [tiles + 1] exclusive prefix of per-tile counts
-  int* toff = tpre + tiles + 1;                                // [tiles] offset of the segment inside its tile
-  uint32_t* srcpos = reinterpret_cast<uint32_t*>(toff + tiles);  // [kVtGroupPass] routed position per record
+  uint32_t* run = reinterpret_cast<uint32_t*>(vt_smem);          // [cpg] points of the cell so far; later
+                                                                 //       (start in region << 8) | kept count
+  uint32_t* srcpos = run + cpg;                                  // [kVtGroupPass] routed position per record
+  int* tpre = reinterpret_cast<int*>(srcpos + kVtGroupPass);     // [tiles + 1] exclusive prefix of per-tile counts
+  int* toff = tpre + tiles + 1;                                  // [tiles] offset of the segment inside its tile
+  uint32_t* tfirst = reinterpret_cast<uint32_t*>(toff + tiles);  // [tiles] first points seen per tile
   int frame, grp;
   vt_unit(blockIdx.x, (uint32_t)groups, (uint32_t)batch, frame, grp);
   const int lane = threadIdx.x;
 
-  // directory row of this group (contiguous) -> per-tile (offset, count) and the exclusive scan
-  const uint32_t* drow = dir + ((int64_t)frame * groups + grp) * tiles;
-  int running = 0;
+  // directory column of this group -> per-tile (offset, count) and the exclusive scan
+  const uint32_t* dcol = dir + (int64_t)frame * tiles * groups + grp;
+  int running = 0, offsum = 0;
   for (int t0 = 0; t0 < tiles; t0 += kWave) {
     const int t = t0 + lane;
     int c = 0;
     if (t < tiles) {
-      const uint32_t d = drow[t];
+      const uint32_t d = dcol[(int64_t)t * groups];
       toff[t] = (int)(d & 0xFFFFu);
+      offsum += (int)(d & 0xFFFFu);
       c = (int)(d >> 16);
+      tfirst[t] = 0u;
     }
     const int inc = wave_inclusive_scan(c);
     if (t < tiles) tpre[t] = running + inc - c;
@@ -315,223 +333,298 @@ __global__ __launch_bounds__(kWave) void vt_group_kernel(
 
   const int64_t stride = (int64_t)tiles * kVtTile;
   const uint32_t* rf = recs + (int64_t)frame * stride;
-  unsigned char* slot_f = slot8 + (int64_t)frame * stride;
+  uint32_t* cpos_f = cposr + (int64_t)frame * stride;
   const uint32_t cell_mask = (uint32_t)cpg - 1u;
 
-  for (int p0 = 0; p0 < n_g; p0 += kVtGroupPass) {
-    // source address of every record of this pass: lanes = tiles expand their segments into LDS
-    const int p1 = min(p0 + kVtGroupPass, n_g);
-    for (int t = lane; t < tiles; t += kWave) {
-      const int lo = max(tpre[t], p0), hi = min(tpre[t + 1], p1);
-      const uint32_t src = (uint32_t)t * kVtTile + (uint32_t)toff[t] - (uint32_t)tpre[t];
-      for (int j = lo; j < hi; ++j) srcpos[j - p0] = src + (uint32_t)j;
-    }
-    vt_wave_sync();
-    uint32_t rec[kVtGroupSteps];
+  // the group's region of the compact array is sized by its record count: it starts where the records of the
+  // groups before it would end = the sum over the tiles of this group's offset inside the tile's slice
 #pragma unroll
-    for (int u = 0; u < kVtGroupSteps; ++u) {
-      const int j = p0 + u * kWave + lane;
-      rec[u] = 0xFFFFFFFFu;  // idx field all ones never occurs (N < 2^(32-low) - 1 is enforced by the plan)
-      if (j < p1) rec[u] = rf[srcpos[j - p0]];
-    }
+  for (int d = 1; d < kWave; d <<= 1) offsum += __shfl_xor(offsum, d, kWave);
+  const uint32_t region = (uint32_t)offsum;
+  uint4* owner_f = owner + (int64_t)frame * stride;
+
+  // a record's compact position (or "dropped"); a cell's first point parks the cell's facts at its index
+#define PD3_VT_PLACE(REC, SP, SLOT)                                                                            \
+  {                                                                                                            \
+    const uint32_t cell_ = (REC) & cell_mask, sp_ = (SP);                                                      \
+    const uint32_t packed_ = run[cell_];                                                                       \
+    const uint32_t start_ = region + (packed_ >> 8);                                                           \
+    uint32_t cp_ = (SLOT) < (uint32_t)max_pts ? start_ + (SLOT) : kVtDropped;                                  \
+    if ((SLOT) == 0u) {                                                                                        \
+      cp_ |= kVtFirstBit;                                                                                      \
+      owner_f[(REC) >> low] =                                                                                  \
+          make_uint4(vt_group_to_key((uint32_t)grp, cell_, gbits), start_, packed_ & 0xFFu, 0u);              \
+      atomicAdd(&tfirst[sp_ / kVtTile], 1u);                                                                   \
+    }                                                                                                          \
+    cpos_f[sp_] = cp_;                                                                                         \
+  }
+  // cells -> places in the group's region.  Any order of the cells will do (the array is scratch), so lane l
+  // takes cells l, l + 64, ...: conflict-free LDS walks and one scan across the lanes.
+#define PD3_VT_SCAN_CELLS()                                                                                    \
+  {                                                                                                            \
+    uint32_t mine_ = 0;                                                                                        \
+    for (int c = lane; c < cpg; c += kWave) mine_ += min(run[c], (uint32_t)max_pts);                           \
+    uint32_t at_ = (uint32_t)wave_inclusive_scan((int)mine_) - mine_;                                          \
+    for (int c = lane; c < cpg; c += kWave) {                                                                  \
+      const uint32_t kept_ = min(run[c], (uint32_t)max_pts);                                                   \
+      run[c] = (at_ << 8) | kept_;                                                                             \
+      at_ += kept_;                                                                                            \
+    }                                                                                                          \
+    vt_wave_sync();                                                                                            \
+  }
+#define PD3_VT_EXPAND(P0, P1)                                                                                  \
+  {                                                                                                            \
+    for (int t = lane; t < tiles; t += kWave) {                                                                \
+      const int lo_ = max(tpre[t], (P0)), hi_ = min(tpre[t + 1], (P1));                                        \
+      const uint32_t src_ = (uint32_t)t * kVtTile + (uint32_t)toff[t] - (uint32_t)tpre[t];                     \
+      for (int j = lo_; j < hi_; ++j) srcpos[j - (P0)] = src_ + (uint32_t)j;                                   \
+    }                                                                                                          \
+    vt_wave_sync();                                                                                            \
+  }
+
+  // all records of a pass are fetched with independent loads up front (their routed positions stay in LDS)
+#define PD3_VT_LOAD(P0, P1)                                                                                    \
+  uint32_t rec[kVtGroupSteps], sl[kVtGroupSteps];                                                              \
+  _Pragma("unroll") for (int u = 0; u < kVtGroupSteps; ++u) {                                                  \
+    const int j = (P0) + u * kWave + lane;                                                                     \
+    rec[u] = 0xFFFFFFFFu; /* idx field all ones never occurs (N < 2^(32-low) - 1: the plan) */                 \
+    sl[u] = 0;                                                                                                 \
+    if (j < (P1)) rec[u] = rf[srcpos[j - (P0)]];                                                               \
+  }
+
+  if (n_g <= kVtGroupPass) {
+    // the whole group in registers: records are fetched once, slots never leave the wave
+    PD3_VT_EXPAND(0, n_g)
+    PD3_VT_LOAD(0, n_g)
 #pragma unroll
-    for (int u = 0; u < kVtGroupSteps; ++u) {
-      if (rec[u] != 0xFFFFFFFFu) {
-        const uint32_t cell = rec[u] & cell_mask;
-        const uint32_t idx = rec[u] >> low;
-        const uint32_t slot = atomicAdd(&run[cell], 1u);  // number of earlier points in this cell
-        if (slot == 0) first[cell] = idx;                 // the cell's first point: its index orders the voxels
-        slot_f[idx] = (unsigned char)min(slot, 255u);
-      }
-    }
+    for (int u = 0; u < kVtGroupSteps; ++u)
+      if (rec[u] != 0xFFFFFFFFu) sl[u] = atomicAdd(&run[rec[u] & cell_mask], 1u);  // earlier points in this cell
     vt_wave_sync();
-  }
-  // per occupied cell: raise the flag of its first point, park (cell key, kept count) there, bump the
-  // counter of the 64-point chunk the first point lies in (flags in the high word, kept points in the low)
-  const int64_t nchunk = stride / kVtChunk;
-  for (int c = lane; c < cpg; c += kWave) {
-    const uint32_t k = run[c];
-    if (k > 0) {
-      const uint32_t at = first[c];
-      const uint32_t key = vt_group_to_key((uint32_t)grp, (uint32_t)c, gbits);
-      const uint32_t kept = min(k, (uint32_t)max_pts);
-      owner[(int64_t)frame * stride + at] = make_uint2(key, kept);
-      isfirst[(int64_t)frame * stride + at] = 1;
-      atomicAdd(&cnt64[(int64_t)frame * nchunk + at / kVtChunk], (1ull << 32) | (unsigned long long)kept);
+    PD3_VT_SCAN_CELLS()
+#pragma unroll
+    for (int u = 0; u < kVtGroupSteps; ++u)
+      if (rec[u] != 0xFFFFFFFFu) PD3_VT_PLACE(rec[u], srcpos[u * kWave + lane], sl[u])
+  } else {
+    // long record streams (one cell hammered by thousands of points): passes; slots travel through slotr
+    unsigned char* slot_f = slotr + (int64_t)frame * stride;
+    for (int p0 = 0; p0 < n_g; p0 += kVtGroupPass) {
+      const int p1 = min(p0 + kVtGroupPass, n_g);
+      PD3_VT_EXPAND(p0, p1)
+      PD3_VT_LOAD(p0, p1)
+#pragma unroll
+      for (int u = 0; u < kVtGroupSteps; ++u)
+        if (rec[u] != 0xFFFFFFFFu) {
+          sl[u] = atomicAdd(&run[rec[u] & cell_mask], 1u);
+          slot_f[srcpos[u * kWave + lane]] = (unsigned char)min(sl[u], 255u);
+        }
+      vt_wave_sync();
+    }
+    PD3_VT_SCAN_CELLS()
+    for (int p0 = 0; p0 < n_g; p0 += kVtGroupPass) {
+      const int p1 = min(p0 + kVtGroupPass, n_g);
+      PD3_VT_EXPAND(p0, p1)
+      PD3_VT_LOAD(p0, p1)
+#pragma unroll
+      for (int u = 0; u < kVtGroupSteps; ++u)
+        if (rec[u] != 0xFFFFFFFFu) sl[u] = slot_f[srcpos[u * kWave + lane]];
+#pragma unroll
+      for (int u = 0; u < kVtGroupSteps; ++u)
+        if (rec[u] != 0xFFFFFFFFu) PD3_VT_PLACE(rec[u], srcpos[u * kWave + lane], sl[u])
+      vt_wave_sync();
     }
   }
+#undef PD3_VT_LOAD
+#undef PD3_VT_PLACE
+#undef PD3_VT_SCAN_CELLS
+#undef PD3_VT_EXPAND
+  vt_wave_sync();
+  for (int t = lane; t < tiles; t += kWave)
+    if (tfirst[t]) atomicAdd(&tilecnt[(int64_t)frame * tiles + t], tfirst[t]);
 }
 
-// ------------------------------------------------------------------------------------------------ C
-// voxel id = number of first-point flags before the cell's first point; base = kept points of the voxels
-// before it.  Both ride one 64-bit sum (flags in the high word, kept points in the low word).  A thread owns
-// 8 consecutive points (one 64-bit load of their flags); a workgroup 2048 points = 32 chunk counters.
-__device__ __forceinline__ unsigned long long vt_shfl_up64(unsigned long long v, int d) {
-  const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, d, kWave);
-  const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d, kWave);
-  return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ unsigned long long vt_shfl_xor64(unsigned long long v, int d) {
-  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d, kWave);
-  const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, kWave);
-  return ((unsigned long long)hi << 32) | lo;
-}
+// ------------------------------------------------------------------------------------------------ C + D
+// Two independent per-tile jobs share ONE launch (workgroups [0, tiles*batch) run C, the rest D): one kernel
+// boundary less, and C's dependent-latency chain overlaps D's store traffic.
+struct VtAssignLds {
+  uint32_t slice[kVtTile];        // the tile's cposr; later key of the tile's j-th new voxel
+  uint32_t st_info[kVtTile];      // compact start of the tile's j-th new voxel
+  unsigned char st_kept[kVtTile];  // its kept count
+  int s_inc[kVtRouteWaves], s_before[kVtRouteWaves], s_all[kVtRouteWaves];
+};
 
-__global__ __launch_bounds__(kVtAssignThreads) void vt_assign_kernel(
-    const unsigned char* __restrict__ isfirst, int64_t stride, const uint2* __restrict__ owner,
-    const unsigned long long* __restrict__ cnt64, int nblk, int batch, int max_voxels, VtGrid g,
-    uint2* __restrict__ vinfo, uint32_t* __restrict__ cellbase, int* __restrict__ totals,
-    int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ coors4) {
-  constexpr int W = kVtAssignThreads / kWave;
-  __shared__ unsigned long long s_inc[W], s_before[W], s_all[W];
-  int frame, blk;
-  vt_unit(blockIdx.x, (uint32_t)nblk, (uint32_t)batch, frame, blk);
-  const int64_t i = (int64_t)frame * stride + ((int64_t)blk * kVtAssignThreads + threadIdx.x) * 8;
-  const unsigned long long x = *reinterpret_cast<const unsigned long long*>(isfirst + i);
-  uint2 o[8];
+// C: voxel id = number of first-point flags before the cell's first point.  One workgroup per tile; thread t
+// owns the 8 consecutive points 8t .. 8t+7.  The voxels a tile opens have consecutive ids, so their rows of
+// vinfo / coords / num_points / coors4 are staged in LDS and leave coalesced.
+__device__ __forceinline__ void vt_assign_tile(
+    VtAssignLds& L, int frame, int tile, const uint32_t* __restrict__ cposr,
+    const unsigned short* __restrict__ pos16, const uint4* __restrict__ owner,
+    const uint32_t* __restrict__ tilecnt, int tiles, int max_voxels, const VtGrid& g,
+    uint2* __restrict__ vinfo, int* __restrict__ totals, int32_t* __restrict__ coords,
+    int32_t* __restrict__ num_pts, int32_t* __restrict__ coors4) {
+  const int64_t tbase = ((int64_t)frame * tiles + tile) * kVtTile;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(cposr + tbase);
+    uint4* dst = reinterpret_cast<uint4*>(L.slice);
+    for (int j = threadIdx.x; j < kVtTile / 4; j += kVtRouteThreads) dst[j] = src[j];
+  }
+  // first-point counts of the tiles before this one (and of all tiles -> totals)
+  int before = 0, all = 0;
+  for (int t = threadIdx.x; t < tiles; t += kVtRouteThreads) {
+    const int v = (int)tilecnt[(int64_t)frame * tiles + t];
+    all += v;
+    if (t < tile) before += v;
+  }
+  const uint4 pw = *reinterpret_cast<const uint4*>(pos16 + tbase + (int64_t)threadIdx.x * 8);
+  __syncthreads();
+  const uint32_t pword[4] = {pw.x, pw.y, pw.z, pw.w};
+  uint32_t flags = 0;
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
-    o[b] = make_uint2(0u, 0u);
-    if ((x >> (8 * b)) & 1ull) o[b] = owner[i + b];
+    const uint32_t pos = (pword[b >> 1] >> (16 * (b & 1))) & 0xFFFFu;
+    if (pos != 0xFFFFu && (L.slice[pos] & kVtFirstBit)) flags |= 1u << b;
   }
-  // sum of the chunk counters before this block (and, for block 0, of all of them -> totals)
-  const int nchunk = nblk * kVtChunksPerBlock;
-  const unsigned long long* cc = cnt64 + (int64_t)frame * nchunk;
-  unsigned long long before = 0, all = 0;
-  const int lim = blk == 0 ? nchunk : blk * kVtChunksPerBlock;
-  for (int c = threadIdx.x; c < lim; c += kVtAssignThreads) {
-    const unsigned long long v = cc[c];
-    all += v;
-    if (c < blk * kVtChunksPerBlock) before += v;
-  }
-  unsigned long long mine = 0;
+  uint4 o[8];
 #pragma unroll
-  for (int b = 0; b < 8; ++b)
-    if ((x >> (8 * b)) & 1ull) mine += (1ull << 32) | (unsigned long long)o[b].y;
-  // one barrier: wave-level inclusive scan of `mine`, wave-level sums of `before` / `all`
-  unsigned long long inc = mine;
+  for (int b = 0; b < 8; ++b) {
+    o[b] = make_uint4(0u, 0u, 0u, 0u);
+    if (flags & (1u << b)) o[b] = owner[tbase + (int64_t)threadIdx.x * 8 + b];
+  }
+  const int mine = __popc(flags);
+  int inc = mine;
 #pragma unroll
   for (int d = 1; d < kWave; d <<= 1) {
-    const unsigned long long nb = vt_shfl_up64(inc, d);
+    const int nb = __shfl_up(inc, d, kWave);
     if (lane_id() >= d) inc += nb;
-    before += vt_shfl_xor64(before, d);
-    all += vt_shfl_xor64(all, d);
+    before += __shfl_xor(before, d, kWave);
+    all += __shfl_xor(all, d, kWave);
   }
   if (lane_id() == kWave - 1) {
-    s_inc[wave_id()] = inc;
-    s_before[wave_id()] = before;
-    s_all[wave_id()] = all;
+    L.s_inc[wave_id()] = inc;
+    L.s_before[wave_id()] = before;
+    L.s_all[wave_id()] = all;
   }
-  __syncthreads();
-  unsigned long long ex = inc - mine, tot_all = 0;
+  __syncthreads();  // also: every thread is done reading `slice`
+  int vid0 = 0, tot_all = 0, local = inc - mine, tile_new = 0;
 #pragma unroll
-  for (int w = 0; w < W; ++w) {
-    ex += s_before[w];
-    tot_all += s_all[w];
-    if (w < wave_id()) ex += s_inc[w];
+  for (int w = 0; w < kVtRouteWaves; ++w) {
+    vid0 += L.s_before[w];
+    tot_all += L.s_all[w];
+    tile_new += L.s_inc[w];
+    if (w < wave_id()) local += L.s_inc[w];
   }
-  if (blk == 0 && threadIdx.x == 0) totals[frame] = (int)(tot_all >> 32);
+  if (tile == 0 && threadIdx.x == 0) totals[frame] = tot_all;
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
-    if ((x >> (8 * b)) & 1ull) {
-      const uint32_t vid = (uint32_t)(ex >> 32), base = (uint32_t)ex;
-      const uint32_t key = o[b].x;
-      uint32_t cb = 0xFFFFFFFFu;
-      if (vid < (uint32_t)max_voxels) {
-        const int64_t row = (int64_t)frame * max_voxels + vid;
-        vinfo[row] = make_uint2(base, o[b].y);
-        cb = base;
-        const int cx = (int)(key % (uint32_t)g.gx);
-        const uint32_t t = key / (uint32_t)g.gx;
-        const int cy = (int)(t % (uint32_t)g.gy), cz = (int)(t / (uint32_t)g.gy);
-        int32_t* co = coords + row * 3;  // coords (z, y, x)
-        co[0] = cz;
-        co[1] = cy;
-        co[2] = cx;
-        num_pts[row] = (int)o[b].y;
-        if (coors4) *reinterpret_cast<int4*>(coors4 + row * 4) = make_int4(frame, cz, cy, cx);
-      }
-      cellbase[(int64_t)frame * g.ncells + key] = cb;
-      ex += (1ull << 32) | (unsigned long long)o[b].y;
+    if (flags & (1u << b)) {
+      L.slice[local] = o[b].x;
+      L.st_info[local] = o[b].y;
+      L.st_kept[local] = (unsigned char)o[b].z;
+      ++local;
     }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < tile_new; j += kVtRouteThreads) {
+    const int vid = vid0 + j;
+    if (vid >= max_voxels) break;
+    const int64_t row = (int64_t)frame * max_voxels + vid;
+    const uint32_t key = L.slice[j], kept = L.st_kept[j];
+    vinfo[row] = make_uint2(L.st_info[j], kept);
+    const int cx = (int)(key % (uint32_t)g.gx);
+    const uint32_t t = key / (uint32_t)g.gx;
+    const int cy = (int)(t % (uint32_t)g.gy), cz = (int)(t / (uint32_t)g.gy);
+    const VtInt3 c3{cz, cy, cx};  // coords (z, y, x)
+    __builtin_memcpy(coords + row * 3, &c3, sizeof(c3));
+    num_pts[row] = (int)kept;
+    if (coors4) *reinterpret_cast<int4*>(coors4 + row * 4) = make_int4(frame, cz, cy, cx);
   }
 }
 
-// ------------------------------------------------------------------------------------------------ D
-// Second pass over the points: a kept point (slot < max points, cell within the voxel cap) is stored at its
-// destination-ordered place in the compact payload array.  Thread t of the workgroup takes points
-// t, t + 512, ... of the tile: fully coalesced loads; the stores are DIM*4-byte pieces that merge in L2.
+// D: second pass over the points: a kept point is stored at its place in the compact payload array.  Thread t
+// of the workgroup takes points t, t + 512, ... of the tile: fully coalesced loads; the destination comes from
+// the tile's cposr slice (staged in LDS) through pos16; the stores are DIM*4-byte pieces that merge in L2.
 template <int DIM>
-__global__ __launch_bounds__(kVtRouteThreads) void vt_emit_kernel(
-    const float* __restrict__ points, const int32_t* __restrict__ num_points, int64_t n, int dim_rt, VtGrid g,
-    int tiles, int batch, int max_pts, const unsigned char* __restrict__ slot8,
-    const uint32_t* __restrict__ cellbase, int64_t cap, float* __restrict__ compact) {
+__device__ __forceinline__ void vt_emit_tile(uint32_t* __restrict__ slice, int frame, int tile,
+                                             const float* __restrict__ points, int64_t n, int dim_rt, int tiles,
+                                             const uint32_t* __restrict__ cposr,
+                                             const unsigned short* __restrict__ pos16, int64_t cap,
+                                             float* __restrict__ compact) {
   const int dim = DIM > 0 ? DIM : dim_rt;
-  int frame, tile;
-  vt_unit(blockIdx.x, (uint32_t)tiles, (uint32_t)batch, frame, tile);
-  const int64_t nf = num_points ? min((int64_t)num_points[frame], n) : n;
+  const int64_t tbase = ((int64_t)frame * tiles + tile) * kVtTile;
   const float* pf = points + (int64_t)frame * n * dim;
-  const unsigned char* sf = slot8 + (int64_t)frame * tiles * kVtTile;
-  const uint32_t* cb = cellbase + (int64_t)frame * g.ncells;
   float* cf = compact + (int64_t)frame * cap * dim;
   const int64_t base_i = (int64_t)tile * kVtTile + threadIdx.x;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(cposr + tbase);
+    uint4* dst = reinterpret_cast<uint4*>(slice);
+    for (int j = threadIdx.x; j < kVtTile / 4; j += kVtRouteThreads) dst[j] = src[j];
+  }
+  uint32_t pos[kVtRounds];
+#pragma unroll
+  for (int r = 0; r < kVtRounds; ++r) pos[r] = pos16[tbase + threadIdx.x + r * kVtRouteThreads];
   if (DIM == 4 || DIM == 5) {
     vt_f32x4u a[kVtRounds];
     float e[kVtRounds];
-    uint32_t s[kVtRounds];
 #pragma unroll
     for (int r = 0; r < kVtRounds; ++r) {
       const int64_t i = base_i + r * kVtRouteThreads;
-      a[r] = vt_f32x4u{__builtin_nanf(""), 0.f, 0.f, 0.f};
+      a[r] = vt_f32x4u{0.f, 0.f, 0.f, 0.f};
       e[r] = 0.f;
-      s[r] = 255u;
-      if (i < nf) {
+      if (pos[r] != 0xFFFFu) {  // routed points lie inside the frame
         a[r] = *reinterpret_cast<const vt_f32x4u*>(pf + i * DIM);
         if (DIM == 5) e[r] = pf[i * DIM + 4];
-        s[r] = sf[i];
       }
     }
-    uint32_t dst[kVtRounds];
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < kVtRounds; ++r) {
-      uint32_t key = 0;
-      dst[r] = 0xFFFFFFFFu;
-      if (vt_cell_key(a[r].x, a[r].y, a[r].z, g, key) && s[r] < (uint32_t)max_pts) {
-        const uint32_t b = cb[key];
-        if (b != 0xFFFFFFFFu) dst[r] = b + s[r];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < kVtRounds; ++r) {
-      if (dst[r] != 0xFFFFFFFFu) {
-        float* d = cf + (int64_t)dst[r] * DIM;
-        *reinterpret_cast<vt_f32x4u*>(d) = a[r];
-        if (DIM == 5) d[4] = e[r];
-      }
+      if (pos[r] == 0xFFFFu) continue;
+      const uint32_t cp = slice[pos[r]] & ~kVtFirstBit;
+      if (cp == kVtDropped) continue;
+      float* d = cf + (int64_t)cp * DIM;
+      *reinterpret_cast<vt_f32x4u*>(d) = a[r];
+      if (DIM == 5) d[4] = e[r];
     }
   } else {
+    __syncthreads();
     for (int r = 0; r < kVtRounds; ++r) {
-      const int64_t i = base_i + r * kVtRouteThreads;
-      if (i >= nf) continue;
-      const float* src = pf + i * dim;
-      uint32_t key = 0;
-      const uint32_t s = sf[i];
-      if (!vt_cell_key(src[0], src[1], src[2], g, key) || s >= (uint32_t)max_pts) continue;
-      const uint32_t b = cb[key];
-      if (b == 0xFFFFFFFFu) continue;
-      float* d = cf + ((int64_t)b + s) * dim;
+      if (pos[r] == 0xFFFFu) continue;
+      const uint32_t cp = slice[pos[r]] & ~kVtFirstBit;
+      if (cp == kVtDropped) continue;
+      const float* src = pf + (base_i + r * kVtRouteThreads) * dim;
+      float* d = cf + (int64_t)cp * dim;
       for (int c = 0; c < dim; ++c) d[c] = src[c];
     }
+  }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(kVtRouteThreads, 4) void vt_assign_emit_kernel(
+    const float* __restrict__ points, int64_t n, int dim_rt, int tiles, int batch,
+    const uint32_t* __restrict__ cposr, const unsigned short* __restrict__ pos16,
+    const uint4* __restrict__ owner, const uint32_t* __restrict__ tilecnt, int max_voxels, VtGrid g,
+    uint2* __restrict__ vinfo, int* __restrict__ totals, int32_t* __restrict__ coords,
+    int32_t* __restrict__ num_pts, int32_t* __restrict__ coors4, int64_t cap, float* __restrict__ compact) {
+  __shared__ VtAssignLds L;
+  const uint32_t per_job = (uint32_t)tiles * (uint32_t)batch;
+  int frame, tile;
+  if (blockIdx.x < per_job) {
+    vt_unit(blockIdx.x, (uint32_t)tiles, (uint32_t)batch, frame, tile);
+    vt_assign_tile(L, frame, tile, cposr, pos16, owner, tilecnt, tiles, max_voxels, g, vinfo, totals, coords,
+                   num_pts, coors4);
+  } else {
+    vt_unit(blockIdx.x - per_job, (uint32_t)tiles, (uint32_t)batch, frame, tile);
+    vt_emit_tile<DIM>(L.slice, frame, tile, points, n, dim_rt, tiles, cposr, pos16, cap, compact);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ E
 // Output writer.  The frame's voxels tensor is one flat array of V * P * D floats; a lane owns VEC consecutive
 // floats of it (VEC = 4 when a row is a whole number of float4: one 16-byte store).  Row v's valid floats are
-// the run compact[base(v) * D ... + count(v) * D): one (unaligned) 16-byte load, everything behind is padding.
-// Rows >= num_voxels are zeros, and so are their coords / count rows (the live ones were written by C).
+// the run compact[start(v) * D ... + count(v) * D): one (unaligned) 16-byte load, everything behind is padding.
+// vinfo rows of voxels that never came to life read (0, 0) (route kernel), so nothing here waits for the voxel
+// count except the padding rows of coords / count / coors4 (the live ones were written by C).
 constexpr int kVtRowsThreads = 256;
-constexpr int kVtRowsIlp = 4;
+constexpr int kVtRowsIlp = 8;
 
 template <int VEC>
 __global__ __launch_bounds__(kVtRowsThreads) void vt_rows_kernel(
@@ -541,8 +634,6 @@ __global__ __launch_bounds__(kVtRowsThreads) void vt_rows_kernel(
     int32_t* __restrict__ num_voxels, int32_t* __restrict__ coors4) {
   int frame, unit;
   vt_unit(blockIdx.x, (uint32_t)units, (uint32_t)batch, frame, unit);
-  const int nv = min(totals[frame], max_voxels);
-  if (unit == 0 && threadIdx.x == 0) num_voxels[frame] = nv;
   const uint32_t total_q = (uint32_t)max_voxels * (uint32_t)rowq;
   const float* cf = compact + (int64_t)frame * cap * dim;
   const uint2* vi = vinfo + (int64_t)frame * max_voxels;
@@ -561,12 +652,17 @@ __global__ __launch_bounds__(kVtRowsThreads) void vt_rows_kernel(
       ++v[u];
     }
   }
+  // the rows this workgroup touches are consecutive: their vinfo entries come in through LDS, one coalesced load
+  __shared__ uint2 st_vi[kVtRowsIlp * kVtRowsThreads + 2];
+  const uint32_t qb = (uint32_t)unit * (kVtRowsIlp * kVtRowsThreads);
+  const uint32_t vb = vt_div(min(qb, total_q), (uint32_t)rowq, 1.0f / (float)rowq);
+  const uint32_t ve = vt_div(min(qb + kVtRowsIlp * kVtRowsThreads - 1u, total_q), (uint32_t)rowq, 1.0f / (float)rowq);
+  for (uint32_t r = threadIdx.x; r <= ve - vb; r += kVtRowsThreads)
+    st_vi[r] = vb + r < (uint32_t)max_voxels ? vi[vb + r] : make_uint2(0u, 0u);
+  __syncthreads();
   uint2 info[kVtRowsIlp];
 #pragma unroll
-  for (int u = 0; u < kVtRowsIlp; ++u) {
-    info[u] = make_uint2(0u, 0u);
-    if ((int)v[u] < nv) info[u] = vi[v[u]];
-  }
+  for (int u = 0; u < kVtRowsIlp; ++u) info[u] = st_vi[min(v[u], ve) - vb];
   float val[kVtRowsIlp][VEC];
 #pragma unroll
   for (int u = 0; u < kVtRowsIlp; ++u) {
@@ -587,10 +683,12 @@ __global__ __launch_bounds__(kVtRowsThreads) void vt_rows_kernel(
         if (r0 + c < nfl) val[u][c] = src[c];
     }
   }
+  const int nv = min(totals[frame], max_voxels);
+  if (unit == 0 && threadIdx.x == 0) num_voxels[frame] = nv;
 #pragma unroll
   for (int u = 0; u < kVtRowsIlp; ++u) {
     const uint32_t q = q0 + (uint32_t)u * kVtRowsThreads;
-    if (q >= total_q) continue;
+    if (q >= total_q) break;
     float* dst = vf + (int64_t)q * VEC;
     if (VEC == 4) {
       *reinterpret_cast<float4*>(dst) = make_float4(val[u][0], val[u][1], val[u][2], val[u][3]);
@@ -600,10 +698,8 @@ __global__ __launch_bounds__(kVtRowsThreads) void vt_rows_kernel(
     }
     if (j[u] == 0 && (int)v[u] >= nv) {  // padding rows of coords / count / coors4 (batch = -1: coors_pad)
       const int64_t row = (int64_t)frame * max_voxels + v[u];
-      int32_t* co = coords + row * 3;
-      co[0] = 0;
-      co[1] = 0;
-      co[2] = 0;
+      const VtInt3 z3{0, 0, 0};
+      __builtin_memcpy(coords + row * 3, &z3, sizeof(z3));
       num_pts[row] = 0;
       if (coors4) *reinterpret_cast<int4*>(coors4 + row * 4) = make_int4(-1, 0, 0, 0);
     }
