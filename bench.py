@@ -1,22 +1,30 @@
 #!/usr/bin/env python
 """bench.py -- scenes/s of the CenterPoint-Pillars nuScenes hot path on N MI355X (one process per GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE pass of the whole hot path (hard_voxelize -> PFN -> pointpillars_scatter -> SECOND backbone
-+ FPN -> CenterHead -> centerpoint_postprocess, + for N > 1 the RCCL all-gather of the per-frame box
-records) over one batch of `--batch` synthetic nuScenes-shaped sweeps per GPU (300k points x 5, 0.2 m
-pillars, 30k-voxel cap; BASELINE.json configs[2]).  Inputs are resident in HBM before the timed region.
+Workloads (the default is BASELINE.json's headline; the others give the driver a clock on configs 4 / 5):
+  centerpoint_pillars  hard_voxelize -> PFN -> pointpillars_scatter -> SECOND backbone + FPN -> CenterHead ->
+                       centerpoint_postprocess (+ for N > 1 the RCCL all-gather of the per-frame box records) over
+                       one batch of `--batch` synthetic nuScenes-shaped sweeps per GPU (300k points x 5, 0.2 m
+                       pillars, 30k-voxel cap; BASELINE.json configs[2])
+  centerpoint_voxel    the same graph with 0.075 m voxels, VoxelMean and the sparse-conv middle encoder (configs[3])
+  bev_pool_v2          the camera->BEV pooling op at BEVDet4D size (configs[4]'s bev_pool)
+A "step" is ONE pass of the whole path over one batch.  Inputs are resident in HBM before the timed region.
 Rank 0 prints ONE JSON line.  Weak scaling: every rank processes its own batch, so value = N*B*K / time.
 
 The line also carries
   roofline      hard_voxelize's launch sequence (the op the north star sets the >=50 % HBM target on):
                 algorithmic bytes per launch / its HIP-event duration inside the timed region;
-  rooflines     the same for the other ops (scatter / PFN on HBM, the dense graph on fp32 MFMA);
+  rooflines     the same for the other ops: scatter / postprocess on HBM; PFN and the dense graph on the fp32
+                MFMA peak, both as EXECUTED flops (what the matrix cores do) and as direct-form flops;
+  extras        h2d_inclusive scenes/s (the batch copied from pinned host memory inside every step), batch-1
+                latency, the copy / fill ceilings measured on this device;
   cpu_baseline  the oracle pipeline (reference CPU voxelizer compiled from /root/reference when present,
-                otherwise the port; torch-CPU dense graph) on a bounded sample, rank 0 at N=1 only.
+                otherwise the port; torch-CPU dense graph) on a bounded sample, rank 0 at N=1 only: all host
+                threads, plus 1 thread and P processes x 1 thread.
 """
 from __future__ import annotations
 
@@ -38,117 +46,217 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (MI355X_MICROARCH.md)
 N_POINTS, DIMS, P = 300_000, 5, 20
 
 
-def algorithmic_bytes(v):
+def algorithmic_bytes(v, n=N_POINTS, d=DIMS, p=P):
     """SURVEY.md section 8(d)."""
-    vox = 4 * N_POINTS * DIMS + 4 * v * P * DIMS + 12 * v + 4 * v + 4
+    vox = 4 * n * d + 4 * v * p * d + 12 * v + 4 * v + 4
     scatter = 4 * v * 64 + 16 * v + 4 * 64 * 512 * 512
-    pfn = 4 * v * P * DIMS + 4 * v + 16 * v + 4 * v * 64
+    pfn = 4 * v * p * d + 4 * v + 16 * v + 4 * v * 64
     post = 4 * 128 * 128 * 70
     return dict(hard_voxelize=vox, pointpillars_scatter=scatter, pillar_feature_net=pfn,
                 centerpoint_postprocess=post)
 
 
 def dense_flops():
-    """2*Cin*Cout*k*k*Hout*Wout per conv of backbone + FPN + CenterHead at 512x512 input."""
-    fl = 0
-
+    """(direct-form, executed) flops per scene of backbone + FPN + CenterHead at 512x512 input:
+    direct = 2*Cin*Cout*k*k*Hout*Wout per conv; executed = what the kernels issue: the stride-1 3x3 layers run
+    Winograd F(4x4,3x3) = 36 multiplies per 4x4 outputs x 9 taps -> a quarter of the direct flops."""
     def conv(cin, cout, k, h):
         return 2 * cin * cout * k * k * h * h
 
-    fl += conv(64, 64, 3, 256) + 3 * conv(64, 64, 3, 256)
-    fl += conv(64, 128, 3, 128) + 5 * conv(128, 128, 3, 128)
-    fl += conv(128, 256, 3, 64) + 5 * conv(256, 256, 3, 64)
-    fl += conv(64, 128, 2, 128) + conv(128, 128, 1, 128) + 2 * 256 * 128 * 128 * 128  # deconv k2 s2: 1 tap/output
-    fl += conv(384, 64, 3, 128)
-    fl += 36 * conv(64, 64, 3, 128) + conv(64, 70, 3, 128)
-    return fl
+    s1 = 3 * conv(64, 64, 3, 256) + 5 * conv(128, 128, 3, 128) + 5 * conv(256, 256, 3, 64)   # backbone, stride 1
+    s1 += conv(384, 64, 3, 128) + 36 * conv(64, 64, 3, 128)                                   # head, Winograd
+    s2 = conv(64, 64, 3, 256) + conv(64, 128, 3, 128) + conv(128, 256, 3, 64)                 # stride 2, direct
+    other = conv(64, 128, 2, 128) + conv(128, 128, 1, 128) + 2 * 256 * 128 * 128 * 128        # FPN patch GEMMs
+    other += conv(64, 70, 3, 128)                                                             # final grouped (VALU)
+    return s1 + s2 + other, s1 / 4 + s2 + other
 
 
-def make_batch(batch, seed0, device):
+def pfn_flops(v):
+    """(direct-form, executed) flops per scene of the two-layer PFN: direct = per real-or-padded point
+    2*(10*32 + 64*64); executed = one wave per pillar slot issues 38 v_mfma_f32_16x16x4_f32
+    (2048 flops each) whatever the pillar's fill level."""
+    return v * P * 2 * (10 * 32 + 64 * 64), v * 38 * 2048
+
+
+def make_batch(batch, seed0, device=None, pin=False):
     from paddle3d_amd import synth
 
-    uniq = min(batch, 4)
-    frames = [synth.nuscenes_sweep(seed0 + i) for i in range(uniq)]
-    arr = np.stack([frames[i % uniq] for i in range(batch)])
-    return torch.from_numpy(arr).to(device)
+    arr = np.stack([synth.nuscenes_sweep(seed0 + i) for i in range(batch)])  # `batch` DISTINCT frames
+    t = torch.from_numpy(arr)
+    if pin:
+        return t.pin_memory()
+    return t.to(device)
 
 
-def cpu_baseline(model_cpu, max_voxels, frames=8):
-    """Oracle pipeline on the host cores (bounded sample)."""
+def _oracle_scene(model_cpu, max_voxels, seed):
+    """One scene through the oracle pipeline (the CPU statement of the whole path)."""
     from oracle import pyoracle as O
     from paddle3d_amd import synth
 
     kind = "ref" if O.have_ref() else "port"
-    threads = torch.get_num_threads()
     cfg = model_cpu.test_cfg
+    pts = synth.nuscenes_sweep(seed)
+    vox, co, npv, nv = O.hard_voxelize(pts, synth.NUSC_PILLAR, synth.NUSC_RANGE, P, max_voxels, kind)
+    c4 = np.concatenate([np.zeros((nv, 1), np.int32), co[:nv]], 1)
+    params = []
+    for l in model_cpu.voxel_encoder.pfn_layers:
+        params.append(dict(weight=l.linear.weight.t().detach().numpy(), gamma=l.norm.weight.detach().numpy(),
+                           beta=l.norm.bias.detach().numpy(), mean=l.norm.running_mean.numpy(),
+                           var=l.norm.running_var.numpy()))
+    feats = O.pfn_forward_torch(vox[:nv], npv[:nv], c4, params, synth.NUSC_PILLAR, synth.NUSC_RANGE)
+    canvas = O.pillar_scatter(feats, c4, 1, 512, 512)
+    with torch.no_grad():
+        preds, _ = O.center_head_torch(model_cpu.bbox_head, O.dense_forward_torch(model_cpu, torch.from_numpy(canvas)))
+    tasks = [{k: v.numpy() for k, v in p.items()} for p in preds]
+    O.centerpoint_postprocess(tasks, cfg["voxel_size"] + [8.0], cfg["point_cloud_range"] + [0.0] * 4,
+                              cfg["post_center_limit_range"], [0, 1, 3, 5, 6, 8], cfg["down_ratio"],
+                              cfg["score_threshold"], cfg["nms"]["nms_iou_threshold"],
+                              cfg["nms"]["nms_pre_max_size"], cfg["nms"]["nms_post_max_size"], True)
+    return kind
+
+
+def _oracle_worker(args):
+    """Process-pool worker of the P x 1-thread leg: builds its own model, times one scene with one thread."""
+    state_path, max_voxels, seed = args
+    torch.set_num_threads(1)
+    from paddle3d_amd import centerpoint as cpm
+
+    m = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(max_voxels, max_voxels)).eval()
+    m.load_state_dict(torch.load(state_path))
+    t0 = time.perf_counter()
+    _oracle_scene(m, max_voxels, seed)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(model_cpu, max_voxels, frames=6):
+    """Oracle pipeline on the host cores (bounded samples, ~25 s in all)."""
+    import multiprocessing as mp
+    import tempfile
+
+    threads = torch.get_num_threads()
     t0 = time.perf_counter()
     for i in range(frames):
-        pts = synth.nuscenes_sweep(100 + i)
-        vox, co, npv, nv = O.hard_voxelize(pts, synth.NUSC_PILLAR, synth.NUSC_RANGE, P, max_voxels, kind)
-        c4 = np.concatenate([np.zeros((nv, 1), np.int32), co[:nv]], 1)
-        params = []
-        for l in model_cpu.voxel_encoder.pfn_layers:
-            params.append(dict(weight=l.linear.weight.t().detach().numpy(), gamma=l.norm.weight.detach().numpy(),
-                               beta=l.norm.bias.detach().numpy(), mean=l.norm.running_mean.numpy(),
-                               var=l.norm.running_var.numpy()))
-        feats = O.pfn_forward_torch(vox[:nv], npv[:nv], c4, params, synth.NUSC_PILLAR, synth.NUSC_RANGE)
-        canvas = O.pillar_scatter(feats, c4, 1, 512, 512)
-        with torch.no_grad():
-            x = model_cpu.dense_forward(torch.from_numpy(canvas))
-            preds, _ = model_cpu.bbox_head(x)
-        tasks = [{k: v.numpy() for k, v in p.items()} for p in preds]
-        O.centerpoint_postprocess(tasks, cfg["voxel_size"] + [8.0], cfg["point_cloud_range"] + [0.0] * 4,
-                                  cfg["post_center_limit_range"], [0, 1, 3, 5, 6, 8], cfg["down_ratio"],
-                                  cfg["score_threshold"], cfg["nms"]["nms_iou_threshold"],
-                                  cfg["nms"]["nms_pre_max_size"], cfg["nms"]["nms_post_max_size"], True)
-    dt = time.perf_counter() - t0
-    return dict(value=frames / dt, unit="scenes/s", cores=threads, kind="reference" if kind == "ref" else "port",
-                sample=f"{frames} frames of the same workload: hard_voxelize = "
-                       f"{'reference voxelize_op.cc:19-82 compiled from /root/reference' if kind == 'ref' else 'C port'}"
-                       f" (1 thread), PFN/dense graph = torch CPU fp32 ({threads} threads), scatter/postprocess = C port")
+        kind = _oracle_scene(model_cpu, max_voxels, 100 + i)
+    dt_all = time.perf_counter() - t0
+    src = ("reference voxelize_op.cc:19-82 compiled from /root/reference" if kind == "ref" else "C port")
+    out = dict(value=frames / dt_all, unit="scenes/s", cores=threads, kind="reference" if kind == "ref" else "port",
+               sample=f"{frames} frames of the same workload: hard_voxelize = {src} (1 thread), PFN / dense graph = "
+                      f"torch CPU fp32 ({threads} threads), scatter / postprocess = C port")
+    # (i) one thread, one frame at a time -- how the reference's CPU path runs a frame (voxelize_op.cc:36)
+    torch.set_num_threads(1)
+    try:
+        t0 = time.perf_counter()
+        _oracle_scene(model_cpu, max_voxels, 100)
+        dt1 = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(threads)
+    out["one_thread"] = dict(value=1.0 / dt1, unit="scenes/s", cores=1, sample="1 frame, every stage on 1 thread")
+    # (ii) P processes x 1 thread, one frame each
+    procs = max(1, min(os.cpu_count() or 1, 32))
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "state.pt")
+            torch.save(model_cpu.state_dict(), path)
+            ctx = mp.get_context("spawn")
+            t0 = time.perf_counter()
+            with ctx.Pool(procs) as pool:
+                pool.map(_oracle_worker, [(path, max_voxels, 100 + i) for i in range(procs)])
+            dtp = time.perf_counter() - t0
+        out["procs_x_1thread"] = dict(value=procs / dtp, unit="scenes/s", cores=procs,
+                                      sample=f"{procs} processes x 1 thread, one frame each (wall time incl. process "
+                                             "start and model construction)")
+    except Exception as e:  # noqa: BLE001 -- a reported extra, never required
+        out["procs_x_1thread"] = dict(value=None, unit="scenes/s", cores=procs, sample=f"failed: {e}")
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
-    ap.add_argument("--max-voxels", type=int, default=30000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def measured_ceilings(dev, mb=384):
+    """Device copy / fill rates of this box (GB/s), the practical ceilings next to the 8 TB/s spec."""
+    n = mb * (1 << 20) // 4
+    a = torch.empty(n, dtype=torch.float32, device=dev)
+    b = torch.empty(n, dtype=torch.float32, device=dev)
 
+    def t(fn, it=10):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(it):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / it * 1e-3
+
+    fill = n * 4 / t(lambda: a.fill_(1.0)) / 1e9
+    copy = 2 * n * 4 / t(lambda: b.copy_(a)) / 1e9
+    return dict(fill_GBps=fill, copy_GBps_read_plus_write=copy, buffer_MB=mb)
+
+
+def _events(names, steps):
+    return [[torch.cuda.Event(enable_timing=True) for _ in names] for _ in range(steps)]
+
+
+def _timed_loop(step, args, world, dev, names):
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step(None)
+        torch.cuda.synchronize()
+        barrier()
+        events = _events(names, args.steps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            out = step(events[k])
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    per_op_ms = {names[i]: float(np.mean([events[k][i - 1].elapsed_time(events[k][i]) for k in range(args.steps)]))
+                 for i in range(1, len(names))}
+    return dt, per_op_ms, out
+
+
+def _traffic(batch, v):
+    """HBM traffic per launch from the PMC passes (tools/gpu_traffic.sh -> profiles/*_traffic.json), when a profile
+    of this exact configuration is committed; collected offline because rocprofv3 --pmc cannot wrap the timed run."""
+    import glob
+
+    found = {}
+    try:
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+            t = json.load(open(path))
+            if t.get("batch") == batch and t.get("max_voxels") == v:
+                found = t
+    except Exception:  # noqa: BLE001
+        found = {}
+    return found
+
+
+def bench_pillars(args, rank, world, dev):
     from paddle3d_amd import centerpoint as cpm
     from paddle3d_amd import dist as pdist
-    from paddle3d_amd._lib import lib
 
-    rank, world, local = pdist.init_from_env()
-    if world != args.gpus and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP ops have no CPU path")
-    lib()  # fail loudly if libpaddle3d_amd.so is missing
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    torch.backends.cudnn.benchmark = True  # only matters for PD3_DENSE_BACKEND=miopen (MIOpen find mode)
-    torch.manual_seed(0)
     V, B = args.max_voxels, args.batch
-
     model = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(V, V)).to(dev).eval()
-    pts = make_batch(B, 100 + 16 * rank, dev)
+    pts = make_batch(B, 100 + B * rank, dev)
     cfg = model.test_cfg
     max_per_img = cfg["max_per_img"]
+    names = ["start", "hard_voxelize", "pillar_feature_net", "pointpillars_scatter", "dense", "postprocess", "gather"]
 
-    ev_names = ["start", "hard_voxelize", "pillar_feature_net", "pointpillars_scatter", "dense", "postprocess",
-                "gather"]
-
-    def step(events=None):
+    def run(points, events):
         def mark(i):
             if events is not None:
                 events[i].record()
 
         mark(0)
-        voxels, coors, npv, nv = model.voxelizer(pts)
+        voxels, coors, npv, nv = model.voxelizer(points)
         mark(1)
         b, v, p, d = voxels.shape
         feats = model.voxel_encoder(voxels.view(b * v, p, d), npv.view(b * v), coors.view(b * v, 4))
@@ -165,95 +273,244 @@ def main():
         mark(6)
         return all_rec, all_cnt
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
+    dt, per_op_ms, out = _timed_loop(lambda ev: run(pts, ev), args, world, dev, names)
+    if rank != 0:
+        return None
+    alg = algorithmic_bytes(V)
+    traffic = _traffic(B, V)
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        barrier()
-        events = [[torch.cuda.Event(enable_timing=True) for _ in ev_names] for _ in range(args.steps)]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            out = step(events[k])
-        torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    def hbm(name, key):
+        a = alg[key] * B / (per_op_ms[name] * 1e-3) / 1e9
+        tr = traffic.get(key, {}).get("bytes_per_launch")
+        return dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBPS, unit="GB/s", frac=a / HBM_PEAK_GBPS, traffic=tr,
+                    ms_per_launch=per_op_ms[name], units_per_launch=B, algorithmic_bytes_per_unit=alg[key])
 
-    if rank == 0:
-        per_op_ms = {}
-        for i in range(1, len(ev_names)):
-            per_op_ms[ev_names[i]] = float(np.mean([events[k][i - 1].elapsed_time(events[k][i])
-                                                    for k in range(args.steps)]))
-        alg = algorithmic_bytes(V)
+    def mfma(ms, direct, executed, note):
+        ex = executed * B / (ms * 1e-3) / 1e12
+        return dict(bound="mfma", achieved=ex, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=ex / MFMA_F32_PEAK_TFLOPS, traffic=None, ms_per_launch=ms, units_per_launch=B,
+                    executed_flops_per_unit=executed, direct_form_flops_per_unit=direct,
+                    direct_form_tflops=direct * B / (ms * 1e-3) / 1e12, note=note)
 
-        # HBM traffic per launch from the PMC passes (tools/gpu_traffic.sh -> profiles/*_traffic.json), when a
-        # profile of this exact configuration is committed; collected offline because rocprofv3 --pmc cannot
-        # wrap the timed run itself
-        traffic = {}
-        try:
-            import glob
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
-                t = json.load(open(path))
-                if t.get("batch") == B and t.get("max_voxels") == V:
-                    traffic = t
-        except Exception:  # noqa: BLE001
-            traffic = {}
+    d_direct, d_exec = dense_flops()
+    p_direct, p_exec = pfn_flops(V)
+    rooflines = dict(
+        hard_voxelize=hbm("hard_voxelize", "hard_voxelize"),
+        pointpillars_scatter=hbm("pointpillars_scatter", "pointpillars_scatter"),
+        centerpoint_postprocess=dict(hbm("postprocess", "centerpoint_postprocess"),
+                                     note="latency bound (SURVEY 8(d)): the HBM fraction is for completeness"),
+        pillar_feature_net=mfma(per_op_ms["pillar_feature_net"], p_direct, p_exec,
+                                "achieved / frac = executed MFMA flops (38 v_mfma_f32_16x16x4_f32 per pillar slot, "
+                                "~11 of 16 rows live); direct_form_tflops = the layer's own multiply-adds / time"),
+        dense_backbone_fpn_head=mfma(per_op_ms["dense"], d_direct, d_exec,
+                                     "achieved / frac = executed flops: the 52 stride-1 3x3 layers run Winograd "
+                                     "F(4x4,3x3) (a quarter of the direct multiplies), the 3 stride-2 layers and the "
+                                     "FPN levels run direct GEMMs, all fp32; direct_form_tflops = 127.2 GFLOP/scene "
+                                     "/ time (may exceed the peak: fewer multiplies are issued than counted)"))
+    line = {
+        "metric": "scenes/sec CenterPoint-Pillars nuScenes 300k-pt sweeps",
+        "value": world * B * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "CenterPoint-Pillars nuScenes 10-sweep: 300000 pts x 5 per scene, 0.2 m pillars "
+                               f"(512x512), P=20, max_voxels={V}, batch {B} distinct scenes/GPU/step, random-init "
+                               "weights, full graph voxelize->PFN->scatter->SECOND+FPN->CenterHead->postprocess"
+                               + ("->RCCL all-gather" if world > 1 else ""),
+                   "frames_per_gpu_per_step": B, "max_voxels": V, "parallelism": f"dp{world} (frames)"},
+        "roofline": dict(rooflines["hard_voxelize"],
+                         kernel="hard_voxelize launch sequence (vt_route + vt_group + vt_assign_emit + vt_rows)"),
+        "rooflines": rooflines,
+        # `roofline` is the kernel the north star puts the HBM target on; by time the step is dominated by
+        # the dense graph (rooflines["dense_backbone_fpn_head"], MFMA bound)
+        "dominant_by_time": "dense_backbone_fpn_head",
+        "per_op_ms": per_op_ms,
+        "detections_first_frame": int(out[1][0].item()),
+    }
+    if world == 1:
+        extras = {}
+        with torch.no_grad():
+            # (a) the same steps with the batch copied from pinned host memory inside every step (not overlapped)
+            host = make_batch(B, 100, pin=True)
+            stage = torch.empty_like(pts)
 
-        def hbm(name, key):
-            a = alg[key] * B / (per_op_ms[name] * 1e-3) / 1e9
-            tr = traffic.get(key, {}).get("bytes_per_launch")
-            return dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBPS, unit="GB/s", frac=a / HBM_PEAK_GBPS,
-                        traffic=tr, ms_per_launch=per_op_ms[name], units_per_launch=B,
-                        algorithmic_bytes_per_unit=alg[key])
+            def h2d_step():
+                stage.copy_(host, non_blocking=True)
+                return run(stage, None)
 
-        tf = dense_flops() * B / (per_op_ms["dense"] * 1e-3) / 1e12
-        rooflines = dict(
-            hard_voxelize=hbm("hard_voxelize", "hard_voxelize"),
-            pillar_feature_net=hbm("pillar_feature_net", "pillar_feature_net"),
-            pointpillars_scatter=hbm("pointpillars_scatter", "pointpillars_scatter"),
-            centerpoint_postprocess=hbm("postprocess", "centerpoint_postprocess"),
-            dense_backbone_fpn_head=dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                                         frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=None,
-                                         ms_per_launch=per_op_ms["dense"], units_per_launch=B,
-                                         flops_per_unit=dense_flops(),
-                                         note="direct-form flops of the graph / time; the stride-1 3x3 layers run "
-                                              "Winograd F(2x2,3x3) (2.25x fewer MFMA flops), all fp32"))
-        line = {
-            "metric": "scenes/sec CenterPoint-Pillars nuScenes 300k-pt sweeps",
-            "value": world * B * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "CenterPoint-Pillars nuScenes 10-sweep: 300000 pts x 5 per scene, 0.2 m pillars "
-                                   f"(512x512), P=20, max_voxels={V}, batch {B} scenes/GPU/step, random-init weights, "
-                                   "full graph voxelize->PFN->scatter->SECOND+FPN->CenterHead->postprocess"
-                                   + ("->RCCL all-gather" if world > 1 else ""),
-                       "frames_per_gpu_per_step": B, "max_voxels": V, "parallelism": f"dp{world} (frames)"},
-            "roofline": dict(rooflines["hard_voxelize"], kernel=(
-                "hard_voxelize launch sequence (vt_route + vt_group + vt_count + vt_assign + vt_write)"
-                if os.environ.get("PD3_VOXELIZE_PATH", "tiled") != "sort" else
-                "hard_voxelize launch sequence (cell_key + radix sort + seg_head + scan + gather)")),
-            "rooflines": rooflines,
-            # `roofline` is the kernel the north star puts the HBM target on; by time the step is dominated by
-            # the dense graph (rooflines["dense_backbone_fpn_head"], MFMA bound)
-            "dominant_by_time": "dense_backbone_fpn_head",
-            "per_op_ms": per_op_ms,
-            "detections_first_frame": int(out[1][0].item()),
-        }
-        if world == 1 and not args.no_cpu_baseline:
+            for _ in range(2):
+                h2d_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                h2d_step()
+            torch.cuda.synchronize()
+            dth = time.perf_counter() - t0
+            extras["h2d_inclusive"] = dict(value=B * args.steps / dth, unit="scenes/s",
+                                           note=f"{host.numel() * 4 / B / 1e6:.1f} MB per scene over PCIe from pinned "
+                                                "memory inside every step, not overlapped with compute")
+            # (b) per-frame latency: batch 1, one frame in flight
+            one = pts[:1].contiguous()
+            for _ in range(3):
+                run(one, None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                run(one, None)
+            torch.cuda.synchronize()
+            extras["latency_batch1_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+        extras["measured_ceilings"] = measured_ceilings(dev)
+        line["extras"] = extras
+        if not args.no_cpu_baseline:
             try:
                 model_cpu = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(V, V)).eval()
-                model_cpu.load_state_dict(model.state_dict())
+                model_cpu.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
                 line["cpu_baseline"] = cpu_baseline(model_cpu, V)
             except Exception as e:  # the baseline is reported, never required
                 line["cpu_baseline"] = dict(value=None, unit="scenes/s", cores=0, kind="port", sample=f"failed: {e}")
+    return line
+
+
+def bench_voxel(args, rank, world, dev):
+    """CenterPoint-Voxel (config 4): 0.075 m voxels, sort-path hard_voxelize, VoxelMean, SparseResNet3D, dense
+    graph at 180 x 180, postprocess."""
+    from paddle3d_amd import centerpoint as cpm
+    from paddle3d_amd import dist as pdist
+
+    B = args.batch
+    V = 160000  # the reference's test-time cap (max_num_voxels: [120000, 160000])
+    model = cpm.centerpoint_voxels_nuscenes(max_num_voxels=(120000, V)).to(dev).eval()
+    pts = make_batch(B, 100 + B * rank, dev)
+    cfg = model.test_cfg
+    names = ["start", "hard_voxelize", "voxel_mean_sparse_encoder", "dense", "postprocess", "gather"]
+    stats = {}
+
+    def run(events):
+        def mark(i):
+            if events is not None:
+                events[i].record()
+
+        mark(0)
+        voxels, coors, npv, nv = model.voxelizer(pts)
+        mark(1)
+        b, v, p, d = voxels.shape
+        voxels, coors, npv = voxels.view(b * v, p, d), coors.view(b * v, 4), npv.view(b * v)
+        keep = coors[:, 0] >= 0
+        voxels, coors, npv = voxels[keep], coors[keep].contiguous(), npv[keep]
+        feats = model.voxel_encoder(voxels, npv, coors)
+        x = model.middle_encoder(feats, coors, b)
+        stats["active_voxels"] = int(coors.shape[0])
+        mark(2)
+        x = model.dense_forward(x)
+        preds, _ = model.bbox_head(x)
+        mark(3)
+        bx, sc, lb, cnt = model.bbox_head.predict_by_custom_op(preds, cfg, device_only=True)
+        mark(4)
+        rec = pdist.pack_records(bx, sc, lb, cnt, cfg["max_per_img"])
+        all_rec, all_cnt = pdist.gather_detections(rec, cnt)
+        mark(5)
+        return all_rec, all_cnt
+
+    dt, per_op_ms, out = _timed_loop(run, args, world, dev, names)
+    if rank != 0:
+        return None
+    alg = 4 * N_POINTS * DIMS + 4 * V * 10 * DIMS + 16 * V + 4
+    a = alg * B / (per_op_ms["hard_voxelize"] * 1e-3) / 1e9
+    sp = getattr(model.middle_encoder, "last_flops", None)
+    line = {
+        "metric": "scenes/sec CenterPoint-Voxel nuScenes 300k-pt sweeps",
+        "value": world * B * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "CenterPoint-Voxel nuScenes 10-sweep: 300000 pts x 5 per scene, 0.075 m voxels "
+                               f"(1440x1440x40), P=10, max_voxels={V}, batch {B} distinct scenes/GPU/step, random-init "
+                               "weights, voxelize->VoxelMean->SparseResNet3D->SECOND+FPN->CenterHead->postprocess",
+                   "frames_per_gpu_per_step": B, "max_voxels": V, "parallelism": f"dp{world} (frames)"},
+        "roofline": dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBPS, unit="GB/s", frac=a / HBM_PEAK_GBPS, traffic=None,
+                         ms_per_launch=per_op_ms["hard_voxelize"], units_per_launch=B, algorithmic_bytes_per_unit=alg,
+                         kernel="hard_voxelize launch sequence, generic path (cell_key + radix sort + seg_head + scan "
+                                "+ gather): the 82.9 M-cell grid is beyond the tiled path"),
+        "per_op_ms": per_op_ms, "active_voxels_per_batch": stats.get("active_voxels"),
+        "detections_first_frame": int(out[1][0].item()),
+    }
+    if sp:
+        ms = per_op_ms["voxel_mean_sparse_encoder"]
+        line["rooflines"] = {"sparse_encoder": dict(
+            bound="mfma", achieved=sp["pairs"] / (ms * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+            frac=sp["pairs"] / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, traffic=None, ms_per_launch=ms,
+            units_per_launch=B, flops_existing_pairs=sp["pairs"], flops_dense_equivalent=sp["dense"],
+            note="flops of the (output row, kernel offset) pairs that exist, 2*Cin*Cout each, over the whole encoder "
+                 "stage time (index building included); dense-equivalent counts all 27 offsets")}
+    return line
+
+
+def bench_bev_pool(args, rank, world, dev):
+    """bev_pool_v2 forward at BEVDet4D size: 6 cameras x 118 depth bins x 16 x 44, C = 80, 128 x 128 BEV."""
+    from paddle3d_amd import synth
+    from paddle3d_amd.ops import bev_pool_v2 as bp
+
+    inp = synth.bev_pool_inputs(0)
+    t = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
+    shape = inp["bev_feat_shape"]
+    names = ["start", "bev_pool_v2"]
+
+    def run(events):
+        if events is not None:
+            events[0].record()
+        out = bp.bev_pool_v2(t["depth"], t["feat"], t["ranks_depth"], t["ranks_feat"], t["ranks_bev"],
+                             t["interval_lengths"], t["interval_starts"], shape)
+        if events is not None:
+            events[1].record()
+        return out
+
+    dt, per_op_ms, out = _timed_loop(run, args, world, dev, names)
+    if rank != 0:
+        return None
+    n_pts, n_int, c = int(t["ranks_bev"].numel()), int(t["interval_lengths"].numel()), int(t["feat"].shape[-1])
+    alg = 4 * (n_pts * (1 + c) + 3 * n_pts + 2 * n_int) + 4 * int(out.numel())
+    a = alg / (per_op_ms["bev_pool_v2"] * 1e-3) / 1e9
+    return {
+        "metric": "bev_pool_v2 forward frames/sec (BEVDet4D shapes)", "value": world * args.steps / dt, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"bev_pool_v2 forward: {n_pts} frustum points in {n_int} intervals, C={c}, BEV "
+                               f"{tuple(shape)}", "parallelism": f"dp{world} (frames)"},
+        "roofline": dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBPS, unit="GB/s", frac=a / HBM_PEAK_GBPS, traffic=None,
+                         ms_per_launch=per_op_ms["bev_pool_v2"], units_per_launch=1, algorithmic_bytes_per_unit=alg,
+                         kernel="bev_pool_v2_kernel (gathered operands counted once per use, SURVEY 8(d))"),
+        "per_op_ms": per_op_ms,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 16; 2 for centerpoint_voxel)")
+    ap.add_argument("--max-voxels", type=int, default=30000)
+    ap.add_argument("--workload", default="centerpoint_pillars",
+                    choices=["centerpoint_pillars", "centerpoint_voxel", "bev_pool_v2"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 2 if args.workload == "centerpoint_voxel" else 16
+
+    from paddle3d_amd import dist as pdist
+    from paddle3d_amd._lib import lib
+
+    rank, world, local = pdist.init_from_env()
+    if world != args.gpus and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP ops have no CPU path")
+    lib()  # fail loudly if libpaddle3d_amd.so is missing
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(0)
+
+    fn = dict(centerpoint_pillars=bench_pillars, centerpoint_voxel=bench_voxel, bev_pool_v2=bench_bev_pool)[args.workload]
+    line = fn(args, rank, world, dev)
+    if rank == 0:
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

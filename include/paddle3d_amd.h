@@ -189,7 +189,10 @@ int pd3_centerpoint_postprocess_strided(const float *const *hm, const float *con
                                 int nms_pre_max_size, int nms_post_max_size, int with_velocity,
                                 float *out_bboxes, float *out_scores, int64_t *out_labels,
                                 int32_t *out_count, void *workspace, size_t workspace_bytes,
-                                void *stream);
+                                void *stream, int selection);
+/* selection: how the nms_pre_max_size best cells of a task are found -- 0 automatic (an exact in-LDS top-K
+ * selection where the map allows, else a full sort), 1 always the full stable radix sort of all cells (what the
+ * reference does; the tests run both and require identical output). */
 
 /* ---------------------------------------------------------------------------------------------
  * bev_pool_v2 / bev_pool_v2_bkwd -- replace PD_BUILD_OP(bev_pool_v2) (bev_pool_v2/bev_pool.cc:111-118,
@@ -263,15 +266,21 @@ int pd3_merge_sweeps(const float *points, const int64_t *sweep_offsets, int num_
  * matrix cores: the convolutions of SecondBackbone (paddle3d/models/backbones/second_backbone.py:72-120)
  * and CenterHead / SeparateHead (detection/centerpoint/center_head.py:43-220) with BatchNorm folded into
  * weight and bias (cuDNN convolutions in the reference).
- *   x [batch, cin, h, w] fp32 NCHW (16-byte aligned);  out [batch, cout, h/stride, w/stride];  bias [cout] or NULL
+ *   x [batch, cin, h, w] fp32 NCHW (16-byte aligned);  out [batch, cout, h/stride, out_w];  bias [cout] or NULL
  *   w_packed: the [cout, cin, 3, 3] weight re-ordered to [cout/64][cin/8][4 channel pairs][9 taps][2][64]
  *             (row = (pair*9 + ky*3 + kx)*2 + channel-of-pair; see paddle3d_amd/ops/conv.py)
- *   requires cin % 8 == 0, cout % 64 == 0, h and w multiples of stride, and for the OUTPUT size (ho, wo):
- *   stride 1: wo % 128 == 0 | wo % 64 == 0 & ho % 2 == 0 | wo % 32 == 0 & ho % 4 == 0
- *   stride 2: wo % 64 == 0 & ho % 2 == 0 | wo % 32 == 0 & ho % 4 == 0;   otherwise PD3_EUNSUPPORTED
+ *   w / w_valid / out_w: maps whose width is not a multiple of 4 (CenterPoint-Voxel's 90 x 90 stage) live in rows
+ *             padded with zeros to a multiple of 4: w is the row pitch of x, w_valid <= w its real width (columns
+ *             >= w_valid hold zeros), out_w >= w_valid / stride the row pitch of out, whose columns >=
+ *             w_valid / stride are written as zeros -- the next layer reads them as its own zero padding.
+ *             Ordinary maps: w_valid = w, out_w = w / stride.
+ *   requires cin % 8 == 0, cout % 64 == 0, h and w_valid multiples of stride, w % 4 == 0, out_w % 4 == 0 (rows
+ *   are staged as aligned float4); otherwise PD3_EUNSUPPORTED.  Outputs that are not a multiple of the 4 x 32
+ *   pixel tile get partial border tiles (masked stores).
  */
 int pd3_conv3x3_bias_relu(const float *x, const float *w_packed, const float *bias, int batch, int cin,
-                          int cout, int h, int w, int stride, int relu, float *out, void *stream);
+                          int cout, int h, int w, int w_valid, int stride, int relu, float *out, int out_w,
+                          void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * conv3x3_winograd43_bias_relu -- the same stride-1 convolution by Winograd F(4x4, 3x3) (4x fewer multiplies;
@@ -282,10 +291,11 @@ int pd3_conv3x3_bias_relu(const float *x, const float *w_packed, const float *bi
  *   u_packed: U = G g G^T (6x6) of the [cout, cin, 3, 3] weight, packed [cout/T][cin/4][T/16][4][16][36] for
  *             T = channels_per_tile (16-channel block, input channel, channel, component xi*6+nu;
  *             paddle3d_amd/ops/conv.py:pack_winograd43_weight)
+ *   w / w_valid: row pitch of x and out, and the real width (see conv3x3_bias_relu); w_valid = w for ordinary maps
  *   requires cin % 4 == 0, cout % T == 0, w % 4 == 0 (any h; partial 8 x 64 tiles at the border are masked)
  */
 int pd3_conv3x3_winograd43_bias_relu(const float *x, const float *u_packed, const float *bias, int batch,
-                                     int cin, int cout, int h, int w, int relu, float *out,
+                                     int cin, int cout, int h, int w, int w_valid, int relu, float *out,
                                      int channels_per_tile, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -318,14 +328,15 @@ int pd3_conv3x3_winograd_bias_relu(const float *x, const float *u_packed, const 
  * GEMM with bias + ReLU, written at a channel offset of a wider output tensor (the concat of the FPN levels).
  *   mode 0: Conv2D kernel 2 stride 2      x [batch, cin, h, w] -> out[:, off:off+cout] of [batch, ctot, h/2, w/2]
  *           w_packed = A[co][ci*4 + py*2 + px] from the [cout, cin, 2, 2] weight; needs h % 4 == 0, w % 256 == 0
- *   mode 1: 1x1 convolution               -> [batch, ctot, h, w];  A[co][ci]; needs (h*w) % 256 == 0
- *   mode 2: Conv2DTranspose kernel 2 stride 2 -> [batch, ctot, 2h, 2w];  A[co*4 + dy*2 + dx][ci] from the
- *           [cin, cout, 2, 2] weight; needs (h*w) % 256 == 0
+ *   mode 1: 1x1 convolution               -> [batch, ctot, h, w];  A[co][ci]; needs (h*w) % 4 == 0
+ *   mode 2: Conv2DTranspose kernel 2 stride 2 -> [batch, ctot, 2h, 2 w_valid];  A[co*4 + dy*2 + dx][ci] from the
+ *           [cin, cout, 2, 2] weight; needs (h*w) % 4 == 0; w is the row pitch of x, w_valid <= w its real width
+ *           (see conv3x3_bias_relu); modes 0 and 1 need w_valid == w
  *   A is packed [M/64][K/16][16][64] (paddle3d_amd/ops/conv.py:pack_patch_weight); K % 16 == 0, M % 64 == 0
  */
 int pd3_patch_conv_bias_relu(const float *x, const float *w_packed, const float *bias, int mode, int batch,
-                             int cin, int cout, int h, int w, int relu, float *out, int out_channels_total,
-                             int out_channel_offset, void *stream);
+                             int cin, int cout, int h, int w, int w_valid, int relu, float *out,
+                             int out_channels_total, int out_channel_offset, void *stream);
 
 #ifdef __cplusplus
 }

@@ -337,3 +337,50 @@ def bev_pool_v2_bkwd(out_grad, depth, feat, ranks_depth, ranks_feat, ranks_bev, 
     fn(C.c_int(c), C.c_int(len(il)), _p(g), _p(d), _p(f), _p(rd), _p(rf), _p(rb), _p(is_), _p(il),
        _p(dg), _p(fg))
     return dg, fg
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Dense BEV graph: the reference's layers stated with torch's own convolutions (MIOpen on a GPU tensor, MKL-DNN
+# on a CPU tensor).  The product (paddle3d_amd/centerpoint.py) runs these layers on its hand-written kernels
+# only; the tests and bench.py's cpu_baseline compare / time against the functions below.
+# ---------------------------------------------------------------------------------------------------------
+def second_backbone_torch(backbone, x):
+    """second_backbone.py:114-120: the blocks are Sequential(conv, bn, relu, ...) -- torch runs them as written."""
+    outs = []
+    for blk in backbone.blocks:
+        x = blk(x)
+        outs.append(x)
+    return tuple(outs)
+
+
+def second_fpn_torch(neck, xs):
+    """second_fpn.py:140-157: per level deblock, then channel concat."""
+    import torch
+
+    ups = [d(x) for d, x in zip(neck.deblocks, xs)]
+    return torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+
+
+def dense_forward_torch(model, x):
+    """CenterPoint.extract_feat's dense half (centerpoint.py:133-137): backbone -> neck."""
+    return second_fpn_torch(model.neck, second_backbone_torch(model.backbone, x))
+
+
+def center_head_torch(head, x):
+    """CenterHead.forward (center_head.py:212-220): shared ConvModule, then every SeparateHead branch
+    (ConvModule -> conv); returns (list of per-task dicts, shared map) like the fused product path."""
+    def conv_module(m, t):
+        return m.activate(m.bn(m.conv(t)))
+
+    x = conv_module(head.shared_conv, x)
+    rets = []
+    for task in head.tasks:
+        d = {}
+        for name in task.heads:
+            seq = getattr(task, name)
+            t = x
+            for layer in seq:
+                t = conv_module(layer, t) if hasattr(layer, "bn") else layer(t)
+            d[name] = t
+        rets.append(d)
+    return rets, x

@@ -55,7 +55,7 @@ _SIGNATURES = {
                                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+                                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
     "pd3_bev_pool_v2": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int64, C.c_void_p,
                                                      C.c_void_p]),
     "pd3_bev_pool_v2_bkwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64,
@@ -75,13 +75,15 @@ _SIGNATURES = {
                                    C.c_void_p]),
     "pd3_dynamic_voxelize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pd3_conv3x3_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pd3_conv3x3_winograd_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pd3_conv3x3_winograd43_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                                   C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+                                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                   C.c_void_p]),
     "pd3_patch_conv_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                           C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_void_p]),
     "pd3_grouped_conv3x3_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }

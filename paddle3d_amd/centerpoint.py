@@ -14,25 +14,24 @@ What differs from the reference, by design:
     loops over samples in Python and syncs on num_voxels per sample, voxelize.py:43);
   * padded rows beyond num_voxels are never sliced off on the host: fixed-shape [B, V, ...] tensors flow
     through PFN and scatter, which ignore rows >= num_voxels through the batch column -1;
-  * the dense 2-D convolutions run on the library's own fp32-MFMA kernels in eval mode (Winograd F(2x2,3x3)
-    for the stride-1 3x3 layers, an implicit-GEMM kernel for the stride-2 ones, a patch-GEMM kernel for the
-    FPN levels writing into the concatenated map, a grouped kernel for the final head convolutions), with
-    BatchNorm folded; the 36 first-stage head convolutions that read the same shared feature map are issued
-    as ONE convolution.  PD3_DENSE_BACKEND=miopen routes them through PyTorch-ROCm instead (also the fallback
-    for shapes the kernels do not take, and the training-mode path).
-torch is plumbing here (device memory, streams); the work is in libpaddle3d_amd.so.
+  * the dense 2-D convolutions run on the library's own fp32-MFMA kernels (Winograd F(4x4,3x3) for the
+    stride-1 3x3 layers, an implicit-GEMM kernel for the stride-2 ones, a patch-GEMM kernel for the FPN levels
+    writing into the concatenated map, a grouped kernel for the final head convolutions), with BatchNorm
+    folded; the 36 first-stage head convolutions that read the same shared feature map are issued as ONE
+    convolution.  There is no other backend: a shape no kernel takes raises Paddle3DAmdError (status -3), and
+    the layers refuse to run in training mode (the torch statement of the same layers that the tests compare
+    against lives in oracle/pyoracle.py).
+torch is plumbing here (device memory, streams, parameter containers); the work is in libpaddle3d_amd.so.
 """
 from __future__ import annotations
 
 import math
-import os
-from typing import Sequence
 
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
+from ._lib import Paddle3DAmdError
 from .ops import centerpoint_postprocess as _cp
 from .ops import conv as _conv
 from .ops import pointpillars_scatter as _ps
@@ -88,7 +87,8 @@ class PFNLayer(nn.Module):
 
 
 class PillarFeatureNet(nn.Module):
-    """pillar_encoder.py:108-210 (legacy=False, with_distance=False)."""
+    """pillar_encoder.py:108-210 (legacy=False, with_distance=False).  The folded parameters are rebuilt on
+    every call in training mode and whenever the module is moved / reloaded (see _InferenceCache below)."""
 
     def __init__(self, in_channels=4, feat_channels=(64,), with_distance=False, max_num_points_in_voxel=20,
                  voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1), legacy=False):
@@ -109,6 +109,18 @@ class PillarFeatureNet(nn.Module):
         self.y_offset = self.vy / 2 + point_cloud_range[1]
         self.max_num_points_in_voxel = max_num_points_in_voxel
         self._folded = None
+
+    def train(self, mode: bool = True):
+        self._folded = None
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._folded = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._folded = None
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def _fold(self):
         out = []
@@ -181,13 +193,99 @@ class PointPillarsScatter(nn.Module):
         return _ps.pointpillars_scatter(voxel_features, coords, batch_size, self.ny, self.nx)
 
 
+class _InferenceCache:
+    """Mixin of the parameter-holding layers: weights derived for inference (BatchNorm folded, packed in the
+    kernels' layouts) live in ``self._cache`` and are dropped whenever the parameters can have changed
+    (``train()`` / ``eval()``, ``load_state_dict``, ``.to()`` / ``.cuda()``)."""
+
+    _cache = None
+
+    def _drop_cache(self):
+        self.__dict__["_cache"] = None
+
+    def train(self, mode: bool = True):
+        self._drop_cache()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._drop_cache()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._drop_cache()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _require_eval(self):
+        if self.training:
+            raise RuntimeError(f"{type(self).__name__}: paddle3d_amd implements the inference path only "
+                               "(BatchNorm folded into the HIP kernels); call .eval() first")
+
+
 def _conv_bn_relu(cin, cout, k, stride=1, padding=0, transpose=False, eps=1e-3, momentum=0.01, bias=False):
     conv = (nn.ConvTranspose2d if transpose else nn.Conv2d)(cin, cout, k, stride=stride, padding=padding, bias=bias)
     return [conv, nn.BatchNorm2d(cout, eps=eps, momentum=momentum), nn.ReLU()]
 
 
-class SecondBackbone(nn.Module):
-    """second_backbone.py:72-120 (parameter names blocks.<i>.<j>.* as in the reference)."""
+def _fold_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    if isinstance(conv, nn.ConvTranspose2d):
+        w = conv.weight * scale.reshape(1, -1, 1, 1)
+    else:
+        w = conv.weight * scale.reshape(-1, 1, 1, 1)
+    b = (conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean))
+    return w.detach().contiguous(), ((b - bn.running_mean) * scale + bn.bias).detach().contiguous()
+
+
+class _Conv3x3:
+    """One folded 3x3 / pad 1 convolution + bias + ReLU on the library's kernels: stride 1 by Winograd F(4x4,3x3),
+    otherwise (and for stride 2) the implicit-GEMM kernel.  A shape no kernel takes raises (PD3_EUNSUPPORTED);
+    nothing falls back to another backend.  Packed weights are kept next to the folded ones."""
+
+    def __init__(self, w, b, stride):
+        self.w, self.b, self.stride = w, b, int(stride)
+        self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
+        self.packed = {}
+
+    def __call__(self, x, w_valid=None):
+        """x [n, cin, h, pitch]; w_valid = its real width (default pitch; a width that is not a multiple of 4 lives in
+        zero-padded rows, ops/conv.py:pitch4).  Returns (y, real width of y)."""
+        h, wv = int(x.shape[2]), int(x.shape[3] if w_valid is None else w_valid)
+        if self.stride == 1 and _conv.winograd43_supported(self.cin, self.cout, h, wv):
+            if "w43" not in self.packed:
+                self.packed["w43"] = _conv.pack_winograd43_weight(self.w)
+            return _conv.conv3x3_winograd43_bias_relu(x, self.packed["w43"], self.b, self.cout, relu=True,
+                                                      w_valid=wv), wv
+        if _conv.supported(self.cin, self.cout, h, wv, self.stride):
+            if "direct" not in self.packed:
+                self.packed["direct"] = _conv.pack_conv3x3_weight(self.w)
+            return _conv.conv3x3_bias_relu(x, self.packed["direct"], self.b, self.cout, relu=True, stride=self.stride,
+                                           w_valid=wv), wv // self.stride
+        raise Paddle3DAmdError(f"conv3x3: unsupported configuration (cin {self.cin}, cout {self.cout}, stride "
+                               f"{self.stride}, input {h}x{wv}) (status -3)")
+
+
+def _valid_w(t) -> int:
+    """Real width of a feature map (its rows may be zero-padded to a multiple of 4)."""
+    return int(getattr(t, "_pd3_valid_w", t.shape[3]))
+
+
+def _tag_valid_w(t, wv):
+    if wv != t.shape[3]:
+        t._pd3_valid_w = int(wv)
+    return t
+
+
+def _fold_conv3x3(conv, bn):
+    if (isinstance(conv, nn.ConvTranspose2d) or tuple(conv.kernel_size) != (3, 3) or tuple(conv.padding) != (1, 1)
+            or tuple(conv.stride) not in ((1, 1), (2, 2))):
+        raise Paddle3DAmdError(f"unsupported configuration: {conv} is not a 3x3 / pad 1 / stride 1|2 convolution")
+    w, b = _fold_conv_bn(conv, bn)
+    return _Conv3x3(w, b, conv.stride[0])
+
+
+class SecondBackbone(_InferenceCache, nn.Module):
+    """second_backbone.py:72-120 (parameter names blocks.<i>.<j>.* as in the reference).  The modules hold the
+    parameters; forward runs every convolution (BatchNorm folded, ReLU fused) on the library's kernels."""
 
     def __init__(self, in_channels=128, out_channels=(128, 128, 256), layer_nums=(3, 5, 5),
                  downsample_strides=(2, 2, 2)):
@@ -201,16 +299,34 @@ class SecondBackbone(nn.Module):
             blocks.append(nn.Sequential(*block))
         self.blocks = nn.ModuleList(blocks)
 
+    def _plan(self):
+        if self._cache is None:
+            plan = []
+            for blk in self.blocks:
+                mods = list(blk)
+                plan.append([_fold_conv3x3(mods[i], mods[i + 1]) for i in range(0, len(mods), 3)])
+            self.__dict__["_cache"] = plan
+        return self._cache
+
     def forward(self, x):
-        outs = []
-        for blk in self.blocks:
-            x = blk(x)
-            outs.append(x)
+        """-> the block outputs.  A stage whose width is not a multiple of 4 (CenterPoint-Voxel: 90) comes back in
+        zero-padded rows, tagged with its real width (_valid_w); SecondFPN reads the tag."""
+        self._require_eval()
+        if x.shape[3] % 4:
+            raise Paddle3DAmdError(f"SecondBackbone: unsupported configuration (input width {x.shape[3]} is not a "
+                                   "multiple of 4) (status -3)")
+        outs, wv = [], int(x.shape[3])
+        for layers in self._plan():
+            for conv in layers:
+                x, wv = conv(x, wv)
+            outs.append(_tag_valid_w(x, wv))
         return tuple(outs)
 
 
-class SecondFPN(nn.Module):
-    """second_fpn.py:99-157 (use_spatial_attn_before_concat unsupported: unused on the path)."""
+class SecondFPN(_InferenceCache, nn.Module):
+    """second_fpn.py:99-157 (use_spatial_attn_before_concat unsupported: unused on the path).  Every level is a
+    kernel = stride convolution / transposed convolution: one patch GEMM each, written straight into its channel
+    slice of the concatenated map (no concat pass)."""
 
     def __init__(self, in_channels=(128, 128, 256), out_channels=(256, 256, 256), upsample_strides=(1, 2, 4),
                  use_conv_for_no_stride=False):
@@ -226,13 +342,47 @@ class SecondFPN(nn.Module):
             deblocks.append(nn.Sequential(*layer))
         self.deblocks = nn.ModuleList(deblocks)
 
+    def _plan(self):
+        if self._cache is None:
+            plan, off = [], 0
+            for blk in self.deblocks:
+                conv, bn = blk[0], blk[1]
+                tr = isinstance(conv, nn.ConvTranspose2d)
+                w, b = _fold_conv_bn(conv, bn)
+                mode = _conv.patch_mode(w, conv.stride[0], tr)
+                if mode is None or tuple(conv.padding) != (0, 0) or conv.stride[0] != conv.stride[1]:
+                    raise Paddle3DAmdError(f"unsupported configuration: FPN level {conv} is not a kernel = stride "
+                                           "(1 or 2) convolution (status -3)")
+                cout = int(w.shape[1] if tr else w.shape[0])
+                cin = int(w.shape[0] if tr else w.shape[1])
+                plan.append(dict(mode=mode, w=_conv.pack_patch_weight(w, mode, tr), b=b, cin=cin, cout=cout, off=off,
+                                 scale={0: 0.5, 1: 1, 2: 2}[mode]))
+                off += cout
+            self.__dict__["_cache"] = (plan, off)
+        return self._cache
+
     def forward(self, xs):
-        ups = [d(x) for d, x in zip(self.deblocks, xs)]
-        return torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+        self._require_eval()
+        plan, ctot = self._plan()
+        sizes = {(int(x.shape[2] * p["scale"]), int(_valid_w(x) * p["scale"])) for p, x in zip(plan, xs)}
+        if len(sizes) != 1 or len(plan) != len(xs):
+            raise Paddle3DAmdError(f"SecondFPN: the levels do not meet at one resolution ({sorted(sizes)})")
+        hw = sizes.pop()
+        out = torch.empty((xs[0].shape[0], ctot, hw[0], hw[1]), dtype=torch.float32, device=xs[0].device)
+        for p, x in zip(plan, xs):
+            if not _conv.patch_supported(p["mode"], p["cin"], p["cout"], int(x.shape[2]), int(x.shape[3])):
+                raise Paddle3DAmdError(f"patch_conv: unsupported configuration (mode {p['mode']}, cin {p['cin']}, "
+                                       f"cout {p['cout']}, input {tuple(x.shape[2:])}) (status -3)")
+            if p["mode"] != 2 and _valid_w(x) != x.shape[3]:
+                raise Paddle3DAmdError(f"patch_conv: unsupported configuration (mode {p['mode']} on a map of width "
+                                       f"{_valid_w(x)}, not a multiple of 4) (status -3)")
+            _conv.patch_conv_bias_relu(x, p["w"], p["b"], p["mode"], p["cout"], out, p["off"], relu=True,
+                                       w_valid=_valid_w(x))
+        return out
 
 
 class ConvModule(nn.Module):
-    """center_head.py:43-78: conv(bias) -> BN(eps 1e-5) -> ReLU."""
+    """center_head.py:43-78: conv(bias) -> BN(eps 1e-5) -> ReLU.  Parameters only (CenterHead runs them fused)."""
 
     def __init__(self, cin, cout, k, padding=0):
         super().__init__()
@@ -240,12 +390,10 @@ class ConvModule(nn.Module):
         self.bn = nn.BatchNorm2d(cout, eps=1e-5, momentum=0.1)
         self.activate = nn.ReLU()
 
-    def forward(self, x):
-        return self.activate(self.bn(self.conv(x)))
-
 
 class SeparateHead(nn.Module):
-    """center_head.py:81-153: per head `num_conv-1` ConvModules then a biased conv to `classes` maps."""
+    """center_head.py:81-153: per head `num_conv-1` ConvModules then a biased conv to `classes` maps.
+    Parameters only (CenterHead runs all heads of all tasks as two fused convolutions)."""
 
     def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, init_bias=-2.19):
         super().__init__()
@@ -260,47 +408,11 @@ class SeparateHead(nn.Module):
         with torch.no_grad():
             getattr(self, "hm")[-1].bias.fill_(init_bias)
 
-    def forward(self, x):
-        return {h: getattr(self, h)(x) for h in self.heads}
 
-
-def _fold_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
-    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-    if isinstance(conv, nn.ConvTranspose2d):
-        w = conv.weight * scale.reshape(1, -1, 1, 1)
-    else:
-        w = conv.weight * scale.reshape(-1, 1, 1, 1)
-    b = (conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean))
-    return w.detach().contiguous(), ((b - bn.running_mean) * scale + bn.bias).detach().contiguous()
-
-
-def _hip_conv3x3(x, w, b, stride, cache):
-    """3x3 / pad 1 convolution + bias + ReLU on the hand-written kernels: stride 1 by Winograd F(4x4,3x3)
-    (PD3_CONV_ALGO=winograd selects F(2x2,3x3), =direct turns Winograd off), the direct implicit-GEMM kernel
-    otherwise; None if no kernel takes the shape.  `cache` keeps the packed weights."""
-    cout, cin = w.shape[:2]
-    h, wd = x.shape[2], x.shape[3]
-    algo = os.environ.get("PD3_CONV_ALGO", "winograd43")
-    if stride == 1 and algo == "winograd43" and _conv.winograd43_supported(cin, cout, h, wd):
-        key = ("wino43", w.data_ptr())
-        if key not in cache:
-            cache[key] = _conv.pack_winograd43_weight(w)
-        return _conv.conv3x3_winograd43_bias_relu(x, cache[key], b, cout, relu=True)
-    if stride == 1 and algo in ("winograd", "winograd43") and _conv.winograd_supported(cin, cout, h, wd):
-        key = ("wino", w.data_ptr())
-        if key not in cache:
-            cache[key] = _conv.pack_winograd_weight(w)
-        return _conv.conv3x3_winograd_bias_relu(x, cache[key], b, cout, relu=True)
-    if _conv.supported(cin, cout, h, wd, stride):
-        key = ("direct", w.data_ptr())
-        if key not in cache:
-            cache[key] = _conv.pack_conv3x3_weight(w)
-        return _conv.conv3x3_bias_relu(x, cache[key], b, cout, relu=True, stride=stride)
-    return None
-
-
-class CenterHead(nn.Module):
-    """center_head.py:156-220 forward + :294-339 predict_by_custom_op (inference only)."""
+class CenterHead(_InferenceCache, nn.Module):
+    """center_head.py:156-220 forward + :294-339 predict_by_custom_op (inference only): BatchNorm folded, the 36
+    first-stage 3x3 convolutions on the shared map run as ONE Winograd convolution, the 36 final convolutions as
+    one grouped launch."""
 
     def __init__(self, in_channels, tasks, common_heads, init_bias=-2.19, share_conv_channel=64, num_hm_conv=2,
                  **_unused):
@@ -315,69 +427,49 @@ class CenterHead(nn.Module):
             heads = dict(common_heads)
             heads.update(hm=(ncls, num_hm_conv))
             self.tasks.append(SeparateHead(share_conv_channel, heads, final_kernel=3, init_bias=init_bias))
-        self._fused = None
-        self.dense_backend = os.environ.get("PD3_DENSE_BACKEND", "hip")
 
-    # -- reference-shaped forward: list of per-task dicts -------------------------------------------
+    def _plan(self):
+        if self._cache is None:
+            w0, b0 = _fold_conv_bn(self.shared_conv.conv, self.shared_conv.bn)
+            ws, bs, plan, finals = [], [], [], []
+            for t, task in enumerate(self.tasks):
+                for head in task.heads:
+                    seq = getattr(task, head)
+                    if len(seq) != 2 or tuple(seq[1].kernel_size) != (3, 3):
+                        raise Paddle3DAmdError("unsupported configuration: the fused CenterHead expects num_conv == 2 "
+                                               "and 3x3 final convolutions for every head (status -3)")
+                    w, b = _fold_conv_bn(seq[0].conv, seq[0].bn)
+                    ws.append(w)
+                    bs.append(b)
+                    plan.append((t, head))
+                    finals.append((seq[1].weight.detach(), seq[1].bias.detach()))
+            cmax = max(f[0].shape[0] for f in finals)
+            hc = ws[0].shape[0]
+            # grouped second stage: group g maps its own hc channels to cmax (zero padded) outputs
+            wf = torch.zeros(len(finals) * cmax, hc, 3, 3, device=w0.device, dtype=w0.dtype)
+            bf = torch.zeros(len(finals) * cmax, device=w0.device, dtype=w0.dtype)
+            for g, (w, b) in enumerate(finals):
+                wf[g * cmax:g * cmax + w.shape[0]] = w
+                bf[g * cmax:g * cmax + w.shape[0]] = b
+            self.__dict__["_cache"] = dict(
+                shared=_Conv3x3(w0, b0, 1), first=_Conv3x3(torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous(), 1),
+                pf=_conv.pack_grouped_weight(wf, len(finals)), bf=bf, hc=int(hc), plan=plan, cmax=int(cmax),
+                groups=len(finals), ncls=[int(f[0].shape[0]) for f in finals])
+        return self._cache
+
     def forward(self, x):
-        if not self.training:
-            return self._forward_fused(x)
-        return self.forward_layers(x)
-
-    def forward_layers(self, x):
-        """Layer-by-layer statement of center_head.py:212-220 (what the fused path must equal)."""
-        x = self.shared_conv(x)
-        return [task(x) for task in self.tasks], x
-
-    # -- inference: BN folded; the 36 first-stage 3x3 convs on the shared map run as ONE convolution -----
-    def _build_fused(self):
-        w0, b0 = _fold_conv_bn(self.shared_conv.conv, self.shared_conv.bn)
-        ws, bs, plan = [], [], []
-        finals = []
-        for t, task in enumerate(self.tasks):
-            for head in task.heads:
-                seq = getattr(task, head)
-                if len(seq) != 2:
-                    raise NotImplementedError("fused CenterHead expects num_conv == 2 for every head")
-                w, b = _fold_conv_bn(seq[0].conv, seq[0].bn)
-                ws.append(w)
-                bs.append(b)
-                plan.append((t, head))
-                finals.append((seq[1].weight.detach(), seq[1].bias.detach()))
-        cmax = max(f[0].shape[0] for f in finals)
-        hc = ws[0].shape[0]
-        # grouped second stage: group g maps its own hc channels to cmax (zero padded) outputs
-        wf = torch.zeros(len(finals) * cmax, hc, 3, 3, device=w0.device, dtype=w0.dtype)
-        bf = torch.zeros(len(finals) * cmax, device=w0.device, dtype=w0.dtype)
-        for g, (w, b) in enumerate(finals):
-            wf[g * cmax:g * cmax + w.shape[0]] = w
-            bf[g * cmax:g * cmax + w.shape[0]] = b
-        self._fused = dict(w0=w0, b0=b0, w1=torch.cat(ws, 0).contiguous(), b1=torch.cat(bs, 0).contiguous(),
-                           wf=wf, bf=bf, plan=plan, cmax=cmax, groups=len(finals),
-                           ncls=[f[0].shape[0] for f in finals])
-
-    def _forward_fused(self, x):
-        if self._fused is None:
-            self._build_fused()
-        f = self._fused
-        y = None
-        if self.dense_backend == "hip" and x.is_cuda:
-            pk = f.setdefault("packed", {})
-            x1 = _hip_conv3x3(x, f["w0"], f["b0"], 1, pk)
-            if x1 is not None:
-                y = _hip_conv3x3(x1, f["w1"], f["b1"], 1, pk)
-                if y is not None:
-                    x = x1
-        if y is None:
-            x = F.relu(F.conv2d(x, f["w0"], f["b0"], padding=1))
-            y = F.relu(F.conv2d(x, f["w1"], f["b1"], padding=1))
-        if (self.dense_backend == "hip" and y.is_cuda
-                and _conv.grouped_small_supported(f["wf"].shape[1], f["cmax"], y.shape[2], y.shape[3])):
-            if "pf" not in f:
-                f["pf"] = _conv.pack_grouped_weight(f["wf"], f["groups"])
-            z = _conv.grouped_conv3x3_small(y, f["pf"], f["bf"], f["groups"])
-        else:
-            z = F.conv2d(y, f["wf"], f["bf"], padding=1, groups=f["groups"])
+        """x [B, C, H, W] -> (per task dict of head maps, shared feature map), center_head.py:212-220."""
+        self._require_eval()
+        f = self._plan()
+        if x.shape[3] % 4:
+            raise Paddle3DAmdError(f"CenterHead: unsupported configuration (map width {x.shape[3]} is not a multiple "
+                                   "of 4) (status -3)")
+        x, _ = f["shared"](x)
+        y, _ = f["first"](x)
+        if not _conv.grouped_small_supported(f["hc"], f["cmax"], int(y.shape[2]), int(y.shape[3])):
+            raise Paddle3DAmdError(f"grouped_conv3x3_small: unsupported configuration ({f['hc']} -> {f['cmax']} "
+                                   f"channels per group, map {tuple(y.shape[2:])}) (status -3)")
+        z = _conv.grouped_conv3x3_small(y, f["pf"], f["bf"], f["groups"])
         rets = [dict() for _ in self.tasks]
         for g, (t, head) in enumerate(f["plan"]):
             # channel slices of z stay views: the postprocess op takes them with their common batch stride
@@ -424,11 +516,6 @@ class CenterPoint(nn.Module):
         self.bbox_head = bbox_head
         self.test_cfg = test_cfg
         self.box_with_velocity = box_with_velocity
-        self._dense = None
-        # "hip" (default): the hand-written fp32-MFMA kernel (ops/conv.py) for every 3x3 convolution of the
-        # backbone and the FPN levels; "miopen": PyTorch-ROCm convolutions
-        self.dense_backend = os.environ.get("PD3_DENSE_BACKEND", "hip")
-        self._packed = {}
 
     def _pack(self, points):
         if isinstance(points, torch.Tensor):
@@ -454,77 +541,9 @@ class CenterPoint(nn.Module):
         feats = self.voxel_encoder(voxels, npv, coors)
         return self.middle_encoder(feats, coors, b)
 
-    def _dense_fold(self):
-        """BatchNorm folded into the backbone / neck convolutions for inference."""
-        seqs = []
-        for blk in list(self.backbone.blocks) + list(self.neck.deblocks):
-            layers = []
-            mods = list(blk)
-            for i in range(0, len(mods), 3):
-                conv, bn = mods[i], mods[i + 1]
-                w, bias = _fold_conv_bn(conv, bn)
-                layers.append((isinstance(conv, nn.ConvTranspose2d), w, bias, conv.stride, conv.padding))
-            seqs.append(layers)
-        nb = len(self.backbone.blocks)
-        self._dense = (seqs[:nb], seqs[nb:])
-
-    def _run(self, layers, x):
-        for tr, w, b, stride, padding in layers:
-            if (self.dense_backend == "hip" and x.is_cuda and not tr and tuple(w.shape[2:]) == (3, 3)
-                    and tuple(stride) in ((1, 1), (2, 2)) and tuple(padding) == (1, 1)):
-                y = _hip_conv3x3(x, w, b, stride[0], self._packed)
-                if y is not None:
-                    x = y
-                    continue
-            x = F.conv_transpose2d(x, w, b, stride=stride, padding=padding) if tr else \
-                F.conv2d(x, w, b, stride=stride, padding=padding)
-            x = F.relu_(x)
-        return x
-
-    def _neck_fused(self, outs):
-        """The FPN levels on the patch-GEMM kernel, each writing its channel slice of the concatenated map."""
-        if self.dense_backend != "hip" or not outs[0].is_cuda:
-            return None
-        plan, hw, ctot = [], None, 0
-        for layers, o in zip(self._dense[1], outs):
-            if len(layers) != 1:
-                return None
-            tr, w, b, stride, padding = layers[0]
-            mode = _conv.patch_mode(w, stride[0], tr)
-            cout = w.shape[1] if tr else w.shape[0]
-            cin = w.shape[0] if tr else w.shape[1]
-            if (mode is None or tuple(padding) != (0, 0) or stride[0] != stride[1]
-                    or not _conv.patch_supported(mode, cin, cout, o.shape[2], o.shape[3])):
-                return None
-            scale = {0: 0.5, 1: 1, 2: 2}[mode]
-            size = (int(o.shape[2] * scale), int(o.shape[3] * scale))
-            if hw is not None and size != hw:
-                return None
-            hw = size
-            plan.append((mode, w, b, tr, cout, ctot))
-            ctot += cout
-        out = torch.empty((outs[0].shape[0], ctot, hw[0], hw[1]), dtype=torch.float32, device=outs[0].device)
-        for (mode, w, b, tr, cout, off), o in zip(plan, outs):
-            key = ("patch", w.data_ptr())
-            if key not in self._packed:
-                self._packed[key] = _conv.pack_patch_weight(w, mode, tr)
-            _conv.patch_conv_bias_relu(o, self._packed[key], b, mode, cout, out, off, relu=True)
-        return out
-
     def dense_forward(self, x):
-        if self.training:
-            return self.neck(self.backbone(x))
-        if self._dense is None:
-            self._dense_fold()
-        outs = []
-        for blk in self._dense[0]:
-            x = self._run(blk, x)
-            outs.append(x)
-        fused = self._neck_fused(outs)
-        if fused is not None:
-            return fused
-        ups = [self._run(d, o) for d, o in zip(self._dense[1], outs)]
-        return torch.cat(ups, dim=1)
+        """SecondBackbone -> SecondFPN (centerpoint.py:133-137)."""
+        return self.neck(self.backbone(x))
 
     @torch.no_grad()
     def test_forward(self, points, device_only=False):
@@ -598,7 +617,8 @@ def load_paddle_state_dict(model: nn.Module, state: dict) -> list:
                 continue
             own[name].copy_(t)
     for m in model.modules():
-        for attr in ("_folded", "_fused", "_dense"):
-            if hasattr(m, attr):
-                setattr(m, attr, None)
+        if hasattr(m, "_drop_cache"):
+            m._drop_cache()
+        if hasattr(m, "_folded"):
+            m._folded = None
     return missing

@@ -22,7 +22,6 @@
 #include "../../include/paddle3d_amd.h"
 #include "common.hpp"
 
-#include <cstdlib>
 
 namespace pd3 {
 
@@ -40,8 +39,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
                                                            const float* __restrict__ wp,
                                                            const float* __restrict__ bias,
                                                            float* __restrict__ out, int cin, int cout,
-                                                           int h, int w, int relu, int ptiles) {
-  // h, w: OUTPUT size; the input map is (S*h) x (S*w), S = stride (1 or 2), padding 1
+                                                           int h, int w, int wi, int wv, int relu, int ptiles) {
+  // h, w: OUTPUT rows and row pitch; the input map has S*h rows of pitch wi, S = stride (1 or 2), padding 1.
+  // Output columns >= wv (the valid width) are written as zeros: a map whose width is not a multiple of 4 lives
+  // in rows padded with zeros, which the next layer reads as its own zero padding.
   static_assert(R * WT == 128 || R * WT == 256, "tile must hold 128 or 256 pixels");
   constexpr int NB = R * WT / 128;           // 32-pixel blocks per wave
   constexpr int XR = (R - 1) * S + 3, XW = S * WT + 8;  // staged input columns S*x0-4 .. S*x0+S*WT+3
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
   constexpr int WSZ = kCvK * kCvCo;          // floats per W buffer
   extern __shared__ __attribute__((aligned(16))) float cv_smem[];  // X[XB][XSZ] then W[2][WSZ]
   const int lane = lane_id(), wave = wave_id();
-  const int tiles_x = w / WT, tiles_y = h / R;
+  const int tiles_x = (w + WT - 1) / WT, tiles_y = (h + R - 1) / R;  // border tiles are partial: masked stores
   // XCD-aware tile order (workgroups are dealt round-robin over the 8 XCDs): pixel tile pt lives on XCD
   // pt % 8 and its channel tiles follow each other there -> the input tile is fetched from HBM once per XCD
   const int nct = cout / kCvCo;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
       for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
   const int chunks = cin / kCvCi;
   const int64_t plane = (int64_t)h * w;           // output plane
-  const int hi = S * h, wi = S * w;
+  const int hi = S * h;
   const int64_t iplane = (int64_t)hi * wi;        // input plane
   const float* xin = x + (int64_t)n * cin * iplane;
   // staging pattern, identical for every chunk: float4 e of the LDS image <- global offset inside the chunk
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
 #pragma unroll
   for (int t = 0; t < NB; ++t) {
     const int pj = (wave * NB + t) * 32 + (lane & 31);
+    if (y0 + pj / WT >= h || x0 + pj % WT >= w) continue;  // pixel of a partial border tile
     float* obase = out + (int64_t)n * cout * plane + (int64_t)(y0 + pj / WT) * w + x0 + (pj % WT);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -194,25 +196,23 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
         const int co = ct * kCvCo + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
         float v = acc[m][t][reg] + bv[m][reg];
         if (relu) v = fmaxf(v, 0.f);
-        obase[(int64_t)co * plane] = v;
+        obase[(int64_t)co * plane] = (x0 + pj % WT < wv) ? v : 0.f;
       }
   }
 }
 
 template <int R, int WT, int S, int XB = 2>
 static int launch_conv3x3(int64_t tiles, hipStream_t s, const float* x, const float* wp, const float* bias,
-                          float* out, int cin, int cout, int h, int w, int relu) {
+                          float* out, int cin, int cout, int h, int w, int wi, int wv, int relu) {
   constexpr size_t lds = (size_t)(XB * kCvCi * ((R - 1) * S + 3) * (S * WT + 8) + 2 * kCvK * kCvCo) * sizeof(float);
-  static bool configured = false;  // raise the dynamic-LDS cap once per instantiation
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<R, WT, S, XB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured = true;
-  }
+  // raise the dynamic-LDS cap (per device and per instantiation: set on every launch, it is a host-side table write)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<R, WT, S, XB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
   const int64_t nwg = (tiles + 7) / 8 * 8 * (cout / kCvCo);
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
-  conv3x3_mfma_kernel<R, WT, S, XB><<<(unsigned)nwg, 256, lds, s>>>(x, wp, bias, out, cin, cout, h, w, relu, (int)tiles);
+  conv3x3_mfma_kernel<R, WT, S, XB><<<(unsigned)nwg, 256, lds, s>>>(x, wp, bias, out, cin, cout, h, w, wi, wv, relu,
+                                                                    (int)tiles);
   return launch_status();
 }
 
@@ -301,33 +301,36 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_kernel(const float*
 using namespace pd3;
 
 extern "C" int pd3_conv3x3_bias_relu(const float* x, const float* w_packed, const float* bias,
-                                     int batch, int cin, int cout, int h, int w, int stride, int relu,
-                                     float* out, void* stream) {
-  if (!x || !w_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0)
+                                     int batch, int cin, int cout, int h, int w, int w_valid, int stride, int relu,
+                                     float* out, int out_w, void* stream) {
+  if (!x || !w_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || w_valid <= 0 ||
+      w_valid > w || out_w <= 0)
     return PD3_EINVAL;
   if (stride != 1 && stride != 2) return PD3_EUNSUPPORTED;
-  if (cin % kCvCi != 0 || cout % kCvCo != 0 || h % stride != 0 || w % stride != 0) return PD3_EUNSUPPORTED;
+  if (cin % kCvCi != 0 || cout % kCvCo != 0 || h % stride != 0 || w_valid % stride != 0) return PD3_EUNSUPPORTED;
+  if (w % 4 != 0 || out_w % 4 != 0 || out_w < w_valid / stride) return PD3_EUNSUPPORTED;  // rows: aligned float4
   if (reinterpret_cast<uintptr_t>(w_packed) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0)
     return PD3_EINVAL;
   if ((int64_t)cin * h * w >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int ho = h / stride, wo = w / stride;  // (h + 2 - 3) / stride + 1 for even h
-  const int64_t px = (int64_t)batch * ho * wo;
-#define PD3_CV(R, WT, S) launch_conv3x3<R, WT, S>(px / ((R) * (WT)), s, x, w_packed, bias, out, cin, cout, ho, wo, relu)
+  const int ho = h / stride, wo = out_w, wv = w_valid / stride;  // (h + 2 - 3) / stride + 1 for even h
+#define PD3_CV(R, WT, S)                                                                                     \
+  launch_conv3x3<R, WT, S>((int64_t)batch * ceil_div(ho, R) * ceil_div(wo, WT), s, x, w_packed, bias, out, cin, \
+                           cout, ho, wo, w, wv, relu)
   if (stride == 1) {
     if (wo % 128 == 0 && ho % 2 == 0) return PD3_CV(2, 128, 1);
     if (wo % 64 == 0 && ho % 4 == 0) return PD3_CV(4, 64, 1);
     if (wo % 128 == 0) return PD3_CV(1, 128, 1);
     if (wo % 64 == 0 && ho % 2 == 0) return PD3_CV(2, 64, 1);
-    if (wo % 32 == 0 && ho % 4 == 0) return PD3_CV(4, 32, 1);
+    return PD3_CV(4, 32, 1);  // any size: partial tiles at the right / bottom border
   } else {  // the staged input tile is 4x larger: a 256-pixel tile with ONE X buffer, or 128-pixel tiles
-    if (wo % 128 == 0 && ho % 2 == 0 && !std::getenv("PD3_CONV_S2_SMALL_TILE"))
-      return launch_conv3x3<2, 128, 2, 1>(px / 256, s, x, w_packed, bias, out, cin, cout, ho, wo, relu);
+    if (wo % 128 == 0 && ho % 2 == 0)
+      return launch_conv3x3<2, 128, 2, 1>((int64_t)batch * ho * wo / 256, s, x, w_packed, bias, out, cin, cout, ho, wo,
+                                          w, wv, relu);
     if (wo % 64 == 0 && ho % 2 == 0) return PD3_CV(2, 64, 2);
-    if (wo % 32 == 0 && ho % 4 == 0) return PD3_CV(4, 32, 2);
+    return PD3_CV(4, 32, 2);  // any size
   }
 #undef PD3_CV
-  return PD3_EUNSUPPORTED;
 }
 
 extern "C" int pd3_grouped_conv3x3_small(const float* x, const float* w_grouped, const float* bias, int batch,

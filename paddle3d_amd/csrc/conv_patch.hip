@@ -35,7 +35,8 @@ struct PgArgs {
   const float* bias;
   float* out;
   int cin, m_rows;      // GEMM K (in rows of B per pixel: cin, or 4 cin for mode 0 handled below) and M
-  int hi, wi;           // input map
+  int hi, wi;           // input map (wi = row pitch)
+  int wv;               // valid input columns (mode 2 only: columns >= wv are padding and produce no output)
   int ho, wo;           // output map
   int ctot, coff;       // channels of the output tensor, first channel written
   int relu, ptiles;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(PgArgs a) {
     oy0 = ((pt / tiles_x) % tiles_y) * 2;
     ox0 = (pt % tiles_x) * 128;
   } else {
-    const int tiles = (int)(iplane / kPgP);
+    const int tiles = (int)((iplane + kPgP - 1) / kPgP);  // the last tile of a plane may be partial
     n = pt / tiles;
     p0 = (pt % tiles) * kPgP;
   }
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(PgArgs a) {
       gofs[i] = (int)(ci * iplane + (int64_t)(2 * oy0 + r) * a.wi + 2 * ox0 + c4 * 4);
     } else {          // e -> (ci 0..15, c4 0..63)
       const int ci = e >> 6, c4 = e & 63;
-      gofs[i] = (int)(ci * iplane + p0 + c4 * 4);
+      // columns past the plane are clamped to its last float4: they only feed pixels that are never stored
+      gofs[i] = (int)(ci * iplane + min((int64_t)p0 + c4 * 4, iplane - 4));
     }
   }
   const int cpt = MODE == 0 ? 4 : 16;  // input channels per trip
@@ -148,11 +150,13 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(PgArgs a) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int pj = (wave * 2 + t) * 32 + (lane & 31);
+    if (MODE != 0 && (int64_t)p0 + pj >= iplane) continue;  // pixel of a partial tile
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       if (MODE == 2) {
         // rows 4q .. 4q+3 of a register quad = (dy, dx) of one output channel
         const int p = p0 + pj, y = p / a.wi, xx = p - y * a.wi;
+        if (xx >= a.wv) continue;  // padding column of a map whose width is not a multiple of 4
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
           const int row = mt * kPgM + m * 32 + 8 * qd + 4 * kk;  // = 4 * co
@@ -195,9 +199,11 @@ static int launch_patch_gemm(const PgArgs& a, int64_t ptiles, hipStream_t s) {
 using namespace pd3;
 
 extern "C" int pd3_patch_conv_bias_relu(const float* x, const float* w_packed, const float* bias, int mode,
-                                        int batch, int cin, int cout, int h, int w, int relu, float* out,
-                                        int out_channels_total, int out_channel_offset, void* stream) {
-  if (!x || !w_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return PD3_EINVAL;
+                                        int batch, int cin, int cout, int h, int w, int w_valid, int relu,
+                                        float* out, int out_channels_total, int out_channel_offset, void* stream) {
+  if (!x || !w_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || w_valid <= 0 ||
+      w_valid > w || (mode != 2 && w_valid != w))
+    return PD3_EINVAL;
   if (mode < 0 || mode > 2 || out_channel_offset < 0 || out_channel_offset + cout > out_channels_total)
     return PD3_EINVAL;
   if (reinterpret_cast<uintptr_t>(w_packed) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0 ||
@@ -212,6 +218,7 @@ extern "C" int pd3_patch_conv_bias_relu(const float* x, const float* w_packed, c
   a.cin = cin;
   a.hi = h;
   a.wi = w;
+  a.wv = w_valid;
   a.ctot = out_channels_total;
   a.coff = out_channel_offset;
   a.relu = relu;
@@ -226,8 +233,8 @@ extern "C" int pd3_patch_conv_bias_relu(const float* x, const float* w_packed, c
     a.ptiles = (int)ptiles;
     return launch_patch_gemm<0>(a, ptiles, s);
   }
-  if (((int64_t)h * w) % kPgP != 0 || cin % kPgK != 0) return PD3_EUNSUPPORTED;
-  ptiles = (int64_t)batch * h * w / kPgP;
+  if (((int64_t)h * w) % 4 != 0 || cin % kPgK != 0) return PD3_EUNSUPPORTED;  // planes start float4-aligned
+  ptiles = (int64_t)batch * ceil_div((int64_t)h * w, kPgP);
   a.ptiles = (int)ptiles;
   if (mode == 1) {  // 1x1
     if (cout % kPgM != 0) return PD3_EUNSUPPORTED;
@@ -239,6 +246,6 @@ extern "C" int pd3_patch_conv_bias_relu(const float* x, const float* w_packed, c
   if ((cout * 4) % kPgM != 0) return PD3_EUNSUPPORTED;  // Conv2DTranspose kernel 2 stride 2
   a.m_rows = cout * 4;
   a.ho = 2 * h;
-  a.wo = 2 * w;
+  a.wo = 2 * w_valid;
   return launch_patch_gemm<2>(a, ptiles, s);
 }

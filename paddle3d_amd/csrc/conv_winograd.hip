@@ -259,12 +259,10 @@ extern "C" int pd3_conv3x3_winograd_bias_relu(const float* x, const float* u_pac
   const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / kWgCo);
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
   dim3 grid((unsigned)nwg);
-  static bool configured = false;  // raise the dynamic-LDS cap once
-  if (!configured) {
+  {  // dynamic-LDS cap: per device, so it is set on every launch (a host-side table write)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_winograd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgLds);
     if (e != hipSuccess) return (int)e;
-    configured = true;
   }
   conv3x3_winograd_kernel<<<grid, 256, kWgLds, static_cast<hipStream_t>(stream)>>>(x, u_packed, bias, out, cin,
                                                                                    cout, h, w, relu, (int)ptiles);

@@ -74,7 +74,9 @@ __global__ __launch_bounds__(128 * CB, CB == 2 ? 2 : 1) void conv3x3_winograd43_
                                                                     const float* __restrict__ up,
                                                                     const float* __restrict__ bias,
                                                                     float* __restrict__ out, int cin, int cout,
-                                                                    int h, int w, int relu, int ptiles) {
+                                                                    int h, int w, int wv, int relu, int ptiles) {
+  // w = row pitch of input and output (a multiple of 4), wv <= w the valid width: output columns >= wv are
+  // written as zeros (and the caller guarantees the same of the input), i.e. they are the next layer's padding
   constexpr int THREADS = 128 * CB;
   constexpr int CO = 16 * CB;                       // output channels per workgroup
   constexpr int USZ = CB * kW4Ci * 16 * kW4Cs;      // floats of one U trip
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(128 * CB, CB == 2 ? 2 : 1) void conv3x3_winograd43_
       for (int j = 0; j < 4; ++j) {
         y4[j] += bv[r];
         if (relu) y4[j] = fmaxf(y4[j], 0.f);
+        if (ox + j >= wv) y4[j] = 0.f;
       }
       if (oy + k < h && ox < w)  // partial tiles at the border (w % 4 == 0: a quad is in or out)
         *reinterpret_cast<w4_f32x4*>(o + (int64_t)k * w) = (w4_f32x4){y4[0], y4[1], y4[2], y4[3]};
@@ -282,28 +285,28 @@ using namespace pd3;
 
 template <int CB>
 static int launch_wino43(const float* x, const float* u_packed, const float* bias, int batch, int cin, int cout,
-                         int h, int w, int relu, float* out, hipStream_t s) {
+                         int h, int w, int wv, int relu, float* out, hipStream_t s) {
   constexpr size_t lds = (size_t)(CB * kW4Ci * 16 * kW4Cs + kW4Vsz + kW4RawSz) * sizeof(float);
-  static bool configured = false;  // raise the dynamic-LDS cap once per instantiation
-  if (!configured) {
+  {  // dynamic-LDS cap: per device, so it is set on every launch (a host-side table write)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_winograd43_kernel<CB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    configured = true;
   }
   const int64_t ptiles = (int64_t)batch * ceil_div(h, 4 * kW4TR) * ceil_div(w, 4 * kW4TC);
   const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / (16 * CB));
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
-  conv3x3_winograd43_kernel<CB><<<(unsigned)nwg, 128 * CB, lds, s>>>(x, u_packed, bias, out, cin, cout, h, w, relu,
-                                                                       (int)ptiles);
+  conv3x3_winograd43_kernel<CB><<<(unsigned)nwg, 128 * CB, lds, s>>>(x, u_packed, bias, out, cin, cout, h, w, wv,
+                                                                       relu, (int)ptiles);
   return launch_status();
 }
 
 // channels_per_tile selects the workgroup shape the weights were packed for: 32 (two workgroups per CU) or 64
 extern "C" int pd3_conv3x3_winograd43_bias_relu(const float* x, const float* u_packed, const float* bias,
-                                                int batch, int cin, int cout, int h, int w, int relu,
-                                                float* out, int channels_per_tile, void* stream) {
-  if (!x || !u_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return PD3_EINVAL;
+                                                int batch, int cin, int cout, int h, int w, int w_valid,
+                                                int relu, float* out, int channels_per_tile, void* stream) {
+  if (!x || !u_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || w_valid <= 0 ||
+      w_valid > w)
+    return PD3_EINVAL;
   if (channels_per_tile != 32 && channels_per_tile != 64) return PD3_EINVAL;
   if (cin % kW4Ci != 0 || cout % channels_per_tile != 0 || w % 4 != 0) return PD3_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(u_packed) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0 ||
@@ -311,6 +314,6 @@ extern "C" int pd3_conv3x3_winograd43_bias_relu(const float* x, const float* u_p
     return PD3_EINVAL;
   if ((int64_t)cin * h * w >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return channels_per_tile == 64 ? launch_wino43<4>(x, u_packed, bias, batch, cin, cout, h, w, relu, out, s)
-                                 : launch_wino43<2>(x, u_packed, bias, batch, cin, cout, h, w, relu, out, s);
+  return channels_per_tile == 64 ? launch_wino43<4>(x, u_packed, bias, batch, cin, cout, h, w, w_valid, relu, out, s)
+                                 : launch_wino43<2>(x, u_packed, bias, batch, cin, cout, h, w, w_valid, relu, out, s);
 }

@@ -19,7 +19,6 @@
 #include "radix_sort.hpp"
 
 #include <algorithm>
-#include <cstdlib>
 
 namespace pd3 {
 
@@ -256,7 +255,7 @@ __global__ __launch_bounds__(256) void cp_output_kernel(
     const float* __restrict__ boxes, const float* __restrict__ scores,
     const int* __restrict__ labels, const uint32_t* __restrict__ sidx,
     const int* __restrict__ counts, const int32_t* __restrict__ keep,
-    const int32_t* __restrict__ nkeep, CpHeads h, int num_tasks, int hw, int dims, int cap,
+    const int32_t* __restrict__ nkeep, CpHeads h, int num_tasks, int hw, int dims, int cap, int pre_max,
     int post_max, float* __restrict__ out_boxes, float* __restrict__ out_scores,
     int64_t* __restrict__ out_labels, int32_t* __restrict__ out_count) {
   const int frame = blockIdx.x;
@@ -277,7 +276,8 @@ __global__ __launch_bounds__(256) void cp_output_kernel(
       offset += 1;
       continue;
     }
-    const int rows = min(nkeep[t], post_max);
+    // num_bboxes_for_nms = min(count, nms_pre_max_size) (postprocess.cu:212-216): none with a zero pre-NMS cap
+    const int rows = pre_max > 0 ? min(nkeep[t], post_max) : 0;
     for (int r = threadIdx.x; r < rows; r += blockDim.x) {
       const int pos = keep[(int64_t)t * cap + r];          // index into the sorted order
       const uint32_t cell = sidx[(int64_t)t * hw + pos];   // selected_score_idx[sorted_index[keep]]
@@ -338,7 +338,7 @@ extern "C" size_t pd3_centerpoint_postprocess_workspace(int batch, int num_tasks
 }
 
 static int cp_postprocess_impl(
-    int64_t head_batch_stride,
+    int64_t head_batch_stride, int selection,
     const float* const* hm, const float* const* reg, const float* const* height,
     const float* const* dim, const float* const* vel, const float* const* rot, int batch,
     int num_tasks, const int* hm_channels, int feat_h, int feat_w, const float* voxel_size,
@@ -397,15 +397,12 @@ static int cp_postprocess_impl(
   dim3 dgrid((hw + 255) / 256, sets);
   cp_decode_kernel<<<dgrid, 256, 0, s>>>(h, c, w.boxes, w.scores, w.labels, w.keys_a, w.counts);
   const uint32_t* sidx;
-  if (hw <= kTopkMaxHw && hw % 2 == 0 && cap <= kTopkMaxK && !std::getenv("PD3_POSTPROCESS_FULL_SORT")) {
+  if (selection < 0 || selection > 1) return PD3_EINVAL;
+  if (hw <= kTopkMaxHw && hw % 2 == 0 && cap <= kTopkMaxK && selection == 0) {
     const size_t lds = cp_topk_lds(hw);
-    static bool configured = false;
-    if (!configured) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(cp_topk_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp_topk_lds(kTopkMaxHw));
-      if (e != hipSuccess) return (int)e;
-      configured = true;
-    }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(cp_topk_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp_topk_lds(kTopkMaxHw));
+    if (e != hipSuccess) return (int)e;
     cp_topk_kernel<<<sets, kTopkThreads, lds, s>>>(w.keys_a, w.counts, hw, cap, w.vals_a);
     sidx = w.vals_a;
   } else {
@@ -428,7 +425,7 @@ static int cp_postprocess_impl(
     nms_sweep_kernel<<<sets, 256, lds, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);
   }
   cp_output_kernel<<<batch, 256, 0, s>>>(w.boxes, w.scores, w.labels, sidx, w.counts, w.keep, w.nkeep, h,
-                                     num_tasks, hw, c.dims, cap, nms_post_max_size, out_bboxes,
+                                     num_tasks, hw, c.dims, cap, nms_pre_max_size, nms_post_max_size, out_bboxes,
                                      out_scores, out_labels, out_count);
   return launch_status();
 }
@@ -442,7 +439,7 @@ extern "C" int pd3_centerpoint_postprocess(
     int nms_post_max_size, int with_velocity, float* out_bboxes, float* out_scores,
     int64_t* out_labels, int32_t* out_count, void* workspace, size_t workspace_bytes,
     void* stream) {
-  return cp_postprocess_impl(0, hm, reg, height, dim, vel, rot, batch, num_tasks, hm_channels, feat_h, feat_w,
+  return cp_postprocess_impl(0, 0, hm, reg, height, dim, vel, rot, batch, num_tasks, hm_channels, feat_h, feat_w,
                              voxel_size, point_cloud_range, post_center_range, label_offsets, down_ratio,
                              score_threshold, nms_iou_threshold, nms_pre_max_size, nms_post_max_size,
                              with_velocity, out_bboxes, out_scores, out_labels, out_count, workspace,
@@ -457,9 +454,9 @@ extern "C" int pd3_centerpoint_postprocess_strided(
     int down_ratio, float score_threshold, float nms_iou_threshold, int nms_pre_max_size,
     int nms_post_max_size, int with_velocity, float* out_bboxes, float* out_scores,
     int64_t* out_labels, int32_t* out_count, void* workspace, size_t workspace_bytes,
-    void* stream) {
+    void* stream, int selection) {
   if (head_batch_stride <= 0) return PD3_EINVAL;
-  return cp_postprocess_impl(head_batch_stride, hm, reg, height, dim, vel, rot, batch, num_tasks, hm_channels,
+  return cp_postprocess_impl(head_batch_stride, selection, hm, reg, height, dim, vel, rot, batch, num_tasks, hm_channels,
                              feat_h, feat_w, voxel_size, point_cloud_range, post_center_range, label_offsets,
                              down_ratio, score_threshold, nms_iou_threshold, nms_pre_max_size,
                              nms_post_max_size, with_velocity, out_bboxes, out_scores, out_labels, out_count,

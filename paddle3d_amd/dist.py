@@ -54,7 +54,8 @@ def pack_records(boxes: torch.Tensor, scores: torch.Tensor, labels: torch.Tensor
     rec[:, :k, 9] = scores[:, :k]
     rec[:, :k, 10] = labels[:, :k].to(torch.float32)
     valid = torch.arange(max_per_img, device=boxes.device).unsqueeze(0) < counts.clamp(max=max_per_img).unsqueeze(1)
-    return rec * valid.unsqueeze(-1)
+    # where(), not a 0/1 multiply: rows >= count may hold anything (NaN * 0 = NaN)
+    return torch.where(valid.unsqueeze(-1), rec, torch.zeros((), dtype=rec.dtype, device=rec.device))
 
 
 def gather_detections(records: torch.Tensor, counts: torch.Tensor):

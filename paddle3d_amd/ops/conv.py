@@ -8,20 +8,21 @@ import torch
 
 from ._common import check, lib, ptr, require_gpu, stream_ptr
 
-__all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pack_grouped_weight", "grouped_conv3x3_small",
+__all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pitch4", "pack_grouped_weight", "grouped_conv3x3_small",
            "grouped_small_supported", "winograd_supported", "pack_winograd_weight", "conv3x3_winograd_bias_relu",
            "patch_mode", "patch_supported", "pack_patch_weight", "patch_conv_bias_relu",
            "winograd43_supported", "winograd43_tile", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu"]
 
 
+def pitch4(w: int) -> int:
+    """Row pitch of a map of width w: widths that are not a multiple of 4 are padded with zero columns."""
+    return (int(w) + 3) // 4 * 4
+
+
 def supported(cin: int, cout: int, h: int, w: int, stride: int = 1) -> bool:
-    """Shapes pd3_conv3x3_bias_relu takes ([h, w] = input size)."""
-    if stride not in (1, 2) or cin % 8 or cout % 64 or h % stride or w % stride:
-        return False
-    ho, wo = h // stride, w // stride
-    if stride == 1:
-        return wo % 128 == 0 or (wo % 64 == 0 and ho % 2 == 0) or (wo % 32 == 0 and ho % 4 == 0)
-    return (wo % 64 == 0 and ho % 2 == 0) or (wo % 32 == 0 and ho % 4 == 0)
+    """Shapes pd3_conv3x3_bias_relu takes ([h, w] = input size, w the VALID width: rows of other widths live
+    zero-padded to a multiple of 4, see pitch4): partial border tiles are masked, so any map."""
+    return stride in (1, 2) and cin % 8 == 0 and cout % 64 == 0 and h % stride == 0 and w % stride == 0
 
 
 def pack_conv3x3_weight(weight: torch.Tensor) -> torch.Tensor:
@@ -34,13 +35,17 @@ def pack_conv3x3_weight(weight: torch.Tensor) -> torch.Tensor:
 
 
 def conv3x3_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, relu: bool = True,
-                      stride: int = 1, out: torch.Tensor | None = None) -> torch.Tensor:
+                      stride: int = 1, out: torch.Tensor | None = None, w_valid: int | None = None) -> torch.Tensor:
+    """x [n, cin, h, pitch]: pitch % 4 == 0; w_valid (default pitch) = real width, columns beyond hold zeros.
+    Returns [n, cout, h / stride, pitch4(w_valid / stride)] with zeros in its own padding columns."""
     xx = require_gpu(x, "conv3x3_bias_relu")
     n, cin, h, w = xx.shape
+    wv = w if w_valid is None else int(w_valid)
     if out is None:
-        out = torch.empty((n, cout, h // stride, w // stride), dtype=torch.float32, device=xx.device)
-    check(lib().pd3_conv3x3_bias_relu(ptr(xx), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(stride),
-                                      int(bool(relu)), ptr(out), stream_ptr(xx.device)), "conv3x3_bias_relu")
+        out = torch.empty((n, cout, h // stride, pitch4(wv // stride)), dtype=torch.float32, device=xx.device)
+    check(lib().pd3_conv3x3_bias_relu(ptr(xx), ptr(w_packed), ptr(bias), n, cin, cout, h, w, wv, int(stride),
+                                      int(bool(relu)), ptr(out), int(out.shape[3]), stream_ptr(xx.device)),
+          "conv3x3_bias_relu")
     return out
 
 
@@ -72,7 +77,8 @@ def conv3x3_winograd_bias_relu(x: torch.Tensor, u_packed: torch.Tensor, bias, co
 
 
 def winograd43_supported(cin: int, cout: int, h: int, w: int) -> bool:
-    return cin % 4 == 0 and cout % 32 == 0 and w % 4 == 0
+    """w = the valid width; the tensor's rows are pitch4(w) long (zero padded)."""
+    return cin % 4 == 0 and cout % 32 == 0
 
 
 def winograd43_tile(cout: int) -> int:
@@ -94,14 +100,16 @@ def pack_winograd43_weight(weight: torch.Tensor, tile: int | None = None) -> tor
 
 
 def conv3x3_winograd43_bias_relu(x: torch.Tensor, u_packed: torch.Tensor, bias, cout: int, relu: bool = True,
-                                 out: torch.Tensor | None = None) -> torch.Tensor:
+                                 out: torch.Tensor | None = None, w_valid: int | None = None) -> torch.Tensor:
+    """x [n, cin, h, pitch] (pitch % 4 == 0, columns >= w_valid zero) -> [n, cout, h, pitch], same convention."""
     xx = require_gpu(x, "conv3x3_winograd43_bias_relu")
     n, cin, h, w = xx.shape
     tile = 16 * u_packed.shape[2]  # the packing records the workgroup shape
     if out is None:
         out = torch.empty((n, cout, h, w), dtype=torch.float32, device=xx.device)
     check(lib().pd3_conv3x3_winograd43_bias_relu(ptr(xx), ptr(u_packed), ptr(bias), n, cin, cout, h, w,
-                                                 int(bool(relu)), ptr(out), tile, stream_ptr(xx.device)),
+                                                 w if w_valid is None else int(w_valid), int(bool(relu)), ptr(out),
+                                                 tile, stream_ptr(xx.device)),
           "conv3x3_winograd43_bias_relu")
     return out
 
@@ -119,9 +127,10 @@ def patch_mode(weight: torch.Tensor, stride: int, transpose: bool):
 
 
 def patch_supported(mode: int, cin: int, cout: int, h: int, w: int) -> bool:
+    """[h, w] = input map, w its row pitch (pitch4 of the valid width for mode 2)."""
     if mode == 0:
         return h % 4 == 0 and w % 256 == 0 and (cin * 4) % 16 == 0 and cout % 64 == 0
-    if (h * w) % 256 or cin % 16:
+    if (h * w) % 4 or cin % 16:
         return False
     return cout % 64 == 0 if mode == 1 else (cout * 4) % 64 == 0
 
@@ -141,13 +150,15 @@ def pack_patch_weight(weight: torch.Tensor, mode: int, transpose: bool) -> torch
 
 
 def patch_conv_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, mode: int, cout: int, out: torch.Tensor,
-                         channel_offset: int = 0, relu: bool = True) -> torch.Tensor:
-    """Writes relu(conv(x) + bias) into out[:, channel_offset:channel_offset + cout]."""
+                         channel_offset: int = 0, relu: bool = True, w_valid: int | None = None) -> torch.Tensor:
+    """Writes relu(conv(x) + bias) into out[:, channel_offset:channel_offset + cout].  w_valid (mode 2 only): real
+    width of a zero-padded x."""
     xx = require_gpu(x, "patch_conv_bias_relu")
     n, cin, h, w = xx.shape
     check(lib().pd3_patch_conv_bias_relu(ptr(xx), ptr(w_packed), ptr(bias), int(mode), n, cin, cout, h, w,
-                                         int(bool(relu)), ptr(out), out.shape[1], int(channel_offset),
-                                         stream_ptr(xx.device)), "patch_conv_bias_relu")
+                                         w if w_valid is None else int(w_valid), int(bool(relu)), ptr(out),
+                                         out.shape[1], int(channel_offset), stream_ptr(xx.device)),
+          "patch_conv_bias_relu")
     return out
 
 

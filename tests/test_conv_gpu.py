@@ -80,10 +80,61 @@ def test_grouped_conv3x3_small_matches_torch(co, h, w):
 def test_unsupported_shapes_are_refused():
     from paddle3d_amd.ops import conv
 
-    x = torch.randn(1, 8, 6, 48).cuda()
     wp = torch.zeros(1, 1, 72, 64).cuda()
-    with pytest.raises(RuntimeError):
-        conv.conv3x3_bias_relu(x, wp, None, 64, True)
+    with pytest.raises(RuntimeError):  # rows that are not float4-aligned
+        conv.conv3x3_bias_relu(torch.randn(1, 8, 6, 46).cuda(), wp, None, 64, True)
+    with pytest.raises(RuntimeError):  # odd input height at stride 2
+        conv.conv3x3_bias_relu(torch.randn(1, 8, 7, 48).cuda(), wp, None, 64, True, stride=2)
+    assert not conv.supported(8, 64, 7, 48, 2) and not conv.supported(4, 64, 8, 48)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,stride", [(1, 8, 64, 6, 48, 1), (2, 16, 64, 45, 180, 1), (1, 64, 128, 90, 180, 2),
+                                                   (2, 128, 256, 180, 180, 2), (1, 8, 64, 10, 36, 2), (1, 8, 64, 5, 12, 1)])
+def test_conv3x3_partial_tiles_match_torch(n, cin, cout, h, w, stride):
+    """Maps that are not a multiple of the 4 x 32 pixel tile: partial border tiles with masked stores (the
+    CenterPoint-Voxel stride-2 layer 180 x 180 -> 90 x 90 is one of them)."""
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator().manual_seed(cin + cout + h + w)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = torch.relu(F.conv2d(x, wt, b, stride=stride, padding=1))
+    assert conv.supported(cin, cout, h, w, stride)
+    out = conv.conv3x3_bias_relu(x.cuda(), conv.pack_conv3x3_weight(wt.cuda()), b.cuda(), cout, True, stride=stride).cpu()
+    wo = ref.shape[3]
+    assert out.shape == ref.shape[:3] + (conv.pitch4(wo),)  # rows zero-padded to a multiple of 4
+    assert (out[..., :wo] - ref).abs().max().item() < 2e-4, (out[..., :wo] - ref).abs().max().item()
+    assert not out[..., wo:].any()
+
+
+def test_conv_chain_on_padded_rows_matches_torch():
+    """A 90-wide stage (CenterPoint-Voxel block 2) as the model runs it: stride-2 conv into zero-padded rows of
+    pitch 92, two Winograd convolutions and the transposed FPN convolution reading them through w_valid."""
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 16, 20, 180, generator=g)
+    w0 = torch.randn(64, 16, 3, 3, generator=g) / 12
+    w1 = torch.randn(64, 64, 3, 3, generator=g) / 24
+    wt = torch.randn(64, 32, 2, 2, generator=g) / 8
+    b = torch.randn(64, generator=g) * 0.1
+    bt = torch.randn(32, generator=g) * 0.1
+    ref = torch.relu(F.conv2d(x, w0, b, stride=2, padding=1))
+    ref = torch.relu(F.conv2d(ref, w1, b, padding=1))
+    ref = torch.relu(F.conv2d(ref, w1, b, padding=1))
+    up = torch.relu(F.conv_transpose2d(ref, wt, bt, stride=2))
+    y = conv.conv3x3_bias_relu(x.cuda(), conv.pack_conv3x3_weight(w0.cuda()), b.cuda(), 64, True, stride=2)
+    assert y.shape == (1, 64, 10, 92)
+    u = conv.pack_winograd43_weight(w1.cuda())
+    y = conv.conv3x3_winograd43_bias_relu(y, u, b.cuda(), 64, True, w_valid=90)
+    y = conv.conv3x3_winograd43_bias_relu(y, u, b.cuda(), 64, True, w_valid=90)
+    assert (y.cpu()[..., :90] - ref).abs().max().item() < 5e-4 and not y[..., 90:].any()
+    out = torch.full((1, 40, 20, 180), -7.0, device="cuda")
+    conv.patch_conv_bias_relu(y, conv.pack_patch_weight(wt.cuda(), 2, True), bt.cuda(), 2, 32, out, 4, w_valid=90)
+    got = out.cpu()
+    assert (got[:, 4:36] - up).abs().max().item() < 5e-4
+    assert (got[:, :4] == -7.0).all() and (got[:, 36:] == -7.0).all()
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 128), (1, 8, 32, 8, 32), (1, 128, 96, 16, 64),
@@ -122,13 +173,16 @@ def test_winograd_shift_taps():
             assert (out - want).abs().max().item() < 1e-3, (ky, kx)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 11, 12])
 def test_patch_conv_matches_torch(mode):
-    """FPN patch convolutions (second_fpn.py:99-157) written at a channel offset of a wider tensor."""
+    """FPN patch convolutions (second_fpn.py:99-157) written at a channel offset of a wider tensor; modes 11 / 12
+    are modes 1 / 2 on planes that are not a multiple of the 256-pixel tile (CenterPoint-Voxel: 180 x 180, 90 x 90)."""
     from paddle3d_amd.ops import conv
 
     g = torch.Generator().manual_seed(mode)
     n, off, ctot = 2, 64, 256
+    odd = mode > 2
+    mode = mode % 10
     if mode == 0:
         cin, cout, h, w = 16, 128, 8, 256
         wt = torch.randn(cout, cin, 2, 2, generator=g) / (cin * 4) ** 0.5
@@ -137,14 +191,14 @@ def test_patch_conv_matches_torch(mode):
         ref = torch.relu(F.conv2d(x, wt, b, stride=2))
         tr = False
     elif mode == 1:
-        cin, cout, h, w = 32, 64, 16, 32
+        cin, cout, h, w = (32, 64, 45, 180) if odd else (32, 64, 16, 32)
         wt = torch.randn(cin, cout, 1, 1, generator=g) / cin ** 0.5
         x = torch.randn(n, cin, h, w, generator=g)
         b = torch.randn(cout, generator=g)
         ref = torch.relu(F.conv_transpose2d(x, wt, b, stride=1))
         tr = True
     else:
-        cin, cout, h, w = 48, 128, 16, 16
+        cin, cout, h, w = (48, 128, 90, 90) if odd else (48, 128, 16, 16)
         wt = torch.randn(cin, cout, 2, 2, generator=g) / cin ** 0.5
         x = torch.randn(n, cin, h, w, generator=g)
         b = torch.randn(cout, generator=g)

@@ -50,7 +50,8 @@ def _worker(rank, world, port, q):
     rec = pdist.pack_records(boxes, scores, labels, counts, max_per_img=10)
     all_rec, all_cnt = pdist.gather_detections(rec, counts)
     dist.barrier()
-    q.put((rank, all_rec.clone(), all_cnt.clone(), frames))
+    # numpy arrays travel by value (tensors would go through shared-memory handles that die with this process)
+    q.put((rank, all_rec.numpy().copy(), all_cnt.numpy().copy(), frames))
     dist.destroy_process_group()
 
 
@@ -67,6 +68,7 @@ def test_shard_and_gather_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     results.sort(key=lambda t: t[0])
+    results = [(r, torch.from_numpy(a), torch.from_numpy(b), f) for r, a, b, f in results]
     (_, rec0, cnt0, fr0), (_, rec1, cnt1, fr1) = results
     # both ranks hold identical gathered data
     assert torch.equal(rec0, rec1) and torch.equal(cnt0, cnt1)

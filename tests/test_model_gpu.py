@@ -63,7 +63,7 @@ def test_end_to_end_detections(oracle):
         # same BEV features (already checked against the oracle above) through the CPU dense graph
         bev = model.extract_pillars(torch.from_numpy(pts[b:b + 1]).cuda()).cpu()
         with torch.no_grad():
-            preds, _ = cpu.bbox_head(cpu.dense_forward(bev))
+            preds, _ = oracle.center_head_torch(cpu.bbox_head, oracle.dense_forward_torch(cpu, bev))
         tasks = [{k: v.numpy() for k, v in p.items()} for p in preds]
         rb, rs, rl, margins = oracle.centerpoint_postprocess(
             tasks, cfg["voxel_size"] + [8.0], cfg["point_cloud_range"] + [0.0] * 4, cfg["post_center_limit_range"],
@@ -125,25 +125,24 @@ def test_centerpoint_voxel_forward():
     assert torch.equal(dets[0]["box3d_lidar"], dets2[0]["box3d_lidar"])
 
 
-def test_hip_dense_backend_matches_miopen(monkeypatch):
-    """The hand-written fp32-MFMA convolution path gives the same BEV feature map as the MIOpen path."""
+def test_dense_graph_matches_torch(oracle):
+    """The hand-written fp32-MFMA convolution path gives the same BEV feature map as the torch statement of the
+    same layers (oracle.dense_forward_torch; MIOpen on the GPU)."""
     from paddle3d_amd import centerpoint as cpm
 
     torch.manual_seed(4)
     a = cpm.centerpoint_pillars_nuscenes().cuda().eval()
     _randomise_bn(a)
     x = torch.randn(1, 64, 512, 512, device="cuda")
-    a.dense_backend = "miopen"
-    ref = a.dense_forward(x)
-    a.dense_backend = "hip"
-    a._dense = None
-    out = a.dense_forward(x)
+    with torch.no_grad():
+        ref = oracle.dense_forward_torch(a, x)
+        out = a.dense_forward(x)
     assert out.shape == ref.shape == (1, 384, 128, 128)
     assert (out - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
 
 
-def test_hip_dense_backend_head_matches_miopen():
-    """CenterHead with the shared / first-stage convolutions on the hand-written MFMA kernel."""
+def test_center_head_matches_torch(oracle):
+    """CenterHead with the shared / first-stage / final convolutions on the hand-written kernels vs torch."""
     from paddle3d_amd import centerpoint as cpm
 
     torch.manual_seed(5)
@@ -151,12 +150,66 @@ def test_hip_dense_backend_head_matches_miopen():
     _randomise_bn(a)
     x = torch.randn(2, 384, 128, 128, device="cuda")
     head = a.bbox_head
-    head.dense_backend = "miopen"
-    ref, shared_ref = head(x)
-    head.dense_backend = "hip"
-    out, shared = head(x)
+    with torch.no_grad():
+        ref, shared_ref = oracle.center_head_torch(head, x)
+        out, shared = head(x)
     assert (shared - shared_ref).abs().max().item() < 1e-3 * max(1.0, shared_ref.abs().max().item())
     for r, o in zip(ref, out):
         for k in r:
             assert o[k].shape == r[k].shape
             assert (o[k] - r[k]).abs().max().item() < 1e-3 * max(1.0, r[k].abs().max().item()), k
+
+
+def test_voxel_dense_graph_matches_torch(oracle):
+    """CenterPoint-Voxel's dense half (180 x 180 maps: partial border tiles in every kernel, a stride-2 layer to
+    90 x 90, 1x1 and transposed FPN levels on planes that are not a multiple of the 256-pixel tile) vs torch."""
+    from paddle3d_amd import centerpoint as cpm
+
+    torch.manual_seed(6)
+    a = cpm.centerpoint_voxels_nuscenes().cuda().eval()
+    _randomise_bn(a)
+    x = torch.randn(2, 256, 180, 180, device="cuda")
+    with torch.no_grad():
+        ref = oracle.dense_forward_torch(a, x)
+        out = a.dense_forward(x)
+        href, _ = oracle.center_head_torch(a.bbox_head, ref)
+        hout, _ = a.bbox_head(ref)
+    assert out.shape == ref.shape == (2, 512, 180, 180)
+    assert (out - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+    for r, o in zip(href, hout):
+        for k in r:
+            assert (o[k] - r[k]).abs().max().item() < 1e-3 * max(1.0, r[k].abs().max().item()), k
+
+
+def test_training_mode_and_unsupported_shapes_raise():
+    """No silent change of backend: training mode and shapes without a kernel raise."""
+    from paddle3d_amd import centerpoint as cpm
+    from paddle3d_amd._lib import Paddle3DAmdError
+
+    a = cpm.centerpoint_pillars_nuscenes().cuda()
+    a.train()
+    with pytest.raises(RuntimeError, match="inference path only"):
+        a.backbone(torch.randn(1, 64, 64, 64, device="cuda"))
+    a.eval()
+    with pytest.raises(Paddle3DAmdError, match="unsupported configuration"):
+        a.backbone(torch.randn(1, 64, 62, 62, device="cuda"))  # rows are not float4-aligned
+
+
+def test_packed_weights_follow_the_parameters(oracle):
+    """folded / packed weights must be rebuilt after load_state_dict (no stale data_ptr-keyed cache)."""
+    from paddle3d_amd import centerpoint as cpm
+
+    torch.manual_seed(7)
+    a = cpm.centerpoint_pillars_nuscenes().cuda().eval()
+    b = cpm.centerpoint_pillars_nuscenes().cuda().eval()
+    _randomise_bn(b)
+    x = torch.randn(1, 64, 512, 512, device="cuda")
+    with torch.no_grad():
+        first = a.dense_forward(x)            # builds a's folded + packed weights
+        a.load_state_dict(b.state_dict())     # new parameters: the caches must go
+        got = a.dense_forward(x)
+        want = b.dense_forward(x)
+        ref = oracle.dense_forward_torch(b, x)
+    assert not torch.equal(first, got)
+    assert torch.equal(got, want)
+    assert (got - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())

@@ -62,11 +62,21 @@ def _post(oracle, tasks, with_velocity=True, **over):
     cfg = dict(CP_CFG, **over)
     lists = {k: [_cuda(t[k]) for t in tasks] for k in ("hm", "reg", "height", "dim", "vel", "rot")}
     num_classes = LABEL_OFFSETS * len(tasks)  # the len(tasks)**2 list the reference caller builds
-    b, s, l = cp.centerpoint_postprocess(lists["hm"], lists["reg"], lists["height"], lists["dim"], lists["vel"],
-                                         lists["rot"], cfg["voxel_size"], cfg["point_cloud_range"],
-                                         cfg["post_center_range"], num_classes, cfg["down_ratio"],
-                                         cfg["score_threshold"], cfg["nms_iou_threshold"],
-                                         cfg["nms_pre_max_size"], cfg["nms_post_max_size"], with_velocity)
+    full_sort = cfg.pop("full_sort", False)
+    if full_sort:  # the reference's own selection (full stable sort), through the explicit `selection` argument
+        bb, ss, ll, nn = cp.centerpoint_postprocess_device(
+            lists["hm"], lists["reg"], lists["height"], lists["dim"], lists["vel"], lists["rot"], cfg["voxel_size"],
+            cfg["point_cloud_range"], cfg["post_center_range"], num_classes, cfg["down_ratio"],
+            cfg["score_threshold"], cfg["nms_iou_threshold"], cfg["nms_pre_max_size"], cfg["nms_post_max_size"],
+            with_velocity, full_sort=True)
+        k = int(nn.item())
+        b, s, l = bb[0, :k], ss[0, :k], ll[0, :k]
+    else:
+        b, s, l = cp.centerpoint_postprocess(lists["hm"], lists["reg"], lists["height"], lists["dim"], lists["vel"],
+                                             lists["rot"], cfg["voxel_size"], cfg["point_cloud_range"],
+                                             cfg["post_center_range"], num_classes, cfg["down_ratio"],
+                                             cfg["score_threshold"], cfg["nms_iou_threshold"],
+                                             cfg["nms_pre_max_size"], cfg["nms_post_max_size"], with_velocity)
     rb, rs, rl, margins = oracle.centerpoint_postprocess(
         tasks, cfg["voxel_size"] + [8.0], cfg["point_cloud_range"] + [0.0] * 4, cfg["post_center_range"],
         LABEL_OFFSETS[: len(tasks)], cfg["down_ratio"], cfg["score_threshold"], cfg["nms_iou_threshold"],
@@ -107,16 +117,14 @@ def test_centerpoint_postprocess_edges(oracle):
 
 
 @pytest.mark.parametrize("pre", [37, 100, 1000])
-def test_postprocess_topk_select_equals_full_sort(oracle, monkeypatch, pre):
+def test_postprocess_topk_select_equals_full_sort(oracle, pre):
     """The LDS top-K selection (cut-off key + ties in cell order) gives exactly the full stable sort's result,
     also when many cells share one score: quantised heat maps put hundreds of ties at the cut-off."""
     tasks = synth.center_head_outputs(7, feat_h=128, feat_w=128, n_peaks=50)
     for t in tasks:
         t["hm"] = (np.round(t["hm"] * 2.0) / 2.0 + 3.0).astype(np.float32)  # few distinct values, all selected
-    monkeypatch.delenv("PD3_POSTPROCESS_FULL_SORT", raising=False)
     (b, s, l), (rb, rs, rl), _ = _post(oracle, tasks, nms_pre_max_size=pre, nms_post_max_size=83)
-    monkeypatch.setenv("PD3_POSTPROCESS_FULL_SORT", "1")
-    (b2, s2, l2), _, _ = _post(oracle, tasks, nms_pre_max_size=pre, nms_post_max_size=83)
+    (b2, s2, l2), _, _ = _post(oracle, tasks, nms_pre_max_size=pre, nms_post_max_size=83, full_sort=True)
     assert b.shape == b2.shape
     np.testing.assert_array_equal(l, l2)
     np.testing.assert_array_equal(s, s2)

@@ -6,7 +6,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from paddle3d_amd import centerpoint as cpm  # noqa: E402
 from paddle3d_amd import synth  # noqa: E402
 

@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from paddle3d_amd.ops import conv  # noqa: E402
 
 cin, cout, hw, B = (int(a) for a in (sys.argv[1:5] if len(sys.argv) > 4 else (128, 128, 128, 8)))
