@@ -384,3 +384,59 @@ def center_head_torch(head, x):
             d[name] = t
         rets.append(d)
     return rets, x
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Sparse middle encoders by densification: the public definition of paddle.sparse.nn.SubmConv3D / Conv3D /
+# BatchNorm (Paddle core, not vendored: parity unpinned against Paddle's own kernels) stated with dense torch
+# conv3d on the CPU -- a submanifold convolution keeps the input's active set, a regular one activates every
+# output some active input reaches, BatchNorm / ReLU / add act on active sites only.
+# ---------------------------------------------------------------------------------------------------------
+def sparse_encoder_dense_torch(net, feats, coords, batch):
+    """Dense statement of SparseResNet3D.forward (sparse_resnet.py:184-206) / SparseNet3D.forward
+    (sparsenet.py:140-182) for the module mirrors in paddle3d_amd/sparse.py.  Returns the [B, C*D, H, W] map."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    d, h, w = net.sparse_shape
+    co = torch.as_tensor(np.asarray(coords)).long()
+    x = torch.zeros(batch, feats.shape[1], d, h, w)
+    x[co[:, 0], :, co[:, 1], co[:, 2], co[:, 3]] = torch.as_tensor(np.asarray(feats))
+    mask = torch.zeros(batch, 1, d, h, w)
+    mask[co[:, 0], 0, co[:, 1], co[:, 2], co[:, 3]] = 1
+
+    def conv(m, t, mk):
+        wt = m.weight.detach().cpu().permute(4, 3, 0, 1, 2).contiguous()  # [kd,kh,kw,ci,co] -> [co,ci,kd,kh,kw]
+        b = None if m.bias is None else m.bias.detach().cpu()
+        if m.subm:
+            return F.conv3d(t, wt, b, padding=tuple(k // 2 for k in m.ks)) * mk, mk
+        nm = (F.conv3d(mk, torch.ones(1, 1, *m.ks), stride=m.stride, padding=m.padding) > 0).float()
+        return F.conv3d(t, wt, b, stride=m.stride, padding=m.padding) * nm, nm
+
+    def bn(m, t, mk):
+        sc = (m.weight / torch.sqrt(m.running_var + m.eps)).detach().cpu().view(1, -1, 1, 1, 1)
+        sh = (m.bias.detach().cpu().view(1, -1, 1, 1, 1) - m.running_mean.detach().cpu().view(1, -1, 1, 1, 1) * sc)
+        return (t * sc + sh) * mk
+
+    def run(mod, t, mk):
+        if isinstance(mod, nn.Sequential):
+            for sub in mod:
+                t, mk = run(sub, t, mk)
+            return t, mk
+        if hasattr(mod, "conv1") and hasattr(mod, "bn2"):  # SparseBasicBlock, sparse_resnet.py:92-111
+            o, _ = conv(mod.conv1, t, mk)
+            o = torch.relu(bn(mod.bn1, o, mk))
+            o, _ = conv(mod.conv2, o, mk)
+            return torch.relu(bn(mod.bn2, o, mk) + t), mk
+        if isinstance(mod, nn.BatchNorm1d):
+            return bn(mod, t, mk), mk
+        if isinstance(mod, nn.ReLU):
+            return torch.relu(t), mk
+        return conv(mod, t, mk)
+
+    with torch.no_grad():
+        for stage in (net.conv_input, net.conv1, net.conv2, net.conv3, net.conv4, net.extra_conv):
+            x, mask = run(stage, x, mask)
+    n, c, dd, hh, ww = x.shape
+    return x.reshape(n, c * dd, hh, ww)

@@ -578,14 +578,17 @@ def centerpoint_pillars_nuscenes(max_num_voxels=(30000, 60000)) -> CenterPoint:
         test_cfg=test_cfg, box_with_velocity=True)
 
 
-def centerpoint_voxels_nuscenes(max_num_voxels=(120000, 160000)) -> CenterPoint:
-    """configs/centerpoint/centerpoint_voxels_0075voxel_nuscenes_10sweep.yml:111-173, random init."""
+def centerpoint_voxels_nuscenes(max_num_voxels=(120000, 160000), point_cloud_range=None) -> CenterPoint:
+    """configs/centerpoint/centerpoint_voxels_0075voxel_nuscenes_10sweep.yml:111-173, random init.
+    point_cloud_range overrides the config's [-54, -54, -5, 54, 54, 3] (the tests run a quarter-range copy whose
+    dense statement fits a CPU)."""
     from .sparse import SparseResNet3D
 
-    pcr, vs = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0], [0.075, 0.075, 0.2]
+    pcr = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0] if point_cloud_range is None else list(map(float, point_cloud_range))
+    vs = [0.075, 0.075, 0.2]
     test_cfg = dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], max_per_img=500,
                     nms=dict(nms_pre_max_size=1000, nms_post_max_size=83, nms_iou_threshold=0.2),
-                    score_threshold=0.1, point_cloud_range=[-54.0, -54.0], down_ratio=8, voxel_size=[0.075, 0.075])
+                    score_threshold=0.1, point_cloud_range=pcr[:2], down_ratio=8, voxel_size=[0.075, 0.075])
     return CenterPoint(
         voxelizer=HardVoxelizer(vs, pcr, 10, list(max_num_voxels)),
         voxel_encoder=VoxelMean(5),

@@ -45,6 +45,10 @@ def indices(coords: torch.Tensor, batch: int, spatial_shape, kernel_size, stride
     n_in = c.shape[0]
     kvol = ks[0] * ks[1] * ks[2]
     dev = c.device
+    if n_in == 0:  # an empty voxel set gives an empty sparse tensor (the reference's layers accept nnz == 0)
+        shape = tuple(spatial_shape) if subm else out_spatial_shape(spatial_shape, ks, st, pd)
+        return SparseIndices(torch.empty((0, 4), dtype=torch.int32, device=dev),
+                             torch.empty((0, kvol), dtype=torch.int32, device=dev), 0, shape, kvol)
     if subm:
         out_shape = tuple(spatial_shape)
         cap = n_in

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from .ops import sparse_conv3d as _sp
 
-__all__ = ["SparseConvTensor", "SubmConv3D", "Conv3D", "SparseBasicBlock", "SparseResNet3D"]
+__all__ = ["SparseConvTensor", "SubmConv3D", "Conv3D", "SparseBasicBlock", "SparseResNet3D", "SparseNet3D"]
 
 
 class SparseConvTensor:
@@ -85,15 +85,38 @@ def _fold(bn: nn.BatchNorm1d):
     return scale.detach().contiguous(), (bn.bias - bn.running_mean * scale).detach().contiguous()
 
 
-class _ConvBnRelu(nn.Module):
-    def __init__(self, conv):
-        super().__init__()
-        self.conv = conv
-        self.bn = nn.BatchNorm1d(conv.weight.shape[-1], eps=1e-3, momentum=0.01)
+def _bn(channels):
+    """paddle.sparse.nn.BatchNorm(eps 1e-3) acts on the values only: a BatchNorm1d over the feature rows.  The
+    parameter names (weight, bias, running_mean / running_var <- _mean / _variance) follow the reference's."""
+    return nn.BatchNorm1d(channels, eps=1e-3, momentum=0.01)
 
-    def forward(self, x, residual=None):
-        s, b = _fold(self.bn)
-        return self.conv(x, s, b, residual, relu=True)
+
+def _run_sequential(seq: nn.Sequential, x: SparseConvTensor) -> SparseConvTensor:
+    """Runs a reference-shaped Sequential(conv, BatchNorm, ReLU, blocks ...): every conv + BatchNorm (+ ReLU)
+    triple is ONE fused kernel call (BatchNorm folded into the convolution epilogue)."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, _SparseConv):
+            bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d) else None
+            relu = bn is not None and i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            if bn is None:
+                x = m(x)
+                i += 1
+            else:
+                s, b = _fold(bn)
+                x = m(x, s, b, None, relu=relu)
+                i += 3 if relu else 2
+        elif isinstance(m, nn.Sequential):
+            x = _run_sequential(m, x)
+            i += 1
+        elif isinstance(m, (nn.BatchNorm1d, nn.ReLU)):
+            raise RuntimeError("sparse Sequential: BatchNorm / ReLU without a convolution in front")
+        else:
+            x = m(x)
+            i += 1
+    return x
 
 
 class SparseBasicBlock(nn.Module):
@@ -102,9 +125,9 @@ class SparseBasicBlock(nn.Module):
     def __init__(self, in_channels, out_channels, indice_key=None):
         super().__init__()
         self.conv1 = SubmConv3D(in_channels, out_channels, 3, bias=True, key=indice_key)
-        self.bn1 = nn.BatchNorm1d(out_channels, eps=1e-3, momentum=0.01)
+        self.bn1 = _bn(out_channels)
         self.conv2 = SubmConv3D(out_channels, out_channels, 3, bias=True, key=indice_key)
-        self.bn2 = nn.BatchNorm1d(out_channels, eps=1e-3, momentum=0.01)
+        self.bn2 = _bn(out_channels)
 
     def forward(self, x):
         s1, b1 = _fold(self.bn1)
@@ -113,41 +136,98 @@ class SparseBasicBlock(nn.Module):
         return self.conv2(out, s2, b2, x.features, relu=True)  # relu(bn2(conv2) + identity), :104-109
 
 
+def _sparse_shape(voxel_size, point_cloud_range):
+    pcr = np.array(point_cloud_range, dtype=np.float32)
+    vs = np.array(voxel_size, dtype=np.float32)
+    grid = np.round((pcr[3:] - pcr[:3]) / vs).astype(np.int64)
+    return tuple(int(v) for v in (np.array(grid[::-1]) + [1, 0, 0]))  # sparse_resnet.py:173 / sparsenet.py:121
+
+
+def _raster_order(coors, shape):
+    """Rows in raster order: tiles of consecutive rows are then spatial neighbours, so a tile's kernel offsets are
+    mostly all-present or all-absent (skipped) and its gathers share cache lines.  The final dense map does not
+    depend on the row order."""
+    d, h, w = shape
+    c64 = coors.long()
+    return torch.argsort(((c64[:, 0] * d + c64[:, 1]) * h + c64[:, 2]) * w + c64[:, 3])
+
+
+def _densify(x: SparseConvTensor):
+    return x.dense()  # to_dense + transpose([0, 4, 1, 2, 3]) + reshape [N, C * D, H, W], sparse_resnet.py:202-205
+
+
 class SparseResNet3D(nn.Module):
-    """sparse_resnet.py:115-206.  forward(voxel_features [M, C], coors [M, 4] (b,z,y,x), batch_size) ->
-    dense [B, 128 * D', H', W'] BEV map."""
+    """sparse_resnet.py:115-206, with the reference's parameter names (Sequential indices: conv_input.0.weight,
+    conv_input.1._mean, conv2.0.weight, conv2.3.conv1.weight ...) so that a converted checkpoint places every key.
+    forward(voxel_features [M, C], coors [M, 4] (b,z,y,x), batch_size) -> dense [B, 128 * D', H', W'] BEV map."""
 
     def __init__(self, in_channels=128, voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1)):
         super().__init__()
-        self.conv_input = _ConvBnRelu(SubmConv3D(in_channels, 16, 3, bias=False, key="res0"))
+        self.conv_input = nn.Sequential(SubmConv3D(in_channels, 16, 3, bias=False, key="res0"), _bn(16), nn.ReLU())
         self.conv1 = nn.Sequential(SparseBasicBlock(16, 16, "res0"), SparseBasicBlock(16, 16, "res0"))
-        self.conv2_down = _ConvBnRelu(Conv3D(16, 32, 3, 2, padding=1, bias=False))
-        self.conv2 = nn.Sequential(SparseBasicBlock(32, 32, "res1"), SparseBasicBlock(32, 32, "res1"))
-        self.conv3_down = _ConvBnRelu(Conv3D(32, 64, 3, 2, padding=1, bias=False))
-        self.conv3 = nn.Sequential(SparseBasicBlock(64, 64, "res2"), SparseBasicBlock(64, 64, "res2"))
-        self.conv4_down = _ConvBnRelu(Conv3D(64, 128, 3, 2, padding=(0, 1, 1), bias=False))
-        self.conv4 = nn.Sequential(SparseBasicBlock(128, 128, "res3"), SparseBasicBlock(128, 128, "res3"))
-        self.extra_conv = _ConvBnRelu(Conv3D(128, 128, (3, 1, 1), (2, 1, 1), bias=False))
-        pcr = np.array(point_cloud_range, dtype=np.float32)
-        vs = np.array(voxel_size, dtype=np.float32)
-        grid = np.round((pcr[3:] - pcr[:3]) / vs).astype(np.int64)
-        self.sparse_shape = tuple(int(v) for v in (np.array(grid[::-1]) + [1, 0, 0]))  # :173
+        self.conv2 = nn.Sequential(Conv3D(16, 32, 3, 2, padding=1, bias=False), _bn(32), nn.ReLU(),
+                                   SparseBasicBlock(32, 32, "res1"), SparseBasicBlock(32, 32, "res1"))
+        self.conv3 = nn.Sequential(Conv3D(32, 64, 3, 2, padding=1, bias=False), _bn(64), nn.ReLU(),
+                                   SparseBasicBlock(64, 64, "res2"), SparseBasicBlock(64, 64, "res2"))
+        self.conv4 = nn.Sequential(Conv3D(64, 128, 3, 2, padding=(0, 1, 1), bias=False), _bn(128), nn.ReLU(),
+                                   SparseBasicBlock(128, 128, "res3"), SparseBasicBlock(128, 128, "res3"))
+        self.extra_conv = nn.Sequential(Conv3D(128, 128, (3, 1, 1), (2, 1, 1), bias=False), _bn(128), nn.ReLU())
+        self.sparse_shape = _sparse_shape(voxel_size, point_cloud_range)
         self.in_channels = in_channels
 
     @torch.no_grad()
     def forward(self, voxel_features, coors, batch_size):
-        # rows in raster order: tiles of consecutive rows are then spatial neighbours, so a tile's kernel
-        # offsets are mostly all-present or all-absent (skipped) and its gathers share cache lines.  The
-        # final dense map does not depend on the row order.
-        d, h, w = self.sparse_shape
-        c64 = coors.long()
-        order = torch.argsort(((c64[:, 0] * d + c64[:, 1]) * h + c64[:, 2]) * w + c64[:, 3])
+        order = _raster_order(coors, self.sparse_shape)
         x = SparseConvTensor(voxel_features[order].contiguous(), coors[order].contiguous(), self.sparse_shape,
                              batch_size)
-        x = self.conv_input(x)
-        x = self.conv1(x)
-        x = self.conv2(self.conv2_down(x))
-        x = self.conv3(self.conv3_down(x))
-        x = self.conv4(self.conv4_down(x))
-        x = self.extra_conv(x)
-        return x.dense()
+        for stage in (self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4, self.extra_conv):
+            x = _run_sequential(stage, x)
+        return _densify(x)
+
+
+def _sparse_conv_bn_relu(in_channels, out_channels, kernel_size, stride=1, padding=0, conv_type="subm"):
+    """sparsenet.py:31-64."""
+    if conv_type == "subm":
+        conv = SubmConv3D(in_channels, out_channels, kernel_size, bias=False)
+    elif conv_type == "spconv":
+        conv = Conv3D(in_channels, out_channels, kernel_size, stride, padding, bias=False)
+    else:
+        raise NotImplementedError(conv_type)
+    return nn.Sequential(conv, _bn(out_channels), nn.ReLU())
+
+
+class SparseNet3D(nn.Module):
+    """sparsenet.py:68-182 (the plain conv-bn-relu sparse encoder of the reference's voxel R-CNN family), with the
+    reference's parameter names.  forward -> the reference's batch_dict: spatial_features [B, 128 * D', H', W'],
+    spatial_features_stride 8, multi_scale_3d_features x_conv1..4 (SparseConvTensor) and their strides."""
+
+    def __init__(self, in_channels=128, voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1)):
+        super().__init__()
+        self.conv_input = nn.Sequential(SubmConv3D(in_channels, 16, 3, bias=False), _bn(16), nn.ReLU())
+        self.conv1 = nn.Sequential(_sparse_conv_bn_relu(16, 16, 3, padding=1))
+        self.conv2 = nn.Sequential(_sparse_conv_bn_relu(16, 32, 3, stride=2, padding=1, conv_type="spconv"),
+                                   _sparse_conv_bn_relu(32, 32, 3, padding=1), _sparse_conv_bn_relu(32, 32, 3, padding=1))
+        self.conv3 = nn.Sequential(_sparse_conv_bn_relu(32, 64, 3, stride=2, padding=1, conv_type="spconv"),
+                                   _sparse_conv_bn_relu(64, 64, 3, padding=1), _sparse_conv_bn_relu(64, 64, 3, padding=1))
+        self.conv4 = nn.Sequential(_sparse_conv_bn_relu(64, 64, 3, stride=2, padding=(0, 1, 1), conv_type="spconv"),
+                                   _sparse_conv_bn_relu(64, 64, 3, padding=1), _sparse_conv_bn_relu(64, 64, 3, padding=1))
+        self.extra_conv = nn.Sequential(Conv3D(64, 128, (3, 1, 1), (2, 1, 1), padding=0, bias=False), _bn(128), nn.ReLU())
+        self.sparse_shape = _sparse_shape(voxel_size, point_cloud_range)
+        self.in_channels = in_channels
+        self.num_point_features = 128
+        self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 64}
+
+    @torch.no_grad()
+    def forward(self, voxel_features, coors, batch_size):
+        order = _raster_order(coors, self.sparse_shape)
+        x = SparseConvTensor(voxel_features[order].contiguous(), coors[order].contiguous(), self.sparse_shape,
+                             batch_size)
+        x = _run_sequential(self.conv_input, x)
+        x1 = _run_sequential(self.conv1, x)
+        x2 = _run_sequential(self.conv2, x1)
+        x3 = _run_sequential(self.conv3, x2)
+        x4 = _run_sequential(self.conv4, x3)
+        out = _densify(_run_sequential(self.extra_conv, x4))
+        return {"spatial_features": out, "spatial_features_stride": 8,
+                "multi_scale_3d_features": {"x_conv1": x1, "x_conv2": x2, "x_conv3": x3, "x_conv4": x4},
+                "multi_scale_3d_strides": {"x_conv1": 1, "x_conv2": 2, "x_conv3": 4, "x_conv4": 8}}

@@ -38,8 +38,13 @@ def test_loader_binds_every_symbol(built):
 
 
 def test_library_is_gfx950_code_object(built):
+    """The fat binary holds gfx950 code objects and nothing for another GPU family."""
+    import re
+
     data = open(built, "rb").read()
-    assert b"gfx950" in data and b"sm_" not in data[:0]
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", data))
+    assert targets == {b"gfx950"}, targets
+    assert not re.search(rb"\bsm_[0-9]{2}\b", data) and b".nv.info" not in data and b"nvptx" not in data
 
 
 def test_workspace_queries_need_no_gpu(built):

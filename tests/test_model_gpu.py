@@ -19,17 +19,20 @@ def _randomise_bn(model):
                 m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
 
 
-def test_bev_features_match_oracle(oracle):
-    """fp32 BEV features (scatter output) within 1e-3 abs of the oracle pipeline -- the north star's bar."""
+@pytest.mark.parametrize("cap", [30000, 60000])
+def test_bev_features_match_oracle(oracle, cap):
+    """fp32 BEV features (scatter output) within 1e-3 abs of the oracle pipeline -- the north star's bar -- at the
+    reference's training cap (30 000) and at its inference cap (60 000, max_num_voxels: [30000, 60000])."""
     from paddle3d_amd import centerpoint as cpm
 
     torch.manual_seed(0)
-    model = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(30000, 30000)).cuda().eval()
+    model = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(cap, cap)).cuda().eval()
     _randomise_bn(model)
     frames = [synth.nuscenes_sweep(60 + i) for i in range(2)]
     bev = model.extract_pillars(torch.from_numpy(np.stack(frames)).cuda()).cpu().numpy()
     for b, pts in enumerate(frames):
-        vox, co, npv, nv = oracle.hard_voxelize(pts, synth.NUSC_PILLAR, synth.NUSC_RANGE, 20, 30000)
+        vox, co, npv, nv = oracle.hard_voxelize(pts, synth.NUSC_PILLAR, synth.NUSC_RANGE, 20, cap)
+        assert nv == 30000 if cap == 30000 else 30000 < nv < 60000
         c4 = np.concatenate([np.zeros((nv, 1), np.int32), co[:nv]], 1)
         params = [dict(weight=l.linear.weight.t().detach().cpu().numpy(), gamma=l.norm.weight.detach().cpu().numpy(),
                        beta=l.norm.bias.detach().cpu().numpy(), mean=l.norm.running_mean.cpu().numpy(),
@@ -123,6 +126,58 @@ def test_centerpoint_voxel_forward():
     assert len(dets) == 2 and dets[0]["box3d_lidar"].shape[1] == 9
     dets2 = model.test_forward(pts)
     assert torch.equal(dets[0]["box3d_lidar"], dets2[0]["box3d_lidar"])
+
+
+def test_centerpoint_voxel_end_to_end_vs_oracle(oracle):
+    """CenterPoint-Voxel (config 4) end to end against the oracle pipeline on a quarter-range copy of the config
+    (0.075 m voxels, 41 x 256 x 256 sparse grid: the dense statement of the sparse encoder fits a CPU): reference
+    voxelizer -> voxel mean -> dense conv3d stack -> torch dense graph -> oracle postprocess."""
+    from paddle3d_amd import centerpoint as cpm
+
+    torch.manual_seed(8)
+    pcr = [-9.6, -9.6, -5.0, 9.6, 9.6, 3.0]
+    model = cpm.centerpoint_voxels_nuscenes(max_num_voxels=(40000, 40000), point_cloud_range=pcr).cuda().eval()
+    _randomise_bn(model)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_var.uniform_(0.5, 1.5)
+                m.running_mean.normal_(0, 0.1)
+        for task in model.bbox_head.tasks:
+            task.hm[-1].bias.fill_(-1.0)
+    assert model.middle_encoder.sparse_shape == (41, 256, 256)
+    pts = synth.nuscenes_sweep(93, n_points=120_000)
+    dets = model.test_forward(torch.from_numpy(pts).cuda().unsqueeze(0))
+    bev = model.extract_pillars(torch.from_numpy(pts).cuda().unsqueeze(0)).cpu()
+    cpu = cpm.centerpoint_voxels_nuscenes(max_num_voxels=(40000, 40000), point_cloud_range=pcr).eval()
+    cpu.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    vox, co, npv, nv = oracle.hard_voxelize(pts, synth.NUSC_VOXEL, pcr, 10, 40000)
+    assert 5000 < nv <= 40000
+    mean = oracle.voxel_mean(vox[:nv], npv[:nv])
+    c4 = np.concatenate([np.zeros((nv, 1), np.int32), co[:nv]], 1)
+    ref_bev = oracle.sparse_encoder_dense_torch(cpu.middle_encoder, mean, c4, 1)
+    assert bev.shape == ref_bev.shape == (1, 256, 32, 32)
+    assert (bev - ref_bev).abs().max().item() < 1e-3 * max(1.0, ref_bev.abs().max().item())
+    cfg = cpu.test_cfg
+    with torch.no_grad():
+        preds, _ = oracle.center_head_torch(cpu.bbox_head, oracle.dense_forward_torch(cpu, ref_bev))
+    tasks = [{k: v.numpy() for k, v in p.items()} for p in preds]
+    rb, rs, rl, margins = oracle.centerpoint_postprocess(
+        tasks, cfg["voxel_size"] + [8.0], cfg["point_cloud_range"] + [0.0] * 4, cfg["post_center_limit_range"],
+        [0, 1, 3, 5, 6, 8], cfg["down_ratio"], cfg["score_threshold"], cfg["nms"]["nms_iou_threshold"],
+        cfg["nms"]["nms_pre_max_size"], cfg["nms"]["nms_post_max_size"], True, return_margins=True)
+    got_b = dets[0]["box3d_lidar"].cpu().numpy()
+    got_s = dets[0]["scores"].cpu().numpy()
+    got_l = dets[0]["label_preds"].cpu().numpy()
+    strong = rs > cfg["score_threshold"] + 1e-3
+    assert strong.sum() > 0
+    matched = 0
+    for i in np.nonzero(strong)[0]:
+        d = np.abs(got_b[:, :2] - rb[i, :2]).sum(1) + (got_l != rl[i]) * 1e3
+        j = int(np.argmin(d))
+        if d[j] < 1e-2 and abs(got_s[j] - rs[i]) < 1e-3:
+            matched += 1
+    assert matched >= 0.98 * strong.sum(), (matched, int(strong.sum()), len(got_s))
 
 
 def test_dense_graph_matches_torch(oracle):

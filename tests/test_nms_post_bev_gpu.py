@@ -116,6 +116,32 @@ def test_centerpoint_postprocess_edges(oracle):
     np.testing.assert_allclose(b, rb, rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_centerpoint_postprocess_voxel_config(oracle, seed):
+    """CenterPoint-Voxel's head maps: 180 x 180, down_ratio 8, 0.075 m voxels, range -54 m (the map is larger than
+    the in-LDS top-K selection takes, so this is the full-sort branch) vs the oracle."""
+    tasks = synth.center_head_outputs(10 + seed, feat_h=180, feat_w=180, n_peaks=300)
+    (b, s, l), (rb, rs, rl), margins = _post(oracle, tasks, voxel_size=[0.075, 0.075], point_cloud_range=[-54.0, -54.0],
+                                             down_ratio=8)
+    assert b.shape == rb.shape and b.shape[0] > 50, (b.shape, rb.shape, margins)
+    np.testing.assert_array_equal(l, rl)
+    np.testing.assert_allclose(s, rs, rtol=0, atol=2e-7)
+    np.testing.assert_allclose(b, rb, rtol=2e-6, atol=2e-6)
+
+
+def test_postprocess_zero_pre_nms_cap(oracle):
+    """nms_pre_max_size = 0: num_bboxes_for_nms is 0 (postprocess.cu:212-216) -> no rows for tasks with candidates."""
+    from paddle3d_amd.ops import centerpoint_postprocess as cp
+
+    tasks = synth.center_head_outputs(2, feat_h=32, feat_w=32, n_peaks=30)
+    lists = {k: [_cuda(t[k]) for t in tasks] for k in ("hm", "reg", "height", "dim", "vel", "rot")}
+    b, s, l = cp.centerpoint_postprocess(lists["hm"], lists["reg"], lists["height"], lists["dim"], lists["vel"],
+                                         lists["rot"], CP_CFG["voxel_size"], CP_CFG["point_cloud_range"],
+                                         CP_CFG["post_center_range"], LABEL_OFFSETS * len(tasks), CP_CFG["down_ratio"],
+                                         CP_CFG["score_threshold"], CP_CFG["nms_iou_threshold"], 0, 83, True)
+    assert b.shape[0] == 0 and s.shape[0] == 0 and l.shape[0] == 0
+
+
 @pytest.mark.parametrize("pre", [37, 100, 1000])
 def test_postprocess_topk_select_equals_full_sort(oracle, pre):
     """The LDS top-K selection (cut-off key + ties in cell order) gives exactly the full stable sort's result,
@@ -167,6 +193,36 @@ def test_bev_pool_v2_exact(oracle, seed):
     dg, fg = bp.bev_pool_v2_bkwd(_cuda(g), _cuda(d["depth"]), _cuda(d["feat"]), _cuda(rd), _cuda(rf), _cuda(rb),
                                  _cuda(lengths), _cuda(starts))
     rdg, rfg = oracle.bev_pool_v2_bkwd(g, d["depth"], d["feat"], rd, rf, rb, lengths, starts)
+    np.testing.assert_array_equal(dg.cpu().numpy().view(np.uint32), rdg.view(np.uint32))
+    np.testing.assert_array_equal(fg.cpu().numpy().view(np.uint32), rfg.view(np.uint32))
+
+
+@pytest.mark.parametrize("kind", ["port", "ref"])
+def test_bev_pool_v2_full_size_exact(oracle, kind):
+    """BEVDet4D-sized op (6 x 118 x 16 x 44 frustum points, C = 80, 128 x 128 BEV): forward and both gradients
+    bit-exact against the oracle (ref = the reference's own kernels compiled from /root/reference, run serially)."""
+    from paddle3d_amd.ops import bev_pool_v2 as bp
+
+    if kind == "ref" and not oracle.have_ref():
+        pytest.skip("oracle/_ref not built")
+    d = synth.bev_pool_inputs(9)
+    assert d["ranks_bev"].size > 300_000 and d["feat"].shape[-1] == 80
+    names = ("ranks_depth", "ranks_feat", "ranks_bev", "interval_lengths", "interval_starts")
+    out = bp.bev_pool_v2(_cuda(d["depth"]), _cuda(d["feat"]), *[_cuda(d[k]) for k in names], d["bev_feat_shape"])
+    ref = oracle.bev_pool_v2(d["depth"], d["feat"], *[d[k] for k in names], d["bev_feat_shape"], kind=kind)
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    # backward: points re-sorted and intervals re-cut by ranks_feat, as the reference's PyLayer does
+    # (bevdet_transformer.py:52-79)
+    order = np.argsort(d["ranks_feat"], kind="stable")
+    rd, rf, rb = d["ranks_depth"][order], d["ranks_feat"][order], d["ranks_bev"][order]
+    flag = np.ones(len(rf), bool)
+    flag[1:] = rf[1:] != rf[:-1]
+    starts = np.nonzero(flag)[0].astype(np.int32)
+    lengths = np.diff(np.append(starts, len(rf))).astype(np.int32)
+    g = np.random.default_rng(3).normal(size=d["bev_feat_shape"]).astype(np.float32)
+    dg, fg = bp.bev_pool_v2_bkwd(_cuda(g), _cuda(d["depth"]), _cuda(d["feat"]), _cuda(rd), _cuda(rf), _cuda(rb),
+                                 _cuda(lengths), _cuda(starts))
+    rdg, rfg = oracle.bev_pool_v2_bkwd(g, d["depth"], d["feat"], rd, rf, rb, lengths, starts, kind=kind)
     np.testing.assert_array_equal(dg.cpu().numpy().view(np.uint32), rdg.view(np.uint32))
     np.testing.assert_array_equal(fg.cpu().numpy().view(np.uint32), rfg.view(np.uint32))
 
