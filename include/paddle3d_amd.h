@@ -213,6 +213,41 @@ int pd3_bev_pool_v2_bkwd(const float *out_grad, const float *depth, const float 
                          float *feat_grad, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * frustum_to_lidar -- LSSViewTransformer.get_lidar_coor (paddle3d/models/transformers/bevdet_transformer.py:
+ * 142-192): ego-frame coordinates of every point of the camera frustums.
+ *   frustum        [points_per_camera, 3] fp32 device: (u, v, depth) template of create_frustum (:126-140)
+ *   inv_post_rots  [batch*num_cams, 3, 3]  inverse of the image-space augmentation rotation
+ *   post_trans     [batch*num_cams, 3];  cam_to_ego [batch*num_cams, 3, 3] = rots @ inverse(cam2imgs)
+ *   trans          [batch*num_cams, 3];  bda [batch, 3, 3]                (all fp32, device)
+ *   coor           [batch*num_cams*points_per_camera, 3] fp32
+ */
+int pd3_frustum_to_lidar(const float *frustum, int64_t points_per_camera, int batch, int num_cams,
+                         const float *inv_post_rots, const float *post_trans, const float *cam_to_ego,
+                         const float *trans, const float *bda, float *coor, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * voxel_pooling_prepare -- the index build in front of bev_pool_v2, on the device: replaces
+ * LSSViewTransformer.voxel_pooling_prepare_v2 (paddle3d/models/transformers/bevdet_transformer.py:230-274: quantise
+ * every frustum point, keep the ones inside the grid, argsort by BEV rank, run-length encode into intervals) and
+ * the same steps of LiftSplatShoot.voxel_pooling (models/detection/bevfusion/cam_stream_lss.py:318-346).
+ *   coor           [num_points, 3] fp32 frustum points in the ego frame, num_points = B * N * D * H * W
+ *   depth_bins, feat_hw   D and H * W (ranks_feat of mode 0 drops the depth axis)
+ *   grid_lower / grid_interval / grid_size   host float[3] each, as the reference's float tensors
+ *   mode 0 (BEVDet)  rank = b * (Z*Y*X) + z * (Y*X) + y * X + x;  ranks_feat = camera-pixel index
+ *   mode 1 (LSS)     rank = ((b * Z + z) * X + x) * Y + y  (the cell of the reference's [B, Z, X, Y] output);
+ *                    ranks_feat = point index
+ *   ranks_bev / ranks_depth / ranks_feat [num_points] int32 (first counts[0] valid, sorted by rank, points of
+ *   a cell in index order = a stable argsort), interval_starts / interval_lengths [num_points] int32 (first
+ *   counts[1] valid), counts [2] int32 (device): kept points, intervals.
+ */
+size_t pd3_voxel_pooling_prepare_workspace(int64_t num_points);
+int pd3_voxel_pooling_prepare(const float *coor, int64_t num_points, int batch, int depth_bins, int feat_hw,
+                              const float *grid_lower, const float *grid_interval, const float *grid_size, int mode,
+                              int32_t *ranks_bev, int32_t *ranks_depth, int32_t *ranks_feat,
+                              int32_t *interval_starts, int32_t *interval_lengths, int32_t *counts, void *workspace,
+                              size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * sparse_conv3d -- replaces the Paddle-core sparse ops the CenterPoint-Voxel middle encoder is built
  * from: paddle.sparse.nn.SubmConv3D / Conv3D (+ BatchNorm, ReLU, sparse.add fused into the epilogue) and
  * SparseCooTensor.to_dense (call sites paddle3d/models/middle_encoders/sparse_resnet.py:31-59, :115-206;

@@ -440,3 +440,69 @@ def sparse_encoder_dense_torch(net, feats, coords, batch):
             x, mask = run(stage, x, mask)
     n, c, dd, hh, ww = x.shape
     return x.reshape(n, c * dd, hh, ww)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# NumPy restatements of the reference's Python glue around the ops (pinned to the reference's own Python by
+# tests/golden/python_layers.npz, made by tests/golden/make_python_golden.py through the paddle shim).
+# ---------------------------------------------------------------------------------------------------------
+def rotate_nms_pcdet_numpy(boxes, scores, thresh, pre_max_size=None, post_max_size=None, kind="port"):
+    """layer_libs.py:210-249: column reorder [0,1,2,4,3,5,-1], heading -> -theta - pi/2 (fp32), stable descending
+    argsort, top pre_max_size, rotated NMS (nms_gpu = IoU bits + host sweep), map back, cap post_max_size."""
+    b = np.asarray(boxes, np.float32)[:, [0, 1, 2, 4, 3, 5, -1]].copy()
+    b[:, -1] = -b[:, -1] - np.float32(np.pi / 2)
+    order = np.argsort(-np.asarray(scores, np.float32), kind="stable")
+    if pre_max_size is not None:
+        order = order[:pre_max_size]
+    keep = nms(np.ascontiguousarray(b[order]), float(thresh), kind=kind)
+    sel = order[keep]
+    return sel if post_max_size is None else sel[:post_max_size]
+
+
+def create_frustum_numpy(depth_cfg, input_size, downsample):
+    """bevdet_transformer.py:126-140 -> [D, H, W, 3] (u, v, depth)."""
+    h_in, w_in = input_size
+    hf, wf = h_in // downsample, w_in // downsample
+    d = np.arange(*depth_cfg, dtype=np.float32)
+    x = np.linspace(0, w_in - 1, wf, dtype=np.float32)
+    y = np.linspace(0, h_in - 1, hf, dtype=np.float32)
+    fr = np.empty((len(d), hf, wf, 3), np.float32)
+    fr[..., 0], fr[..., 1], fr[..., 2] = x[None, None, :], y[None, :, None], d[:, None, None]
+    return fr
+
+
+def get_lidar_coor_numpy(frustum, rots, trans, cam2imgs, post_rots, post_trans, bda):
+    """bevdet_transformer.py:142-192 in float32."""
+    f32 = np.float32
+    B, N = trans.shape[:2]
+    pts = frustum[None, None].astype(f32) - post_trans.reshape(B, N, 1, 1, 1, 3).astype(f32)
+    pts = np.einsum("bnij,bndhwj->bndhwi", np.linalg.inv(post_rots.astype(f32)).astype(f32), pts).astype(f32)
+    pts = np.concatenate([pts[..., :2] * pts[..., 2:3], pts[..., 2:3]], -1).astype(f32)
+    comb = np.matmul(rots.astype(f32), np.linalg.inv(cam2imgs.astype(f32)).astype(f32)).astype(f32)
+    pts = np.einsum("bnij,bndhwj->bndhwi", comb, pts).astype(f32) + trans.reshape(B, N, 1, 1, 1, 3).astype(f32)
+    return np.einsum("bij,bndhwj->bndhwi", bda.astype(f32), pts).astype(f32)
+
+
+def voxel_pooling_prepare_v2_numpy(coor, grid_lower_bound, grid_interval, grid_size):
+    """bevdet_transformer.py:230-274: (ranks_bev, ranks_depth, ranks_feat, interval_starts, interval_lengths)."""
+    B, N, D, H, W, _ = coor.shape
+    num = B * N * D * H * W
+    ranks_depth = np.arange(num, dtype=np.int64)
+    ranks_feat = np.broadcast_to(np.arange(num // D, dtype=np.int64).reshape(B, N, 1, H, W), (B, N, D, H, W)).reshape(-1)
+    c = ((coor.astype(np.float32) - np.asarray(grid_lower_bound, np.float32)) /
+         np.asarray(grid_interval, np.float32)).astype(np.float32)
+    c = np.trunc(c).astype(np.int64).reshape(num, 3)  # cast('int64') truncates toward zero
+    batch_idx = np.repeat(np.arange(B, dtype=np.int64), num // B)
+    gs = np.asarray(grid_size, np.float32)
+    kept = (c[:, 0] >= 0) & (c[:, 0] < gs[0]) & (c[:, 1] >= 0) & (c[:, 1] < gs[1]) & (c[:, 2] >= 0) & (c[:, 2] < gs[2])
+    c, ranks_depth, ranks_feat, batch_idx = c[kept], ranks_depth[kept], ranks_feat[kept], batch_idx[kept]
+    g = gs.astype(np.int64)
+    ranks_bev = batch_idx * (g[2] * g[1] * g[0]) + c[:, 2] * (g[1] * g[0]) + c[:, 1] * g[0] + c[:, 0]
+    order = np.argsort(ranks_bev, kind="stable")
+    ranks_bev, ranks_depth, ranks_feat = ranks_bev[order], ranks_depth[order], ranks_feat[order]
+    head = np.ones(len(ranks_bev), bool)
+    head[1:] = ranks_bev[1:] != ranks_bev[:-1]
+    starts = np.nonzero(head)[0]
+    lengths = np.diff(np.append(starts, len(ranks_bev)))
+    i32 = np.int32
+    return ranks_bev.astype(i32), ranks_depth.astype(i32), ranks_feat.astype(i32), starts.astype(i32), lengths.astype(i32)

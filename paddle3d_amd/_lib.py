@@ -60,6 +60,10 @@ _SIGNATURES = {
                                                      C.c_void_p]),
     "pd3_bev_pool_v2_bkwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64,
                                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pd3_frustum_to_lidar": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 7),
+    "pd3_voxel_pooling_prepare_workspace": (C.c_size_t, [C.c_int64]),
+    "pd3_voxel_pooling_prepare": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_size_t, C.c_void_p]),
     "pd3_sparse_conv3d_workspace": (C.c_size_t, [C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "pd3_sparse_conv3d_indices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

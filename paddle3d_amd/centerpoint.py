@@ -599,29 +599,4 @@ def centerpoint_voxels_nuscenes(max_num_voxels=(120000, 160000), point_cloud_ran
         test_cfg=test_cfg, box_with_velocity=True)
 
 
-def load_paddle_state_dict(model: nn.Module, state: dict) -> list:
-    """Copy a Paddle state dict (name -> ndarray, what ``paddle.load`` of a ``.pdparams`` returns; reference
-    apis/checkpoint.py:148-212) into the torch mirror.  Layout rules: Linear weights
-    are [in, out] in Paddle (transposed here), BatchNorm statistics are ``_mean`` / ``_variance``.
-    Returns the list of keys that could not be placed."""
-    own = dict(model.state_dict())
-    missing = []
-    with torch.no_grad():
-        for k, v in state.items():
-            t = torch.as_tensor(np.asarray(v))
-            name = k.replace("._mean", ".running_mean").replace("._variance", ".running_var")
-            if name not in own:
-                missing.append(k)
-                continue
-            if name.endswith("linear.weight") and t.dim() == 2:
-                t = t.t()
-            if own[name].shape != t.shape:
-                missing.append(k)
-                continue
-            own[name].copy_(t)
-    for m in model.modules():
-        if hasattr(m, "_drop_cache"):
-            m._drop_cache()
-        if hasattr(m, "_folded"):
-            m._folded = None
-    return missing
+from .checkpoint import load_paddle_state_dict  # noqa: E402,F401  (re-exported: the models' loader)

@@ -8,11 +8,12 @@ Reference caller: QuickCumsumCuda, paddle3d/models/transformers/bevdet_transform
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from ._common import check, lib, ptr, require_gpu, stream_ptr
 
-__all__ = ["bev_pool_v2", "bev_pool_v2_bkwd", "BevPoolV2", "lss_voxel_pooling"]
+__all__ = ["bev_pool_v2", "bev_pool_v2_bkwd", "BevPoolV2", "lss_voxel_pooling", "voxel_pooling_prepare_v2"]
 
 
 def _i32(t, op):
@@ -75,6 +76,37 @@ class BevPoolV2(torch.autograd.Function):
         return dg, fg, None, None, None, None, None, None
 
 
+def _prepare(coor, batch, depth_bins, feat_hw, lower, interval, size, mode):
+    """pd3_voxel_pooling_prepare; one host read of the two counts to hand back exact-size index tensors."""
+    from ._common import host_f32, workspace
+
+    op = "voxel_pooling_prepare"
+    c = require_gpu(coor, op).reshape(-1, 3)
+    n = int(c.shape[0])
+    dev = c.device
+    outs = [torch.empty((n,), dtype=torch.int32, device=dev) for _ in range(5)]
+    counts = torch.empty((2,), dtype=torch.int32, device=dev)
+    L = lib()
+    ws = workspace(L.pd3_voxel_pooling_prepare_workspace(n), dev)
+    check(L.pd3_voxel_pooling_prepare(ptr(c), n, int(batch), int(depth_bins), int(feat_hw), ptr(host_f32(lower, 3)),
+                                      ptr(host_f32(interval, 3)), ptr(host_f32(size, 3)), int(mode),
+                                      *[ptr(o) for o in outs], ptr(counts), ptr(ws), ws.numel(), stream_ptr(dev)), op)
+    n_kept, n_int = counts.cpu().tolist()
+    rb, rd, rf, st, ln = outs
+    return rb[:n_kept], rd[:n_kept], rf[:n_kept], st[:n_int], ln[:n_int]
+
+
+def voxel_pooling_prepare_v2(coor: torch.Tensor, grid_lower_bound, grid_interval, grid_size):
+    """LSSViewTransformer.voxel_pooling_prepare_v2 (paddle3d/models/transformers/bevdet_transformer.py:230-274) on
+    the device.  coor [B, N, D, H, W, 3] fp32 -> (ranks_bev, ranks_depth, ranks_feat, interval_starts,
+    interval_lengths) int32, or five Nones when no frustum point falls inside the grid."""
+    B, N, D, H, W, _ = coor.shape
+    out = _prepare(coor, B, D, H * W, grid_lower_bound, grid_interval, grid_size, 0)
+    if out[3].numel() == 0:
+        return None, None, None, None, None
+    return out
+
+
 def lss_voxel_pooling(geom_feats: torch.Tensor, x: torch.Tensor, dx, bx, nx) -> torch.Tensor:
     """BEVFusion's camera->BEV pooling, `LiftSplatShoot.voxel_pooling`
     (paddle3d/models/detection/bevfusion/cam_stream_lss.py:318-373), expressed through the bev_pool kernel.
@@ -83,7 +115,8 @@ def lss_voxel_pooling(geom_feats: torch.Tensor, x: torch.Tensor, dx, bx, nx) -> 
     [B, C, Z, X, Y] (the reference's layout).  The reference sorts every frustum point by voxel rank and
     takes differences of one global cumulative sum (the "cumsum trick", :111-121); here the sorted points
     are run-length encoded into intervals and each interval is summed on its own by bev_pool_v2 with unit
-    depth weights -- the same sums without the cancellation error of subtracting large running totals.
+    depth weights -- the same sums without the cancellation error of subtracting large running totals.  The
+    index build (quantise, filter, stable sort by cell, run-length) is pd3_voxel_pooling_prepare, mode 1.
     """
     op = "lss_voxel_pooling"
     xg = require_gpu(x, op)
@@ -91,26 +124,11 @@ def lss_voxel_pooling(geom_feats: torch.Tensor, x: torch.Tensor, dx, bx, nx) -> 
     B, C = int(xg.shape[0]), int(xg.shape[-1])
     nprime = xg.numel() // C
     dev = xg.device
-    dxt = torch.as_tensor(dx, dtype=torch.float32, device=dev)
-    bxt = torch.as_tensor(bx, dtype=torch.float32, device=dev)
-    g = ((gg.reshape(nprime, 3) - (bxt - dxt / 2.0)) / dxt).to(torch.int64)  # trunc toward zero like astype
-    batch_ix = torch.arange(B, device=dev).repeat_interleave(nprime // B)
-    kept = (g[:, 0] >= 0) & (g[:, 0] < nx[0]) & (g[:, 1] >= 0) & (g[:, 1] < nx[1]) & (g[:, 2] >= 0) & (g[:, 2] < nx[2])
-    idx = torch.nonzero(kept).squeeze(1)
-    g, b = g[idx], batch_ix[idx]
-    # output cell in the reference's final layout [B, Z, X, Y]
-    cell = ((b * nx[2] + g[:, 2]) * nx[0] + g[:, 0]) * nx[1] + g[:, 1]
-    order = torch.argsort(cell, stable=True)
-    cell, src = cell[order], idx[order]
-    head = torch.ones(cell.shape[0], dtype=torch.bool, device=dev)
-    head[1:] = cell[1:] != cell[:-1]
-    starts = torch.nonzero(head).squeeze(1).to(torch.int32)
-    lengths = torch.empty_like(starts)
-    if starts.numel() > 0:
-        lengths[:-1] = starts[1:] - starts[:-1]
-        lengths[-1] = cell.shape[0] - starts[-1]
+    dxn = np.asarray(dx, dtype=np.float32).reshape(3)
+    bxn = np.asarray(bx, dtype=np.float32).reshape(3)
+    lower = bxn - dxn / np.float32(2.0)  # (bx - dx / 2.) in fp32, as the reference's tensors evaluate it (:328-329)
+    cell, _, src, starts, lengths = _prepare(gg, B, 1, 1, lower, dxn, np.asarray(nx, dtype=np.float32), 1)
     ones = torch.ones(1, dtype=torch.float32, device=dev)
     zeros = torch.zeros(cell.shape[0], dtype=torch.int32, device=dev)
-    out = bev_pool_v2(ones, xg.reshape(nprime, C), zeros, src.to(torch.int32), cell.to(torch.int32), lengths,
-                      starts, (B, nx[2], nx[0] * nx[1], C))
+    out = bev_pool_v2(ones, xg.reshape(nprime, C), zeros, src, cell, lengths, starts, (B, nx[2], nx[0] * nx[1], C))
     return out.reshape(B, nx[2], nx[0], nx[1], C).permute(0, 4, 1, 2, 3)

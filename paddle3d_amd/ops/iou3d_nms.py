@@ -7,7 +7,10 @@
 `keep` / `num_to_keep` come back as CPU int32 tensors exactly like the reference, so the caller idiom
 `order[keep[:num_out]]` (paddle3d/models/layers/layer_libs.py:244) works unchanged.  The *_device
 variants keep everything on the GPU (no sync) for fused pipelines.
-boxes_iou_bev_cpu has no counterpart: this library has no CPU path.
+  boxes_iou_bev_cpu(a, b)       -> iou  [N, M] CPU (host tensors in and out)         iou3d_cpu.cpp:241-264
+boxes_iou_bev_cpu keeps the reference's contract (CPU tensors in, CPU tensor out) but not its arithmetic unit:
+the library has no CPU path, so the host tensors are staged through the same pd3_boxes_iou_bev kernel, which
+evaluates the reference's fp32 expressions (iou3d_cpu.cpp:36-239 == iou3d_nms_kernel.cu:28-273).
 """
 from __future__ import annotations
 
@@ -18,7 +21,7 @@ import torch
 from ._common import check, lib, ptr, require_gpu, stream_ptr, workspace
 
 __all__ = ["nms_gpu", "nms_normal_gpu", "nms_gpu_device", "nms_normal_gpu_device", "boxes_iou_bev_gpu",
-           "boxes_overlap_bev_gpu"]
+           "boxes_overlap_bev_gpu", "boxes_iou_bev_cpu"]
 
 
 def _check_boxes(b, op):
@@ -75,3 +78,12 @@ def boxes_iou_bev_gpu(boxes_a, boxes_b):
 
 def boxes_overlap_bev_gpu(boxes_a, boxes_b):
     return _pairwise(boxes_a, boxes_b, False)
+
+
+def boxes_iou_bev_cpu(boxes_a, boxes_b, device=None):
+    """iou3d_cpu.cpp:241-264: [N, 7] x [M, 7] CPU fp32 tensors -> [N, M] CPU fp32."""
+    for t in (boxes_a, boxes_b):
+        if not isinstance(t, torch.Tensor) or t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != 7:
+            raise RuntimeError("boxes_iou_bev_cpu: boxes must be CPU float32 tensors of shape [N, 7]")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    return boxes_iou_bev_gpu(boxes_a.to(dev), boxes_b.to(dev)).cpu()

@@ -169,3 +169,33 @@ def bev_pool_inputs(seed: int, n_cam: int = 6, depth_bins: int = 118, fh: int = 
                 ranks_feat=ranks_feat.astype(np.int32), ranks_bev=ranks_bev.astype(np.int32),
                 interval_starts=starts.astype(np.int32), interval_lengths=lengths.astype(np.int32),
                 bev_feat_shape=(1, bev, bev, channels))
+
+
+def camera_rig(seed: int, n_cam: int = 6, input_size=(256, 704), batch: int = 1):
+    """Calibration of a nuScenes-like ring of cameras in the form BEVDet's view transformer consumes
+    (reference bevdet_transformer.py:142-192 get_lidar_coor): rots [B,N,3,3] / trans [B,N,3] camera -> ego,
+    cam2imgs [B,N,3,3] intrinsics of the 1600 x 900 sensor, post_rots / post_trans the image-space resize + crop
+    down to `input_size`, bda [B,3,3] the BEV augmentation (identity at test time)."""
+    rng = np.random.default_rng(seed)
+    h_in, w_in = input_size
+    r0 = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])  # camera (x right, y down, z fwd) -> ego
+    rots, trans, k, prot, ptran = [], [], [], [], []
+    resize = w_in / 1600.0
+    crop_h = 900.0 * resize - h_in
+    for _ in range(batch):
+        for c in range(n_cam):
+            yaw = 2 * np.pi * c / n_cam + rng.normal(0, 0.02)
+            pitch = rng.normal(0, 0.01)
+            rz = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
+            ry = np.array([[np.cos(pitch), 0, np.sin(pitch)], [0, 1, 0], [-np.sin(pitch), 0, np.cos(pitch)]])
+            rots.append(rz @ ry @ r0)
+            trans.append([1.5 * np.cos(yaw) + rng.normal(0, 0.05), 1.5 * np.sin(yaw) + rng.normal(0, 0.05), 1.5])
+            f = 1266.0 + rng.normal(0, 5.0)
+            k.append([[f, 0, 816.0 + rng.normal(0, 3.0)], [0, f, 491.0 + rng.normal(0, 3.0)], [0, 0, 1]])
+            prot.append(np.diag([resize, resize, 1.0]))
+            ptran.append([0.0, -crop_h, 0.0])
+    sh = (batch, n_cam)
+    f32 = np.float32
+    return dict(rots=np.asarray(rots, f32).reshape(*sh, 3, 3), trans=np.asarray(trans, f32).reshape(*sh, 3),
+                cam2imgs=np.asarray(k, f32).reshape(*sh, 3, 3), post_rots=np.asarray(prot, f32).reshape(*sh, 3, 3),
+                post_trans=np.asarray(ptran, f32).reshape(*sh, 3), bda=np.tile(np.eye(3, dtype=f32), (batch, 1, 1)))

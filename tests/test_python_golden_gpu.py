@@ -1,0 +1,152 @@
+"""The HIP ops against golden vectors recorded from the reference's own PYTHON layers (tests/golden/
+python_layers.npz, made by executing the reference source through tests/golden/paddle_shim.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from state_util import rebuild_state  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pg():
+    return np.load(os.path.join(HERE, "golden", "python_layers.npz"))
+
+
+def _cuda(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("tag,cin,feat,p", [("pfn2", 5, (64, 64), 20), ("pfn1", 4, (64,), 32)])
+def test_pillar_feature_net_vs_reference_python(pg, tag, cin, feat, p):
+    from paddle3d_amd import centerpoint as cpm
+    from paddle3d_amd import checkpoint
+
+    net = cpm.PillarFeatureNet(cin, feat, False, p, (0.2, 0.2, 8.0), (-51.2, -51.2, -5.0, 51.2, 51.2, 3.0), legacy=False)
+    assert checkpoint.load_paddle_state_dict(net, rebuild_state(pg[f"{tag}_keys"], pg[f"{tag}_shapes"], 11)) == []
+    net = net.cuda().eval()
+    out = net(_cuda(pg[f"{tag}_voxels"]), _cuda(pg[f"{tag}_num_points"]), _cuda(pg[f"{tag}_coors"])).cpu().numpy()
+    assert out.shape == pg[f"{tag}_out"].shape
+    assert np.abs(out - pg[f"{tag}_out"]).max() < 1e-3  # the north star's bar on fp32 features
+
+
+def test_hard_vfe_and_voxel_mean_vs_reference_python(pg):
+    from paddle3d_amd import centerpoint as cpm
+    from paddle3d_amd import checkpoint
+
+    vfe = cpm.HardVFE(4, (64, 64), False, True, True, (0.25, 0.25, 8.0), (-50.0, -50.0, -5.0, 50.0, 50.0, 3.0))
+    assert checkpoint.load_paddle_state_dict(vfe, rebuild_state(pg["vfe_keys"], pg["vfe_shapes"], 12)) == []
+    vfe = vfe.cuda().eval()
+    out = vfe(_cuda(pg["vfe_voxels"]), _cuda(pg["vfe_num_points"]), _cuda(pg["vfe_coors"])).cpu().numpy()
+    assert np.abs(out - pg["vfe_out"]).max() < 1e-3
+    vm = cpm.VoxelMean(5)(_cuda(pg["vmean_voxels"]), _cuda(pg["vmean_num_points"])).cpu().numpy()
+    np.testing.assert_allclose(vm, pg["vmean_out"], rtol=1e-6, atol=1e-6)
+
+
+def test_scatter_vs_reference_python(pg):
+    from paddle3d_amd.ops import pointpillars_scatter as ps
+
+    out = ps.pointpillars_scatter(_cuda(pg["scatter_feats"]), _cuda(pg["scatter_coors"]), 2, 32, 48).cpu().numpy()
+    np.testing.assert_array_equal(out, pg["scatter_out"])
+
+
+def test_lss_voxel_pooling_vs_reference_python(pg):
+    from paddle3d_amd.ops import bev_pool_v2 as bp
+
+    out = bp.lss_voxel_pooling(_cuda(pg["lss_geom"]), _cuda(pg["lss_x"]), np.array([0.5, 0.5, 20.0], np.float32),
+                               np.array([-9.75, -9.75, 0.0], np.float32), [40, 40, 1]).cpu().numpy()
+    assert out.shape == pg["lss_out"].shape
+    # the reference's cumsum trick carries the rounding of one global running total; per-cell sums do not
+    assert np.abs(out - pg["lss_out"]).max() < 5e-3
+    np.testing.assert_array_equal(out != 0, pg["lss_out"] != 0)
+
+
+@pytest.mark.parametrize("tag,pre,post", [("a", 300, 80), ("b", None, None), ("c", 50, 500)])
+def test_rotate_nms_pcdet_vs_reference_python(pg, tag, pre, post):
+    from paddle3d_amd.layer_libs import rotate_nms_pcdet
+
+    sel = rotate_nms_pcdet(_cuda(pg["rnms_boxes"]), _cuda(pg["rnms_scores"]), 0.2, pre, post)
+    assert sel.dtype == torch.int64 and sel.is_cuda
+    np.testing.assert_array_equal(sel.cpu().numpy(), pg[f"rnms_sel_{tag}"])
+
+
+def test_index_prep_and_frustum_vs_reference_python(pg):
+    from paddle3d_amd.bevdet import LSSViewTransformer
+
+    grid = dict(x=[-51.2, 51.2, 0.8], y=[-51.2, 51.2, 0.8], z=[-5, 3, 8], depth=[1.0, 60.0, 0.5])
+    vt = LSSViewTransformer(grid, (64, 176), 16)
+    assert vt.frustum.shape == (118, 4, 11, 3)
+    cams = {k[len("prep_cam_"):]: _cuda(pg[k]) for k in pg.files if k.startswith("prep_cam_")}
+    coor = vt.get_lidar_coor(cams["rots"], cams["trans"], cams["cam2imgs"], cams["post_rots"], cams["post_trans"],
+                             cams["bda"])
+    np.testing.assert_allclose(coor.cpu().numpy(), pg["prep_coor"], rtol=2e-5, atol=2e-4)
+    # the index build is integer logic on fp32 coordinates: exact, given the reference's own coordinates
+    got = vt.voxel_pooling_prepare_v2(_cuda(pg["prep_coor"]))
+    for a, name in zip(got, ("ranks_bev", "ranks_depth", "ranks_feat", "interval_starts", "interval_lengths")):
+        assert a.dtype == torch.int32
+        np.testing.assert_array_equal(a.cpu().numpy(), pg[f"prep_{name}"], err_msg=name)
+    # nothing inside the grid -> the reference's five Nones
+    far = torch.full((1, 1, 2, 2, 2, 3), 1e4, device="cuda")
+    assert vt.voxel_pooling_prepare_v2(far) == (None,) * 5
+
+
+def test_bevdet4d_pooling_end_to_end(oracle):
+    """BEVDet4D-size view transformer: frustum geometry of 6 cameras -> device index build -> bev_pool_v2, against
+    the oracle chain (NumPy geometry + index prep, reference pooling kernel run serially)."""
+    from paddle3d_amd import synth
+    from paddle3d_amd.bevdet import LSSViewTransformer
+
+    vt = LSSViewTransformer()  # bevdet4d_r50_depth_nuscenes.yml:174-186
+    cams = synth.camera_rig(1)
+    coor = vt.get_lidar_coor(*[_cuda(cams[k]) for k in ("rots", "trans", "cam2imgs", "post_rots", "post_trans", "bda")])
+    assert coor.shape == (1, 6, 118, 16, 44, 3)
+    rng = np.random.default_rng(2)
+    depth = rng.random((6, 118, 16, 44)).astype(np.float32)
+    feat = rng.normal(size=(6, 80, 16, 44)).astype(np.float32)
+    bev = vt.voxel_pooling_v2(coor, _cuda(depth), _cuda(feat)).cpu().numpy()
+    assert bev.shape == (1, 80, 128, 128)
+    # oracle chain on the GPU's own coordinates (the geometry itself is compared with tolerance above)
+    rb, rd, rf, st, ln = oracle.voxel_pooling_prepare_v2_numpy(coor.cpu().numpy(), vt.grid_lower_bound,
+                                                               vt.grid_interval, vt.grid_size)
+    assert 250_000 < len(rb) <= 498_432 and len(st) <= 16384
+    ref = oracle.bev_pool_v2(depth, np.ascontiguousarray(feat.transpose(0, 2, 3, 1)), rd, rf, rb, ln, st,
+                             (1, 128, 128, 80), kind="ref" if oracle.have_ref() else "port")
+    np.testing.assert_array_equal(bev.view(np.uint32), np.ascontiguousarray(ref.transpose(0, 3, 1, 2)).view(np.uint32))
+
+
+def test_dense_graph_vs_reference_python(pg):
+    """SecondBackbone + SecondFPN + CenterHead on the hand-written kernels, parameters loaded from the reference's
+    state dict, against the reference's forward (reduced-width copy of the graph, 512 x 512 input)."""
+    sys.path.insert(0, HERE)
+    from test_python_golden import SUB, _load_dense
+
+    backbone, neck, head = [m.cuda() for m in _load_dense(pg)]
+    x = torch.from_numpy(np.random.default_rng(31).normal(size=(1, 16, 512, 512)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        feats = neck(backbone(x))
+        preds, shared = head(feats)
+    assert np.abs(feats.cpu().numpy()[SUB] - pg["dense_neck_out_sub"]).max() < 1e-3
+    assert np.abs(shared.cpu().numpy()[SUB] - pg["dense_shared_sub"]).max() < 1e-3
+    for t, pd in enumerate(preds):
+        for name, v in pd.items():
+            assert np.abs(v.cpu().numpy()[SUB] - pg[f"dense_task{t}_{name}_sub"]).max() < 1e-3, (t, name)
+
+
+def test_boxes_iou_bev_cpu_contract(oracle):
+    from paddle3d_amd import synth
+    from paddle3d_amd.ops import iou3d_nms
+
+    a, _ = synth.nms_boxes(1, n=70)
+    b, _ = synth.nms_boxes(2, n=33)
+    out = iou3d_nms.boxes_iou_bev_cpu(torch.from_numpy(a), torch.from_numpy(b))
+    assert not out.is_cuda and out.shape == (70, 33) and out.dtype == torch.float32
+    ref = oracle.boxes_iou_bev(a, b, kind="ref" if oracle.have_ref() else "port")
+    np.testing.assert_allclose(out.numpy(), ref, rtol=0, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        iou3d_nms.boxes_iou_bev_cpu(torch.from_numpy(a).cuda(), torch.from_numpy(b))
