@@ -415,7 +415,15 @@ def bench_voxel(args, rank, world, dev):
         return None
     alg = 4 * N_POINTS * DIMS + 4 * V * 10 * DIMS + 16 * V + 4
     a = alg * B / (per_op_ms["hard_voxelize"] * 1e-3) / 1e9
-    sp = getattr(model.middle_encoder, "last_flops", None)
+    with torch.no_grad():  # untimed: how many multiply-adds the encoder's rulebooks hold for this batch
+        from paddle3d_amd import sparse as _sparse
+
+        voxels, coors, npv, nv = model.voxelizer(pts)
+        b, v, p, d = voxels.shape
+        keep = coors.view(b * v, 4)[:, 0] >= 0
+        cs = coors.view(b * v, 4)[keep].contiguous()
+        sp = _sparse.count_flops(model.middle_encoder, model.voxel_encoder(voxels.view(b * v, p, d)[keep],
+                                                                          npv.view(b * v)[keep], cs), cs, b)
     line = {
         "metric": "scenes/sec CenterPoint-Voxel nuScenes 300k-pt sweeps",
         "value": world * B * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
@@ -446,11 +454,21 @@ def bench_voxel(args, rank, world, dev):
 def bench_bev_pool(args, rank, world, dev):
     """bev_pool_v2 forward at BEVDet4D size: 6 cameras x 118 depth bins x 16 x 44, C = 80, 128 x 128 BEV."""
     from paddle3d_amd import synth
+    from paddle3d_amd.bevdet import LSSViewTransformer
     from paddle3d_amd.ops import bev_pool_v2 as bp
 
-    inp = synth.bev_pool_inputs(0)
-    t = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
-    shape = inp["bev_feat_shape"]
+    # index sets from the real frustum geometry of bevdet4d_r50_depth_nuscenes.yml:174-186 (6 cameras of a synthetic
+    # nuScenes-like rig), built on the device by pd3_frustum_to_lidar + pd3_voxel_pooling_prepare
+    vt = LSSViewTransformer()
+    cams = synth.camera_rig(0)
+    coor = vt.get_lidar_coor(*[torch.from_numpy(cams[k]).to(dev) for k in ("rots", "trans", "cam2imgs", "post_rots",
+                                                                           "post_trans", "bda")])
+    rb, rd, rf, st, ln = vt.voxel_pooling_prepare_v2(coor)
+    rng = np.random.default_rng(0)
+    t = dict(depth=torch.from_numpy(rng.random((6, 118, 16, 44)).astype(np.float32)).to(dev),
+             feat=torch.from_numpy(rng.normal(size=(6, 16, 44, 80)).astype(np.float32)).to(dev),
+             ranks_depth=rd, ranks_feat=rf, ranks_bev=rb, interval_lengths=ln, interval_starts=st)
+    shape = (1, 128, 128, 80)
     names = ["start", "bev_pool_v2"]
 
     def run(events):

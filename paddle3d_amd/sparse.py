@@ -36,6 +36,21 @@ def _triple(v):
     return (v, v, v) if isinstance(v, int) else tuple(int(x) for x in v)
 
 
+_STATS = None  # dict(pairs=..., dense=...) while count_flops() runs
+
+
+def count_flops(encoder, voxel_features, coors, batch_size) -> dict:
+    """Flops of one forward of a sparse encoder: `pairs` = 2 * Cin * Cout per existing (output row, kernel offset)
+    pair, `dense` = the same with all kernel offsets counted.  Host syncs per convolution: not for timed code."""
+    global _STATS
+    _STATS = dict(pairs=0, dense=0)
+    try:
+        encoder(voxel_features, coors, batch_size)
+        return dict(_STATS)
+    finally:
+        _STATS = None
+
+
 class _SparseConv(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, subm=False,
                  key=None):
@@ -59,6 +74,10 @@ class _SparseConv(nn.Module):
 
     def forward(self, x: SparseConvTensor, scale=None, shift=None, residual=None, relu=False):
         idx = self._indices(x)
+        if _STATS is not None:  # measurement aid (bench.py): multiply-adds of the pairs that exist
+            cin, cout = int(self.weight.shape[-2]), int(self.weight.shape[-1])
+            _STATS["pairs"] += 2 * cin * cout * int((idx.nbr >= 0).sum().item())
+            _STATS["dense"] += 2 * cin * cout * idx.n_out * idx.kernel_volume
         out = _sp.features(x.features, idx, self.weight, self.bias, scale, shift, residual, relu)
         if self.subm:
             return x.replace(out)
