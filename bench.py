@@ -326,7 +326,7 @@ def bench_pillars(args, rank, world, dev):
         "per_op_ms": per_op_ms,
         "detections_first_frame": int(out[1][0].item()),
     }
-    if world == 1:
+    if world == 1 and not args.no_extras:
         extras = {}
         with torch.no_grad():
             # (a) the same steps with the batch copied from pinned host memory inside every step (not overlapped)
@@ -360,6 +360,7 @@ def bench_pillars(args, rank, world, dev):
             extras["latency_batch1_ms"] = (time.perf_counter() - t0) / 20 * 1e3
         extras["measured_ceilings"] = measured_ceilings(dev)
         line["extras"] = extras
+    if world == 1:
         if not args.no_cpu_baseline:
             try:
                 model_cpu = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(V, V)).eval()
@@ -509,6 +510,8 @@ def main():
     ap.add_argument("--workload", default="centerpoint_pillars",
                     choices=["centerpoint_pillars", "centerpoint_voxel", "bev_pool_v2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the h2d-inclusive / batch-1 / ceiling measurements "
+                    "(profiling runs: only warm-up + timed steps are launched)")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 2 if args.workload == "centerpoint_voxel" else 16

@@ -4,9 +4,10 @@ traffic per launch -> profiles/<tag>_traffic.json (read back by bench.py to fill
     usage: collect_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps> <out.json> <batch> <max_voxels>
 
 Units / corrections (MI355X_MICROARCH.md section HBM): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950
-FETCH_SIZE reports exactly half of a streamed read -- calibrated here on vt_route_kernel, whose only HBM
-reads are the points (batch * 6.0 MB): the x2 factor reproduces that byte count to 2 %; WRITE_SIZE of
-vt_write_kernel matches its known 100.4 MB per 8 scenes to 3 % without correction.
+FETCH_SIZE reports exactly half of a streamed read -- calibrated on vt_route_kernel, whose only HBM reads are
+the points (batch * 6.0 MB): the x2 factor reproduces that byte count to 2 %; WRITE_SIZE of the output writer
+(vt_rows_kernel) matches its known 12.5 MB per scene to 3 % without correction.  Per-kernel rows are kept next to
+the per-op sums (`kernels`).
 """
 import csv
 import json
@@ -14,7 +15,7 @@ import sys
 from collections import defaultdict
 
 OPS = {
-    "hard_voxelize": ("vt_route", "vt_group", "vt_count", "vt_assign", "vt_write", "cell_key", "seg_head",
+    "hard_voxelize": ("vt_route", "vt_group", "vt_assign", "vt_rows", "cell_key", "seg_head",
                       "gather_voxels", "voxel_meta", "EpiVoxelStart", "LoadNonNegative"),
     "pillar_feature_net": ("pfn_",),
     "pointpillars_scatter": ("fill_i32", "inverse_map", "canvas_write"),
@@ -45,8 +46,11 @@ def main():
         w = sum(v for k, v in write.items() if any(p in k for p in pats))
         out[op] = {"fetch_size_kib_raw": f / launches, "write_size_kib": w / launches,
                    "bytes_per_launch": (2.0 * f + w) * 1024.0 / launches}
+    out["kernels"] = {k[:60]: {"fetch_bytes_x2": 2.0 * fetch.get(k, 0.0) * 1024.0 / launches,
+                               "write_bytes": write.get(k, 0.0) * 1024.0 / launches}
+                      for k in sorted(set(fetch) | set(write)) if "pd3" in k or "vt_" in k}
     json.dump(out, open(sys.argv[4], "w"), indent=1)
-    print(json.dumps(out, indent=1))
+    print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1))
 
 
 if __name__ == "__main__":
