@@ -226,8 +226,7 @@ static VoxWorkspace carve(void* base, int batch, int64_t n, int max_voxels, cons
 struct VtWorkspace {
   uint32_t *recs, *dir, *cposr, *tilecnt;
   unsigned short* pos16;
-  unsigned char* slotr;
-  uint4* owner;
+  uint32_t* gstart;
   uint2* vinfo;
   float* compact;
   int* totals;
@@ -247,9 +246,8 @@ static VtWorkspace vt_carve(void* base, int batch, int64_t n, int dim, int max_p
   w.recs = c.take<uint32_t>((size_t)batch * w.stride);
   w.cposr = c.take<uint32_t>((size_t)batch * w.stride);
   w.pos16 = c.take<unsigned short>((size_t)batch * w.stride);
-  w.slotr = c.take<unsigned char>((size_t)batch * w.stride);
   w.dir = c.take<uint32_t>((size_t)batch * p.tiles * p.groups);
-  w.owner = c.take<uint4>((size_t)batch * w.stride);
+  w.gstart = c.take<uint32_t>((size_t)batch * p.groups * p.cpg);
   w.vinfo = c.take<uint2>((size_t)batch * max_voxels);
   w.tilecnt = c.take<uint32_t>((size_t)batch * p.tiles);
   w.compact = c.take<float>((size_t)batch * w.cap * dim + 4);
@@ -280,12 +278,12 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
   vt_route_kernel<<<tile_grid, kVtRouteThreads, lds_a, s>>>(points, num_points, n, dim, vg, plan.low, plan.gbits,
                                                             plan.tiles, batch, max_voxels, w.recs, w.dir, w.pos16,
                                                             w.tilecnt, w.vinfo);
-  vt_group_kernel<<<(unsigned)(plan.groups * batch), kWave, lds_b, s>>>(w.recs, w.dir, plan.low, plan.gbits,
-                                                                        plan.tiles, batch, max_pts, w.slotr, w.cposr,
-                                                                        w.owner, w.tilecnt);
+  vt_group_kernel<<<(unsigned)(plan.groups * batch), kVgThreads, lds_b, s>>>(
+      w.recs, w.dir, plan.low, plan.gbits, plan.tiles, batch, max_pts, w.cposr, w.gstart, w.tilecnt);
 #define PD3_VT_EMIT(D)                                                                                         \
   vt_assign_emit_kernel<D><<<2 * tile_grid, kVtRouteThreads, 0, s>>>(                                          \
-      points, n, dim, plan.tiles, batch, w.cposr, w.pos16, w.owner, w.tilecnt, max_voxels, vg, w.vinfo, w.totals, \
+      points, n, dim, plan.tiles, batch, w.cposr, w.pos16, w.recs, w.dir, plan.low, plan.gbits, w.tilecnt,      \
+      max_voxels, vg, w.vinfo, w.totals,                                                                       \
       coords, num_pts, coors4, w.cap, w.compact)
   switch (dim) {
     case 4: PD3_VT_EMIT(4); break;

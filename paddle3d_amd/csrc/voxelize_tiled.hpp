@@ -1,45 +1,46 @@
-// hard_voxelize fast path for BEV-sized grids ("tiled" path): no global sort, no global gather, five kernels.
+// hard_voxelize fast path for BEV-sized grids ("tiled" path): no global sort, no global gather, four launches.
 //
 // Same order-independent restatement of the reference's sequential scan as voxelize.hip
 // (voxel id of a cell = rank of its first point among all first points; slot of a point = number of earlier
 // points in its cell).  What this machine charges for is memory TRANSACTIONS, not bytes (tools/hwcheck/
-// memrates.hip on MI355X: ~190 G scattered 4-byte stores/s and ~80 G scattered 20-byte stores/s chip-wide,
-// i.e. 25 / 60 us for one access per point of a 16-frame batch, against 15 us to stream the batch), so every
-// array is laid out such that it is read and written in coalesced runs; the only scattered accesses left are
-// one 16-byte record per occupied cell (B -> C) and the 20-byte payload store of the kept points (D).
+// memrates.hip on MI355X: ~190 G scattered 4-byte stores/s and ~60 G scattered 20-byte stores/s chip-wide,
+// i.e. 25 / 36 us for one access per kept point of a 16-frame batch, against 15 us to stream the batch), so
+// every array is laid out such that it is read and written in coalesced runs; the only scattered accesses left
+// are the 20-byte payload store of the kept points (D) and one 4-byte record read per occupied cell (C).
 //
 //   A  route_kernel   (tile of 4096 consecutive points, 512 threads)
-//        point -> cell key -> (group, cell-in-group); a group is a diagonal set of 2^LOW (<= 512) cells
+//        point -> cell key -> (group, cell-in-group); a group is a diagonal set of 2^LOW (<= 4096) cells
 //        (see kVtSkew).  The tile's 4-byte records are sorted BY GROUP, stable in point order, in LDS and
 //        written as one coalesced 16 KB slice, plus the directory row dir[tile][group] = (offset, count) and
 //        pos16[point] = the point's position in the slice.  The in-order rank of a point among the wave's
 //        points of the same group is the value a returning LDS atomic add hands back (lanes of one ds_add_rtn
 //        are served in ascending lane order, instructions of a wave in order -- checked on gfx950 by
 //        tools/hwcheck/lds_atomic_order.hip and, implicitly, by every bit-exact test).
-//   B  group_kernel   (one wave per group)
-//        walks the directory column of its group in tile order -> its points in INPUT ORDER (contiguous runs
-//        of the routed slices).  Phase 1: slot of a point = what a returning LDS atomic add on its cell's
-//        counter hands back.  Then a scan over the group's cells of min(count, P) places every cell in the
-//        group's region of the compact payload array (the region is sized by the group's record count, so its
-//        start is the sum of the group's offsets inside the tiles' slices: no global counter).  Phase 2: every
-//        record gets cposr[routed position] = compact position (or "dropped"), bit 31 marking a cell's first
-//        point; the first point also parks (cell key, compact start, kept count) at its point index and bumps
-//        its tile's first-point counter.
-//   C  assign_kernel  (tile)  prefix over the first-point flags in point order = voxel id (the reference's
-//        hand-out order); writes vinfo[voxel] = (compact start, count) and the voxel's coords / count rows
+//   B  group_kernel   (one 256-thread workgroup per group)
+//        walks the directory column of its group in tile order -> its points in INPUT ORDER as contiguous runs
+//        of the routed slices (a nuScenes run is ~58 records: one wave-wide load).  Slot of a point = earlier
+//        points of its cell (LDS counters, see the kernel).  Then a scan over the group's cells of
+//        min(count, P) places every cell in the group's region of the compact payload array (the region is
+//        sized by the group's record count, so its start is the sum of the group's offsets inside the tiles'
+//        slices: no global counter), and every record gets cposr[routed position] = compact position (or
+//        "dropped"); a cell's first point also carries the cell's kept count and bumps its tile's first-point
+//        counter.  All global accesses are coalesced runs.
+//   C  assign job     (tile)  prefix over the first-point flags in point order = voxel id (the reference's
+//        hand-out order); the cell of a first point = (group owning its slice position, cell field of its
+//        routed record); writes vinfo[voxel] = (compact start, count) and the voxel's coords / count rows
 //        (staged in LDS, coalesced).
-//   D  emit_kernel    (tile)  streams the points a second time (coalesced; still in the Infinity Cache) and
-//        stores each kept point at compact[cposr[pos16[point]]]: the payload grouped by cell, densely packed
-//        (2.7 MB per nuScenes frame; the 20-byte stores merge in L2).  Independent of C.
+//   D  emit job       (tile)  streams the points a second time (coalesced; still in the Infinity Cache) and
+//        stores each kept point at compact[cposr[pos16[point]]]: the payload grouped by cell (the 20-byte
+//        stores merge in L2).  Independent of C; C and D share one launch.
 //   E  rows_kernel    voxel-parallel, one 16-byte store per lane: a row's valid floats are one contiguous run
 //        of the compact array; the complete fixed-shape voxels tensor (rows and zero padding) and the padding
-//        of the coords / count rows are written exactly once.
+//        of the coords / count rows are written exactly once (streaming stores: nothing re-reads them here).
 //
 // HBM traffic per frame: points read (A) and re-read (D), outputs written once (E); everything between is a few
 // MB of scratch.  Workgroups are mapped XCD-aware (vt_unit): with batch % 8 == 0 every frame's workgroups of
 // every kernel run on one XCD, so the small stores of a frame merge in that XCD's L2.
-// Preconditions (else the generic sort path of voxelize.hip runs): cells <= 2^19, N < 2^(32-LOW) - 1,
-// N <= 4096 * 1024, max points per voxel <= 254.
+// Preconditions (else the generic sort path of voxelize.hip runs): cells <= 2^22 with <= 1024 groups,
+// N <= 2^22 - 3, max points per voxel <= 254.
 #pragma once
 #include "common.hpp"
 
@@ -51,12 +52,16 @@ constexpr int kVtTile = 4096;
 constexpr int kVtRouteThreads = 512;
 constexpr int kVtRounds = kVtTile / kVtRouteThreads;  // 8
 constexpr int kVtRouteWaves = kVtRouteThreads / kWave;
-constexpr int kVtMaxLow = 9;       // cells per group <= 512: short record streams, one wave per group
+constexpr int kVtMaxLow = 12;      // cells per group <= 4096: a tile's run of one group is ~a wave of records
 constexpr int kVtMaxGbits = 10;    // groups <= 1024: two per thread in the route kernel's scan
 constexpr int kVtMaxTiles = 1024;
 constexpr int kVtMaxPts = 254;
-constexpr uint32_t kVtDropped = 0x7FFFFFFFu;  // cposr: the point is not stored
-constexpr uint32_t kVtFirstBit = 0x80000000u;  // cposr: the point is the first of its cell
+// cposr word of a routed record: bits 0..21 compact position (all ones: the point is not stored), and for the
+// first point of a cell bit 31 set and bits 22..29 = points kept for the cell
+constexpr uint32_t kVtCpMask = 0x3FFFFFu;
+constexpr uint32_t kVtDropped = kVtCpMask;
+constexpr int kVtKeptShift = 22;
+constexpr uint32_t kVtFirstBit = 0x80000000u;
 
 struct VtGrid {  // mirror of VoxGrid (kept separate so this header stands alone)
   float min_x, min_y, min_z, size_x, size_y, size_z;
@@ -78,13 +83,14 @@ static inline VtPlan vt_plan(uint32_t ncells, int64_t n, int max_pts) {
   VtPlan p{};
   int bits = 0;
   while (((int64_t)1 << bits) < (int64_t)ncells) ++bits;
-  p.gbits = std::min(std::max(bits - kVtMaxLow, 2), kVtMaxGbits);
-  p.low = std::max(bits - p.gbits, 0);
+  p.low = std::max(std::min(bits - 2, kVtMaxLow), 0);
+  while (p.low > 0 && n >= ((int64_t)1 << (32 - p.low)) - 1) --p.low;  // a record = (point index << low) | cell
+  p.gbits = std::max(bits - p.low, 2);
   p.groups = 1 << p.gbits;
   p.cpg = 1 << p.low;
   p.tiles = (int)ceil_div(n, kVtTile);
-  p.ok = p.low <= kVtMaxLow && p.tiles <= kVtMaxTiles && n < ((int64_t)1 << (32 - p.low)) - 1 &&
-         n < ((int64_t)1 << 31) - 1 && max_pts <= kVtMaxPts;
+  p.ok = p.gbits <= kVtMaxGbits && p.tiles <= kVtMaxTiles && n < (int64_t)kVtCpMask - 1 &&
+         max_pts <= kVtMaxPts;
   return p;
 }
 
@@ -281,165 +287,311 @@ __global__ __launch_bounds__(kVtRouteThreads, 8) void vt_route_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------ B
-constexpr int kVtGroupSteps = 24;                          // 64-record steps per pass
-constexpr int kVtGroupPass = kWave * kVtGroupSteps;        // 1536 records per pass
+constexpr int kVgThreads = 256;
+constexpr int kVgWaves = kVgThreads / kWave;        // 4
+constexpr int kVgSteps = 40;                        // 64-record steps per wave per pass (<= 64: step facts
+                                                    // live one per lane)
+constexpr int kVgChunk = 4;                         // steps whose LDS traffic is issued back to back
+constexpr int kVgPassSteps = kVgWaves * kVgSteps;   // 160
 
 static inline size_t vt_group_lds(int cpg, int tiles) {
-  return (size_t)cpg * 4 + (size_t)kVtGroupPass * 4 + (size_t)(tiles + 1) * 4 + (size_t)tiles * 4 * 2;
+  const size_t cw = (size_t)std::max(cpg >> 1, 1), bw = (size_t)std::max(cpg >> 2, 1);
+  return kVgWaves * cw * 4 + bw * 4 + (size_t)kVgPassSteps * 8 + (size_t)(3 * tiles + 1) * 4 +
+         (kVgWaves + 2) * 4 + 16;
 }
 
-// One WAVE per group, one wave per workgroup: fully wave-synchronous (no barrier anywhere).  The group's
-// record stream (its points in input order) is cut into passes of 1536 records (a nuScenes group has ~530;
-// a group that fits one pass never leaves the registers); ALL records of a pass are fetched with independent
-// loads up front.
-__global__ __launch_bounds__(kWave, 4) void vt_group_kernel(
+// One 256-thread workgroup per group (<= 4096 cells; a nuScenes group receives ~4200 records, ~58 from each
+// tile's slice).  The group's record stream in INPUT ORDER is the concatenation, in tile order, of its runs in
+// the routed slices; it is cut into STEPS of <= 64 records of one run (so every load and store of a step is one
+// contiguous piece), and a PASS of <= 160 steps is dealt to the four waves in contiguous, balanced shares.
+// Slot of a record = records of its cell in earlier passes (`base`, one saturating byte per cell: only
+//                    min(count, P) matters)
+//                  + in earlier waves of this pass (prefix over the per-wave count tables)
+//                  + earlier in this wave (what the returning LDS atomic add hands back).
+// A group that fits one pass (the normal case) keeps records and slots in registers; longer streams are walked
+// twice (count, then place), cell starts parked in `gstart`.  Every global access is a coalesced run; there is
+// no scattered access in this kernel.  The LDS work is latency-bound (one wave per SIMD when the batch is
+// small), so it is written branch-free in chunks of 8 steps whose LDS operations are all in flight together.
+__global__ __launch_bounds__(kVgThreads, 4) void vt_group_kernel(
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ dir, int low, int gbits, int tiles,
-    int batch, int max_pts, unsigned char* __restrict__ slotr, uint32_t* __restrict__ cposr,
-    uint4* __restrict__ owner, uint32_t* __restrict__ tilecnt) {
+    int batch, int max_pts, uint32_t* __restrict__ cposr, uint32_t* __restrict__ gstart,
+    uint32_t* __restrict__ tilecnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
   const int cpg = 1 << low, groups = 1 << gbits;
-  uint32_t* run = reinterpret_cast<uint32_t*>(vt_smem);          // [cpg] points of the cell so far; later
-                                                                 //       (start in region << 8) | kept count
-  uint32_t* srcpos = run + cpg;                                  // [kVtGroupPass] routed position per record
-  int* tpre = reinterpret_cast<int*>(srcpos + kVtGroupPass);     // [tiles + 1] exclusive prefix of per-tile counts
-  int* toff = tpre + tiles + 1;                                  // [tiles] offset of the segment inside its tile
-  uint32_t* tfirst = reinterpret_cast<uint32_t*>(toff + tiles);  // [tiles] first points seen per tile
+  const int cw = max(cpg >> 1, 1);                                   // two 16-bit counters per word
+  const int bw = max(cpg >> 2, 1);                                   // four byte counters per word
+  uint32_t* cntw = reinterpret_cast<uint32_t*>(vt_smem);             // [waves][cw]; later the cell start table
+  uint32_t* base = cntw + kVgWaves * cw;                             // [bw] records so far, a byte per cell
+  uint32_t* stepsrc = base + bw;                                     // [pass] routed position of the step
+  uint32_t* stepcnt = stepsrc + kVgPassSteps;                        // [pass] records of the step
+  uint32_t* tdir = stepcnt + kVgPassSteps;                           // [tiles] directory entries of the group
+  uint32_t* tstep = tdir + tiles;                                    // [tiles + 1] exclusive prefix of steps
+  uint32_t* tfirst = tstep + tiles + 1;                              // [tiles] first points seen per tile
+  int* scan_tmp = reinterpret_cast<int*>(tfirst + tiles);            // [waves + 2]
   int frame, grp;
   vt_unit(blockIdx.x, (uint32_t)groups, (uint32_t)batch, frame, grp);
-  const int lane = threadIdx.x;
+  const int lane = lane_id(), wave = wave_id();
+#ifdef PD3_VT_TRACE
+  long long tr[12];
+  int trn = 0;
+#define PD3_MARK() tr[trn++] = __builtin_readcyclecounter()
+#else
+#define PD3_MARK()
+#endif
+  PD3_MARK();
 
-  // directory column of this group -> per-tile (offset, count) and the exclusive scan
+  // directory column: thread t takes the tiles t*tpt .. (steps scanned across the workgroup)
   const uint32_t* dcol = dir + (int64_t)frame * tiles * groups + grp;
-  int running = 0, offsum = 0;
-  for (int t0 = 0; t0 < tiles; t0 += kWave) {
-    const int t = t0 + lane;
-    int c = 0;
+  const int tpt = (int)ceil_div(tiles, kVgThreads);
+  int my_steps = 0, my_off = 0;
+  if (threadIdx.x == 0) scan_tmp[kVgWaves + 1] = 0;
+  for (int k = 0; k < tpt; ++k) {
+    const int t = (int)threadIdx.x * tpt + k;
     if (t < tiles) {
       const uint32_t d = dcol[(int64_t)t * groups];
-      toff[t] = (int)(d & 0xFFFFu);
-      offsum += (int)(d & 0xFFFFu);
-      c = (int)(d >> 16);
+      tdir[t] = d;
       tfirst[t] = 0u;
+      my_steps += (int)((d >> 16) + 63u) >> 6;
+      my_off += (int)(d & 0xFFFFu);
     }
-    const int inc = wave_inclusive_scan(c);
-    if (t < tiles) tpre[t] = running + inc - c;
-    running += __shfl(inc, kWave - 1, kWave);
   }
-  const int n_g = running;
-  if (lane == 0) tpre[tiles] = n_g;
-  for (int c = lane; c < cpg; c += kWave) run[c] = 0u;
-  vt_wave_sync();
-  if (n_g == 0) return;
+  for (int i = threadIdx.x; i < bw; i += kVgThreads) base[i] = 0u;
+  int total_steps;
+  int at_step = block_exclusive_scan<kVgThreads>(my_steps, scan_tmp, total_steps);
+  for (int k = 0; k < tpt; ++k) {
+    const int t = (int)threadIdx.x * tpt + k;
+    if (t < tiles) {
+      tstep[t] = (uint32_t)at_step;
+      at_step += (int)((tdir[t] >> 16) + 63u) >> 6;
+    }
+  }
+  if (threadIdx.x == 0) tstep[tiles] = (uint32_t)total_steps;
+  // the group's region of the compact array is sized by its record count: it starts where the records of the
+  // groups before it would end = the sum over the tiles of this group's offset inside the tile's slice.
+  // (Packing the regions densely -- exclusive scan of the groups' kept totals, applied per point in the emit
+  // job -- was tried: 2.7 instead of 5.4 MB per frame, but the lookups cost more than the locality gives.)
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) my_off += __shfl_xor(my_off, d, kWave);
+  if (lane == 0 && my_off) atomicAdd(&scan_tmp[kVgWaves + 1], my_off);
+  __syncthreads();
+  PD3_MARK();
+  if (total_steps == 0) return;
+  const uint32_t region = (uint32_t)scan_tmp[kVgWaves + 1];
 
   const int64_t stride = (int64_t)tiles * kVtTile;
   const uint32_t* rf = recs + (int64_t)frame * stride;
   uint32_t* cpos_f = cposr + (int64_t)frame * stride;
+  uint32_t* gs = gstart + ((int64_t)frame * groups + grp) * cpg;
   const uint32_t cell_mask = (uint32_t)cpg - 1u;
+  const int npass = (int)ceil_div(total_steps, kVgPassSteps);
+  uint32_t* cnt_mine = cntw + wave * cw;
 
-  // the group's region of the compact array is sized by its record count: it starts where the records of the
-  // groups before it would end = the sum over the tiles of this group's offset inside the tile's slice
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) offsum += __shfl_xor(offsum, d, kWave);
-  const uint32_t region = (uint32_t)offsum;
-  uint4* owner_f = owner + (int64_t)frame * stride;
+  // per record ONE register: bits 0..11 cell in group, bits 12..27 slot (<= 2048 per pass + 255), bit 31 = the
+  // lane holds no record (its cell field then names some cell of the group, a harmless LDS address)
+  uint32_t rec[kVgSteps];
+  constexpr uint32_t kNoRec = 0x80000000u;
+  int s_n = 0;                       // steps of this wave in the current pass
+  uint32_t my_src = 0, my_cnt = 0;   // lane u: routed position / record count of the wave's step u
 
-  // a record's compact position (or "dropped"); a cell's first point parks the cell's facts at its index
-#define PD3_VT_PLACE(REC, SP, SLOT)                                                                            \
-  {                                                                                                            \
-    const uint32_t cell_ = (REC) & cell_mask, sp_ = (SP);                                                      \
-    const uint32_t packed_ = run[cell_];                                                                       \
-    const uint32_t start_ = region + (packed_ >> 8);                                                           \
-    uint32_t cp_ = (SLOT) < (uint32_t)max_pts ? start_ + (SLOT) : kVtDropped;                                  \
-    if ((SLOT) == 0u) {                                                                                        \
-      cp_ |= kVtFirstBit;                                                                                      \
-      owner_f[(REC) >> low] =                                                                                  \
-          make_uint4(vt_group_to_key((uint32_t)grp, cell_, gbits), start_, packed_ & 0xFFu, 0u);              \
-      atomicAdd(&tfirst[sp_ / kVtTile], 1u);                                                                   \
-    }                                                                                                          \
-    cpos_f[sp_] = cp_;                                                                                         \
-  }
-  // cells -> places in the group's region.  Any order of the cells will do (the array is scratch), so lane l
-  // takes cells l, l + 64, ...: conflict-free LDS walks and one scan across the lanes.
-#define PD3_VT_SCAN_CELLS()                                                                                    \
-  {                                                                                                            \
-    uint32_t mine_ = 0;                                                                                        \
-    for (int c = lane; c < cpg; c += kWave) mine_ += min(run[c], (uint32_t)max_pts);                           \
-    uint32_t at_ = (uint32_t)wave_inclusive_scan((int)mine_) - mine_;                                          \
-    for (int c = lane; c < cpg; c += kWave) {                                                                  \
-      const uint32_t kept_ = min(run[c], (uint32_t)max_pts);                                                   \
-      run[c] = (at_ << 8) | kept_;                                                                             \
-      at_ += kept_;                                                                                            \
-    }                                                                                                          \
-    vt_wave_sync();                                                                                            \
-  }
-#define PD3_VT_EXPAND(P0, P1)                                                                                  \
-  {                                                                                                            \
-    for (int t = lane; t < tiles; t += kWave) {                                                                \
-      const int lo_ = max(tpre[t], (P0)), hi_ = min(tpre[t + 1], (P1));                                        \
-      const uint32_t src_ = (uint32_t)t * kVtTile + (uint32_t)toff[t] - (uint32_t)tpre[t];                     \
-      for (int j = lo_; j < hi_; ++j) srcpos[j - (P0)] = src_ + (uint32_t)j;                                   \
-    }                                                                                                          \
-    vt_wave_sync();                                                                                            \
-  }
-
-  // all records of a pass are fetched with independent loads up front (their routed positions stay in LDS)
-#define PD3_VT_LOAD(P0, P1)                                                                                    \
-  uint32_t rec[kVtGroupSteps], sl[kVtGroupSteps];                                                              \
-  _Pragma("unroll") for (int u = 0; u < kVtGroupSteps; ++u) {                                                  \
-    const int j = (P0) + u * kWave + lane;                                                                     \
-    rec[u] = 0xFFFFFFFFu; /* idx field all ones never occurs (N < 2^(32-low) - 1: the plan) */                 \
-    sl[u] = 0;                                                                                                 \
-    if (j < (P1)) rec[u] = rf[srcpos[j - (P0)]];                                                               \
-  }
-
-  if (n_g <= kVtGroupPass) {
-    // the whole group in registers: records are fetched once, slots never leave the wave
-    PD3_VT_EXPAND(0, n_g)
-    PD3_VT_LOAD(0, n_g)
-#pragma unroll
-    for (int u = 0; u < kVtGroupSteps; ++u)
-      if (rec[u] != 0xFFFFFFFFu) sl[u] = atomicAdd(&run[rec[u] & cell_mask], 1u);  // earlier points in this cell
-    vt_wave_sync();
-    PD3_VT_SCAN_CELLS()
-#pragma unroll
-    for (int u = 0; u < kVtGroupSteps; ++u)
-      if (rec[u] != 0xFFFFFFFFu) PD3_VT_PLACE(rec[u], srcpos[u * kWave + lane], sl[u])
-  } else {
-    // long record streams (one cell hammered by thousands of points): passes; slots travel through slotr
-    unsigned char* slot_f = slotr + (int64_t)frame * stride;
-    for (int p0 = 0; p0 < n_g; p0 += kVtGroupPass) {
-      const int p1 = min(p0 + kVtGroupPass, n_g);
-      PD3_VT_EXPAND(p0, p1)
-      PD3_VT_LOAD(p0, p1)
-#pragma unroll
-      for (int u = 0; u < kVtGroupSteps; ++u)
-        if (rec[u] != 0xFFFFFFFFu) {
-          sl[u] = atomicAdd(&run[rec[u] & cell_mask], 1u);
-          slot_f[srcpos[u * kWave + lane]] = (unsigned char)min(sl[u], 255u);
+  // Sweep 0 counts (and, when the group is one pass, ranks); the cells are then placed; sweep 1 writes the cposr
+  // words -- from the registers of sweep 0 when the group is one pass, else by walking the passes again.
+  const bool one_pass = npass == 1;
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    for (int p = 0; p < npass; ++p) {
+      if (!(sweep == 1 && one_pass)) {
+        __syncthreads();  // the previous pass is done with the step table and the count tables
+        const int s0 = p * kVgPassSteps, s1 = min(s0 + kVgPassSteps, total_steps);
+        for (int t = threadIdx.x; t < tiles; t += kVgThreads) {
+          const uint32_t d = tdir[t];
+          const int a = (int)tstep[t], b = (int)tstep[t + 1];
+          for (int s = max(a, s0); s < min(b, s1); ++s) {
+            const uint32_t chunk = (uint32_t)(s - a);
+            stepsrc[s - s0] = (uint32_t)t * kVtTile + (d & 0xFFFFu) + chunk * kWave;
+            stepcnt[s - s0] = min((d >> 16) - chunk * kWave, (uint32_t)kWave);
+          }
         }
-      vt_wave_sync();
+        for (int i = threadIdx.x; i < kVgWaves * cw; i += kVgThreads) cntw[i] = 0u;
+        __syncthreads();
+        {
+          const int spw = (int)ceil_div(s1 - s0, kVgWaves);
+          const int s_lo = min(wave * spw, s1 - s0);
+          s_n = min(spw, s1 - s0 - s_lo);
+          my_src = lane < s_n ? stepsrc[s_lo + lane] : 0u;
+          my_cnt = lane < s_n ? stepcnt[s_lo + lane] : 0u;
+        }
+        // every lane loads (lanes past the end of a step re-read its first record): no divergent branch, so
+        // the loads of all steps are in flight together
+#pragma unroll
+        for (int c0 = 0; c0 < kVgSteps; c0 += kVgChunk) {
+#pragma unroll
+          for (int k = 0; k < kVgChunk; ++k) rec[c0 + k] = 0u;
+          if (c0 < s_n) {
+#pragma unroll
+            for (int k = 0; k < kVgChunk; ++k) {
+              const int c = __builtin_amdgcn_readlane((int)my_cnt, c0 + k);
+              const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)my_src, c0 + k);
+              rec[c0 + k] = (rf + src)[lane < c ? lane : 0];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kVgSteps; ++u) {  // (the loaded word is used either way: it stays a plain load)
+          const int c = __builtin_amdgcn_readlane((int)my_cnt, u);
+          rec[u] = (rec[u] & cell_mask) | (lane < c ? 0u : kNoRec);
+        }
+        PD3_MARK();
+#pragma unroll
+        for (int c0 = 0; c0 < kVgSteps; c0 += kVgChunk) {
+          if (c0 < s_n) {
+            uint32_t old[kVgChunk];
+#pragma unroll
+            for (int k = 0; k < kVgChunk; ++k) {
+              // ds_add_rtn_u32: lanes in ascending order within the step, steps in order; lanes without a
+              // record add 0 to the last counter
+              const uint32_t r = rec[c0 + k], cell = r & cell_mask;
+              old[k] = atomicAdd(&cnt_mine[cell >> 1], (r & kNoRec) ? 0u : 1u << ((cell & 1u) * 16u));
+            }
+#pragma unroll
+            for (int k = 0; k < kVgChunk; ++k)
+              rec[c0 + k] |= ((old[k] >> ((rec[c0 + k] & cell_mask & 1u) * 16u)) & 0xFFFFu) << 12;
+          }
+        }
+        PD3_MARK();
+        __syncthreads();
+        // per cell: counts of the four waves -> each wave's base (carry from earlier passes included).  A
+        // thread takes base words j, j + 256, ...: four cells = two words of every wave's table.
+        for (int j0 = threadIdx.x; j0 < bw; j0 += 2 * kVgThreads) {
+          uint32_t v[2][kVgWaves][2], bb[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int j = min(j0 + q * kVgThreads, bw - 1);
+            bb[q] = base[j];
+#pragma unroll
+            for (int w = 0; w < kVgWaves; ++w) {
+              v[q][w][0] = cntw[w * cw + min(2 * j, cw - 1)];
+              v[q][w][1] = cntw[w * cw + min(2 * j + 1, cw - 1)];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int j = j0 + q * kVgThreads;
+            if (j >= bw) break;
+            uint32_t b0 = bb[q] & 0xFFu, b1 = (bb[q] >> 8) & 0xFFu, b2 = (bb[q] >> 16) & 0xFFu, b3 = bb[q] >> 24;
+#pragma unroll
+            for (int w = 0; w < kVgWaves; ++w) {
+              cntw[w * cw + 2 * j] = b0 | (b1 << 16);
+              if (2 * j + 1 < cw) cntw[w * cw + 2 * j + 1] = b2 | (b3 << 16);
+              b0 = min(b0 + (v[q][w][0] & 0xFFFFu), 255u);
+              b1 = min(b1 + (v[q][w][0] >> 16), 255u);
+              if (2 * j + 1 < cw) {
+                b2 = min(b2 + (v[q][w][1] & 0xFFFFu), 255u);
+                b3 = min(b3 + (v[q][w][1] >> 16), 255u);
+              }
+            }
+            base[j] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+          }
+        }
+        if (sweep == 1 || one_pass) {
+          __syncthreads();
+          PD3_MARK();
+#pragma unroll
+          for (int c0 = 0; c0 < kVgSteps; c0 += kVgChunk) {
+            if (c0 < s_n) {
+              uint32_t b[kVgChunk];
+#pragma unroll
+              for (int k = 0; k < kVgChunk; ++k) b[k] = cnt_mine[(rec[c0 + k] & cell_mask) >> 1];
+#pragma unroll
+              for (int k = 0; k < kVgChunk; ++k)  // a saturated base (255) is past every limit (P <= 254)
+                rec[c0 + k] += ((b[k] >> ((rec[c0 + k] & cell_mask & 1u) * 16u)) & 0xFFFFu) << 12;
+            }
+          }
+        }
+      }
+      if (sweep == 1) {
+        // cposr words of the pass; cell starts (kept << 24 | start) come from the table in LDS (one pass) or gs
+        uint32_t firsts = 0;  // lane u: first points seen in the wave's step u
+#pragma unroll
+        for (int c0 = 0; c0 < kVgSteps; c0 += kVgChunk) {
+          if (c0 < s_n) {
+            uint32_t packed[kVgChunk];
+            if (one_pass) {
+#pragma unroll
+              for (int k = 0; k < kVgChunk; ++k) packed[k] = cntw[rec[c0 + k] & cell_mask];
+            } else {
+#pragma unroll
+              for (int k = 0; k < kVgChunk; ++k) packed[k] = gs[rec[c0 + k] & cell_mask];
+            }
+#pragma unroll
+            for (int k = 0; k < kVgChunk; ++k) {
+              const int u = c0 + k;
+              const bool valid = !(rec[u] & kNoRec);
+              const uint32_t slot = (rec[u] >> 12) & 0xFFFFu;
+              const bool first = valid && slot == 0u;
+              const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)my_src, u);
+              uint32_t w = slot < (uint32_t)max_pts ? region + (packed[k] & 0xFFFFFFu) + slot : kVtDropped;
+              if (first) w |= kVtFirstBit | ((packed[k] >> 24) << kVtKeptShift);
+              if (valid) (cpos_f + src)[lane] = w;
+              const uint32_t nfirst = (uint32_t)__popcll(__ballot(first));
+              firsts = lane == u ? nfirst : firsts;
+            }
+          }
+        }
+        if (lane < s_n && firsts) atomicAdd(&tfirst[my_src / kVtTile], firsts);
+      }
     }
-    PD3_VT_SCAN_CELLS()
-    for (int p0 = 0; p0 < n_g; p0 += kVtGroupPass) {
-      const int p1 = min(p0 + kVtGroupPass, n_g);
-      PD3_VT_EXPAND(p0, p1)
-      PD3_VT_LOAD(p0, p1)
+    if (sweep == 0) {
+      // cells -> places in the group's region.  Any order of the cells will do (the array is scratch): thread
+      // t takes the cells of base words t, t + 256, ...  Entry = (kept << 24) | start.  With one pass the count
+      // tables are dead and the start table takes their place; else it goes to gs and `base` starts over.
+      PD3_MARK();
+      __syncthreads();
+      uint32_t mine = 0;
+      for (int j = threadIdx.x; j < bw; j += kVgThreads) {
+        const uint32_t b = base[j];
+        mine += min(b & 0xFFu, (uint32_t)max_pts) + min((b >> 8) & 0xFFu, (uint32_t)max_pts) +
+                min((b >> 16) & 0xFFu, (uint32_t)max_pts) + min(b >> 24, (uint32_t)max_pts);
+      }
+      int all;
+      uint32_t at = (uint32_t)block_exclusive_scan<kVgThreads>((int)mine, scan_tmp, all);
+      for (int j = threadIdx.x; j < bw; j += kVgThreads) {
+        const uint32_t b = base[j];
+        uint32_t e[4];
 #pragma unroll
-      for (int u = 0; u < kVtGroupSteps; ++u)
-        if (rec[u] != 0xFFFFFFFFu) sl[u] = slot_f[srcpos[u * kWave + lane]];
-#pragma unroll
-      for (int u = 0; u < kVtGroupSteps; ++u)
-        if (rec[u] != 0xFFFFFFFFu) PD3_VT_PLACE(rec[u], srcpos[u * kWave + lane], sl[u])
-      vt_wave_sync();
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t kept = min((b >> (8 * q)) & 0xFFu, (uint32_t)max_pts);
+          e[q] = (kept << 24) | at;
+          at += kept;
+        }
+        if (one_pass) {
+          if (cpg >= 4) {
+            *reinterpret_cast<uint4*>(cntw + 4 * j) = make_uint4(e[0], e[1], e[2], e[3]);
+          } else {
+            for (int q = 0; q < cpg; ++q) cntw[q] = e[q];
+          }
+        } else {
+          for (int q = 0; q < min(cpg, 4); ++q) gs[4 * j + q] = e[q];
+          base[j] = 0u;
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+      PD3_MARK();
     }
   }
-#undef PD3_VT_LOAD
-#undef PD3_VT_PLACE
-#undef PD3_VT_SCAN_CELLS
-#undef PD3_VT_EXPAND
-  vt_wave_sync();
-  for (int t = lane; t < tiles; t += kWave)
+  PD3_MARK();
+  __syncthreads();
+  for (int t = threadIdx.x; t < tiles; t += kVgThreads)
     if (tfirst[t]) atomicAdd(&tilecnt[(int64_t)frame * tiles + t], tfirst[t]);
+#ifdef PD3_VT_TRACE
+  PD3_MARK();
+  if (lane == 0 && wave == 0 && gridDim.x <= 64)
+    printf("WG %d steps %d npass %d total %lld\n", (int)blockIdx.x, total_steps, npass, tr[trn - 1] - tr[0]);
+  if ((blockIdx.x == 0 || blockIdx.x == 37) && lane == 0)
+    printf("wg %d wave %d steps %d npass %d: %lld %lld %lld %lld %lld %lld %lld %lld %lld\n", (int)blockIdx.x, wave,
+           total_steps, npass, tr[1] - tr[0], tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3], tr[5] - tr[4],
+           tr[6] - tr[5], tr[7] - tr[6], tr[8] - tr[7], 0ll);
+#endif
+#undef PD3_MARK
 }
 
 // ------------------------------------------------------------------------------------------------ C + D
@@ -449,24 +601,43 @@ struct VtAssignLds {
   uint32_t slice[kVtTile];        // the tile's cposr; later key of the tile's j-th new voxel
   uint32_t st_info[kVtTile];      // compact start of the tile's j-th new voxel
   unsigned char st_kept[kVtTile];  // its kept count
+  unsigned short goff[1 << kVtMaxGbits];  // the tile's directory row: start of every group's run in the slice
   int s_inc[kVtRouteWaves], s_before[kVtRouteWaves], s_all[kVtRouteWaves];
 };
+
+// Both jobs start from the tile's cposr slice and directory row in LDS.  Ends with a barrier.
+__device__ __forceinline__ void vt_load_slice(VtAssignLds& L, int frame, int tile, int tiles, int gbits,
+                                              const uint32_t* __restrict__ cposr,
+                                              const uint32_t* __restrict__ dir) {
+  const int groups = 1 << gbits;
+  const int64_t tbase = ((int64_t)frame * tiles + tile) * kVtTile;
+  const uint4* src = reinterpret_cast<const uint4*>(cposr + tbase);
+  uint4* dst = reinterpret_cast<uint4*>(L.slice);
+  for (int j = threadIdx.x; j < kVtTile / 4; j += kVtRouteThreads) dst[j] = src[j];
+  const uint32_t* drow = dir + ((int64_t)frame * tiles + tile) * groups;
+  for (int j = threadIdx.x; j < groups; j += kVtRouteThreads) L.goff[j] = (unsigned short)drow[j];
+  __syncthreads();
+}
+
+// the last group whose run in the slice starts at or before pos (empty groups share their successor's start)
+__device__ __forceinline__ uint32_t vt_group_of(const VtAssignLds& L, uint32_t pos, int gbits) {
+  uint32_t grp = 0;
+  for (int step = 1 << (gbits - 1); step > 0; step >>= 1)
+    if ((uint32_t)L.goff[grp + step] <= pos) grp += step;
+  return grp;
+}
 
 // C: voxel id = number of first-point flags before the cell's first point.  One workgroup per tile; thread t
 // owns the 8 consecutive points 8t .. 8t+7.  The voxels a tile opens have consecutive ids, so their rows of
 // vinfo / coords / num_points / coors4 are staged in LDS and leave coalesced.
 __device__ __forceinline__ void vt_assign_tile(
     VtAssignLds& L, int frame, int tile, const uint32_t* __restrict__ cposr,
-    const unsigned short* __restrict__ pos16, const uint4* __restrict__ owner,
+    const unsigned short* __restrict__ pos16, const uint32_t* __restrict__ recs,
+    const uint32_t* __restrict__ dir, int low, int gbits,
     const uint32_t* __restrict__ tilecnt, int tiles, int max_voxels, const VtGrid& g,
     uint2* __restrict__ vinfo, int* __restrict__ totals, int32_t* __restrict__ coords,
     int32_t* __restrict__ num_pts, int32_t* __restrict__ coors4) {
   const int64_t tbase = ((int64_t)frame * tiles + tile) * kVtTile;
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(cposr + tbase);
-    uint4* dst = reinterpret_cast<uint4*>(L.slice);
-    for (int j = threadIdx.x; j < kVtTile / 4; j += kVtRouteThreads) dst[j] = src[j];
-  }
   // first-point counts of the tiles before this one (and of all tiles -> totals)
   int before = 0, all = 0;
   for (int t = threadIdx.x; t < tiles; t += kVtRouteThreads) {
@@ -475,19 +646,24 @@ __device__ __forceinline__ void vt_assign_tile(
     if (t < tile) before += v;
   }
   const uint4 pw = *reinterpret_cast<const uint4*>(pos16 + tbase + (int64_t)threadIdx.x * 8);
-  __syncthreads();
+  vt_load_slice(L, frame, tile, tiles, gbits, cposr, dir);
   const uint32_t pword[4] = {pw.x, pw.y, pw.z, pw.w};
+  // a first point's cposr word carries (compact start, kept count); its cell = (group, cell in group): the
+  // group is the run of the slice its position lies in, the cell in the group sits in its routed record
   uint32_t flags = 0;
+  uint32_t o_word[8], o_key[8];
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
     const uint32_t pos = (pword[b >> 1] >> (16 * (b & 1))) & 0xFFFFu;
-    if (pos != 0xFFFFu && (L.slice[pos] & kVtFirstBit)) flags |= 1u << b;
-  }
-  uint4 o[8];
-#pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    o[b] = make_uint4(0u, 0u, 0u, 0u);
-    if (flags & (1u << b)) o[b] = owner[tbase + (int64_t)threadIdx.x * 8 + b];
+    o_word[b] = 0u;
+    o_key[b] = 0u;
+    if (pos != 0xFFFFu && (L.slice[pos] & kVtFirstBit)) {
+      flags |= 1u << b;
+      o_key[b] = recs[tbase + pos];
+      const uint32_t grp = vt_group_of(L, pos, gbits);
+      o_word[b] = L.slice[pos];
+      o_key[b] = vt_group_to_key(grp, o_key[b] & ((1u << low) - 1u), gbits);
+    }
   }
   const int mine = __popc(flags);
   int inc = mine;
@@ -516,9 +692,9 @@ __device__ __forceinline__ void vt_assign_tile(
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
     if (flags & (1u << b)) {
-      L.slice[local] = o[b].x;
-      L.st_info[local] = o[b].y;
-      L.st_kept[local] = (unsigned char)o[b].z;
+      L.slice[local] = o_key[b];
+      L.st_info[local] = o_word[b] & kVtCpMask;
+      L.st_kept[local] = (unsigned char)((o_word[b] >> kVtKeptShift) & 0xFFu);
       ++local;
     }
   }
@@ -543,21 +719,18 @@ __device__ __forceinline__ void vt_assign_tile(
 // of the workgroup takes points t, t + 512, ... of the tile: fully coalesced loads; the destination comes from
 // the tile's cposr slice (staged in LDS) through pos16; the stores are DIM*4-byte pieces that merge in L2.
 template <int DIM>
-__device__ __forceinline__ void vt_emit_tile(uint32_t* __restrict__ slice, int frame, int tile,
+__device__ __forceinline__ void vt_emit_tile(VtAssignLds& L, int frame, int tile,
                                              const float* __restrict__ points, int64_t n, int dim_rt, int tiles,
-                                             const uint32_t* __restrict__ cposr,
+                                             int gbits, const uint32_t* __restrict__ cposr,
+                                             const uint32_t* __restrict__ dir,
                                              const unsigned short* __restrict__ pos16, int64_t cap,
                                              float* __restrict__ compact) {
+  const uint32_t* slice = L.slice;
   const int dim = DIM > 0 ? DIM : dim_rt;
   const int64_t tbase = ((int64_t)frame * tiles + tile) * kVtTile;
   const float* pf = points + (int64_t)frame * n * dim;
   float* cf = compact + (int64_t)frame * cap * dim;
   const int64_t base_i = (int64_t)tile * kVtTile + threadIdx.x;
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(cposr + tbase);
-    uint4* dst = reinterpret_cast<uint4*>(slice);
-    for (int j = threadIdx.x; j < kVtTile / 4; j += kVtRouteThreads) dst[j] = src[j];
-  }
   uint32_t pos[kVtRounds];
 #pragma unroll
   for (int r = 0; r < kVtRounds; ++r) pos[r] = pos16[tbase + threadIdx.x + r * kVtRouteThreads];
@@ -574,21 +747,21 @@ __device__ __forceinline__ void vt_emit_tile(uint32_t* __restrict__ slice, int f
         if (DIM == 5) e[r] = pf[i * DIM + 4];
       }
     }
-    __syncthreads();
+    vt_load_slice(L, frame, tile, tiles, gbits, cposr, dir);
 #pragma unroll
     for (int r = 0; r < kVtRounds; ++r) {
       if (pos[r] == 0xFFFFu) continue;
-      const uint32_t cp = slice[pos[r]] & ~kVtFirstBit;
+      const uint32_t cp = slice[pos[r]] & kVtCpMask;
       if (cp == kVtDropped) continue;
       float* d = cf + (int64_t)cp * DIM;
       *reinterpret_cast<vt_f32x4u*>(d) = a[r];
       if (DIM == 5) d[4] = e[r];
     }
   } else {
-    __syncthreads();
+    vt_load_slice(L, frame, tile, tiles, gbits, cposr, dir);
     for (int r = 0; r < kVtRounds; ++r) {
       if (pos[r] == 0xFFFFu) continue;
-      const uint32_t cp = slice[pos[r]] & ~kVtFirstBit;
+      const uint32_t cp = slice[pos[r]] & kVtCpMask;
       if (cp == kVtDropped) continue;
       const float* src = pf + (base_i + r * kVtRouteThreads) * dim;
       float* d = cf + (int64_t)cp * dim;
@@ -598,10 +771,11 @@ __device__ __forceinline__ void vt_emit_tile(uint32_t* __restrict__ slice, int f
 }
 
 template <int DIM>
-__global__ __launch_bounds__(kVtRouteThreads, 4) void vt_assign_emit_kernel(
+__global__ __launch_bounds__(kVtRouteThreads, 8) void vt_assign_emit_kernel(
     const float* __restrict__ points, int64_t n, int dim_rt, int tiles, int batch,
     const uint32_t* __restrict__ cposr, const unsigned short* __restrict__ pos16,
-    const uint4* __restrict__ owner, const uint32_t* __restrict__ tilecnt, int max_voxels, VtGrid g,
+    const uint32_t* __restrict__ recs, const uint32_t* __restrict__ dir, int low, int gbits,
+    const uint32_t* __restrict__ tilecnt, int max_voxels, VtGrid g,
     uint2* __restrict__ vinfo, int* __restrict__ totals, int32_t* __restrict__ coords,
     int32_t* __restrict__ num_pts, int32_t* __restrict__ coors4, int64_t cap, float* __restrict__ compact) {
   __shared__ VtAssignLds L;
@@ -609,11 +783,11 @@ __global__ __launch_bounds__(kVtRouteThreads, 4) void vt_assign_emit_kernel(
   int frame, tile;
   if (blockIdx.x < per_job) {
     vt_unit(blockIdx.x, (uint32_t)tiles, (uint32_t)batch, frame, tile);
-    vt_assign_tile(L, frame, tile, cposr, pos16, owner, tilecnt, tiles, max_voxels, g, vinfo, totals, coords,
-                   num_pts, coors4);
+    vt_assign_tile(L, frame, tile, cposr, pos16, recs, dir, low, gbits, tilecnt, tiles, max_voxels, g, vinfo,
+                   totals, coords, num_pts, coors4);
   } else {
     vt_unit(blockIdx.x - per_job, (uint32_t)tiles, (uint32_t)batch, frame, tile);
-    vt_emit_tile<DIM>(L.slice, frame, tile, points, n, dim_rt, tiles, cposr, pos16, cap, compact);
+    vt_emit_tile<DIM>(L, frame, tile, points, n, dim_rt, tiles, gbits, cposr, dir, pos16, cap, compact);
   }
 }
 
@@ -691,7 +865,9 @@ __global__ __launch_bounds__(kVtRowsThreads) void vt_rows_kernel(
     if (q >= total_q) break;
     float* dst = vf + (int64_t)q * VEC;
     if (VEC == 4) {
-      *reinterpret_cast<float4*>(dst) = make_float4(val[u][0], val[u][1], val[u][2], val[u][3]);
+      typedef float f32x4a __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(f32x4a{val[u][0], val[u][1], val[u][2], val[u][3]},
+                                  reinterpret_cast<f32x4a*>(dst));  // written once, read by the next op
     } else {
 #pragma unroll
       for (int c = 0; c < VEC; ++c) dst[c] = val[u][c];
