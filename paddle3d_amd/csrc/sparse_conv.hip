@@ -404,6 +404,183 @@ __global__ __launch_bounds__(256) void sp_gemm_mfma_kernel(SpGemmArgs a, int cin
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// gather-GEMM, second form: the one the encoder's layers run (cin a multiple of 16, K <= 27).
+// Tile = 128 output rows per workgroup (4 waves x 2 blocks of 16 rows) x all Cout = 16 NB columns.
+// The A operand never touches LDS: with the MFMA's K index kk = lane >> 4 standing for the input channels
+// ci0 + kk*T + t (t = K step 0..T-1; A and B only have to agree on the assignment), lane (i, kk) needs T
+// CONSECUTIVE floats of input row nbr[row i][k] -- one or two 16-byte global loads straight into the operand
+// registers (the four kk lanes of a row read one 64/128-byte piece of it), fetched one (offset, chunk) step
+// ahead of their MFMAs.  W[k] chunks (4T input channels x Cout) go global -> registers (a step ahead) -> LDS,
+// transposed on the way into "one line per lane": line (kk, j) holds W[ci0 + kk*T + t][16 u + j] as [u][t], so a
+// lane's B values for a column block are T consecutive floats (ds_read_b128; lines are padded to NB*T + 4
+// floats: conflict-free).  LDS is double-buffered: one barrier per step.  Per step and wave: 2*NB*T MFMAs
+// behind 2*NB*T/8 LDS reads.
+// The tile's [128][K] slice of the rulebook is loaded once (coalesced); offsets that no row of the workgroup /
+// of a wave needs are skipped for the workgroup / the wave.  The summation order (k ascending, then the
+// channel chunks, then t) is fixed => bit-reproducible results.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSg2Rows = 128;
+constexpr int kSg2MaxK = 27;
+
+template <int NB, int T>
+__global__ __launch_bounds__(256, 2) void sp_gemm_rows_kernel(SpGemmArgs a) {
+  constexpr int CH = 4 * T;                 // input channels per step
+  constexpr int S = NB * T + 4;             // floats per W line in LDS
+  constexpr int WSZ = 64 * S;               // one staged W chunk
+  constexpr int WQ = CH * NB * 4;           // float4 of a W chunk in global memory
+  constexpr int WPT = (WQ + 255) / 256;     // per thread
+  constexpr int AQ = T / 4;                 // float4 of A per lane and row block
+  extern __shared__ __attribute__((aligned(16))) float sp_smem[];
+  float* Ws = sp_smem;                                        // [2][WSZ]
+  int* nbs = reinterpret_cast<int*>(Ws + 2 * WSZ);            // [128][K]
+  uint32_t* masks = reinterpret_cast<uint32_t*>(nbs + kSg2Rows * a.K);  // [0] workgroup, [1 + row block]
+  const int lane = lane_id(), wave = wave_id();
+  const int K = a.K, cin = a.cin;
+  const int n_out = a.n_out_dev ? min(*a.n_out_dev, a.n_out_cap) : a.n_out_cap;
+  const int row0 = blockIdx.x * kSg2Rows;
+  if (row0 >= n_out) return;
+  {
+    const int live = min(kSg2Rows, n_out - row0) * K;
+    const int32_t* src = a.nbr + (int64_t)row0 * K;
+    for (int e = threadIdx.x; e < kSg2Rows * K; e += 256) nbs[e] = e < live ? src[e] : -1;
+    if (threadIdx.x < 9) masks[threadIdx.x] = 0u;
+  }
+  __syncthreads();
+  if (threadIdx.x < kSg2Rows) {  // which offsets does each block of 16 rows need
+    uint32_t m = 0;
+    for (int k = 0; k < K; ++k) m |= nbs[threadIdx.x * K + k] >= 0 ? 1u << k : 0u;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) m |= (uint32_t)__shfl_xor((int)m, d, kWave);
+    if ((lane & 15) == 0 && m) {
+      atomicOr(&masks[1 + (threadIdx.x >> 4)], m);
+      atomicOr(&masks[0], m);
+    }
+  }
+  __syncthreads();
+  const uint32_t wg_mask = masks[0];
+  const uint32_t wave_mask = masks[1 + 2 * wave] | masks[2 + 2 * wave];
+  const int nchunks = cin / CH;
+  const int cout = NB * 16;
+  const int ai = lane & 15, akk = lane >> 4;
+
+  sp_f32x4 acc[NB][2];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) acc[u][0] = acc[u][1] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+  sp_f32x4 wreg[WPT], acur[2][AQ], anext[2][AQ];
+
+  auto fetch_w = [&](int k, int c) {
+    const float* wk = a.weight + ((int64_t)k * cin + (int64_t)c * CH) * cout;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int e = threadIdx.x + i * 256;
+      wreg[i] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (WQ % 256 == 0 || e < WQ) wreg[i] = *reinterpret_cast<const sp_f32x4*>(wk + (int64_t)e * 4);
+    }
+  };
+  auto stash_w = [&](float* dst) {  // row r = kk*T + t of the chunk, columns 4 c4 .. 4 c4 + 3 = 16 u + j ..
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int e = threadIdx.x + i * 256;
+      if (WQ % 256 != 0 && e >= WQ) break;
+      const int r = e / (NB * 4), c4 = e - r * (NB * 4);
+      const int kk = r / T, t = r - kk * T, u = c4 >> 2, j = (c4 & 3) * 4;
+      float* d = dst + (kk * 16 + j) * S + u * T + t;
+      d[0] = wreg[i][0];
+      d[S] = wreg[i][1];
+      d[2 * S] = wreg[i][2];
+      d[3 * S] = wreg[i][3];
+    }
+  };
+  auto fetch_a = [&](int k, int c, sp_f32x4 (&dst)[2][AQ]) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int j = nbs[(wave * 32 + rb * 16 + ai) * K + k];
+#pragma unroll
+      for (int q = 0; q < AQ; ++q) dst[rb][q] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (j >= 0) {
+        const sp_f32x4* src = reinterpret_cast<const sp_f32x4*>(a.in + (int64_t)j * cin + c * CH + akk * T);
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) dst[rb][q] = src[q];
+      }
+    }
+  };
+  auto next_step = [&](int& k, int& c) {  // (k, c) -> the following step, k = -1 at the end
+    if (++c < nchunks) return;
+    c = 0;
+    const uint32_t rest = k + 1 < 32 ? wg_mask >> (k + 1) : 0u;
+    k = rest ? k + 1 + __builtin_ctz(rest) : -1;
+  };
+
+  int k = wg_mask ? __builtin_ctz(wg_mask) : -1, c = 0, buf = 0;
+  if (k >= 0) {
+    fetch_w(k, c);
+    if ((wave_mask >> k) & 1u) fetch_a(k, c, acur);
+    stash_w(Ws);
+  }
+  __syncthreads();
+  while (k >= 0) {
+    int k2 = k, c2 = c;
+    next_step(k2, c2);
+    const bool more = k2 >= 0;
+    const bool need = (wave_mask >> k) & 1u, need2 = more && ((wave_mask >> k2) & 1u);
+    if (more) fetch_w(k2, c2);
+    if (need2) fetch_a(k2, c2, anext);
+    if (need) {
+      const float* wl = Ws + buf * WSZ + lane * S;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        float b[T];
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+          const sp_f32x4 v = *reinterpret_cast<const sp_f32x4*>(wl + u * T + q * 4);
+          b[q * 4 + 0] = v[0];
+          b[q * 4 + 1] = v[1];
+          b[q * 4 + 2] = v[2];
+          b[q * 4 + 3] = v[3];
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[0][t >> 2][t & 3], b[t], acc[u][0], 0, 0, 0);
+          acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[1][t >> 2][t & 3], b[t], acc[u][1], 0, 0, 0);
+        }
+      }
+    }
+    if (more) stash_w(Ws + (buf ^ 1) * WSZ);
+    if (need2) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) acur[rb][q] = anext[rb][q];
+    }
+    __syncthreads();
+    buf ^= 1;
+    k = k2;
+    c = c2;
+  }
+  // epilogue: D layout col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const int co = u * 16 + (lane & 15);
+    const float bias = a.bias ? a.bias[co] : 0.f;
+    const float sc = a.scale ? a.scale[co] : 1.f, sh = a.scale ? a.shift[co] : 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + wave * 32 + rb * 16 + (lane >> 4) * 4 + r;
+        if (row >= n_out) continue;
+        float v = acc[u][rb][r];
+        if (a.bias) v += bias;
+        if (a.scale) v = fmaf(v, sc, sh);
+        if (a.residual) v += a.residual[(int64_t)row * cout + co];
+        if (a.relu) v = fmaxf(v, 0.f);
+        a.out[(int64_t)row * cout + co] = v;
+      }
+    }
+  }
+}
+
 // values [n, c] at coords (b,z,y,x) -> dense [B, C*D, H, W]  (to_dense + transpose + reshape of
 // sparse_resnet.py:202-205 in one pass; the destination is zero-filled first)
 __global__ __launch_bounds__(256) void sp_to_dense_kernel(const float* __restrict__ feats,
@@ -563,9 +740,38 @@ extern "C" int pd3_sparse_conv3d_features(const float* in_feats, const int32_t* 
                kernel_volume, cin, cout, relu ? 1 : 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e;
+  if (cin % 16 == 0 && kernel_volume <= kSg2MaxK && (cout == 16 || cout == 32 || cout == 64 || cout == 128) &&
+      reinterpret_cast<uintptr_t>(weight) % 16 == 0 && reinterpret_cast<uintptr_t>(in_feats) % 16 == 0) {
+    // the encoder's shapes: 128-row tiles, A operand straight from global memory
+    const int t = cin % 32 == 0 ? 8 : 4, nb = cout / 16;
+    const size_t lds = (size_t)2 * 64 * (nb * t + 4) * sizeof(float) +
+                       ((size_t)kSg2Rows * kernel_volume + 16) * sizeof(int);
+    const unsigned grid = (unsigned)ceil_div(n_out_cap, kSg2Rows);
+#define PD3_SP_ROWS(NBV, TV)                                                                      \
+  do {                                                                                            \
+    if (lds > 48 * 1024) {                                                                        \
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gemm_rows_kernel<NBV, TV>),        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+      if (e != hipSuccess) return (int)e;                                                         \
+    }                                                                                             \
+    sp_gemm_rows_kernel<NBV, TV><<<grid, 256, lds, s>>>(a);                                       \
+  } while (0)
+    switch (nb * 16 + t) {
+      case 1 * 16 + 4: PD3_SP_ROWS(1, 4); break;
+      case 1 * 16 + 8: PD3_SP_ROWS(1, 8); break;
+      case 2 * 16 + 4: PD3_SP_ROWS(2, 4); break;
+      case 2 * 16 + 8: PD3_SP_ROWS(2, 8); break;
+      case 4 * 16 + 4: PD3_SP_ROWS(4, 4); break;
+      case 4 * 16 + 8: PD3_SP_ROWS(4, 8); break;
+      case 8 * 16 + 4: PD3_SP_ROWS(8, 4); break;
+      default: PD3_SP_ROWS(8, 8); break;
+    }
+#undef PD3_SP_ROWS
+    return launch_status();
+  }
   if (cout % 16 == 0 && (reinterpret_cast<uintptr_t>(weight) % 16 == 0) &&
       (cin % 4 != 0 || reinterpret_cast<uintptr_t>(in_feats) % 16 == 0)) {
-    // matrix-core path
+    // matrix-core path, any cin (the encoder's input layer: cin = 5)
     const int cin_pad = (cin + 3) / 4 * 4;
     const int astride = ((cin_pad - 2 + 15) / 16) * 16 + 2;
     const int wstride = cout == 16 ? 16 : cout + 16;

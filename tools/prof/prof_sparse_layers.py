@@ -1,0 +1,56 @@
+"""Per-layer timing of the sparse encoder of CenterPoint-Voxel (not a test): rows, kernel volume, channels,
+existing (row, offset) pairs, (16-row block, offset) pairs the matrix-core kernel executes, time, TFLOP/s."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from paddle3d_amd import centerpoint as cpm  # noqa: E402
+from paddle3d_amd import synth  # noqa: E402
+from paddle3d_amd.ops import sparse_conv3d as _sp  # noqa: E402
+
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+model = cpm.centerpoint_voxels_nuscenes(max_num_voxels=(120000, 160000)).cuda().eval()
+pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(100 + i) for i in range(batch)])).cuda()
+rows = []
+_feat = _sp.features
+
+
+def traced(in_feats, idx, weight, *a, **kw):
+    for _ in range(2):
+        _feat(in_feats, idx, weight, *a, **kw)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        out = _feat(in_feats, idx, weight, *a, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    nbr = idx.nbr[: idx.n_out]
+    present = nbr >= 0
+    pairs = int(present.sum())
+    n16 = (idx.n_out + 15) // 16 * 16
+    pad = torch.zeros(n16 - idx.n_out, nbr.shape[1], dtype=torch.bool, device=nbr.device)
+    blocks = int(torch.cat([present, pad]).view(-1, 16, nbr.shape[1]).any(1).sum()) * 16
+    cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
+    rows.append((idx.n_out, nbr.shape[1], cin, cout, pairs, blocks, ms))
+    return out
+
+
+_sp.features = traced
+with torch.no_grad():
+    voxels, coors, npv, nv = model.voxelizer(pts)
+    b, v, p, d = voxels.shape
+    keep = coors.view(b * v, 4)[:, 0] >= 0
+    cs = coors.view(b * v, 4)[keep].contiguous()
+    feats = model.voxel_encoder(voxels.view(b * v, p, d)[keep], npv.view(b * v)[keep], cs)
+    model.middle_encoder(feats, cs, b)
+tot = 0.0
+print(f"{'rows':>8} {'K':>3} {'cin':>4} {'cout':>4} {'pairs/row':>9} {'exec/useful':>11} {'ms':>8} {'useful TF':>9} {'exec TF':>8}")
+for n, k, ci, co, pairs, blocks, ms in rows:
+    tot += ms
+    print(f"{n:8d} {k:3d} {ci:4d} {co:4d} {pairs / n:9.2f} {blocks / max(pairs, 1):11.2f} {ms:8.3f} "
+          f"{2 * ci * co * pairs / ms / 1e9:9.1f} {2 * ci * co * blocks / ms / 1e9:8.1f}")
+print("sum of feature kernels (ms):", tot)
