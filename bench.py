@@ -395,11 +395,8 @@ def bench_voxel(args, rank, world, dev):
         mark(1)
         b, v, p, d = voxels.shape
         voxels, coors, npv = voxels.view(b * v, p, d), coors.view(b * v, 4), npv.view(b * v)
-        keep = coors[:, 0] >= 0
-        voxels, coors, npv = voxels[keep], coors[keep].contiguous(), npv[keep]
-        feats = model.voxel_encoder(voxels, npv, coors)
+        feats = model.voxel_encoder(voxels, npv, coors)  # padding rows included: the encoder skips them
         x = model.middle_encoder(feats, coors, b)
-        stats["active_voxels"] = int(coors.shape[0])
         mark(2)
         x = model.dense_forward(x)
         preds, _ = model.bbox_head(x)
@@ -423,6 +420,7 @@ def bench_voxel(args, rank, world, dev):
         b, v, p, d = voxels.shape
         keep = coors.view(b * v, 4)[:, 0] >= 0
         cs = coors.view(b * v, 4)[keep].contiguous()
+        stats["active_voxels"] = int(cs.shape[0])
         sp = _sparse.count_flops(model.middle_encoder, model.voxel_encoder(voxels.view(b * v, p, d)[keep],
                                                                           npv.view(b * v)[keep], cs), cs, b)
     line = {

@@ -275,6 +275,35 @@ int pd3_sparse_conv3d_features(const float *in_feats, const int32_t *nbr, const 
                                const float *weight, const float *bias, const float *scale,
                                const float *shift, const float *residual, int relu, float *out,
                                void *stream);
+/* Plan path: the index sets of a whole encoder without a host round trip between the convolutions (the
+ * reference's layers read nnz on the host after every sparse op).  An index set is a SORTED array of keys
+ * ((b*D + z)*H + y)*W + x (raster order; 0xFFFFFFFF = padding, at the end) with its length in device memory.
+ *   pd3_sparse_sort_coords   coords [n, 4] (rows with batch < 0 are padding) -> keys_sorted [n], order [n]
+ *                            (keys_sorted[i] belongs to input row order[i]), n_valid [1]
+ *   pd3_sparse_conv_outputs  the output set of a regular convolution: every position an active input reaches
+ *                            (paddle.sparse.nn.Conv3D), sorted; n_in / n_out are device counts, out_cap >= the
+ *                            number of outputs (min(n_in_cap * prod(ceil(k/s)), batch * D' * H' * W') always is)
+ *   pd3_sparse_rulebook      nbr [n_out_cap, kd*kh*kw] (input row or -1) and, if out_coords != NULL, the (b, z,
+ *                            y, x) rows of the output set; in_keys / out_keys as produced above (subm != 0: pass
+ *                            the same array twice); n_in / n_out may be NULL (= the caps).  A neighbour is looked
+ *                            up by a binary search inside its (b, z, y) line of the sorted input array.
+ * Workspaces: pd3_sparse_plan_workspace(n) for the sort, pd3_sparse_conv_outputs_workspace (a byte map of the
+ * output grid) and pd3_sparse_rulebook_workspace (first row of every (b, z, y) line of the input set). */
+size_t pd3_sparse_plan_workspace(int n_cap);
+size_t pd3_sparse_conv_outputs_workspace(int batch, const int *spatial_shape, const int *kernel_size,
+                                         const int *stride, const int *padding);
+int pd3_sparse_sort_coords(const int32_t *coords, int n, int batch, const int *spatial_shape,
+                           uint32_t *keys_sorted, int32_t *order, int32_t *n_valid, void *workspace,
+                           size_t workspace_bytes, void *stream);
+int pd3_sparse_conv_outputs(const uint32_t *in_keys, const int32_t *n_in, int n_in_cap, int batch,
+                            const int *spatial_shape, const int *kernel_size, const int *stride,
+                            const int *padding, uint32_t *out_keys, int32_t *n_out, int out_cap,
+                            void *workspace, size_t workspace_bytes, void *stream);
+size_t pd3_sparse_rulebook_workspace(int batch, const int *spatial_shape);  /* spatial_shape of the INPUT set */
+int pd3_sparse_rulebook(const uint32_t *in_keys, const int32_t *n_in, int n_in_cap, const uint32_t *out_keys,
+                        const int32_t *n_out, int n_out_cap, int batch, const int *spatial_shape,
+                        const int *kernel_size, const int *stride, const int *padding, int subm, int32_t *nbr,
+                        int32_t *out_coords, void *workspace, size_t workspace_bytes, void *stream);
 /* values [n, C] at coords -> dense [batch, C*D, H, W] fp32 (to_dense + transpose + reshape of
  * sparse_resnet.py:202-205); `dense` is fully written (zero where inactive). n may be NULL (= n_cap). */
 int pd3_sparse_to_dense(const float *feats, const int32_t *coords, const int32_t *n, int n_cap,

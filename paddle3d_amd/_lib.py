@@ -71,6 +71,17 @@ _SIGNATURES = {
     "pd3_sparse_conv3d_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_sparse_plan_workspace": (C.c_size_t, [C.c_int]),
+    "pd3_sparse_conv_outputs_workspace": (C.c_size_t, [C.c_int] + [C.c_void_p] * 4),
+    "pd3_sparse_sort_coords": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pd3_sparse_conv_outputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_size_t, C.c_void_p]),
+    "pd3_sparse_rulebook_workspace": (C.c_size_t, [C.c_int, C.c_void_p]),
+    "pd3_sparse_rulebook": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pd3_sparse_to_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "pd3_merge_sweeps_workspace": (C.c_size_t, [C.c_int64]),

@@ -533,9 +533,11 @@ class CenterPoint(nn.Module):
         voxels, coors, npv, nv = self.voxelizer(points, num_points)
         b, v, p, d = voxels.shape
         voxels, coors, npv = voxels.view(b * v, p, d), coors.view(b * v, 4), npv.view(b * v)
-        if not isinstance(self.middle_encoder, PointPillarsScatter):
-            # the sparse middle encoder works on the occupied voxels only (one host sync, like the
-            # reference's voxels[0:num_voxels] slice, voxelize.py:43)
+        if not isinstance(self.middle_encoder, PointPillarsScatter) and \
+                not getattr(self.middle_encoder, "accepts_padding_rows", False):
+            # a middle encoder that wants the occupied voxels only (one host sync, like the reference's
+            # voxels[0:num_voxels] slice, voxelize.py:43); the sparse encoders of this package skip padding
+            # rows (batch index -1) themselves
             keep = coors[:, 0] >= 0
             voxels, coors, npv = voxels[keep], coors[keep].contiguous(), npv[keep]
         feats = self.voxel_encoder(voxels, npv, coors)

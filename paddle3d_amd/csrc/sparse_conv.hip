@@ -639,6 +639,198 @@ static SpWorkspace sp_carve(void* base, int n_in, int K, bool subm, int out_cap)
   return w;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Plan path (pd3_sparse_sort_coords / pd3_sparse_conv_outputs / pd3_sparse_rulebook): every index set of an
+// encoder is a SORTED key array (raster order of (b, z, y, x)) with its length in device memory, so a chain of
+// convolutions is enqueued without a host round trip.  Sortedness replaces the hash table: a (b, z, y) line is a
+// contiguous piece of the array, the output set of a regular convolution is the compaction of a byte map of
+// marked cells (sorted by construction), and a neighbour is found by a binary search inside one line.  Nothing
+// on this path is atomic (global atomics run at a few G/s on this machine).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sp_plan_keys_kernel(const int32_t* __restrict__ coords, int n, SpShape s,
+                                                           uint32_t cells, uint32_t* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = coords[i * 4], z = coords[i * 4 + 1], y = coords[i * 4 + 2], x = coords[i * 4 + 3];
+  const bool ok = b >= 0 && b < s.batch && z >= 0 && z < s.d && y >= 0 && y < s.h && x >= 0 && x < s.w;
+  keys[i] = ok ? sp_key(b, z, y, x, s) : cells;  // padding sorts last and needs no extra key bits
+}
+
+// sorted (keys [, order]) -> the caller's arrays, padding marked kSpEmpty; count = number of real keys
+__global__ __launch_bounds__(256) void sp_plan_finish_kernel(const uint32_t* __restrict__ sorted,
+                                                             const uint32_t* __restrict__ vals, int n,
+                                                             uint32_t cells, const int* __restrict__ limit,
+                                                             uint32_t* __restrict__ keys_out,
+                                                             int32_t* __restrict__ order_out,
+                                                             int* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = sorted[i];
+  const bool real = k < cells;
+  keys_out[i] = real ? k : kSpEmpty;
+  if (order_out) order_out[i] = (int32_t)vals[i];
+  if (real && (i == n - 1 || sorted[i + 1] >= cells)) *count = limit ? min(i + 1, *limit) : i + 1;
+  if (i == 0 && !real) *count = 0;
+}
+
+// regular convolution: the set of outputs the inputs reach.  Every (input row, offset) marks its output cell in a
+// byte map of the output grid (plain stores of the same value: no atomics); compacting the map in cell order
+// yields the sorted key array directly -- no hash set, no sort.
+__global__ __launch_bounds__(256) void sp_plan_mark_kernel(
+    const uint32_t* __restrict__ in_keys, const int* __restrict__ n_in_dev, int n_in_cap, SpShape in_s,
+    SpShape out_s, SpConv c, unsigned char* __restrict__ map) {
+  const int K = c.kd * c.kh * c.kw;
+  const int64_t total = (int64_t)min(*n_in_dev, n_in_cap) * K;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(t / K), k = (int)(t - (int64_t)row * K);
+    const uint32_t key = in_keys[row];
+    if (key == kSpEmpty) continue;
+    uint32_t r = key;
+    const int x = (int)(r % (uint32_t)in_s.w);
+    r /= (uint32_t)in_s.w;
+    const int y = (int)(r % (uint32_t)in_s.h);
+    r /= (uint32_t)in_s.h;
+    const int z = (int)(r % (uint32_t)in_s.d);
+    const int b = (int)(r / (uint32_t)in_s.d);
+    const int kz = k / (c.kh * c.kw), ky = (k / c.kw) % c.kh, kx = k % c.kw;
+    const int nz = z + c.pd - kz, ny = y + c.ph - ky, nx = x + c.pw - kx;  // = q * stride
+    if (nz < 0 || ny < 0 || nx < 0 || nz % c.sd != 0 || ny % c.sh != 0 || nx % c.sw != 0) continue;
+    const int qz = nz / c.sd, qy = ny / c.sh, qx = nx / c.sw;
+    if (qz >= out_s.d || qy >= out_s.h || qx >= out_s.w) continue;
+    map[sp_key(b, qz, qy, qx, out_s)] = 1;
+  }
+}
+
+constexpr int kMapTile = 16384;  // cells per workgroup: 256 threads x 4 x 16 bytes
+
+__device__ __forceinline__ int sp_nonzero_bytes(uint4 v) {  // the map holds 0 / 1 only
+  return __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) +
+         __popc(v.w & 0x01010101u);
+}
+
+// pass 1: marked cells per tile;  pass 2 (after the scan of the tile counts): keys = indices of the marked cells
+template <bool EMIT>
+__global__ __launch_bounds__(256) void sp_plan_compact_kernel(const unsigned char* __restrict__ map, int64_t cells,
+                                                              int* __restrict__ partial,
+                                                              uint32_t* __restrict__ out_keys, int out_cap) {
+  __shared__ int smem[256 / kWave + 1];
+  const int64_t base = (int64_t)blockIdx.x * kMapTile + (int64_t)threadIdx.x * 64;
+  uint4 v[4];
+  int mine = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (base + i * 16 + 16 <= cells) {
+      v[i] = *reinterpret_cast<const uint4*>(map + base + i * 16);
+    } else {
+      unsigned char tmp[16];
+      for (int j = 0; j < 16; ++j) tmp[j] = base + i * 16 + j < cells ? map[base + i * 16 + j] : 0;
+      __builtin_memcpy(&v[i], tmp, 16);
+    }
+    mine += sp_nonzero_bytes(v[i]);
+  }
+  int total;
+  int at = block_exclusive_scan<256>(mine, smem, total);
+  if (!EMIT) {
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+    return;
+  }
+  if (mine == 0) return;
+  at += partial[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) {
+        if (at < out_cap) out_keys[at] = (uint32_t)(base + i * 16 + j);
+        ++at;
+      }
+    }
+  }
+}
+
+// tail of the key array = padding; n_out = min(total, cap)
+__global__ __launch_bounds__(256) void sp_plan_pad_kernel(const int* __restrict__ total, int cap,
+                                                          uint32_t* __restrict__ keys, int* __restrict__ n_out) {
+  const int n = min(*total, cap);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *n_out = n;
+  if (i >= n && i < cap) keys[i] = kSpEmpty;
+}
+
+// first row of every (b, z, y) line of a sorted key array (entry `lines` = row count): thread per line, a
+// lower_bound over the array (the top levels of the search stay in cache)
+__global__ __launch_bounds__(256) void sp_line_start_kernel(const uint32_t* __restrict__ keys,
+                                                            const int* __restrict__ n_dev, int n_cap, int w,
+                                                            int lines, int* __restrict__ line_start) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l > lines) return;
+  const int n = n_dev ? min(*n_dev, n_cap) : n_cap;
+  const int64_t first = (int64_t)l * w;  // smallest key of the line
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int64_t)keys[mid] < first) lo = mid + 1;
+    else hi = mid;
+  }
+  line_start[l] = lo;
+}
+
+// Rulebook by line search: thread per (output row, kz, ky).  The input line the row looks at is
+// [line_start[l], line_start[l + 1]) of the sorted input array -- a few keys to a few hundred, ascending in x --
+// so the first of the kw wanted keys is found by a binary search inside the line and the others are its
+// successors.  Neighbouring threads search the same or neighbouring lines (rows are in raster order): the loads
+// hit L1 / L2.  No table is built, nothing is atomic.
+__global__ __launch_bounds__(256) void sp_rulebook_lines_kernel(
+    const uint32_t* __restrict__ in_keys, const int* __restrict__ line_start, const uint32_t* __restrict__ out_keys,
+    const int* __restrict__ n_out_dev, int n_out_cap, SpShape in_s, SpShape out_s, SpConv c,
+    int32_t* __restrict__ nbr, int32_t* __restrict__ out_coords) {
+  const int G = c.kd * c.kh, K = G * c.kw;
+  const int n_out = n_out_dev ? min(*n_out_dev, n_out_cap) : n_out_cap;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)n_out * G) return;
+  const int row = (int)(t / G), g = (int)(t - (int64_t)row * G);
+  uint32_t r = out_keys[row];
+  const int x = (int)(r % (uint32_t)out_s.w);
+  r /= (uint32_t)out_s.w;
+  const int y = (int)(r % (uint32_t)out_s.h);
+  r /= (uint32_t)out_s.h;
+  const int z = (int)(r % (uint32_t)out_s.d);
+  const int b = (int)(r / (uint32_t)out_s.d);
+  if (out_coords && g == 0) *reinterpret_cast<int4*>(out_coords + (int64_t)row * 4) = make_int4(b, z, y, x);
+  int32_t* dst = nbr + (int64_t)row * K + g * c.kw;
+  const int iz = z * c.sd - c.pd + g / c.kh, iy = y * c.sh - c.ph + g % c.kh;
+  int lo = 0, hi = 0;
+  uint32_t line_key = 0;
+  if (iz >= 0 && iz < in_s.d && iy >= 0 && iy < in_s.h) {
+    const int l = (b * in_s.d + iz) * in_s.h + iy;
+    lo = line_start[l];
+    hi = line_start[l + 1];
+    line_key = sp_key(b, iz, iy, 0, in_s);
+  }
+  const int ix0 = x * c.sw - c.pw;
+  // first input row of the line with x >= ix0
+  const int64_t want0 = (int64_t)line_key + ix0;
+  int a = lo, e = hi;
+  while (a < e) {
+    const int mid = (a + e) >> 1;
+    if ((int64_t)in_keys[mid] < want0) a = mid + 1;
+    else e = mid;
+  }
+  for (int kx = 0; kx < c.kw; ++kx) {
+    const int ix = ix0 + kx;
+    int found = -1;
+    if (ix >= 0 && ix < in_s.w) {
+      const uint32_t want = line_key + (uint32_t)ix;
+      while (a < hi && in_keys[a] < want) ++a;      // (at most kw - 1 steps in total)
+      while (a < hi && in_keys[a] == want) found = a++;  // duplicate input coordinates: the highest row wins
+    }
+    dst[kx] = found;
+  }
+}
+
 static bool out_shape(const SpShape& in, const SpConv& c, SpShape& out) {
   out.batch = in.batch;
   out.d = (in.d + 2 * c.pd - c.kd) / c.sd + 1;
@@ -723,6 +915,157 @@ extern "C" int pd3_sparse_conv3d_indices(const int32_t* in_coords, int n_in, int
   sp_set_count_kernel<<<1, 1, 0, s>>>(w.total, 0, out_cap, n_out);
   sp_rulebook_kernel<<<(unsigned)ceil_div((int64_t)out_cap * K, 256), 256, 0, s>>>(
       w.out_keys, n_out, out_cap, in_s, out_s, c, w.tkeys, w.tvals, w.tsize - 1, nbr);
+  return launch_status();
+}
+
+
+// ---- plan path entries ----------------------------------------------------------------------------------
+namespace pd3 {
+struct SpPlanWs {
+  uint32_t *ka, *kb, *va, *vb, *table;
+  int *hist, *partial, *counter;
+  uint32_t tsize;
+  size_t bytes;
+};
+static SpPlanWs sp_plan_carve(void* base, int64_t n, uint32_t max_key, bool with_table) {
+  Carver c(base);
+  SpPlanWs w{};
+  (void)max_key;
+  const size_t hist_ints = (size_t)kRsMaxBins * (size_t)ceil_div(n, kRsTile);  // whatever digit width the keys get
+  w.ka = c.take<uint32_t>((size_t)n);
+  w.kb = c.take<uint32_t>((size_t)n);
+  w.va = c.take<uint32_t>((size_t)n);
+  w.vb = c.take<uint32_t>((size_t)n);
+  w.hist = c.take<int>(hist_ints);
+  w.partial = c.take<int>((size_t)scan_num_tiles((int64_t)hist_ints));
+  w.counter = c.take<int>(1);
+  if (with_table) {
+    w.tsize = table_size((int)std::min<int64_t>(n, (int64_t)1 << 30));
+    w.table = c.take<uint32_t>(w.tsize);
+  }
+  w.bytes = c.off;
+  return w;
+}
+static bool sp_shape_ok(const SpShape& s) {
+  return s.batch > 0 && s.d > 0 && s.h > 0 && s.w > 0 &&
+         (int64_t)s.batch * s.d * s.h * s.w < (int64_t)0xFFFFFFFE;
+}
+}  // namespace pd3
+
+extern "C" size_t pd3_sparse_plan_workspace(int n_cap) {
+  if (n_cap <= 0) return 0;
+  return sp_plan_carve(nullptr, n_cap, 0xFFFFFFFEu, true).bytes;
+}
+
+extern "C" int pd3_sparse_sort_coords(const int32_t* coords, int n, int batch, const int* spatial_shape,
+                                      uint32_t* keys_sorted, int32_t* order, int32_t* n_valid,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!coords || !spatial_shape || !keys_sorted || !order || !n_valid || !workspace || n <= 0) return PD3_EINVAL;
+  SpShape sh{batch, spatial_shape[0], spatial_shape[1], spatial_shape[2]};
+  if (!sp_shape_ok(sh)) return PD3_EUNSUPPORTED;
+  const uint32_t cells = (uint32_t)((int64_t)sh.batch * sh.d * sh.h * sh.w);
+  SpPlanWs w = sp_plan_carve(workspace, n, 0xFFFFFFFEu, true);
+  if (workspace_bytes < w.bytes) return PD3_EWORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned gb = (unsigned)ceil_div(n, 256);
+  sp_plan_keys_kernel<<<gb, 256, 0, s>>>(coords, n, sh, cells, w.ka);
+  const RadixPlan plan = radix_plan(cells, n);
+  const int where = enqueue_radix_sort(w.ka, w.va, w.kb, w.vb, n, n, 1, plan, /*identity_vals=*/true, w.hist,
+                                       w.partial, s);
+  sp_plan_finish_kernel<<<gb, 256, 0, s>>>(where ? w.kb : w.ka, where ? w.vb : w.va, n, cells, nullptr,
+                                           keys_sorted, order, n_valid);
+  return launch_status();
+}
+
+extern "C" size_t pd3_sparse_conv_outputs_workspace(int batch, const int* spatial_shape, const int* kernel_size,
+                                                    const int* stride, const int* padding) {
+  if (!spatial_shape || !kernel_size || !stride || !padding) return 0;
+  SpShape in_s{batch, spatial_shape[0], spatial_shape[1], spatial_shape[2]}, out_s{};
+  SpConv c{kernel_size[0], kernel_size[1], kernel_size[2], stride[0], stride[1], stride[2],
+           padding[0], padding[1], padding[2]};
+  if (c.kd <= 0 || c.kh <= 0 || c.kw <= 0 || c.sd <= 0 || c.sh <= 0 || c.sw <= 0) return 0;
+  if (!sp_shape_ok(in_s) || !out_shape(in_s, c, out_s) || !sp_shape_ok(out_s)) return 0;
+  const int64_t cells = (int64_t)out_s.batch * out_s.d * out_s.h * out_s.w;
+  Carver cv(nullptr);
+  cv.take<unsigned char>((size_t)cells + 16);
+  cv.take<int>((size_t)ceil_div(cells, kMapTile) + 1);
+  cv.take<int>(1);
+  return cv.off;
+}
+
+extern "C" int pd3_sparse_conv_outputs(const uint32_t* in_keys, const int32_t* n_in, int n_in_cap, int batch,
+                                       const int* spatial_shape, const int* kernel_size, const int* stride,
+                                       const int* padding, uint32_t* out_keys, int32_t* n_out, int out_cap,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (!in_keys || !n_in || !spatial_shape || !kernel_size || !stride || !padding || !out_keys || !n_out ||
+      !workspace || n_in_cap <= 0 || out_cap <= 0)
+    return PD3_EINVAL;
+  SpShape in_s{batch, spatial_shape[0], spatial_shape[1], spatial_shape[2]}, out_s{};
+  SpConv c{kernel_size[0], kernel_size[1], kernel_size[2], stride[0], stride[1], stride[2],
+           padding[0], padding[1], padding[2]};
+  if (c.kd <= 0 || c.kh <= 0 || c.kw <= 0 || c.sd <= 0 || c.sh <= 0 || c.sw <= 0) return PD3_EINVAL;
+  if (!sp_shape_ok(in_s) || !out_shape(in_s, c, out_s) || !sp_shape_ok(out_s)) return PD3_EUNSUPPORTED;
+  const int64_t cells = (int64_t)out_s.batch * out_s.d * out_s.h * out_s.w;
+  const int tiles = (int)ceil_div(cells, kMapTile);
+  Carver cv(workspace);
+  unsigned char* map = cv.take<unsigned char>((size_t)cells + 16);
+  int* partial = cv.take<int>((size_t)tiles + 1);
+  int* total = cv.take<int>(1);
+  if (workspace_bytes < cv.off) return PD3_EWORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(map, 0, (size_t)cells, s);
+  if (e != hipSuccess) return (int)e;
+  const int K = c.kd * c.kh * c.kw;
+  const int64_t work = (int64_t)n_in_cap * K;
+  const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(work, 256), 256 * 64);
+  sp_plan_mark_kernel<<<grid, 256, 0, s>>>(in_keys, n_in, n_in_cap, in_s, out_s, c, map);
+  sp_plan_compact_kernel<false><<<(unsigned)tiles, 256, 0, s>>>(map, cells, partial, nullptr, 0);
+  scan_partials_kernel<<<1, 1024, 0, s>>>(partial, tiles, total);
+  sp_plan_compact_kernel<true><<<(unsigned)tiles, 256, 0, s>>>(map, cells, partial, out_keys, out_cap);
+  sp_plan_pad_kernel<<<(unsigned)ceil_div(out_cap, 256), 256, 0, s>>>(total, out_cap, out_keys, n_out);
+  return launch_status();
+}
+
+extern "C" size_t pd3_sparse_rulebook_workspace(int batch, const int* spatial_shape) {
+  if (batch <= 0 || !spatial_shape || spatial_shape[0] <= 0 || spatial_shape[1] <= 0) return 0;
+  const int64_t lines = (int64_t)batch * spatial_shape[0] * spatial_shape[1] + 1;
+  Carver c(nullptr);
+  c.take<int>((size_t)lines);
+  return c.off;
+}
+
+extern "C" int pd3_sparse_rulebook(const uint32_t* in_keys, const int32_t* n_in, int n_in_cap,
+                                   const uint32_t* out_keys, const int32_t* n_out, int n_out_cap, int batch,
+                                   const int* spatial_shape, const int* kernel_size, const int* stride,
+                                   const int* padding, int subm, int32_t* nbr, int32_t* out_coords,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!in_keys || !out_keys || !spatial_shape || !kernel_size || !stride || !padding || !nbr || !workspace ||
+      n_in_cap <= 0 || n_out_cap <= 0)
+    return PD3_EINVAL;
+  SpShape in_s{batch, spatial_shape[0], spatial_shape[1], spatial_shape[2]}, out_s{};
+  SpConv c{kernel_size[0], kernel_size[1], kernel_size[2], stride[0], stride[1], stride[2],
+           padding[0], padding[1], padding[2]};
+  if (c.kd <= 0 || c.kh <= 0 || c.kw <= 0 || c.sd <= 0 || c.sh <= 0 || c.sw <= 0) return PD3_EINVAL;
+  if ((int64_t)n_out_cap * c.kd * c.kh >= ((int64_t)1 << 31)) return PD3_EUNSUPPORTED;
+  if (!sp_shape_ok(in_s)) return PD3_EUNSUPPORTED;
+  if (subm) {
+    if (c.sd != 1 || c.sh != 1 || c.sw != 1 || c.pd * 2 + 1 != c.kd || c.ph * 2 + 1 != c.kh ||
+        c.pw * 2 + 1 != c.kw)
+      return PD3_EUNSUPPORTED;
+    out_s = in_s;
+  } else if (!out_shape(in_s, c, out_s)) {
+    return PD3_EUNSUPPORTED;
+  }
+  const int64_t lines = (int64_t)in_s.batch * in_s.d * in_s.h + 1;
+  if (lines >= ((int64_t)1 << 31)) return PD3_EUNSUPPORTED;
+  Carver cv(workspace);
+  int* line_start = cv.take<int>((size_t)lines);
+  if (workspace_bytes < cv.off) return PD3_EWORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  sp_line_start_kernel<<<(unsigned)ceil_div(lines, 256), 256, 0, s>>>(in_keys, n_in, n_in_cap, in_s.w,
+                                                                      (int)lines - 1, line_start);
+  sp_rulebook_lines_kernel<<<(unsigned)ceil_div((int64_t)n_out_cap * (c.kd * c.kh), 256), 256, 0, s>>>(
+      in_keys, line_start, out_keys, n_out, n_out_cap, in_s, out_s, c, nbr, out_coords);
   return launch_status();
 }
 

@@ -88,8 +88,9 @@ def _prepare(coor, batch, depth_bins, feat_hw, lower, interval, size, mode):
     counts = torch.empty((2,), dtype=torch.int32, device=dev)
     L = lib()
     ws = workspace(L.pd3_voxel_pooling_prepare_workspace(n), dev)
-    check(L.pd3_voxel_pooling_prepare(ptr(c), n, int(batch), int(depth_bins), int(feat_hw), ptr(host_f32(lower, 3)),
-                                      ptr(host_f32(interval, 3)), ptr(host_f32(size, 3)), int(mode),
+    hlo, hiv, hsz = host_f32(lower, 3), host_f32(interval, 3), host_f32(size, 3)  # must outlive the call
+    check(L.pd3_voxel_pooling_prepare(ptr(c), n, int(batch), int(depth_bins), int(feat_hw), ptr(hlo),
+                                      ptr(hiv), ptr(hsz), int(mode),
                                       *[ptr(o) for o in outs], ptr(counts), ptr(ws), ws.numel(), stream_ptr(dev)), op)
     n_kept, n_int = counts.cpu().tolist()
     rb, rd, rf, st, ln = outs

@@ -3,6 +3,7 @@ middle encoder uses them (paddle3d/models/middle_encoders/sparse_resnet.py:31-59
 has no `paddle3d.ops.sparse_conv3d` module -- the arithmetic is Paddle core -- so the signatures here are ours:
 
   indices(coords, batch, spatial_shape, kernel_size, stride, padding, subm) -> SparseIndices
+  plan(coords, batch, spatial_shape, specs) -> SparsePlan   (all index sets of an encoder, ONE host sync)
   features(in_feats, idx, weight, bias=None, scale=None, shift=None, residual=None, relu=False) -> out_feats
   to_dense(feats, coords, batch, spatial_shape) -> [B, C*D, H, W]
 """
@@ -16,7 +17,8 @@ import torch
 
 from ._common import check, host_i32, lib, ptr, require_gpu, stream_ptr, workspace
 
-__all__ = ["SparseIndices", "indices", "features", "to_dense", "out_spatial_shape"]
+__all__ = ["SparseIndices", "ConvSpec", "SparsePlan", "indices", "plan", "features", "to_dense",
+           "out_spatial_shape"]
 
 
 @dataclass
@@ -72,6 +74,106 @@ def indices(coords: torch.Tensor, batch: int, spatial_shape, kernel_size, stride
     return SparseIndices(out_coords[:n], nbr[:n], n, out_shape, kvol)
 
 
+@dataclass(frozen=True)
+class ConvSpec:
+    """One convolution of a chain: kernel / stride / padding triples, submanifold or regular; convolutions with
+    the same `key` (and the same input set) share one rulebook, like the reference's `key=` hint."""
+    kernel_size: tuple
+    stride: tuple = (1, 1, 1)
+    padding: tuple = (0, 0, 0)
+    subm: bool = False
+    key: object = None
+
+
+@dataclass
+class SparsePlan:
+    order: torch.Tensor       # [n_in] int64: input row of the i-th row of the (sorted) first index set
+    coords: torch.Tensor      # [n_in, 4] int32 coordinates of the first index set (raster order)
+    n_in: int
+    indices: list             # one SparseIndices per ConvSpec (shared objects where rulebooks are shared)
+
+
+def plan(coords: torch.Tensor, batch: int, spatial_shape, specs) -> SparsePlan:
+    """Index sets and rulebooks of a chain of sparse convolutions (an encoder).  Every index set is a sorted key
+    array whose length stays on the device while the chain is enqueued; the lengths are read back ONCE, then the
+    rulebooks are built at their exact sizes (LDS-staged hash lookups).  `coords` may contain padding rows
+    (batch < 0), e.g. the voxelizer's fixed-shape output; row i of the first set is input row order[i]."""
+    c = require_gpu(coords, "sparse_conv3d", torch.int32)
+    if c.dim() != 2 or c.shape[1] != 4:
+        raise RuntimeError("sparse_conv3d: coords must be [N, 4] int32 (batch, z, y, x)")
+    specs = [sp if isinstance(sp, ConvSpec) else ConvSpec(*sp) for sp in specs]
+    dev, n0 = c.device, int(c.shape[0])
+    L = lib()
+    n_sets = 1 + sum(1 for sp in specs if not sp.subm)
+    counts = torch.zeros((n_sets,), dtype=torch.int32, device=dev)
+    order = torch.empty((max(n0, 1),), dtype=torch.int32, device=dev)
+    sets = [dict(keys=torch.empty((max(n0, 1),), dtype=torch.int32, device=dev), cap=n0,
+                 shape=tuple(int(v) for v in spatial_shape))]
+    if n0 > 0:
+        ws = workspace(L.pd3_sparse_plan_workspace(n0), dev)
+        hsh = host_i32(sets[0]["shape"])  # (host arrays must outlive the call: keep them in locals)
+        check(L.pd3_sparse_sort_coords(ptr(c), n0, batch, ptr(hsh), ptr(sets[0]["keys"]),
+                                       ptr(order), ptr(counts[0:1]), ptr(ws), ws.numel(), stream_ptr(dev)),
+              "sparse_sort_coords")
+    pairs, cur = [], 0
+    for sp in specs:
+        ks, st, pd = _triple(sp.kernel_size), _triple(sp.stride), _triple(sp.padding)
+        if sp.subm:
+            pairs.append((cur, cur))
+            continue
+        shape = out_spatial_shape(sets[cur]["shape"], ks, st, pd)
+        if min(shape) <= 0:
+            raise RuntimeError("sparse_conv3d: empty output shape")
+        per_in = math.prod(-(-k // s) for k, s in zip(ks, st))
+        cap = int(min(sets[cur]["cap"] * per_in, batch * math.prod(shape)))
+        new = dict(keys=torch.empty((max(cap, 1),), dtype=torch.int32, device=dev), cap=cap, shape=shape)
+        if cap > 0 and sets[cur]["cap"] > 0:
+            j = len(sets)
+            hsh, hk, hs, hp = host_i32(sets[cur]["shape"]), host_i32(ks), host_i32(st), host_i32(pd)
+            ws = workspace(L.pd3_sparse_conv_outputs_workspace(batch, ptr(hsh), ptr(hk), ptr(hs), ptr(hp)), dev)
+            check(L.pd3_sparse_conv_outputs(ptr(sets[cur]["keys"]), ptr(counts[cur:cur + 1]), sets[cur]["cap"],
+                                            batch, ptr(hsh), ptr(hk), ptr(hs), ptr(hp), ptr(new["keys"]),
+                                            ptr(counts[j:j + 1]), cap, ptr(ws), ws.numel(), stream_ptr(dev)),
+                  "sparse_conv_outputs")
+        sets.append(new)
+        pairs.append((cur, len(sets) - 1))
+        cur = len(sets) - 1
+    n = [int(v) for v in counts.cpu().tolist()]  # the one host sync of the encoder
+    for st_, nn_ in zip(sets, n):
+        st_["n"] = min(nn_, st_["cap"])
+        st_["coords"] = None
+    books, out = {}, []
+    for sp, (i, o) in zip(specs, pairs):
+        ks, st, pd = _triple(sp.kernel_size), _triple(sp.stride), _triple(sp.padding)
+        if sp.subm:
+            pd = tuple(k // 2 for k in ks)
+        kvol = ks[0] * ks[1] * ks[2]
+        tag = (i, o, ks, st, pd, sp.subm) if sp.key is None else (i, o, sp.key, ks)
+        if tag not in books:
+            n_in, n_out = sets[i]["n"], sets[o]["n"]
+            nbr = torch.empty((n_out, kvol), dtype=torch.int32, device=dev)
+            want_coords = sets[o]["coords"] is None
+            oc = torch.empty((n_out, 4), dtype=torch.int32, device=dev) if want_coords else sets[o]["coords"]
+            if n_out > 0 and n_in > 0:
+                hsh, hk, hs, hp = host_i32(sets[i]["shape"]), host_i32(ks), host_i32(st), host_i32(pd)
+                ws = workspace(L.pd3_sparse_rulebook_workspace(batch, ptr(hsh)), dev)
+                check(L.pd3_sparse_rulebook(ptr(sets[i]["keys"]), None, n_in, ptr(sets[o]["keys"]), None, n_out,
+                                            batch, ptr(hsh), ptr(hk), ptr(hs), ptr(hp), int(sp.subm), ptr(nbr),
+                                            ptr(oc) if want_coords else None, ptr(ws), ws.numel(),
+                                            stream_ptr(dev)),
+                      "sparse_rulebook")
+            elif n_out > 0:
+                nbr.fill_(-1)
+            sets[o]["coords"] = oc
+            books[tag] = SparseIndices(oc, nbr, n_out, sets[o]["shape"], kvol)
+        out.append(books[tag])
+    if sets[0]["coords"] is None:  # a chain that starts with a regular convolution: decode the first set here
+        k = sets[0]["keys"][: sets[0]["n"]].long() & 0xFFFFFFFF
+        d, h, w = sets[0]["shape"]
+        sets[0]["coords"] = torch.stack([k // (d * h * w), (k // (h * w)) % d, (k // w) % h, k % w], 1).int()
+    return SparsePlan(order[: sets[0]["n"]].long(), sets[0]["coords"], sets[0]["n"], out)
+
+
 def features(in_feats: torch.Tensor, idx: SparseIndices, weight: torch.Tensor, bias=None, scale=None,
              shift=None, residual=None, relu: bool = False) -> torch.Tensor:
     """weight [kd, kh, kw, Cin, Cout] (Paddle layout)."""
@@ -100,6 +202,7 @@ def to_dense(feats: torch.Tensor, coords: torch.Tensor, batch: int, spatial_shap
     n = f.shape[0]
     if n == 0:
         return out.zero_()
-    check(lib().pd3_sparse_to_dense(ptr(f), ptr(c), None, n, ch, batch, ptr(host_i32(spatial_shape)), ptr(out),
+    hsh = host_i32(spatial_shape)
+    check(lib().pd3_sparse_to_dense(ptr(f), ptr(c), None, n, ch, batch, ptr(hsh), ptr(out),
                                     stream_ptr(f.device)), "sparse_to_dense")
     return out

@@ -18,15 +18,16 @@ __all__ = ["SparseConvTensor", "SubmConv3D", "Conv3D", "SparseBasicBlock", "Spar
 class SparseConvTensor:
     """features [N, C] fp32 + indices [N, 4] int32 (b, z, y, x) + dense spatial shape (D, H, W)."""
 
-    def __init__(self, features, indices, spatial_shape, batch_size, cache=None):
+    def __init__(self, features, indices, spatial_shape, batch_size, cache=None, plan=None):
         self.features = features
         self.indices = indices
         self.spatial_shape = tuple(int(s) for s in spatial_shape)
         self.batch_size = int(batch_size)
         self.cache = {} if cache is None else cache  # indice_key -> SparseIndices
+        self.plan = plan  # id(conv module) -> SparseIndices, when the encoder planned its index sets up front
 
     def replace(self, features):
-        return SparseConvTensor(features, self.indices, self.spatial_shape, self.batch_size, self.cache)
+        return SparseConvTensor(features, self.indices, self.spatial_shape, self.batch_size, self.cache, self.plan)
 
     def dense(self):
         return _sp.to_dense(self.features, self.indices, self.batch_size, self.spatial_shape)
@@ -63,7 +64,12 @@ class _SparseConv(nn.Module):
         nn.init.uniform_(self.weight, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
 
+    def spec(self):
+        return _sp.ConvSpec(self.ks, self.stride, self.padding, self.subm, self.key)
+
     def _indices(self, x: SparseConvTensor):
+        if x.plan is not None and id(self) in x.plan:
+            return x.plan[id(self)]
         if self.subm and self.key is not None and self.key in x.cache:
             return x.cache[self.key]
         pad = tuple(k // 2 for k in self.ks) if self.subm else self.padding
@@ -81,7 +87,7 @@ class _SparseConv(nn.Module):
         out = _sp.features(x.features, idx, self.weight, self.bias, scale, shift, residual, relu)
         if self.subm:
             return x.replace(out)
-        return SparseConvTensor(out, idx.out_coords, idx.out_shape, x.batch_size)
+        return SparseConvTensor(out, idx.out_coords, idx.out_shape, x.batch_size, plan=x.plan)
 
 
 class SubmConv3D(_SparseConv):
@@ -100,8 +106,30 @@ class Conv3D(_SparseConv):
 
 
 def _fold(bn: nn.BatchNorm1d):
-    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-    return scale.detach().contiguous(), (bn.bias - bn.running_mean * scale).detach().contiguous()
+    """(scale, shift) of an eval-mode BatchNorm, computed once and kept on the module.  The cache entry is tied to
+    the identity AND the in-place version of the four tensors, so load_state_dict / .to() / an optimizer step all
+    invalidate it."""
+    src = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    tag = tuple((t.data_ptr(), t._version, t.device) for t in src)
+    hit = getattr(bn, "_pd3_folded", None)
+    if hit is not None and hit[0] == tag:
+        return hit[1], hit[2]
+    scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().contiguous()
+    shift = (bn.bias - bn.running_mean * scale).detach().contiguous()
+    object.__setattr__(bn, "_pd3_folded", (tag, scale, shift))
+    return scale, shift
+
+
+def _planned_input(encoder, voxel_features, coors, batch_size):
+    """The encoder's index sets are planned before any feature is touched (ops.sparse_conv3d.plan: sorted key
+    sets, one host sync, exact-size rulebooks); rows travel in raster order, so tiles of consecutive rows are
+    spatial neighbours (a tile's kernel offsets are mostly all-present or all-absent, its gathers share cache
+    lines).  `coors` may carry the voxelizer's padding rows (batch = -1)."""
+    convs = [m for m in encoder.modules() if isinstance(m, _SparseConv)]
+    pl = _sp.plan(coors, batch_size, encoder.sparse_shape, [m.spec() for m in convs])
+    feats = voxel_features.index_select(0, pl.order)
+    return SparseConvTensor(feats, pl.coords, encoder.sparse_shape, batch_size,
+                            plan={id(m): idx for m, idx in zip(convs, pl.indices)})
 
 
 def _bn(channels):
@@ -162,15 +190,6 @@ def _sparse_shape(voxel_size, point_cloud_range):
     return tuple(int(v) for v in (np.array(grid[::-1]) + [1, 0, 0]))  # sparse_resnet.py:173 / sparsenet.py:121
 
 
-def _raster_order(coors, shape):
-    """Rows in raster order: tiles of consecutive rows are then spatial neighbours, so a tile's kernel offsets are
-    mostly all-present or all-absent (skipped) and its gathers share cache lines.  The final dense map does not
-    depend on the row order."""
-    d, h, w = shape
-    c64 = coors.long()
-    return torch.argsort(((c64[:, 0] * d + c64[:, 1]) * h + c64[:, 2]) * w + c64[:, 3])
-
-
 def _densify(x: SparseConvTensor):
     return x.dense()  # to_dense + transpose([0, 4, 1, 2, 3]) + reshape [N, C * D, H, W], sparse_resnet.py:202-205
 
@@ -194,11 +213,11 @@ class SparseResNet3D(nn.Module):
         self.sparse_shape = _sparse_shape(voxel_size, point_cloud_range)
         self.in_channels = in_channels
 
+    accepts_padding_rows = True  # rows with batch index < 0 are ignored (no boolean-mask sync in the caller)
+
     @torch.no_grad()
     def forward(self, voxel_features, coors, batch_size):
-        order = _raster_order(coors, self.sparse_shape)
-        x = SparseConvTensor(voxel_features[order].contiguous(), coors[order].contiguous(), self.sparse_shape,
-                             batch_size)
+        x = _planned_input(self, voxel_features, coors, batch_size)
         for stage in (self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4, self.extra_conv):
             x = _run_sequential(stage, x)
         return _densify(x)
@@ -236,11 +255,11 @@ class SparseNet3D(nn.Module):
         self.num_point_features = 128
         self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 64}
 
+    accepts_padding_rows = True
+
     @torch.no_grad()
     def forward(self, voxel_features, coors, batch_size):
-        order = _raster_order(coors, self.sparse_shape)
-        x = SparseConvTensor(voxel_features[order].contiguous(), coors[order].contiguous(), self.sparse_shape,
-                             batch_size)
+        x = _planned_input(self, voxel_features, coors, batch_size)
         x = _run_sequential(self.conv_input, x)
         x1 = _run_sequential(self.conv1, x)
         x2 = _run_sequential(self.conv2, x1)

@@ -183,3 +183,68 @@ def test_sparse_parameter_names_follow_the_reference():
     for k in ("conv_input.0.weight", "conv1.0.0.weight", "conv1.0.1.running_mean", "conv2.0.0.weight", "conv2.2.1.bias",
               "conv4.2.0.weight", "extra_conv.0.weight"):
         assert k in keys, k
+
+
+PLAN_CHAINS = [
+    # the CenterPoint-Voxel encoder's chain on a small grid; a chain with an unpadded stride-3 kernel-3 convolution
+    ("resnet_like", 2, (21, 40, 36), 3000,
+     [((3, 3, 3), (1, 1, 1), (1, 1, 1), True, "a"), ((3, 3, 3), (1, 1, 1), (1, 1, 1), True, "a"),
+      ((3, 3, 3), (2, 2, 2), (1, 1, 1), False, None), ((3, 3, 3), (1, 1, 1), (1, 1, 1), True, "b"),
+      ((3, 3, 3), (2, 2, 2), (0, 1, 1), False, None), ((3, 3, 3), (1, 1, 1), (1, 1, 1), True, "c"),
+      ((3, 1, 1), (2, 1, 1), (0, 0, 0), False, None)]),
+    ("odd_paddings", 1, (9, 30, 31), 1500,
+     [((3, 3, 3), (3, 3, 3), (0, 0, 0), False, None), ((1, 3, 3), (1, 1, 1), (0, 1, 1), True, None),
+      ((2, 2, 2), (2, 2, 2), (1, 0, 1), False, None)]),
+    ("dense_line", 1, (1, 1, 700), 650, [((1, 1, 3), (1, 1, 1), (0, 0, 1), True, None),
+                                          ((1, 1, 3), (1, 1, 2), (0, 0, 1), False, None)]),
+]
+
+
+@pytest.mark.parametrize("chain", PLAN_CHAINS, ids=[c[0] for c in PLAN_CHAINS])
+def test_plan_equals_per_conv_indices(chain):
+    """plan() (sorted key sets, device-side counts, LDS-staged hash rulebooks) against indices() applied conv by
+    conv (global hash table): identical output coordinate sets, identical neighbour tables.  The input carries
+    padding rows (batch = -1) in shuffled order, like the voxelizer's fixed-shape output."""
+    from paddle3d_amd.ops import sparse_conv3d as sp
+    _, batch, shape, n, convs = chain
+    rng = np.random.default_rng(11)
+    coords, _ = _random_sparse(rng, batch, shape, n, 1)
+    pad = np.full((n // 3, 4), -1, np.int32)
+    mixed = np.concatenate([coords, pad])
+    perm = rng.permutation(len(mixed))
+    mixed = mixed[perm]
+    specs = [sp.ConvSpec(*c) for c in convs]
+    pl = sp.plan(torch.from_numpy(mixed).cuda(), batch, shape, specs)
+    assert pl.n_in == n
+    got_rows = mixed[pl.order.cpu().numpy()]
+    assert (got_rows == pl.coords.cpu().numpy()).all()
+    lin = ((got_rows[:, 0].astype(np.int64) * shape[0] + got_rows[:, 1]) * shape[1] + got_rows[:, 2]) * shape[2] + \
+        got_rows[:, 3]
+    assert (np.diff(lin) > 0).all()  # raster order, every real row exactly once
+    cur, cur_shape = pl.coords, tuple(shape)
+    for spec, idx in zip(specs, pl.indices):
+        ref = sp.indices(cur, batch, cur_shape, spec.kernel_size, spec.stride, spec.padding, spec.subm)
+        assert ref.n_out == idx.n_out and tuple(ref.out_shape) == tuple(idx.out_shape)
+        assert torch.equal(ref.out_coords, idx.out_coords)
+        assert torch.equal(ref.nbr, idx.nbr)
+        cur, cur_shape = idx.out_coords, idx.out_shape
+    # rulebooks are shared where the key says so
+    assert pl.indices[0] is pl.indices[1] if chain[0] == "resnet_like" else True
+
+
+def test_plan_large_tiles_and_empty():
+    """more rows than one rulebook tile and more neighbours per (kz, ky) piece than one LDS chunk; empty input"""
+    from paddle3d_amd.ops import sparse_conv3d as sp
+    rng = np.random.default_rng(5)
+    shape = (3, 64, 2048)
+    coords, _ = _random_sparse(rng, 1, shape, 150000, 1)
+    specs = [sp.ConvSpec((3, 3, 3), (1, 1, 1), (1, 1, 1), True), sp.ConvSpec((3, 3, 3), (2, 2, 2), (1, 1, 1))]
+    c = torch.from_numpy(coords).cuda()
+    pl = sp.plan(c, 1, shape, specs)
+    cur = pl.coords
+    ref0 = sp.indices(cur, 1, shape, (3, 3, 3), 1, 1, True)
+    assert torch.equal(ref0.nbr, pl.indices[0].nbr)
+    ref1 = sp.indices(cur, 1, shape, (3, 3, 3), 2, 1, False)
+    assert torch.equal(ref1.out_coords, pl.indices[1].out_coords) and torch.equal(ref1.nbr, pl.indices[1].nbr)
+    empty = sp.plan(torch.full((10, 4), -1, dtype=torch.int32).cuda(), 1, shape, specs)
+    assert empty.n_in == 0 and all(i.n_out == 0 for i in empty.indices)
