@@ -274,7 +274,8 @@ __global__ __launch_bounds__(128 * CB, CB == 2 ? 2 : 1) void conv3x3_winograd43_
         if (ox + j >= wv) y4[j] = 0.f;
       }
       if (oy + k < h && ox < w)  // partial tiles at the border (w % 4 == 0: a quad is in or out)
-        *reinterpret_cast<w4_f32x4*>(o + (int64_t)k * w) = (w4_f32x4){y4[0], y4[1], y4[2], y4[3]};
+        __builtin_nontemporal_store((w4_f32x4){y4[0], y4[1], y4[2], y4[3]},
+                                    reinterpret_cast<w4_f32x4*>(o + (int64_t)k * w));
     }
   }
 }

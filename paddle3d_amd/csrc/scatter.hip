@@ -47,10 +47,13 @@ __global__ __launch_bounds__(256) void canvas_write_vec4_kernel(const float* __r
   for (int k = 0; k < 4; ++k)
     r[k] = id[k] >= 0 ? *reinterpret_cast<const float4*>(feats + (int64_t)id[k] * channels + c)
                       : make_float4(0.f, 0.f, 0.f, 0.f);
-  *reinterpret_cast<float4*>(out + 0 * plane) = make_float4(r[0].x, r[1].x, r[2].x, r[3].x);
-  *reinterpret_cast<float4*>(out + 1 * plane) = make_float4(r[0].y, r[1].y, r[2].y, r[3].y);
-  *reinterpret_cast<float4*>(out + 2 * plane) = make_float4(r[0].z, r[1].z, r[2].z, r[3].z);
-  *reinterpret_cast<float4*>(out + 3 * plane) = make_float4(r[0].w, r[1].w, r[2].w, r[3].w);
+  // streaming stores: the 67 MB canvas of a frame is far beyond the caches, keeping it out of L2 leaves the
+  // inverse map and the feature rows there
+  typedef float sc_f32x4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(sc_f32x4{r[0].x, r[1].x, r[2].x, r[3].x}, reinterpret_cast<sc_f32x4*>(out + 0 * plane));
+  __builtin_nontemporal_store(sc_f32x4{r[0].y, r[1].y, r[2].y, r[3].y}, reinterpret_cast<sc_f32x4*>(out + 1 * plane));
+  __builtin_nontemporal_store(sc_f32x4{r[0].z, r[1].z, r[2].z, r[3].z}, reinterpret_cast<sc_f32x4*>(out + 2 * plane));
+  __builtin_nontemporal_store(sc_f32x4{r[0].w, r[1].w, r[2].w, r[3].w}, reinterpret_cast<sc_f32x4*>(out + 3 * plane));
 }
 
 // Generic shape fallback: one thread per (channel, cell).
