@@ -450,6 +450,65 @@ def bench_voxel(args, rank, world, dev):
     return line
 
 
+def bench_bevfusion_lidar(args, rank, world, dev):
+    """BEVFusion LiDAR stream front half (config 5, configs/bevfusion/bevf_pp_2x8_1x_nusc.yaml:87-116): 0.25 m pillars
+    on +-50 m (400 x 400), P = 64, V = 40 000, D = 4: hard_voxelize -> HardVFE (64, 64) -> PointPillarsScatter."""
+    from paddle3d_amd import centerpoint as cpm
+    from paddle3d_amd import synth
+
+    B, V, PV, D4 = args.batch, 40000, 64, 4
+    vs, pr = (0.25, 0.25, 8.0), (-50.0, -50.0, -5.0, 50.0, 50.0, 3.0)
+    voxelizer = cpm.HardVoxelizer(vs, pr, PV, [30000, V]).eval()
+    vfe = cpm.HardVFE(D4, (64, 64), False, True, True, vs, pr).to(dev).eval()
+    scatter = cpm.PointPillarsScatter(64, vs, pr)
+    pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(100 + B * rank + i, dims=D4) for i in range(B)])).to(dev)
+    names = ["start", "hard_voxelize", "hard_vfe", "pointpillars_scatter"]
+
+    def run(events):
+        def mark(i):
+            if events is not None:
+                events[i].record()
+
+        mark(0)
+        voxels, coors, npv, nv = voxelizer(pts)
+        mark(1)
+        b, v, p, d = voxels.shape
+        feats = vfe(voxels.view(b * v, p, d), npv.view(b * v), coors.view(b * v, 4))
+        mark(2)
+        canvas = scatter(feats, coors.view(b * v, 4), b)
+        mark(3)
+        return canvas, nv
+
+    with torch.no_grad():
+        dt, per_op_ms, out = _timed_loop(run, args, world, dev, names)
+    if rank != 0:
+        return None
+    alg_v = 4 * N_POINTS * D4 + 4 * V * PV * D4 + 16 * V + 4
+    a = alg_v * B / (per_op_ms["hard_voxelize"] * 1e-3) / 1e9
+    alg_s = 4 * V * 64 + 16 * V + 4 * 64 * 400 * 400
+    a_s = alg_s * B / (per_op_ms["pointpillars_scatter"] * 1e-3) / 1e9
+    return {
+        "metric": "frames/sec BEVFusion LiDAR stream front half (voxelize + HardVFE + scatter)",
+        "value": world * B * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BEVFusion LiDAR stream: {N_POINTS} pts x {D4} per scene, 0.25 m pillars (400x400), "
+                               f"P={PV}, max_voxels={V}, batch {B} distinct scenes/GPU/step, random-init weights, "
+                               "hard_voxelize->HardVFE->PointPillarsScatter",
+                   "frames_per_gpu_per_step": B, "max_voxels": V, "parallelism": f"dp{world} (frames)"},
+        "roofline": dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBPS, unit="GB/s", frac=a / HBM_PEAK_GBPS, traffic=None,
+                         ms_per_launch=per_op_ms["hard_voxelize"], units_per_launch=B,
+                         algorithmic_bytes_per_unit=alg_v,
+                         kernel="hard_voxelize launch sequence, tiled path (vt_route + vt_group + vt_assign_emit + "
+                                "vt_rows); the fixed-shape [V, 64, 4] output dominates the bytes"),
+        "rooflines": {"pointpillars_scatter": dict(bound="hbm", achieved=a_s, peak=HBM_PEAK_GBPS, unit="GB/s",
+                                                   frac=a_s / HBM_PEAK_GBPS, traffic=None,
+                                                   ms_per_launch=per_op_ms["pointpillars_scatter"],
+                                                   units_per_launch=B, algorithmic_bytes_per_unit=alg_s)},
+        "per_op_ms": per_op_ms, "voxels_first_frame": int(out[1][0]),
+    }
+
+
 def bench_bev_pool(args, rank, world, dev):
     """bev_pool_v2 forward at BEVDet4D size: 6 cameras x 118 depth bins x 16 x 44, C = 80, 128 x 128 BEV."""
     from paddle3d_amd import synth
@@ -506,7 +565,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 16; 2 for centerpoint_voxel)")
     ap.add_argument("--max-voxels", type=int, default=30000)
     ap.add_argument("--workload", default="centerpoint_pillars",
-                    choices=["centerpoint_pillars", "centerpoint_voxel", "bev_pool_v2"])
+                    choices=["centerpoint_pillars", "centerpoint_voxel", "bev_pool_v2", "bevfusion_lidar"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the h2d-inclusive / batch-1 / ceiling measurements "
                     "(profiling runs: only warm-up + timed steps are launched)")
@@ -527,7 +586,8 @@ def main():
     dev = torch.device("cuda", local)
     torch.manual_seed(0)
 
-    fn = dict(centerpoint_pillars=bench_pillars, centerpoint_voxel=bench_voxel, bev_pool_v2=bench_bev_pool)[args.workload]
+    fn = dict(centerpoint_pillars=bench_pillars, centerpoint_voxel=bench_voxel, bev_pool_v2=bench_bev_pool,
+              bevfusion_lidar=bench_bevfusion_lidar)[args.workload]
     line = fn(args, rank, world, dev)
     if rank == 0:
         print(json.dumps(line))

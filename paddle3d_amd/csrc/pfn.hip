@@ -282,40 +282,46 @@ __global__ __launch_bounds__(256) void pfn_single64_kernel(PfnArgs a) {
 // passes through a wave-private LDS tile (row stride 34 floats: conflict-free A-operand reads); rows past the
 // pillar's last one repeat point 0, so no row masks are needed in the two max reductions.  The only global
 // traffic is the pillar's raw floats (one coalesced load, prefetched a pillar ahead) and its 64 outputs.
+// The same kernel serves HardVFE's two VFE layers (voxel_encoder.py:142-283: Linear(10, 64), then
+// Linear([y1 | max y1] = 128, 64), P = 64, D = 4): template C1 = first layer's width (32 / 64), MAXP = rows of a
+// pillar (32 / 64), LINE = floats of a pillar's raw copy (128 / 256).
 typedef float pfn_f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kPfYs = 34;
-constexpr int kPfWaveFloats = 128 + 32 * kPfYs + 32 + 64 + 4 * 64;  // line, y1s, m1, base, part
 
-template <int D, int CD>
-__global__ __launch_bounds__(256, 3) void pfn_two_mfma_kernel(PfnArgs a) {
+template <int D, int CD, int C1, int MAXP, int LINE>
+__global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_two_mfma_kernel(PfnArgs a) {
   constexpr int IN = D + 3 + CD;
   static_assert(IN <= 12, "layer-1 K is padded to 12");
-  __shared__ __attribute__((aligned(16))) float smem[4 * kPfWaveFloats];
+  constexpr int NB1 = C1 / 16;   // layer-1 column blocks
+  constexpr int KS2 = C1 / 4;    // layer-2 k-steps over the point-wise half of the concat
+  constexpr int YS = C1 + 2;     // y1s row stride: conflict-free A-operand reads
+  constexpr int NV = LINE / 64;  // raw floats per lane
+  constexpr int kWaveFloats = LINE + MAXP * YS + C1 + 64 + 4 * 64;  // line, y1s, m1, base, part
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = lane_id(), wave = wave_id();
   const int r16 = lane & 15, g = lane >> 4;
-  float* ln = smem + wave * kPfWaveFloats;  // raw pillar, [k][D]
-  float* y1s = ln + 128;                    // [32 rows][34]
-  float* m1s = y1s + 32 * kPfYs;            // [32]
-  float* bases = m1s + 32;                  // [64]
+  float* ln = smem + wave * kWaveFloats;    // raw pillar, [k][D]
+  float* y1s = ln + LINE;                   // [MAXP rows][YS]
+  float* m1s = y1s + MAXP * YS;             // [C1]
+  float* bases = m1s + C1;                  // [64]
   float* part = bases + 64;                 // [4][64]
   // ---- weights and folded BatchNorm in registers ------------------------------------------------
-  float w1r[3][2], w2a[8][4], w2b[32];
+  float w1r[3][NB1], w2a[KS2][4], w2b[C1];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < NB1; ++cb) {
       const int k = ks * 4 + g;
-      w1r[ks][cb] = k < IN ? a.w1[k * 32 + cb * 16 + r16] : 0.f;
+      w1r[ks][cb] = k < IN ? a.w1[k * C1 + cb * 16 + r16] : 0.f;
     }
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks)
+  for (int ks = 0; ks < KS2; ++ks)
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) w2a[ks][cb] = a.w2[(ks * 4 + g) * 64 + cb * 16 + r16];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) w2b[i] = a.w2[(32 + i) * 64 + lane];
-  float sc1[2], sh1[2], sc2[4], sh2[4];
+  for (int i = 0; i < C1; ++i) w2b[i] = a.w2[(C1 + i) * 64 + lane];
+  float sc1[NB1], sh1[NB1], sc2[4], sh2[4];
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
+  for (int cb = 0; cb < NB1; ++cb) {
     sc1[cb] = a.scale1[cb * 16 + r16];
     sh1[cb] = a.shift1[cb * 16 + r16];
   }
@@ -332,23 +338,23 @@ __global__ __launch_bounds__(256, 3) void pfn_two_mfma_kernel(PfnArgs a) {
     fkind[ks] = i >= IN ? 3 : (i < D ? 0 : (i < D + 3 ? 1 : 2));
     fsrc[ks] = i >= IN ? 0 : (i < D ? i : (i < D + 3 ? i - D : i - D - 3));
   }
-  const int pd = a.p * D;  // <= 128 floats per pillar
+  const int pd = a.p * D;  // <= LINE floats per pillar
   const int64_t stride = (int64_t)gridDim.x * 4;
   int64_t pil = (int64_t)blockIdx.x * 4 + wave;
   if (pil >= a.m) return;
-  float v0 = 0.f, v1 = 0.f;
+  float vreg[NV];
   int npn = a.num_points[pil];
   int c1 = a.coors[pil * 4 + 1], c2 = a.coors[pil * 4 + 2], c3 = a.coors[pil * 4 + 3];
-  if (lane < pd) v0 = a.voxels[pil * pd + lane];
-  if (lane + 64 < pd) v1 = a.voxels[pil * pd + 64 + lane];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) vreg[q] = lane + 64 * q < pd ? a.voxels[pil * pd + 64 * q + lane] : 0.f;
   for (; pil < a.m; pil += stride) {
     const int np_raw = npn;
     float pc[3];
     pc[0] = (float)c3 * a.vx + a.x_off;
     pc[1] = (float)c2 * a.vy + a.y_off;
     pc[2] = (float)c1 * a.vz + a.z_off;
-    ln[lane] = v0;
-    ln[64 + lane] = v1;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) ln[64 * q + lane] = vreg[q];
     wave_lds_order();
     const int64_t nxt = pil + stride;
     if (nxt < a.m) {  // next pillar's loads fly while this one is evaluated
@@ -356,8 +362,8 @@ __global__ __launch_bounds__(256, 3) void pfn_two_mfma_kernel(PfnArgs a) {
       c1 = a.coors[nxt * 4 + 1];
       c2 = a.coors[nxt * 4 + 2];
       c3 = a.coors[nxt * 4 + 3];
-      v0 = lane < pd ? a.voxels[nxt * pd + lane] : 0.f;
-      v1 = lane + 64 < pd ? a.voxels[nxt * pd + 64 + lane] : 0.f;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) vreg[q] = lane + 64 * q < pd ? a.voxels[nxt * pd + 64 * q + lane] : 0.f;
     }
     if (np_raw <= 0) {  // padding row of a fixed-shape [B*V] batch: no pillar here
       a.out[pil * 64 + lane] = 0.f;
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(256, 3) void pfn_two_mfma_kernel(PfnArgs a) {
     }
     const int np = min(np_raw, a.p);
     const int rows = np + (np < a.p ? 1 : 0);  // + one representative padded (all-zero) row
-    const int nblk = rows > 16 ? 2 : 1;
+    const int nblk = (rows + 15) >> 4;
     // ---- decorate (pillar_encoder.py:166-199) straight into the layer-1 A operand ------------------
     float mean[3] = {0.f, 0.f, 0.f};
     for (int k = 0; k < np; ++k) {
@@ -387,40 +393,43 @@ __global__ __launch_bounds__(256, 3) void pfn_two_mfma_kernel(PfnArgs a) {
     }
     // ---- layer 1 on the matrix cores; Y1 = relu(bn1(X W1)) -> y1s ---------------------------------
     // rows >= `rows` repeat point 0, so every row of a block is a legitimate member of the max below
-    float pm1[2] = {-INFINITY, -INFINITY};
+    float pm1[NB1];
+#pragma unroll
+    for (int cb = 0; cb < NB1; ++cb) pm1[cb] = -INFINITY;
     for (int b = 0; b < nblk; ++b) {
       const int k = b * 16 + r16;
       const bool real = k < np, zero_row = (k == np) && (np < a.p);
       const int kk = real ? k : 0;
-      pfn_f32x4 acc1[2];
+      pfn_f32x4 acc1[NB1];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) acc1[cb] = (pfn_f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int cb = 0; cb < NB1; ++cb) acc1[cb] = (pfn_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
         float av = ln[kk * D + fsrc[ks]] - sub[ks];
         av = (zero_row || fkind[ks] == 3) ? 0.f : av;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1r[ks][cb], acc1[cb], 0, 0, 0);
+        for (int cb = 0; cb < NB1; ++cb)
+          acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1r[ks][cb], acc1[cb], 0, 0, 0);
       }
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+      for (int cb = 0; cb < NB1; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float y = fmaxf(fmaf(acc1[cb][r], sc1[cb], sh1[cb]), 0.f);
-          y1s[(b * 16 + 4 * g + r) * kPfYs + cb * 16 + r16] = y;
+          y1s[(b * 16 + 4 * g + r) * YS + cb * 16 + r16] = y;
           pm1[cb] = fmaxf(pm1[cb], y);
         }
     }
-    // ---- max over the rows of Y1 (the concat half of PFNLayer :100-104), base = m1 W2[32:64] --------
-    part[g * 64 + r16] = pm1[0];
-    part[g * 64 + 16 + r16] = pm1[1];
+    // ---- max over the rows of Y1 (the concat half of PFNLayer :100-104), base = m1 W2[C1:2 C1] ------
+#pragma unroll
+    for (int cb = 0; cb < NB1; ++cb) part[g * 64 + cb * 16 + r16] = pm1[cb];
     wave_lds_order();
-    if (lane < 32)
+    if (lane < C1)
       m1s[lane] = fmaxf(fmaxf(part[lane], part[64 + lane]), fmaxf(part[128 + lane], part[192 + lane]));
     wave_lds_order();
     float base = 0.f;
 #pragma unroll
-    for (int i4 = 0; i4 < 32; i4 += 4) {
+    for (int i4 = 0; i4 < C1; i4 += 4) {
       const pfn_f32x4 mv = *reinterpret_cast<const pfn_f32x4*>(m1s + i4);
       base = fmaf(mv[0], w2b[i4 + 0], base);
       base = fmaf(mv[1], w2b[i4 + 1], base);
@@ -441,8 +450,8 @@ __global__ __launch_bounds__(256, 3) void pfn_two_mfma_kernel(PfnArgs a) {
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) acc2[cb] = (pfn_f32x4){bs[cb], bs[cb], bs[cb], bs[cb]};
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const float av = y1s[(b * 16 + r16) * kPfYs + ks * 4 + g];
+      for (int ks = 0; ks < KS2; ++ks) {
+        const float av = y1s[(b * 16 + r16) * YS + ks * 4 + g];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2a[ks][cb], acc2[cb], 0, 0, 0);
       }
@@ -528,15 +537,32 @@ extern "C" int pd3_pillar_feature_net(const float* voxels, const int32_t* num_po
     else pfn_single64_kernel<5, 3><<<blocks, 256, 0, s>>>(a);
     return launch_status();
   }
+#define PD3_PFN_MFMA(DD, CDV, C1V, MAXPV, LINEV)                                                                \
+  do {                                                                                                        \
+    constexpr size_t lds_ = (size_t)4 * (LINEV + MAXPV * (C1V + 2) + C1V + 64 + 4 * 64) * sizeof(float);       \
+    if (lds_ > 48 * 1024) {                                                                                    \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(pfn_two_mfma_kernel<DD, CDV, C1V, MAXPV, LINEV>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);              \
+      if (e_ != hipSuccess) return (int)e_;                                                                    \
+    }                                                                                                          \
+    pfn_two_mfma_kernel<DD, CDV, C1V, MAXPV, LINEV><<<blocks, 256, lds_, s>>>(a);                              \
+  } while (0)
   if (w2 && c1 == 32 && c2 == 64 && max_points * num_point_dim <= 128 && max_points <= 32 &&
       (num_point_dim == 4 || num_point_dim == 5) && a.in_dim <= 12) {
     const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(num_pillars, 4), 256 * 8);
-    if (num_point_dim == 4 && voxel_center_dims == 2) pfn_two_mfma_kernel<4, 2><<<blocks, 256, 0, s>>>(a);
-    else if (num_point_dim == 4) pfn_two_mfma_kernel<4, 3><<<blocks, 256, 0, s>>>(a);
-    else if (voxel_center_dims == 2) pfn_two_mfma_kernel<5, 2><<<blocks, 256, 0, s>>>(a);
-    else pfn_two_mfma_kernel<5, 3><<<blocks, 256, 0, s>>>(a);
+    if (num_point_dim == 4 && voxel_center_dims == 2) PD3_PFN_MFMA(4, 2, 32, 32, 128);
+    else if (num_point_dim == 4) PD3_PFN_MFMA(4, 3, 32, 32, 128);
+    else if (voxel_center_dims == 2) PD3_PFN_MFMA(5, 2, 32, 32, 128);
+    else PD3_PFN_MFMA(5, 3, 32, 32, 128);
     return launch_status();
   }
+  if (w2 && c1 == 64 && c2 == 64 && max_points * num_point_dim <= 256 && max_points <= 64 &&
+      num_point_dim == 4 && voxel_center_dims == 3 && a.in_dim <= 12) {  // HardVFE (BEVFusion LiDAR stream)
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(num_pillars, 4), 256 * 8);
+    PD3_PFN_MFMA(4, 3, 64, 64, 256);
+    return launch_status();
+  }
+#undef PD3_PFN_MFMA
   const size_t w_floats = (size_t)a.in_pad * c1 + (w2 ? (size_t)2 * c1 * c2 : 0);
   const size_t wave_floats = (size_t)max_points * a.in_pad + (size_t)max_points * c1;
   int waves = kPfnMaxWaves;
