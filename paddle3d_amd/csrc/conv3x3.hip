@@ -248,16 +248,35 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_kernel(const float*
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[c][p] = 0.f;
   constexpr int XQ = kGcXW / 4, XN4 = kGcCi * kGcXR * XQ;  // 1360 float4 per trip
+  constexpr int XPT = (XN4 + 255) / 256;                   // 6 per thread
+  // staging pattern (identical for every trip): element -> offset in a channel-plane quadruple, zero outside
+  int gofs[XPT];
+  unsigned live = 0;
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    const int e = min((int)threadIdx.x + i * 256, XN4 - 1);
+    const int ci = e / (kGcXR * XQ), rem = e - ci * (kGcXR * XQ);
+    const int r = rem / XQ, c4 = rem - r * XQ;
+    const int gy = y0 - 1 + r, gx = x0 - 4 + c4 * 4;
+    const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
+    gofs[i] = ok ? (int)(ci * plane + (int64_t)gy * w + gx) : 0;
+    live |= ok ? 1u << i : 0u;
+  }
+  cv_f32x4 xr[XPT];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) xr[i] = *reinterpret_cast<const cv_f32x4*>(xin + gofs[i]);
   for (int c0 = 0; c0 < cg; c0 += kGcCi) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < XN4; e += 256) {
-      const int ci = e / (kGcXR * XQ), rem = e - ci * (kGcXR * XQ);
-      const int r = rem / XQ, c4 = rem - r * XQ;
-      const int gy = y0 - 1 + r, gx = x0 - 4 + c4 * 4;
-      cv_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gy >= 0 && gy < h && gx >= 0 && gx < w)
-        v = *reinterpret_cast<const cv_f32x4*>(xin + (int64_t)(c0 + ci) * plane + (int64_t)gy * w + gx);
-      *reinterpret_cast<cv_f32x4*>(Xs + e * 4) = v;
+    __syncthreads();  // the previous trip's reads of Xs are done
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      const int e = min((int)threadIdx.x + i * 256, XN4 - 1);
+      const cv_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<cv_f32x4*>(Xs + e * 4) = ((live >> i) & 1u) ? xr[i] : z;
+    }
+    if (c0 + kGcCi < cg) {  // the next trip's loads fly while this one is multiplied
+      const float* xn = xin + (int64_t)(c0 + kGcCi) * plane;
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) xr[i] = *reinterpret_cast<const cv_f32x4*>(xn + gofs[i]);
     }
     __syncthreads();
 #pragma unroll
@@ -267,13 +286,13 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_kernel(const float*
       for (int ky = 0; ky < 3; ++ky) {
         // input columns tc-1 .. tc+4 of row tr+ky live at LDS columns tc+3 .. tc+8
         const float* row = Xs + (ci * kGcXR + tr + ky) * kGcXW + tc;
-        float in[6];
-        in[0] = row[3];
         const cv_f32x4 mid = *reinterpret_cast<const cv_f32x4*>(row + 4);
+        float in[6];
         in[1] = mid[0];
         in[2] = mid[1];
         in[3] = mid[2];
         in[4] = mid[3];
+        in[0] = row[3];
         in[5] = row[8];
 #pragma unroll
         for (int c = 0; c < CO; ++c)
