@@ -6,7 +6,8 @@
 // gathered feature row is a contiguous read and the output row a contiguous write.  The depth weight
 // and the three rank words are wave-uniform per interval row and come from the scalar/L1 path.
 // Accumulation is fp32 in interval order without FMA contraction, i.e. bit-identical to the reference
-// kernel.  Backward splits the reference's one-thread-per-interval loop into its two independent
+// kernel; the loads of sixteen consecutive points are issued together (the walk is latency-bound: the long
+// intervals near the cameras set the kernel's duration).  Backward splits the reference's one-thread-per-interval loop into its two independent
 // halves: depth_grad per frustum point (serial over channels, reference order), feat_grad per
 // (interval, channel).
 #include "../../include/paddle3d_amd.h"
@@ -29,8 +30,27 @@ __global__ __launch_bounds__(256) void bev_pool_fwd_kernel(
   if (iv >= n_intervals) return;
   const int s = interval_starts[iv], len = interval_lengths[iv];
   float acc = 0.f;
-  for (int i = 0; i < len; ++i)
-    acc += feat[(int64_t)ranks_feat[s + i] * c + ch] * depth[ranks_depth[s + i]];
+  // the walk is a chain of dependent loads (rank -> row): sixteen points are fetched together, the sum itself
+  // stays in the reference's order
+  constexpr int U = 16;
+  int i = 0;
+  for (; i + U <= len; i += U) {
+    int rf[U], rd[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      rf[u] = ranks_feat[s + i + u];
+      rd[u] = ranks_depth[s + i + u];
+    }
+    float f[U], d[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      f[u] = feat[(int64_t)rf[u] * c + ch];
+      d[u] = depth[rd[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += f[u] * d[u];
+  }
+  for (; i < len; ++i) acc += feat[(int64_t)ranks_feat[s + i] * c + ch] * depth[ranks_depth[s + i]];
   out[(int64_t)ranks_bev[s] * c + ch] = acc;
 }
 
@@ -59,8 +79,25 @@ __global__ __launch_bounds__(256) void bev_pool_bwd_feat_kernel(
   if (iv >= n_intervals) return;
   const int s = interval_starts[iv], len = interval_lengths[iv];
   float acc = 0.f;
-  for (int i = 0; i < len; ++i)
-    acc += out_grad[(int64_t)ranks_bev[s + i] * c + ch] * depth[ranks_depth[s + i]];
+  constexpr int U = 16;  // as in the forward kernel: loads in batches, the sum in the reference's order
+  int i = 0;
+  for (; i + U <= len; i += U) {
+    int rb[U], rd[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      rb[u] = ranks_bev[s + i + u];
+      rd[u] = ranks_depth[s + i + u];
+    }
+    float g[U], d[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      g[u] = out_grad[(int64_t)rb[u] * c + ch];
+      d[u] = depth[rd[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += g[u] * d[u];
+  }
+  for (; i < len; ++i) acc += out_grad[(int64_t)ranks_bev[s + i] * c + ch] * depth[ranks_depth[s + i]];
   feat_grad[(int64_t)ranks_feat[s] * c + ch] = acc;
 }
 
