@@ -12,7 +12,6 @@ from __future__ import annotations
 import math
 from dataclasses import dataclass
 
-import numpy as np
 import torch
 
 from ._common import check, host_i32, lib, ptr, require_gpu, stream_ptr, workspace

@@ -7,7 +7,6 @@ same fixed shapes / dtypes (fp32 [V,P,D], int32 [V,3] (z,y,x), int32 [V], int32 
 """
 from __future__ import annotations
 
-import ctypes as C
 
 import torch
 
