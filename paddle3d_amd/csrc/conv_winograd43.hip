@@ -85,9 +85,11 @@ __global__ __launch_bounds__(128 * CB, CB == 2 ? 2 : 1) void conv3x3_winograd43_
   constexpr int UPT = (UN4 + 255) / 256;            // 5 (tail repeats the last one) / 9
   constexpr int XPT = (kW4XN4 + THREADS - 1) / THREADS;  // 3 / 2
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Us = smem;
-  float* Vs = smem + USZ;
-  float* Raw = smem + USZ + kW4Vsz;
+  constexpr int NBUF = CB == 4 ? 2 : 1;              // CB = 4: U and V double-buffered (see the trip loop)
+  float* Us = smem;                                  // [NBUF][USZ]
+  float* Vs = smem + NBUF * USZ;                     // [NBUF][kW4Vsz]
+  float* Raw = Vs + NBUF * kW4Vsz;
+  float *Ucur = Us, *Vcur = Vs, *Unext = Us, *Vnext = Vs;  // buffers of the trip being multiplied / prepared
   const int lane = lane_id(), wave = wave_id();
   const int tiles_x = (w + 4 * kW4TC - 1) / (4 * kW4TC), tiles_y = (h + 4 * kW4TR - 1) / (4 * kW4TR);
   // XCD-aware tile order (see conv_winograd.hip): pixel tile pt lives on XCD pt % 8 with all its channel tiles
@@ -137,15 +139,16 @@ __global__ __launch_bounds__(128 * CB, CB == 2 ? 2 : 1) void conv3x3_winograd43_
 
   w4_f32x4 xr[XPT], ur[UPT];
 
-#define W4_FETCH(cc)                                                                     \
+#define W4_FETCH_X(cc)                                                                   \
   {                                                                                      \
     const float* xc_ = xin + (int64_t)(cc) * kW4Ci * plane;                              \
     _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                      \
         xr[i] = *reinterpret_cast<const w4_f32x4*>(xc_ + gofs[i]);                       \
+  }
+#define W4_FETCH_U(cc)                                                                   \
+  if (CB == 2 || moves_u) {                                                              \
     const w4_f32x4* uc_ = usrc + (int64_t)(cc) * UN4;                                    \
-    if (CB == 2 || moves_u) {                                                            \
-      _Pragma("unroll") for (int i = 0; i < UPT; ++i) ur[i] = uc_[uofs[i]];              \
-    }                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < UPT; ++i) ur[i] = uc_[uofs[i]];                \
   }
 #define W4_STASH_X()                                                                     \
   {                                                                                      \
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(128 * CB, CB == 2 ? 2 : 1) void conv3x3_winograd43_
 #define W4_STASH_U()                                                                     \
   if (CB == 2 || moves_u) {                                                              \
     _Pragma("unroll") for (int i = 0; i < UPT; ++i)                                      \
-        *reinterpret_cast<w4_f32x4*>(Us + uofs[i] * 4) = ur[i];                          \
+        *reinterpret_cast<w4_f32x4*>(Unext + uofs[i] * 4) = ur[i];                       \
   }
   // V = B^T d B.  Row pass on this lane's three columns, halves swapped between the pair, column pass on this
   // lane's three rows; components (row, nu) -> 6 row + nu.
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(128 * CB, CB == 2 ? 2 : 1) void conv3x3_winograd43_
     /* the even lane runs the column pass for rows 0..2, the odd lane for rows 3..5; what a lane lacks are \
        the other three columns of its rows, i.e. the partner's lo_ (even lane) or hi_ (odd lane): one      \
        select with a DPP-swapped operand per value */                                    \
-    float* v_ = Vs + vdst;                                                               \
+    float* v_ = Vnext + vdst;                                                            \
     _Pragma("unroll") for (int a = 0; a < 3; ++a) {                                      \
       float f_[3], l_[3]; /* columns 0..2 / 3..5 of row 3 hf + a of B^T d */             \
       _Pragma("unroll") for (int b = 0; b < 3; ++b) {                                    \
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(128 * CB, CB == 2 ? 2 : 1) void conv3x3_winograd43_
   // 9 groups of 4 components: two b128 reads feed four MFMAs; reads run two groups ahead (ring of three)
 #define W4_LOAD(g_, slot_)                                                               \
   {                                                                                      \
-    a_[slot_] = *reinterpret_cast<const w4_f32x4*>(Us + abase + (g_) * 4);               \
-    b_[slot_] = *reinterpret_cast<const w4_f32x4*>(Vs + bbase + (g_) * 4);               \
+    a_[slot_] = *reinterpret_cast<const w4_f32x4*>(Ucur + abase + (g_) * 4);             \
+    b_[slot_] = *reinterpret_cast<const w4_f32x4*>(Vcur + bbase + (g_) * 4);             \
   }
 #define W4_MFMA()                                                                        \
   {                                                                                      \
@@ -212,31 +215,74 @@ __global__ __launch_bounds__(128 * CB, CB == 2 ? 2 : 1) void conv3x3_winograd43_
     }                                                                                    \
   }
 
-  W4_FETCH(0)
+  // The U slice of a trip is 37 KB (CB = 4): its loads back-pressure at issue for ~1700 cycles (the L2 -> CU
+  // path delivers ~16 B/clk), and a wave issues in order -- so they are issued where their waves have slack, right
+  // after parking the previous slice during the other waves' transform, not in front of the MFMA phase.
+  W4_FETCH_X(0)
+  W4_FETCH_U(0)
   W4_STASH_X()
   __syncthreads();
   W4_TRANSFORM()
   W4_STASH_U()
+  if (chunks > 1) W4_FETCH_U(1)
+  if (CB == 4 && chunks > 1) W4_FETCH_X(1)
   __syncthreads();
-  // steady state (no conditionals around the activation loads); last trip peeled
-  for (int cc = 0; cc + 1 < chunks; ++cc) {
-    W4_FETCH(cc + 1)
-    __builtin_amdgcn_sched_barrier(0);  // keep the loads in flight ahead of the MFMA block
-    __builtin_amdgcn_s_setprio(1);  // the matrix phase outranks the co-resident waves' transform VALU
+  if (CB == 4) {
+    // 64-channel form.  Wave w and wave w + 4 share a SIMD and take turns on its pipes inside a trip:
+    //   waves 0-3:  transform(c+1) -> V[next]           then  MFMA(c)
+    //   waves 4-7:  MFMA(c)                             then  park U(c+1) -> U[next], issue the loads of U(c+2)
+    // so one wave of every SIMD feeds the matrix pipe while its partner runs the VALU / LDS chain (a wave issues
+    // in order and does not overlap its own MFMAs with its own VALU work; two waves of a SIMD do).  Two barriers
+    // per trip: after the raw patch of trip c+1 is staged, and at the end.  (The first round-2 attempt at such a
+    // ping-pong gave every group its own transform and lost: the chain then ran twice per trip.)
+    for (int cc = 0; cc < chunks; ++cc) {
+      const bool more = cc + 1 < chunks;
+      Ucur = Us + (cc & 1) * USZ;
+      Vcur = Vs + (cc & 1) * kW4Vsz;
+      Unext = Us + ((cc + 1) & 1) * USZ;
+      Vnext = Vs + ((cc + 1) & 1) * kW4Vsz;
+      if (more) {
+        W4_STASH_X()  // X(cc + 1), fetched a trip ago
+        if (cc + 2 < chunks) W4_FETCH_X(cc + 2)
+      }
+      __syncthreads();
+      if (transforms) {
+        if (more) W4_TRANSFORM()
+        __builtin_amdgcn_s_setprio(1);
+        W4_MFMA()
+        __builtin_amdgcn_s_setprio(0);
+      } else {
+        __builtin_amdgcn_s_setprio(1);
+        W4_MFMA()
+        __builtin_amdgcn_s_setprio(0);
+        if (more) W4_STASH_U()
+        if (cc + 2 < chunks) W4_FETCH_U(cc + 2)
+      }
+      __syncthreads();
+    }
+  } else {
+    // steady state (no conditionals around the activation loads); last trip peeled
+    for (int cc = 0; cc + 1 < chunks; ++cc) {
+      W4_FETCH_X(cc + 1)
+      __builtin_amdgcn_sched_barrier(0);  // keep the loads in flight ahead of the MFMA block
+      __builtin_amdgcn_s_setprio(1);  // the matrix phase outranks the co-resident waves' transform VALU
+      W4_MFMA()
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();  // every wave is done with U and V of this trip
+      W4_STASH_X()
+      __syncthreads();
+      W4_TRANSFORM()
+      W4_STASH_U()
+      if (cc + 2 < chunks) W4_FETCH_U(cc + 2)
+      __syncthreads();
+    }
     W4_MFMA()
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();  // every wave is done with U and V of this trip
-    W4_STASH_X()
-    __syncthreads();
-    W4_TRANSFORM()  // CB = 4: waves 0-3 transform while waves 4-7 park U
-    W4_STASH_U()
-    __syncthreads();
   }
-  W4_MFMA()
 #undef W4_MFMA
 #undef W4_LOAD
-#undef W4_FETCH
+#undef W4_FETCH_X
+#undef W4_FETCH_U
 #undef W4_STASH_X
 #undef W4_STASH_U
 #undef W4_TRANSFORM
@@ -287,7 +333,7 @@ using namespace pd3;
 template <int CB>
 static int launch_wino43(const float* x, const float* u_packed, const float* bias, int batch, int cin, int cout,
                          int h, int w, int wv, int relu, float* out, hipStream_t s) {
-  constexpr size_t lds = (size_t)(CB * kW4Ci * 16 * kW4Cs + kW4Vsz + kW4RawSz) * sizeof(float);
+  constexpr size_t lds = (size_t)((CB == 4 ? 2 : 1) * (CB * kW4Ci * 16 * kW4Cs + kW4Vsz) + kW4RawSz) * sizeof(float);
   {  // dynamic-LDS cap: per device, so it is set on every launch (a host-side table write)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_winograd43_kernel<CB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
