@@ -396,11 +396,45 @@ int pd3_conv3x3_winograd_bias_relu(const float *x, const float *u_packed, const 
  *   mode 2: Conv2DTranspose kernel 2 stride 2 -> [batch, ctot, 2h, 2 w_valid];  A[co*4 + dy*2 + dx][ci] from the
  *           [cin, cout, 2, 2] weight; needs (h*w) % 4 == 0; w is the row pitch of x, w_valid <= w its real width
  *           (see conv3x3_bias_relu); modes 0 and 1 need w_valid == w
- *   A is packed [M/64][K/16][16][64] (paddle3d_amd/ops/conv.py:pack_patch_weight); K % 16 == 0, M % 64 == 0
+ *   mode 3: Conv2DTranspose kernel 4 stride 4 -> [batch, ctot, 4h, 4 w_valid];  A[co*16 + dy*4 + dx][ci] from the
+ *           [cin, cout, 4, 4] weight (PointPillars' third FPN level, upsample_strides [1, 2, 4]); out 16-byte aligned
+ *   A is packed [M/64][K/16][16][64] (paddle3d_amd/ops/conv.py:pack_patch_weight); K % 16 == 0, M % 64 == 0 --
+ *   except mode 1, which takes any cout >= 1 with A zero-padded to ceil(cout / 64) * 64 rows (SSDHead's 1x1
+ *   convolutions, pointpillars_head.py:62-69; rows >= cout are never stored)
  */
 int pd3_patch_conv_bias_relu(const float *x, const float *w_packed, const float *bias, int mode, int batch,
                              int cin, int cout, int h, int w, int w_valid, int relu, float *out,
                              int out_channels_total, int out_channel_offset, void *stream);
+
+/*
+ * ssd_postprocess -- SSDHead.post_process of PointPillars for a whole batch (paddle3d/models/detection/
+ * pointpillars/pointpillars_head.py:86-196: PointPillarsCoder.decode (pointpillars_coder.py:126-148), the
+ * anchors_mask selection, sigmoid -> max / argmax, direction argmax, score (>=) and centre-range filter, heading
+ * flip, rotate_nms_pcdet (models/layers/layer_libs.py:210-249), index_select) together with
+ * AnchorGenerator.generate_anchors_mask (anchors_generator.py:103-121, :191-210) that test_forward runs per frame
+ * in front of it (pointpillars.py:120-127).
+ *   head_map     [batch, C, feat_h, feat_w] fp32, the 1x1 head convolutions' output as they write it (NCHW);
+ *                batch_stride = elements between frames; class logits of anchor j at channels
+ *                cls_channel0 + j*(num_classes + !encode_background_as_zeros) + k, box code at box_channel0 + j*7 + k,
+ *                direction logits at dir_channel0 + j*2 + k (dir_channel0 < 0: use_direction_classifier=False)
+ *   anchors      [A, 7] fp32 (x, y, z, w, l, h, r), A = feat_h*feat_w*anchors_per_loc, index (y*feat_w + x)*apl + j
+ *   anchors_bv   [A, 4] int32 pillar-index boxes (xmin, ymin, xmax, ymax) (AnchorGenerator.anchors_bv)
+ *   coors        [num_coors, 4] int32 (batch, z, y, x) of the batch's pillars; rows with batch outside [0, batch) skipped
+ *   center_limit_range  6 host floats or NULL (prediction_center_limit_range=None)
+ * Outputs (device): out_boxes [batch, max(post,1), 7], out_scores [batch, max(post,1)], out_labels int64, out_count
+ * [batch] int32.  A frame without detections (no anchor passes the area test, or none the score / range test) has
+ * count 0 and the reference's `_box_empty` row (zeros, -1, -1) in row 0.  No host synchronisation.
+ */
+size_t pd3_ssd_postprocess_workspace(int batch, int feat_h, int feat_w, int anchors_per_loc, int grid_x, int grid_y,
+                                     int nms_pre_max_size);
+int pd3_ssd_postprocess(const float *head_map, int64_t batch_stride, int cls_channel0, int box_channel0,
+                        int dir_channel0, int batch, int feat_h, int feat_w, int anchors_per_loc, int num_classes,
+                        int encode_background_as_zeros, const float *anchors, const int32_t *anchors_bv,
+                        const int32_t *coors, int64_t num_coors, int grid_x, int grid_y,
+                        float anchor_area_threshold, float score_threshold, const float *center_limit_range,
+                        float nms_iou_threshold, int nms_pre_max_size, int nms_post_max_size, float *out_boxes,
+                        float *out_scores, int64_t *out_labels, int32_t *out_count, void *workspace,
+                        size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

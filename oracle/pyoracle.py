@@ -506,3 +506,102 @@ def voxel_pooling_prepare_v2_numpy(coor, grid_lower_bound, grid_interval, grid_s
     lengths = np.diff(np.append(starts, len(ranks_bev)))
     i32 = np.int32
     return ranks_bev.astype(i32), ranks_depth.astype(i32), ranks_feat.astype(i32), starts.astype(i32), lengths.astype(i32)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# PointPillars SSD head path (anchors, anchor mask, box decoding, per-frame post-processing), float32 NumPy;
+# pinned to the reference's own Python by tests/golden/python_ssd.npz (tests/golden/make_ssd_golden.py).
+# ---------------------------------------------------------------------------------------------------------
+def ssd_anchors_numpy(point_cloud_range, voxel_size, anchor_configs, output_stride_factor=2):
+    """anchors_generator.py:44-101 + :123-156 -> (anchors [A, 7] f32 in (y, x, config, rotation) order with
+    columns (x, y, z, w, l, h, r), anchors_bv [A, 4] int64 pillar-index boxes (xmin, ymin, xmax, ymax),
+    (feature_h, feature_w), grid (nx, ny))."""
+    f32 = np.float32
+    pr, vs = np.asarray(point_cloud_range, f32), np.asarray(voxel_size, f32)
+    grid = np.round((pr[3:6] - pr[:3]) / vs).astype(np.int64)
+    fw, fh = int(grid[0] // output_stride_factor), int(grid[1] // output_stride_factor)
+    per_cfg = []
+    for cfg in anchor_configs:
+        xs_, ys_, zs_ = [f32(v) for v in cfg["anchor_strides"]]
+        xo, yo, zo = [f32(v) for v in cfg["anchor_offsets"]]
+        xc = np.arange(fw, dtype=f32) * xs_ + xo
+        yc = np.arange(fh, dtype=f32) * ys_ + yo
+        zc = np.arange(1, dtype=f32) * zs_ + zo
+        rot = np.asarray(cfg["rotations"], f32)
+        sizes = np.asarray(cfg["sizes"], f32).reshape(-1, 3)
+        a = np.empty((1, fh, fw, sizes.shape[0], len(rot), 7), f32)   # [z, y, x, size, rotation, 7]
+        a[..., 0], a[..., 1], a[..., 2] = xc[None, None, :, None, None], yc[None, :, None, None, None], zc[0]
+        a[..., 3:6] = sizes[None, None, None, :, None, :]
+        a[..., 6] = rot[None, None, None, None, :]
+        per_cfg.append(a.reshape(1, fh, fw, -1, 7))
+    anchors = np.concatenate(per_cfg, axis=-2).reshape(-1, 7)
+    # rbbox2d_to_circumscribed (:158-176) on (x, y, w, l, r)
+    r = anchors[:, 6]
+    r = np.abs(r - np.floor(r / f32(np.pi) + f32(0.5)) * f32(np.pi))
+    lying = r > f32(np.pi / 4)
+    cx, cy = anchors[:, 0], anchors[:, 1]
+    dx = np.where(lying, anchors[:, 4], anchors[:, 3])
+    dy = np.where(lying, anchors[:, 3], anchors[:, 4])
+    bv = np.stack([cx - dx / f32(2), cy - dy / f32(2), cx + dx / f32(2), cy + dy / f32(2)], 1).astype(f32)
+    out = np.empty_like(bv)
+    out[:, 0] = np.maximum(np.floor((bv[:, 0] - pr[0]) / vs[0]), 0)
+    out[:, 1] = np.maximum(np.floor((bv[:, 1] - pr[1]) / vs[1]), 0)
+    out[:, 2] = np.minimum(np.floor((bv[:, 2] - pr[0]) / vs[0]), f32(grid[0] - 1))
+    out[:, 3] = np.minimum(np.floor((bv[:, 3] - pr[1]) / vs[1]), f32(grid[1] - 1))
+    return anchors, out.astype(np.int64), (fh, fw), (int(grid[0]), int(grid[1]))
+
+
+def ssd_anchor_mask_numpy(coords_zyx, anchors_bv, grid_xy, area_threshold=1.0):
+    """anchors_generator.py:103-121, :191-210: occupancy map [ny, nx] of the frame's pillars, summed along both
+    axes, four corner look-ups per anchor (the reference's corners as they are: no -1 on the lower side)."""
+    nx, ny = grid_xy
+    m = np.zeros((ny, nx), np.float32)
+    np.add.at(m, (coords_zyx[:, 1], coords_zyx[:, 2]), np.float32(1))
+    m = np.cumsum(np.cumsum(m, 0, dtype=np.float32), 1, dtype=np.float32)
+    bv = anchors_bv
+    area = m[bv[:, 3], bv[:, 2]] - m[bv[:, 3], bv[:, 0]] - m[bv[:, 1], bv[:, 2]] + m[bv[:, 1], bv[:, 0]]
+    return area > np.float32(area_threshold)
+
+
+def ssd_box_decode_numpy(encodings, anchors):
+    """pointpillars_coder.py:126-148 (second_box_decode_paddle), float32."""
+    f32 = np.float32
+    e, a = np.asarray(encodings, f32), np.asarray(anchors, f32)
+    xa, ya, za, wa, la, ha, ra = [a[..., k] for k in range(7)]
+    xt, yt, zt, wt, lt, ht, rt = [e[..., k] for k in range(7)]
+    diag = np.sqrt(la * la + wa * wa).astype(f32)
+    out = np.stack([xt * diag + xa, yt * diag + ya, zt * ha + za, np.exp(wt).astype(f32) * wa,
+                    np.exp(lt).astype(f32) * la, np.exp(ht).astype(f32) * ha, rt + ra], -1)
+    return out.astype(f32)
+
+
+def ssd_post_process_frame_numpy(box_preds, cls_preds, dir_preds, anchors, anchors_mask, score_threshold,
+                                 center_limit_range, nms_pre_max_size, nms_post_max_size, nms_iou_threshold,
+                                 kind="port"):
+    """pointpillars_head.py:86-196 for one frame: decode, anchors_mask, sigmoid / max / argmax, direction argmax,
+    score (>=) and centre-range filter, heading flip by the direction bit, bottom -> object centre, rotate_nms_pcdet,
+    back to the bottom centre.  Returns (boxes [K, 7], scores [K], labels [K] int64); the reference's `_box_empty`
+    row (zeros, -1, -1) when nothing survives."""
+    f32 = np.float32
+    empty = (np.zeros((1, 7), f32), -np.ones(1, f32), -np.ones(1, np.int64))
+    if not anchors_mask.any():
+        return empty
+    box = ssd_box_decode_numpy(box_preds, anchors)[anchors_mask]
+    cls = np.asarray(cls_preds, f32)[anchors_mask]
+    conf = (f32(1) / (f32(1) + np.exp(-cls).astype(f32))).astype(f32)
+    scores, labels = conf.max(-1), conf.argmax(-1).astype(np.int64)
+    kept = scores >= f32(score_threshold)
+    if center_limit_range is not None:
+        lim = np.asarray(center_limit_range, f32)
+        kept &= (box[:, :3] >= lim[:3]).all(1) & (box[:, :3] <= lim[3:]).all(1)
+    if not kept.any():
+        return empty
+    box, scores, labels = box[kept].copy(), scores[kept], labels[kept]
+    if dir_preds is not None:
+        dl = np.asarray(dir_preds, f32)[anchors_mask][kept].argmax(-1).astype(bool)
+        box[:, 6] += np.where((box[:, 6] > 0) ^ dl, f32(np.pi), f32(0))
+    box[:, 2] = box[:, 2] + box[:, 5] * f32(0.5)
+    sel = rotate_nms_pcdet_numpy(box, scores, nms_iou_threshold, nms_pre_max_size, nms_post_max_size, kind=kind)
+    box = box[sel]
+    box[:, 2] = box[:, 2] - box[:, 5] * f32(0.5)
+    return box, scores[sel], labels[sel]

@@ -352,11 +352,11 @@ class SecondFPN(_InferenceCache, nn.Module):
                 mode = _conv.patch_mode(w, conv.stride[0], tr)
                 if mode is None or tuple(conv.padding) != (0, 0) or conv.stride[0] != conv.stride[1]:
                     raise Paddle3DAmdError(f"unsupported configuration: FPN level {conv} is not a kernel = stride "
-                                           "(1 or 2) convolution (status -3)")
+                                           "(conv 1 / 2, transposed conv 1 / 2 / 4) layer (status -3)")
                 cout = int(w.shape[1] if tr else w.shape[0])
                 cin = int(w.shape[0] if tr else w.shape[1])
                 plan.append(dict(mode=mode, w=_conv.pack_patch_weight(w, mode, tr), b=b, cin=cin, cout=cout, off=off,
-                                 scale={0: 0.5, 1: 1, 2: 2}[mode]))
+                                 scale={0: 0.5, 1: 1, 2: 2, 3: 4}[mode]))
                 off += cout
             self.__dict__["_cache"] = (plan, off)
         return self._cache
@@ -373,7 +373,7 @@ class SecondFPN(_InferenceCache, nn.Module):
             if not _conv.patch_supported(p["mode"], p["cin"], p["cout"], int(x.shape[2]), int(x.shape[3])):
                 raise Paddle3DAmdError(f"patch_conv: unsupported configuration (mode {p['mode']}, cin {p['cin']}, "
                                        f"cout {p['cout']}, input {tuple(x.shape[2:])}) (status -3)")
-            if p["mode"] != 2 and _valid_w(x) != x.shape[3]:
+            if p["mode"] < 2 and _valid_w(x) != x.shape[3]:
                 raise Paddle3DAmdError(f"patch_conv: unsupported configuration (mode {p['mode']} on a map of width "
                                        f"{_valid_w(x)}, not a multiple of 4) (status -3)")
             _conv.patch_conv_bias_relu(x, p["w"], p["b"], p["mode"], p["cout"], out, p["off"], relu=True,

@@ -9,6 +9,10 @@
 //   mode 0  Conv2D k2 s2:        m = co,            k = (ci, py, px),  B = in[ci][2y+py][2x+px]
 //   mode 1  1x1 (conv or deconv): m = co,            k = ci,            B = in[ci][y][x]
 //   mode 2  Conv2DTranspose k2 s2: m = (co, dy, dx),  k = ci,            B = in[ci][y][x],  D -> out[co][2y+dy][2x+dx]
+//   mode 3  Conv2DTranspose k4 s4: m = (co, dy, dx),  k = ci,            B = in[ci][y][x],  D -> out[co][4y+dy][4x+dx]
+//           (the third level of PointPillars' SECOND FPN, configs/pointpillars/*.yml: upsample_strides [1, 2, 4])
+// Mode 1 also takes a row count that is not a multiple of 64 (the SSD head's 1x1 convolutions, 20 maps): the packed
+// A matrix is zero-padded to 64 rows by the host packer and rows >= m_valid are never stored.
 // A comes pre-packed from the host as [M/64][K/16][16][64]; B rows are staged with aligned float4 loads
 // (mode 0: the 4 x 256 input window of 2 x 128 output pixels, read back at stride 2).  Same software
 // pipeline as conv3x3.hip: trip c+1 travels global -> registers while trip c is multiplied out of
@@ -35,6 +39,7 @@ struct PgArgs {
   const float* bias;
   float* out;
   int cin, m_rows;      // GEMM K (in rows of B per pixel: cin, or 4 cin for mode 0 handled below) and M
+  int m_valid;          // rows that exist (modes 0, 1: output channels; the packed matrix is padded to m_rows)
   int hi, wi;           // input map (wi = row pitch)
   int wv;               // valid input columns (mode 2 only: columns >= wv are padding and produce no output)
   int ho, wo;           // output map
@@ -153,7 +158,24 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(PgArgs a) {
     if (MODE != 0 && (int64_t)p0 + pj >= iplane) continue;  // pixel of a partial tile
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      if (MODE == 2) {
+      if (MODE == 3) {
+        // a register quad = the four dx of one (co, dy): row = r + 8 q + 4 kk of the 32-row block, 16 rows per co
+        const int p = p0 + pj, y = p / a.wi, xx = p - y * a.wi;
+        if (xx >= a.wv) continue;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int co = mt * (kPgM / 16) + m * 2 + (qd >> 1);
+          const int dy = (qd & 1) * 2 + kk;
+          const float bv = a.bias ? a.bias[co] : 0.f;
+          pg_f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[m][t][qd * 4 + r] + bv;
+            if (a.relu) v[r] = fmaxf(v[r], 0.f);
+          }
+          *reinterpret_cast<pg_f32x4*>(obase + (int64_t)co * oplane + (int64_t)(4 * y + dy) * a.wo + 4 * xx) = v;
+        }
+      } else if (MODE == 2) {
         // rows 4q .. 4q+3 of a register quad = (dy, dx) of one output channel
         const int p = p0 + pj, y = p / a.wi, xx = p - y * a.wi;
         if (xx >= a.wv) continue;  // padding column of a map whose width is not a multiple of 4
@@ -177,6 +199,7 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(PgArgs a) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
           const int co = mt * kPgM + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+          if (co >= a.m_valid) continue;
           float v = acc[m][t][reg] + (a.bias ? a.bias[co] : 0.f);
           if (a.relu) v = fmaxf(v, 0.f);
           obase[(int64_t)co * oplane + opix] = v;
@@ -202,12 +225,12 @@ extern "C" int pd3_patch_conv_bias_relu(const float* x, const float* w_packed, c
                                         int batch, int cin, int cout, int h, int w, int w_valid, int relu,
                                         float* out, int out_channels_total, int out_channel_offset, void* stream) {
   if (!x || !w_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || w_valid <= 0 ||
-      w_valid > w || (mode != 2 && w_valid != w))
+      w_valid > w || (mode < 2 && w_valid != w))
     return PD3_EINVAL;
-  if (mode < 0 || mode > 2 || out_channel_offset < 0 || out_channel_offset + cout > out_channels_total)
+  if (mode < 0 || mode > 3 || out_channel_offset < 0 || out_channel_offset + cout > out_channels_total)
     return PD3_EINVAL;
   if (reinterpret_cast<uintptr_t>(w_packed) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0 ||
-      reinterpret_cast<uintptr_t>(out) % 8 != 0)
+      reinterpret_cast<uintptr_t>(out) % (mode == 3 ? 16 : 8) != 0)
     return PD3_EINVAL;
   if ((int64_t)cin * h * w >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
   PgArgs a;
@@ -227,6 +250,7 @@ extern "C" int pd3_patch_conv_bias_relu(const float* x, const float* w_packed, c
   if (mode == 0) {  // Conv2D kernel 2 stride 2
     if (h % 4 != 0 || w % 256 != 0 || (cin * 4) % kPgK != 0 || cout % kPgM != 0) return PD3_EUNSUPPORTED;
     a.m_rows = cout;
+    a.m_valid = cout;
     a.ho = h / 2;
     a.wo = w / 2;
     ptiles = (int64_t)batch * (a.ho / 2) * (a.wo / 128);
@@ -236,12 +260,20 @@ extern "C" int pd3_patch_conv_bias_relu(const float* x, const float* w_packed, c
   if (((int64_t)h * w) % 4 != 0 || cin % kPgK != 0) return PD3_EUNSUPPORTED;  // planes start float4-aligned
   ptiles = (int64_t)batch * ceil_div((int64_t)h * w, kPgP);
   a.ptiles = (int)ptiles;
-  if (mode == 1) {  // 1x1
-    if (cout % kPgM != 0) return PD3_EUNSUPPORTED;
-    a.m_rows = cout;
+  a.m_valid = INT32_MAX;
+  if (mode == 1) {  // 1x1; w_packed holds ceil(cout / 64) * 64 rows
+    a.m_rows = (int)ceil_div(cout, kPgM) * kPgM;
+    a.m_valid = cout;
     a.ho = h;
     a.wo = w;
     return launch_patch_gemm<1>(a, ptiles, s);
+  }
+  if (mode == 3) {  // Conv2DTranspose kernel 4 stride 4
+    if ((cout * 16) % kPgM != 0) return PD3_EUNSUPPORTED;
+    a.m_rows = cout * 16;
+    a.ho = 4 * h;
+    a.wo = 4 * w_valid;
+    return launch_patch_gemm<3>(a, ptiles, s);
   }
   if ((cout * 4) % kPgM != 0) return PD3_EUNSUPPORTED;  // Conv2DTranspose kernel 2 stride 2
   a.m_rows = cout * 4;

@@ -123,27 +123,32 @@ def patch_mode(weight: torch.Tensor, stride: int, transpose: bool):
         return 1
     if k == 2:
         return 2 if transpose else 0
+    if k == 4 and transpose:
+        return 3
     return None
 
 
 def patch_supported(mode: int, cin: int, cout: int, h: int, w: int) -> bool:
-    """[h, w] = input map, w its row pitch (pitch4 of the valid width for mode 2)."""
+    """[h, w] = input map, w its row pitch (pitch4 of the valid width for modes 2, 3)."""
     if mode == 0:
         return h % 4 == 0 and w % 256 == 0 and (cin * 4) % 16 == 0 and cout % 64 == 0
     if (h * w) % 4 or cin % 16:
         return False
-    return cout % 64 == 0 if mode == 1 else (cout * 4) % 64 == 0
+    return {1: cout >= 1, 2: (cout * 4) % 64 == 0, 3: (cout * 16) % 64 == 0}.get(mode, False)
 
 
 def pack_patch_weight(weight: torch.Tensor, mode: int, transpose: bool) -> torch.Tensor:
     """GEMM A matrix [M, K] of the layer, packed [M/64][K/16][16][64].
-    Conv2D weights are [cout, cin, k, k], Conv2DTranspose weights [cin, cout, k, k]."""
+    Conv2D weights are [cout, cin, k, k], Conv2DTranspose weights [cin, cout, k, k].  Mode 1 pads M with zero rows to a
+    multiple of 64 (the kernel never stores them)."""
     if mode == 0:
         a = weight.reshape(weight.shape[0], -1)                       # [co][ci*4 + py*2 + px]
     elif mode == 1:
         a = weight[:, :, 0, 0].t() if transpose else weight[:, :, 0, 0]  # [co][ci]
+        if a.shape[0] % 64:
+            a = torch.cat([a, a.new_zeros(64 - a.shape[0] % 64, a.shape[1])], 0)
     else:
-        a = weight.permute(1, 2, 3, 0).reshape(-1, weight.shape[0])   # [co*4 + dy*2 + dx][ci]
+        a = weight.permute(1, 2, 3, 0).reshape(-1, weight.shape[0])   # [co*k*k + dy*k + dx][ci], k = 2 or 4
     m, k = a.shape
     assert m % 64 == 0 and k % 16 == 0
     return a.reshape(m // 64, 64, k // 16, 16).permute(0, 2, 3, 1).contiguous()
@@ -151,7 +156,7 @@ def pack_patch_weight(weight: torch.Tensor, mode: int, transpose: bool) -> torch
 
 def patch_conv_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, mode: int, cout: int, out: torch.Tensor,
                          channel_offset: int = 0, relu: bool = True, w_valid: int | None = None) -> torch.Tensor:
-    """Writes relu(conv(x) + bias) into out[:, channel_offset:channel_offset + cout].  w_valid (mode 2 only): real
+    """Writes relu(conv(x) + bias) into out[:, channel_offset:channel_offset + cout].  w_valid (modes 2, 3 only): real
     width of a zero-padded x."""
     xx = require_gpu(x, "patch_conv_bias_relu")
     n, cin, h, w = xx.shape

@@ -204,6 +204,19 @@ def _mk_paddle():
         (lambda a, b: _wrap(torch.atan2(a, b))), (lambda x: _wrap(torch.abs(x)))
     p.clip = lambda x, min=None, max=None: _wrap(torch.clamp(x, min=min, max=max))
     p.floor = lambda x: _wrap(torch.floor(x))
+    p.round = lambda x: _wrap(torch.round(x))
+    p.meshgrid = lambda *xs: [_wrap(t) for t in torch.meshgrid(*xs, indexing="ij")]
+    p.tile = lambda x, reps: _wrap(x.as_subclass(torch.Tensor).repeat(*[int(r) for r in reps]))
+    p.split = lambda x, n, axis=0: [_wrap(t) for t in torch.split(x, x.shape[axis] // n if isinstance(n, int) else n,
+                                                                  dim=axis)]
+
+    def scatter_nd_add(x, index, updates):
+        out = x.clone()
+        out.index_put_(tuple(index.long().unbind(-1)), updates, accumulate=True)
+        return _wrap(out)
+
+    p.scatter_nd_add = scatter_nd_add
+    p.gather_nd = lambda x, index: _wrap(x[tuple(index.long().unbind(-1))])
     p.flatten = lambda x, start_axis=0, stop_axis=-1: _wrap(torch.flatten(x, start_axis, stop_axis))
     p.squeeze = lambda x, axis=None: _wrap(x).squeeze(axis)
     p.unsqueeze = lambda x, axis: _wrap(torch.unsqueeze(x, axis))
@@ -429,12 +442,18 @@ def install(reference_root="/root/reference"):
     for extra in ("paddle.distributed", "paddle.distributed.fleet", "paddle.distributed.fleet.utils", "paddle.vision",
                   "paddle.vision.models", "paddle.vision.models.resnet", "paddle.static", "paddle.jit", "paddle.utils", "paddle.utils.cpp_extension"):
         sys.modules[extra] = _AnyAttr(extra)
+    # paddle.static.nn.cond in dynamic mode: evaluate the predicate, run one branch (pointpillars_head.py:101-131)
+    static_nn = types.ModuleType("paddle.static.nn")
+    static_nn.cond = lambda pred, true_fn=None, false_fn=None: true_fn() if bool(pred) else false_fn()
+    sys.modules["paddle.static"].nn = static_nn
+    sys.modules["paddle.static.nn"] = static_nn
+    p.static = sys.modules["paddle.static"]
     root = os.path.join(reference_root, "paddle3d")
     _pkg("paddle3d", root)
     # sub-packages that resolve to the reference's source directories; their __init__.py never runs
     for sub in ("models", "models/voxel_encoders", "models/middle_encoders", "models/backbones", "models/necks",
                 "models/layers", "models/transformers", "models/detection", "models/detection/centerpoint",
-                "models/detection/bevfusion", "geometries", "utils"):
+                "models/detection/bevfusion", "models/detection/pointpillars", "geometries", "utils"):
         _pkg("paddle3d." + sub.replace("/", "."), os.path.join(root, sub), permissive=sub == "models/layers")
     # framework services the layer files import but the forward paths do not need
     for stub in ("paddle3d.apis", "paddle3d.apis.manager", "paddle3d.ops", "paddle3d.models.losses",
@@ -444,6 +463,8 @@ def install(reference_root="/root/reference"):
     sys.modules["paddle3d.apis"].manager = _Anything("manager")
     sys.modules["paddle3d.utils.logger"].logger = _Anything("logger")
     sys.modules["paddle3d.models"].layers = sys.modules["paddle3d.models.layers"]
+    for name in ("BBoxes3D", "CoordMode"):  # result containers the SSD head imports and only _parse_result_to_sample uses
+        setattr(sys.modules["paddle3d.geometries"], name, _Anything(name))
     return p
 
 
