@@ -245,6 +245,7 @@ def bench_pillars(args, rank, world, dev):
 
     V, B = args.max_voxels, args.batch
     model = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(V, V)).to(dev).eval()
+    model.voxelizer.path = args.vox_path
     pts = make_batch(B, 100 + B * rank, dev)
     cfg = model.test_cfg
     max_per_img = cfg["max_per_img"]
@@ -513,19 +514,19 @@ def bench_bevfusion_lidar(args, rank, world, dev):
 
 
 def bench_pointpillars_kitti(args, rank, world, dev):
-    """PointPillars-KITTI front half (config 1, configs/pointpillars/pointpillars_xyres16_kitti_car.yml:86-126):
-    16 384 camera-FOV points x 4, 0.16 m pillars (432 x 496), P = 32, V = 40 000:
-    hard_voxelize -> PillarFeatureNet (64) -> PointPillarsScatter."""
-    from paddle3d_amd import centerpoint as cpm
+    """PointPillars-KITTI, the whole inference graph (config 1, configs/pointpillars/pointpillars_xyres16_kitti_car.yml:
+    86-146): 16 384 camera-FOV points x 4, 0.16 m pillars (432 x 496), P = 32, V = 40 000: hard_voxelize ->
+    PillarFeatureNet (64) -> PointPillarsScatter -> SECOND backbone -> FPN (transposed convolutions 1 / 2 / 4) -> SSD
+    head (one 1x1 GEMM) -> anchor masks + decode + rotated NMS (ssd_postprocess)."""
+    from paddle3d_amd import pointpillars as ppm
     from paddle3d_amd import synth
 
     B, V, PV, D4, NK = args.batch, 40000, 32, 4, 16384
-    vs, pr = synth.KITTI_PILLAR, synth.KITTI_RANGE
-    voxelizer = cpm.HardVoxelizer(vs, pr, PV, [16000, V]).eval()
-    pfn = cpm.PillarFeatureNet(D4, (64,), False, PV, vs, pr, legacy=False).to(dev).eval()
-    scatter = cpm.PointPillarsScatter(64, vs, pr)
+    model = ppm.pointpillars_kitti_car((16000, V)).to(dev).eval()
+    with torch.no_grad():
+        model.head.cls_head.bias.fill_(-2.0)  # random weights: a few hundred anchors per frame pass the 0.05 threshold
     pts = torch.from_numpy(np.stack([synth.kitti_frame(100 + B * rank + i, NK) for i in range(B)])).to(dev)
-    names = ["start", "hard_voxelize", "pillar_feature_net", "pointpillars_scatter"]
+    names = ["start", "hard_voxelize", "pillar_feature_net", "pointpillars_scatter", "dense", "ssd_head_postprocess"]
 
     def run(events):
         def mark(i):
@@ -533,14 +534,19 @@ def bench_pointpillars_kitti(args, rank, world, dev):
                 events[i].record()
 
         mark(0)
-        voxels, coors, npv, nv = voxelizer(pts)
+        voxels, coors, npv, nv = model.voxelizer(pts)
         mark(1)
         b, v, p, d = voxels.shape
-        feats = pfn(voxels.view(b * v, p, d), npv.view(b * v), coors.view(b * v, 4))
+        c4 = coors.view(b * v, 4)
+        feats = model.pillar_encoder(voxels.view(b * v, p, d), npv.view(b * v), c4)
         mark(2)
-        canvas = scatter(feats, coors.view(b * v, 4), b)
+        canvas = model.middle_encoder(feats, c4, b)
         mark(3)
-        return canvas, nv
+        x = model.neck(model.backbone(canvas))
+        mark(4)
+        out = model.head.post_process(model.head.head_map(x), model.anchor_generator, c4, device_only=True)
+        mark(5)
+        return out, nv
 
     with torch.no_grad():
         dt, per_op_ms, out = _timed_loop(run, args, world, dev, names)
@@ -550,14 +556,24 @@ def bench_pointpillars_kitti(args, rank, world, dev):
     a = alg_v * B / (per_op_ms["hard_voxelize"] * 1e-3) / 1e9
     alg_s = 4 * V * 64 + 16 * V + 4 * 64 * 432 * 496
     a_s = alg_s * B / (per_op_ms["pointpillars_scatter"] * 1e-3) / 1e9
+
+    def conv(cin, cout, k, h, w):
+        return 2 * cin * cout * k * k * h * w
+
+    s1 = 3 * conv(64, 64, 3, 248, 216) + 5 * conv(128, 128, 3, 124, 108) + 5 * conv(256, 256, 3, 62, 54)
+    s2 = conv(64, 64, 3, 248, 216) + conv(64, 128, 3, 124, 108) + conv(128, 256, 3, 62, 54)
+    other = conv(64, 128, 1, 248, 216) + conv(128, 128, 2, 124, 108) + conv(256, 128, 4, 62, 54)
+    direct, executed = s1 + s2 + other, s1 / 4 + s2 + other
+    tf = executed * B / (per_op_ms["dense"] * 1e-3) / 1e12
     return {
-        "metric": "frames/sec PointPillars-KITTI front half (voxelize + PFN + scatter)",
+        "metric": "frames/sec PointPillars-KITTI (whole inference graph)",
         "value": world * B * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"PointPillars-KITTI: {NK} pts x {D4} per frame, 0.16 m pillars (432x496), P={PV}, "
                                f"max_voxels={V}, batch {B} distinct frames/GPU/step, random-init weights, "
-                               "hard_voxelize->PillarFeatureNet(64)->PointPillarsScatter",
+                               "hard_voxelize->PillarFeatureNet(64)->PointPillarsScatter->SECOND+FPN->SSDHead->"
+                               "anchor mask + decode + rotated NMS",
                    "frames_per_gpu_per_step": B, "max_voxels": V, "parallelism": f"dp{world} (frames)"},
         "roofline": dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBPS, unit="GB/s", frac=a / HBM_PEAK_GBPS, traffic=None,
                          ms_per_launch=per_op_ms["hard_voxelize"], units_per_launch=B,
@@ -567,8 +583,15 @@ def bench_pointpillars_kitti(args, rank, world, dev):
         "rooflines": {"pointpillars_scatter": dict(bound="hbm", achieved=a_s, peak=HBM_PEAK_GBPS, unit="GB/s",
                                                    frac=a_s / HBM_PEAK_GBPS, traffic=None,
                                                    ms_per_launch=per_op_ms["pointpillars_scatter"],
-                                                   units_per_launch=B, algorithmic_bytes_per_unit=alg_s)},
+                                                   units_per_launch=B, algorithmic_bytes_per_unit=alg_s),
+                      "dense_backbone_fpn": dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                                                 frac=tf / MFMA_F32_PEAK_TFLOPS, traffic=None,
+                                                 ms_per_launch=per_op_ms["dense"], units_per_launch=B,
+                                                 executed_flops_per_unit=executed, direct_form_flops_per_unit=direct,
+                                                 note="executed flops: stride-1 3x3 layers by Winograd F(4x4,3x3) (a "
+                                                      "quarter of the direct multiplies), the rest direct GEMMs")},
         "per_op_ms": per_op_ms, "voxels_first_frame": int(out[1][0]),
+        "detections_first_frame": int(out[0][3][0]),
     }
 
 
@@ -630,6 +653,8 @@ def main():
     ap.add_argument("--workload", default="centerpoint_pillars",
                     choices=["centerpoint_pillars", "centerpoint_voxel", "bev_pool_v2", "bevfusion_lidar",
                              "pointpillars_kitti"])
+    ap.add_argument("--vox-path", type=int, default=0, help="pd3_hard_voxelize_path selector (0 = library default, "
+                    "1 generic sort, 2 tiled with a compact payload array, 3 tiled with gathered rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the h2d-inclusive / batch-1 / ceiling measurements "
                     "(profiling runs: only warm-up + timed steps are launched)")

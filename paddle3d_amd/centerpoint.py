@@ -53,8 +53,9 @@ class HardVoxelizer(nn.Module):
     """models/voxelizers/voxelize.py:27-82.  forward(points [B, N, D]) -> (voxels [B,V,P,D],
     coors [B,V,4] int32 (batch, z, y, x; batch = -1 on padding rows), num_points [B,V], num_voxels [B])."""
 
-    def __init__(self, voxel_size, point_cloud_range, max_num_points_in_voxel, max_num_voxels):
+    def __init__(self, voxel_size, point_cloud_range, max_num_points_in_voxel, max_num_voxels, path: int = 0):
         super().__init__()
+        self.path = int(path)  # pd3_hard_voxelize_path selector (0 = the library's choice)
         self.voxel_size = list(map(float, voxel_size))
         self.point_cloud_range = list(map(float, point_cloud_range))
         self.max_num_points_in_voxel = int(max_num_points_in_voxel)
@@ -69,7 +70,7 @@ class HardVoxelizer(nn.Module):
         # itself; -1 marks padding rows
         voxels, _, npv, nv, coors = _vox.hard_voxelize_batch(points, self.voxel_size, self.point_cloud_range,
                                                              self.max_num_points_in_voxel, v, num_points,
-                                                             with_batch_coors=True)
+                                                             with_batch_coors=True, path=self.path)
         return voxels, coors, npv, nv
 
 

@@ -267,21 +267,25 @@ static bool tiled_applicable(const VoxGrid& g, int64_t n, int dim, int max_pts, 
 static int run_tiled(const float* points, const int32_t* num_points, int batch, int64_t n, int dim,
                      const VoxGrid& g, int max_pts, int max_voxels, const VtPlan& plan,
                      float* voxels, int32_t* coords, int32_t* num_pts, int32_t* num_voxels,
-                     int32_t* coors4, void* workspace, hipStream_t s) {
+                     int32_t* coors4, void* workspace, hipStream_t s, bool gather) {
   VtWorkspace w = vt_carve(workspace, batch, n, dim, max_pts, max_voxels, g.ncells, plan);
   VtGrid vg{g.min_x, g.min_y, g.min_z, g.size_x, g.size_y, g.size_z,
             (float)(1.0 / (double)g.size_x), (float)(1.0 / (double)g.size_y), (float)(1.0 / (double)g.size_z),
             g.gx, g.gy, g.gz, g.ncells};
   const size_t lds_a = ((size_t)kVtTile + (size_t)kVtRouteWaves * plan.groups + kVtRouteWaves + 2) * 4;
   const size_t lds_b = vt_group_lds(plan.cpg, plan.tiles);
+  // the gather form keeps a list of point indices where the default form keeps the payload itself (same places)
+  uint32_t* clist = reinterpret_cast<uint32_t*>(w.compact);
   const unsigned tile_grid = (unsigned)(plan.tiles * batch);
   vt_route_kernel<<<tile_grid, kVtRouteThreads, lds_a, s>>>(points, num_points, n, dim, vg, plan.low, plan.gbits,
                                                             plan.tiles, batch, max_voxels, w.recs, w.dir, w.pos16,
                                                             w.tilecnt, w.vinfo);
   vt_group_kernel<<<(unsigned)(plan.groups * batch), kVgThreads, lds_b, s>>>(
-      w.recs, w.dir, plan.low, plan.gbits, plan.tiles, batch, max_pts, w.cposr, w.gstart, w.tilecnt);
+      w.recs, w.dir, plan.low, plan.gbits, plan.tiles, batch, max_pts, w.cposr, w.gstart, w.tilecnt,
+      gather ? clist : nullptr, w.cap);
+  // gather form: only the assign job of the C + D launch runs (the emit job's workgroups are not launched)
 #define PD3_VT_EMIT(D)                                                                                         \
-  vt_assign_emit_kernel<D><<<2 * tile_grid, kVtRouteThreads, 0, s>>>(                                          \
+  vt_assign_emit_kernel<D><<<(gather ? 1 : 2) * tile_grid, kVtRouteThreads, 0, s>>>(                                          \
       points, n, dim, plan.tiles, batch, w.cposr, w.pos16, w.recs, w.dir, plan.low, plan.gbits, w.tilecnt,      \
       max_voxels, vg, w.vinfo, w.totals,                                                                       \
       coords, num_pts, coors4, w.cap, w.compact)
@@ -296,6 +300,17 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
   const int rowq = (int)(vec4 ? row / 4 : row);
   const int units = (int)ceil_div((int64_t)max_voxels * rowq, kVtRowsThreads * kVtRowsIlp);
   const int step_v = kVtRowsThreads / rowq, step_j = kVtRowsThreads % rowq;
+  if (gather) {
+    if (vec4)
+      vt_rows_gather_kernel<4><<<(unsigned)(units * batch), kVtRowsThreads, 0, s>>>(
+          points, n, clist, w.cap, w.vinfo, w.totals, batch, units, max_voxels, rowq, step_v, step_j, dim, voxels,
+          coords, num_pts, num_voxels, coors4);
+    else
+      vt_rows_gather_kernel<1><<<(unsigned)(units * batch), kVtRowsThreads, 0, s>>>(
+          points, n, clist, w.cap, w.vinfo, w.totals, batch, units, max_voxels, rowq, step_v, step_j, dim, voxels,
+          coords, num_pts, num_voxels, coors4);
+    return launch_status();
+  }
   if (vec4)
     vt_rows_kernel<4><<<(unsigned)(units * batch), kVtRowsThreads, 0, s>>>(
         w.compact, w.cap, w.vinfo, w.totals, batch, units, max_voxels, rowq, step_v, step_j, dim, voxels, coords,
@@ -340,7 +355,7 @@ extern "C" int pd3_hard_voxelize_path(const float* points, const int32_t* num_po
   if (batch <= 0 || max_points <= 0 || max_points >= ((int64_t)1 << 31) || num_point_dim < 3 ||
       max_num_points_in_voxel <= 0 || max_voxels <= 0)
     return PD3_EINVAL;
-  if (!make_grid(voxel_size, point_cloud_range, g) || path < 0 || path > 2) return PD3_EINVAL;
+  if (!make_grid(voxel_size, point_cloud_range, g) || path < 0 || path > 3) return PD3_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t n = max_points;
   if (workspace_bytes < pd3_hard_voxelize_workspace(batch, max_points, num_point_dim, voxel_size,
@@ -350,11 +365,11 @@ extern "C" int pd3_hard_voxelize_path(const float* points, const int32_t* num_po
   {
     VtPlan vp;
     const bool can = tiled_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, vp);
-    if (path == 2 && !can) return PD3_EUNSUPPORTED;
+    if (path >= 2 && !can) return PD3_EUNSUPPORTED;
     if (can && path != 1)
       return run_tiled(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel,
                        max_voxels, vp, voxels, coords, num_points_per_voxel, num_voxels, coors_batched,
-                       workspace, s);
+                       workspace, s, path == 3);
   }
   const RadixPlan plan = radix_plan(g.ncells, max_points);
   VoxWorkspace w = carve(workspace, batch, max_points, max_voxels, plan);

@@ -315,7 +315,7 @@ static inline size_t vt_group_lds(int cpg, int tiles) {
 __global__ __launch_bounds__(kVgThreads, 4) void vt_group_kernel(
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ dir, int low, int gbits, int tiles,
     int batch, int max_pts, uint32_t* __restrict__ cposr, uint32_t* __restrict__ gstart,
-    uint32_t* __restrict__ tilecnt) {
+    uint32_t* __restrict__ tilecnt, uint32_t* __restrict__ clist, int64_t cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
   const int cpg = 1 << low, groups = 1 << gbits;
   const int cw = max(cpg >> 1, 1);                                   // two 16-bit counters per word
@@ -381,6 +381,7 @@ __global__ __launch_bounds__(kVgThreads, 4) void vt_group_kernel(
   const int64_t stride = (int64_t)tiles * kVtTile;
   const uint32_t* rf = recs + (int64_t)frame * stride;
   uint32_t* cpos_f = cposr + (int64_t)frame * stride;
+  uint32_t* clist_f = clist ? clist + (int64_t)frame * cap : nullptr;  // gather form: point index per compact place
   uint32_t* gs = gstart + ((int64_t)frame * groups + grp) * cpg;
   const uint32_t cell_mask = (uint32_t)cpg - 1u;
   const int npass = (int)ceil_div(total_steps, kVgPassSteps);
@@ -513,7 +514,17 @@ __global__ __launch_bounds__(kVgThreads, 4) void vt_group_kernel(
 #pragma unroll
         for (int c0 = 0; c0 < kVgSteps; c0 += kVgChunk) {
           if (c0 < s_n) {
-            uint32_t packed[kVgChunk];
+            uint32_t packed[kVgChunk], full[kVgChunk];
+#pragma unroll
+            for (int k = 0; k < kVgChunk; ++k) full[k] = 0u;
+            if (clist_f) {  // the records again (coalesced, L2): their upper bits are the point indices
+#pragma unroll
+              for (int k = 0; k < kVgChunk; ++k) {
+                const int c = __builtin_amdgcn_readlane((int)my_cnt, c0 + k);
+                const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)my_src, c0 + k);
+                full[k] = (rf + src)[lane < c ? lane : 0];
+              }
+            }
             if (one_pass) {
 #pragma unroll
               for (int k = 0; k < kVgChunk; ++k) packed[k] = cntw[rec[c0 + k] & cell_mask];
@@ -531,6 +542,8 @@ __global__ __launch_bounds__(kVgThreads, 4) void vt_group_kernel(
               uint32_t w = slot < (uint32_t)max_pts ? region + (packed[k] & 0xFFFFFFu) + slot : kVtDropped;
               if (first) w |= kVtFirstBit | ((packed[k] >> 24) << kVtKeptShift);
               if (valid) (cpos_f + src)[lane] = w;
+              // gather form: the list the row writer walks (a 4-byte store inside the group's ~17 KB region)
+              if (clist_f && valid && slot < (uint32_t)max_pts) clist_f[w & kVtCpMask] = full[k] >> low;
               const uint32_t nfirst = (uint32_t)__popcll(__ballot(first));
               firsts = lane == u ? nfirst : firsts;
             }
@@ -873,6 +886,100 @@ __global__ __launch_bounds__(kVtRowsThreads) void vt_rows_kernel(
       for (int c = 0; c < VEC; ++c) dst[c] = val[u][c];
     }
     if (j[u] == 0 && (int)v[u] >= nv) {  // padding rows of coords / count / coors4 (batch = -1: coors_pad)
+      const int64_t row = (int64_t)frame * max_voxels + v[u];
+      const VtInt3 z3{0, 0, 0};
+      __builtin_memcpy(coords + row * 3, &z3, sizeof(z3));
+      num_pts[row] = 0;
+      if (coors4) *reinterpret_cast<int4*>(coors4 + row * 4) = make_int4(-1, 0, 0, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ E'
+// Gather form of the output writer (hard_voxelize path 3): no compact payload array and no second pass over the
+// points.  The group kernel leaves clist[compact place] = point index; a row's j-th point is
+// points[clist[start(v) + j]].  A lane still owns VEC consecutive floats of the flat voxels array; they belong to
+// at most two points (dim >= 3), whose indices come from clist (neighbouring lanes read neighbouring entries) and
+// whose floats are single dword loads (lanes of a row hit the same 20-byte records: the texture path merges them).
+// Every load is issued for every lane with a clamped address (no divergent branch in front of a load), so the index
+// loads of all eight elements and then the point loads of all eight elements are in flight together.
+template <int VEC>
+__global__ __launch_bounds__(kVtRowsThreads) void vt_rows_gather_kernel(
+    const float* __restrict__ points, int64_t n, const uint32_t* __restrict__ clist, int64_t cap,
+    const uint2* __restrict__ vinfo, const int* __restrict__ totals, int batch, int units, int max_voxels, int rowq,
+    int step_v, int step_j, int dim, float* __restrict__ voxels, int32_t* __restrict__ coords,
+    int32_t* __restrict__ num_pts, int32_t* __restrict__ num_voxels, int32_t* __restrict__ coors4) {
+  int frame, unit;
+  vt_unit(blockIdx.x, (uint32_t)units, (uint32_t)batch, frame, unit);
+  const uint32_t total_q = (uint32_t)max_voxels * (uint32_t)rowq;
+  const float* pf = points + (int64_t)frame * n * dim;
+  const uint32_t* cl = clist + (int64_t)frame * cap;
+  const uint2* vi = vinfo + (int64_t)frame * max_voxels;
+  float* vf = voxels + (int64_t)frame * max_voxels * ((int64_t)rowq * VEC);
+  const uint32_t q0 = (uint32_t)unit * (kVtRowsIlp * kVtRowsThreads) + threadIdx.x;
+  uint32_t v[kVtRowsIlp], j[kVtRowsIlp];
+  v[0] = vt_div(min(q0, total_q), (uint32_t)rowq, 1.0f / (float)rowq);
+  j[0] = min(q0, total_q) - v[0] * (uint32_t)rowq;
+#pragma unroll
+  for (int u = 1; u < kVtRowsIlp; ++u) {
+    v[u] = v[u - 1] + (uint32_t)step_v;
+    j[u] = j[u - 1] + (uint32_t)step_j;
+    if (j[u] >= (uint32_t)rowq) {
+      j[u] -= (uint32_t)rowq;
+      ++v[u];
+    }
+  }
+  __shared__ uint2 st_vi[kVtRowsIlp * kVtRowsThreads + 2];
+  const uint32_t qb = (uint32_t)unit * (kVtRowsIlp * kVtRowsThreads);
+  const uint32_t vb = vt_div(min(qb, total_q), (uint32_t)rowq, 1.0f / (float)rowq);
+  const uint32_t ve = vt_div(min(qb + kVtRowsIlp * kVtRowsThreads - 1u, total_q), (uint32_t)rowq, 1.0f / (float)rowq);
+  for (uint32_t r = threadIdx.x; r <= ve - vb; r += kVtRowsThreads)
+    st_vi[r] = vb + r < (uint32_t)max_voxels ? vi[vb + r] : make_uint2(0u, 0u);
+  __syncthreads();
+  const float inv_dim = 1.0f / (float)dim;
+  uint32_t k0[kVtRowsIlp], nfl[kVtRowsIlp], r0[kVtRowsIlp], i0[kVtRowsIlp], i1[kVtRowsIlp];
+#pragma unroll
+  for (int u = 0; u < kVtRowsIlp; ++u) {
+    const uint2 info = st_vi[min(v[u], ve) - vb];
+    nfl[u] = info.y * (uint32_t)dim;  // valid floats of the row
+    r0[u] = j[u] * VEC;
+    const uint32_t s0 = vt_div(r0[u], (uint32_t)dim, inv_dim);  // first point the lane's floats belong to
+    k0[u] = r0[u] - s0 * (uint32_t)dim;
+    // clamped to the row's last point (to entry 0 of the frame's list for an empty row): always a mapped address
+    const uint32_t last = info.x + (info.y ? info.y - 1u : 0u);
+    i0[u] = cl[min(info.x + s0, last)];
+    i1[u] = cl[min(info.x + s0 + 1u, last)];
+  }
+  float val[kVtRowsIlp][VEC];
+#pragma unroll
+  for (int u = 0; u < kVtRowsIlp; ++u) {
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      uint32_t k = k0[u] + (uint32_t)c;
+      const bool second = k >= (uint32_t)dim;
+      k -= second ? (uint32_t)dim : 0u;
+      const bool live = r0[u] + (uint32_t)c < nfl[u];
+      const uint32_t idx = live ? (second ? i1[u] : i0[u]) : 0u;  // a dead lane reads point 0 (in bounds) and drops it
+      const float x = pf[(int64_t)idx * dim + k];
+      val[u][c] = live ? x : 0.f;
+    }
+  }
+  const int nv = min(totals[frame], max_voxels);
+  if (unit == 0 && threadIdx.x == 0) num_voxels[frame] = nv;
+#pragma unroll
+  for (int u = 0; u < kVtRowsIlp; ++u) {
+    const uint32_t q = q0 + (uint32_t)u * kVtRowsThreads;
+    if (q >= total_q) break;
+    float* dst = vf + (int64_t)q * VEC;
+    if (VEC == 4) {
+      typedef float f32x4a __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(f32x4a{val[u][0], val[u][1], val[u][2], val[u][3]},
+                                  reinterpret_cast<f32x4a*>(dst));
+    } else {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) dst[c] = val[u][c];
+    }
+    if (j[u] == 0 && (int)v[u] >= nv) {  // padding rows of coords / count / coors4
       const int64_t row = (int64_t)frame * max_voxels + v[u];
       const VtInt3 z3{0, 0, 0};
       __builtin_memcpy(coords + row * 3, &z3, sizeof(z3));

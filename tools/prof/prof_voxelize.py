@@ -1,4 +1,6 @@
-"""Profiling driver (not a test): runs hard_voxelize on C3-sized batches; use under rocprofv3."""
+"""Profiling driver (not a test): hard_voxelize on C3-sized batches of DISTINCT frames, every path timed with HIP
+events and checked for identical bytes against path 1; use under rocprofv3 for the per-kernel split.
+usage: prof_voxelize.py [batch] [max_voxels] [iters] [paths, e.g. 2,3]"""
 import os
 import sys
 
@@ -9,13 +11,26 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from paddle3d_amd import synth  # noqa: E402
 from paddle3d_amd.ops import voxelize  # noqa: E402
 
-batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 v = int(sys.argv[2]) if len(sys.argv) > 2 else 30000
-iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-frames = np.stack([synth.nuscenes_sweep(100 + i) for i in range(min(batch, 4))])
-frames = np.concatenate([frames] * (batch // len(frames) or 1))[:batch]
-pts = torch.from_numpy(frames).cuda()
-for _ in range(iters):
-    out = voxelize.hard_voxelize_batch(pts, list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20, v)
-torch.cuda.synchronize()
-print("nv", out[3].tolist())
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+paths = [int(p) for p in sys.argv[4].split(",")] if len(sys.argv) > 4 else [2, 3]
+pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(100 + i) for i in range(batch)])).cuda()
+args = (list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20, v)
+ref = voxelize.hard_voxelize_batch(pts, *args, with_batch_coors=True, path=1)
+alg = (4 * 300000 * 5 + 4 * v * 20 * 5 + 16 * v + 4) * batch
+for path in paths:
+    for _ in range(3):
+        out = voxelize.hard_voxelize_batch(pts, *args, with_batch_coors=True, path=path)
+    same = all(torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a,
+                           b.view(torch.int32) if b.dtype == torch.float32 else b) for a, b in zip(out, ref))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        out = voxelize.hard_voxelize_batch(pts, *args, with_batch_coors=True, path=path)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(f"path {path}: {ms * 1e3:.1f} us per {batch} frames = {alg / ms / 1e6:.0f} GB/s = "
+          f"{alg / ms / 1e6 / 8000:.3f} of 8 TB/s; identical to the sort path: {same}; nv {out[3].tolist()[:4]}")
