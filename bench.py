@@ -322,7 +322,8 @@ def bench_pillars(args, rank, world, dev):
                                + ("->RCCL all-gather" if world > 1 else ""),
                    "frames_per_gpu_per_step": B, "max_voxels": V, "parallelism": f"dp{world} (frames)"},
         "roofline": dict(rooflines["hard_voxelize"],
-                         kernel="hard_voxelize launch sequence (vt_route + vt_group + vt_assign_emit + vt_rows)"),
+                         kernel="hard_voxelize launch sequence (vt_route + vt_group + vt_assign + vt_rows_gather; --vox-path picks "
+                                "another form)"),
         "rooflines": rooflines,
         # `roofline` is the kernel the north star puts the HBM target on; by time the step is dominated by
         # the dense graph (rooflines["dense_backbone_fpn_head"], MFMA bound)
@@ -503,8 +504,8 @@ def bench_bevfusion_lidar(args, rank, world, dev):
         "roofline": dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBPS, unit="GB/s", frac=a / HBM_PEAK_GBPS, traffic=None,
                          ms_per_launch=per_op_ms["hard_voxelize"], units_per_launch=B,
                          algorithmic_bytes_per_unit=alg_v,
-                         kernel="hard_voxelize launch sequence, tiled path (vt_route + vt_group + vt_assign_emit + "
-                                "vt_rows); the fixed-shape [V, 64, 4] output dominates the bytes"),
+                         kernel="hard_voxelize launch sequence, tiled path (vt_route + vt_group + vt_assign + "
+                                "vt_rows_gather); the fixed-shape [V, 64, 4] output dominates the bytes"),
         "rooflines": {"pointpillars_scatter": dict(bound="hbm", achieved=a_s, peak=HBM_PEAK_GBPS, unit="GB/s",
                                                    frac=a_s / HBM_PEAK_GBPS, traffic=None,
                                                    ms_per_launch=per_op_ms["pointpillars_scatter"],

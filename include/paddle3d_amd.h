@@ -63,7 +63,7 @@ int pd3_hard_voxelize(const float *points, const int32_t *num_points, int batch,
                       int32_t *num_points_per_voxel, int32_t *num_voxels, int32_t *coors_batched,
                       void *workspace, size_t workspace_bytes, void *stream);
 /* Same operator with the implementation chosen by the caller (diagnostics and the parity tests, which run
- * every case on all of them): path 0 = automatic (what pd3_hard_voxelize does), 1 = generic radix-sort path (any
+ * every case on all of them): path 0 = automatic (what pd3_hard_voxelize does: 3 where the grid qualifies, else 1), 1 = generic radix-sort path (any
  * grid below 2^31 cells), 2 = tiled path, payload copied once into a cell-ordered compact array, 3 = tiled path,
  * rows gathered from the points through a cell-ordered index list (2 and 3: BEV-sized grids; PD3_EUNSUPPORTED when
  * the shape does not qualify).

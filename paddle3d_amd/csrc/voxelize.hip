@@ -369,7 +369,7 @@ extern "C" int pd3_hard_voxelize_path(const float* points, const int32_t* num_po
     if (can && path != 1)
       return run_tiled(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel,
                        max_voxels, vp, voxels, coords, num_points_per_voxel, num_voxels, coors_batched,
-                       workspace, s, path == 3);
+                       workspace, s, path != 2);  // the library's choice (path 0) is the gather form
   }
   const RadixPlan plan = radix_plan(g.ncells, max_points);
   VoxWorkspace w = carve(workspace, batch, max_points, max_voxels, plan);

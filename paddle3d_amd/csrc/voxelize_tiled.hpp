@@ -35,6 +35,10 @@
 //   E  rows_kernel    voxel-parallel, one 16-byte store per lane: a row's valid floats are one contiguous run
 //        of the compact array; the complete fixed-shape voxels tensor (rows and zero padding) and the padding
 //        of the coords / count rows are written exactly once (streaming stores: nothing re-reads them here).
+// The library's default is the GATHER FORM of the same pipeline (path 3): B also leaves clist[compact place] =
+// point index (the list the compact array would have been filled from), D is not launched at all, and E'
+// (rows_gather_kernel) reads a row's points straight from the input through clist -- no compact payload array,
+// no second pass over the points: 163 -> 135 us per 16 nuScenes frames.  Path 2 keeps D + E as described.
 //
 // HBM traffic per frame: points read (A) and re-read (D), outputs written once (E); everything between is a few
 // MB of scratch.  Workgroups are mapped XCD-aware (vt_unit): with batch % 8 == 0 every frame's workgroups of
