@@ -59,8 +59,8 @@ class Tensor(torch.Tensor):
 
     cast = astype
 
-    def tile(self, reps):
-        return torch.Tensor.repeat(self, *reps)
+    def tile(self, reps=None, repeat_times=None):
+        return torch.Tensor.repeat(self, *(reps if reps is not None else repeat_times))
 
     def expand(self, shape, *rest):
         if rest or not isinstance(shape, (list, tuple, torch.Size)):
@@ -205,7 +205,9 @@ def _mk_paddle():
     p.clip = lambda x, min=None, max=None: _wrap(torch.clamp(x, min=min, max=max))
     p.floor = lambda x: _wrap(torch.floor(x))
     p.round = lambda x: _wrap(torch.round(x))
-    p.meshgrid = lambda *xs: [_wrap(t) for t in torch.meshgrid(*xs, indexing="ij")]
+    p.meshgrid = lambda *xs: [_wrap(t) for t in torch.meshgrid(*(xs[0] if len(xs) == 1 and isinstance(xs[0], (list, tuple))
+                                                                    else xs), indexing="ij")]
+    p.logical_not = lambda x: _wrap(torch.logical_not(x))
     p.tile = lambda x, reps: _wrap(x.as_subclass(torch.Tensor).repeat(*[int(r) for r in reps]))
     p.split = lambda x, n, axis=0: [_wrap(t) for t in torch.split(x, x.shape[axis] // n if isinstance(n, int) else n,
                                                                   dim=axis)]

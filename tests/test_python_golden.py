@@ -174,3 +174,25 @@ def test_sparse_encoder_takes_reference_names():
     assert checkpoint.load_paddle_state_dict(net, state) == []
     np.testing.assert_array_equal(net.conv2[0].weight.detach().numpy(), state["conv2.0.weight"])
     np.testing.assert_array_equal(net.conv2[3].bn1.running_var.numpy(), state["conv2.3.bn1._variance"])
+
+
+def test_centerpoint_postprocess_orchestration_vs_reference_python(oracle):
+    """P / P0: the oracle's statement of the centerpoint_postprocess operator against the reference's own Python
+    post-processing (CenterHead.predict -> single_post_processing, center_head.py:341-510, executed through the
+    shim by tests/golden/make_predict_golden.py): same rows in the same order, same labels (per-task offsets), boxes
+    and scores to an ulp of exp / atan2.  (The centre-range test is the one step the two reference paths apply to
+    different values; the fixture's range keeps it always true.)"""
+    import make_predict_golden as G
+
+    gold = np.load(os.path.join(HERE, "golden", "python_predict.npz"))
+    maps, cfg = G.head_maps(), G.CFG
+    offsets = np.concatenate([[0], np.cumsum([t["num_class"] for t in G.TASKS])[:-1]]).astype(int).tolist()
+    for b in range(G.BATCH):
+        tasks = [{k: v[b:b + 1] for k, v in t.items()} for t in maps]
+        rb, rs, rl = oracle.centerpoint_postprocess(
+            tasks, cfg["voxel_size"] + [8.0], cfg["point_cloud_range"] + [0.0] * 4, cfg["post_center_limit_range"],
+            offsets, cfg["down_ratio"], cfg["score_threshold"], cfg["nms"]["nms_iou_threshold"],
+            cfg["nms"]["nms_pre_max_size"], cfg["nms"]["nms_post_max_size"], True)
+        np.testing.assert_array_equal(rl, gold[f"labels_{b}"])
+        np.testing.assert_allclose(rs, gold[f"scores_{b}"], rtol=0, atol=2e-7)
+        np.testing.assert_allclose(rb, gold[f"boxes_{b}"], rtol=2e-6, atol=2e-6)

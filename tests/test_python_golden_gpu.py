@@ -150,3 +150,37 @@ def test_boxes_iou_bev_cpu_contract(oracle):
     np.testing.assert_allclose(out.numpy(), ref, rtol=0, atol=1e-4)
     with pytest.raises(RuntimeError):
         iou3d_nms.boxes_iou_bev_cpu(torch.from_numpy(a).cuda(), torch.from_numpy(b))
+
+
+def test_centerpoint_postprocess_vs_reference_python():
+    """The device operator (whole batch, all tasks, one launch sequence) against the reference's own Python
+    post-processing executed through the shim (tests/golden/python_predict.npz, center_head.py:341-510): rows, order
+    and labels exact, boxes / scores to an ulp of exp / atan2; both candidate selections."""
+    import make_predict_golden as G
+    from paddle3d_amd.ops import centerpoint_postprocess as cp
+
+    gold = np.load(os.path.join(HERE, "golden", "python_predict.npz"))
+    maps, cfg = G.head_maps(), G.CFG
+    offsets = np.concatenate([[0], np.cumsum([t["num_class"] for t in G.TASKS])[:-1]]).astype(int).tolist()
+    heads = {k: [_cuda(t[k]) for t in maps] for k in ("hm", "reg", "height", "dim", "vel", "rot")}
+    for full_sort in (False, True):
+        if full_sort:  # the full-sort selection takes one frame (or one batch-strided map) at a time
+            outs = [cp.centerpoint_postprocess_device(
+                *[[t[b:b + 1].contiguous() for t in heads[k]] for k in ("hm", "reg", "height", "dim", "vel", "rot")],
+                cfg["voxel_size"], cfg["point_cloud_range"], cfg["post_center_limit_range"], offsets * len(maps),
+                cfg["down_ratio"], cfg["score_threshold"], cfg["nms"]["nms_iou_threshold"],
+                cfg["nms"]["nms_pre_max_size"], cfg["nms"]["nms_post_max_size"], True, full_sort=True)
+                for b in range(G.BATCH)]
+            res = [(o[0][0], o[1][0], o[2][0], int(o[3][0])) for o in outs]
+        else:
+            bx, sc, lb, cnt = cp.centerpoint_postprocess_device(
+                heads["hm"], heads["reg"], heads["height"], heads["dim"], heads["vel"], heads["rot"], cfg["voxel_size"],
+                cfg["point_cloud_range"], cfg["post_center_limit_range"], offsets * len(maps), cfg["down_ratio"],
+                cfg["score_threshold"], cfg["nms"]["nms_iou_threshold"], cfg["nms"]["nms_pre_max_size"],
+                cfg["nms"]["nms_post_max_size"], True, allow_batch=True)
+            res = [(bx[b], sc[b], lb[b], int(cnt[b])) for b in range(G.BATCH)]
+        for b, (rb, rs, rl, k) in enumerate(res):
+            assert k == gold[f"labels_{b}"].shape[0]
+            np.testing.assert_array_equal(rl[:k].cpu().numpy(), gold[f"labels_{b}"])
+            np.testing.assert_allclose(rs[:k].cpu().numpy(), gold[f"scores_{b}"], rtol=0, atol=2e-7)
+            np.testing.assert_allclose(rb[:k].cpu().numpy(), gold[f"boxes_{b}"], rtol=2e-6, atol=2e-6)
