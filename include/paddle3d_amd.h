@@ -426,6 +426,9 @@ int pd3_patch_conv_bias_relu(const float *x, const float *w_packed, const float 
  * Outputs (device): out_boxes [batch, max(post,1), 7], out_scores [batch, max(post,1)], out_labels int64, out_count
  * [batch] int32.  A frame without detections (no anchor passes the area test, or none the score / range test) has
  * count 0 and the reference's `_box_empty` row (zeros, -1, -1) in row 0.  No host synchronisation.
+ * selection: how the top nms_pre_max_size anchors by score are found -- 0 = radix select + ordered compaction
+ * (nms_pre_max_size <= 1024; larger caps take the sort), 1 = a full stable sort of every anchor's key (the
+ * reference's argsort); identical results, the argument exists so that tests run both.
  */
 size_t pd3_ssd_postprocess_workspace(int batch, int feat_h, int feat_w, int anchors_per_loc, int grid_x, int grid_y,
                                      int nms_pre_max_size);
@@ -436,7 +439,7 @@ int pd3_ssd_postprocess(const float *head_map, int64_t batch_stride, int cls_cha
                         float anchor_area_threshold, float score_threshold, const float *center_limit_range,
                         float nms_iou_threshold, int nms_pre_max_size, int nms_post_max_size, float *out_boxes,
                         float *out_scores, int64_t *out_labels, int32_t *out_count, void *workspace,
-                        size_t workspace_bytes, void *stream);
+                        size_t workspace_bytes, void *stream, int selection);
 
 #ifdef __cplusplus
 }

@@ -104,7 +104,7 @@ _SIGNATURES = {
                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
-                                      C.c_void_p]),
+                                      C.c_void_p, C.c_int]),
     "pd3_grouped_conv3x3_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 }

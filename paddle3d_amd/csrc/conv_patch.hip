@@ -47,7 +47,9 @@ struct PgArgs {
   int relu, ptiles;
 };
 
-template <int MODE>
+// HALF (mode 1 with <= 32 output rows, e.g. the 20 maps of the fused SSD head): the second 32-row MFMA block of the tile
+// would only multiply padding, so it is not issued -- the layer is bound by reading its input once.
+template <int MODE, bool HALF = false>
 __global__ __launch_bounds__(256) void patch_gemm_kernel(PgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float pg_smem[];  // X[2][4096] then W[2][1024]
   const int lane = lane_id(), wave = wave_id();
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(PgArgs a) {
       for (int t = 0; t < 2; ++t) {
         const float b = Xs[xb[t] + xo];
         acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][t], 0, 0, 0);
-        acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][t], 0, 0, 0);
+        if (!HALF) acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][t], 0, 0, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(PgArgs a) {
     const int pj = (wave * 2 + t) * 32 + (lane & 31);
     if (MODE != 0 && (int64_t)p0 + pj >= iplane) continue;  // pixel of a partial tile
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < (HALF ? 1 : 2); ++m) {
       if (MODE == 3) {
         // a register quad = the four dx of one (co, dy): row = r + 8 q + 4 kk of the 32-row block, 16 rows per co
         const int p = p0 + pj, y = p / a.wi, xx = p - y * a.wi;
@@ -209,11 +211,11 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(PgArgs a) {
   }
 }
 
-template <int MODE>
+template <int MODE, bool HALF = false>
 static int launch_patch_gemm(const PgArgs& a, int64_t ptiles, hipStream_t s) {
   const int64_t nwg = (ptiles + 7) / 8 * 8 * (a.m_rows / kPgM);
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
-  patch_gemm_kernel<MODE><<<(unsigned)nwg, 256, kPgLds, s>>>(a);
+  patch_gemm_kernel<MODE, HALF><<<(unsigned)nwg, 256, kPgLds, s>>>(a);
   return launch_status();
 }
 
@@ -266,7 +268,7 @@ extern "C" int pd3_patch_conv_bias_relu(const float* x, const float* w_packed, c
     a.m_valid = cout;
     a.ho = h;
     a.wo = w;
-    return launch_patch_gemm<1>(a, ptiles, s);
+    return cout <= 32 ? launch_patch_gemm<1, true>(a, ptiles, s) : launch_patch_gemm<1>(a, ptiles, s);
   }
   if (mode == 3) {  // Conv2DTranspose kernel 4 stride 4
     if ((cout * 16) % kPgM != 0) return PD3_EUNSUPPORTED;

@@ -11,8 +11,10 @@
 //   2. ssd_integral_rows/cols    summed-area table in place (integers: the reference's fp32 cumsums are exact)
 //   3. ssd_decode_kernel         per anchor: area test, sigmoid -> max / argmax, direction bit, box decode, score
 //                                and centre-range test, heading flip, bottom -> object centre, sort key
-//   4. stable radix sort         key = bits(1.0f) - bits(score) for kept anchors (descending score, ties in anchor
-//                                order = boolean-mask order + stable argsort), 0x3FFFFFFF otherwise
+//   4. top-K selection           key = bits(1.0f) - bits(score) for kept anchors (descending score, ties in anchor
+//                                order = boolean-mask order + stable argsort), 0x3FFFFFFF otherwise; ssd_topk_kernel
+//                                (radix select + ordered compaction + bitonic sort of <= 1024 pairs), or with
+//                                selection = 1 a full stable radix sort of all keys -- identical results
 //   5. ssd_nms_boxes_kernel      top min(kept, nms_pre_max_size) boxes in the NMS kernel's layout
 //                                (x, y, z, l, w, h, -theta - pi/2)
 //   6. nms_mask_kernel + nms_sweep_kernel (nms_kernels.hpp)
@@ -176,6 +178,121 @@ __global__ __launch_bounds__(256) void ssd_decode_kernel(const float* __restrict
   }
 }
 
+// Top-K selection in place of the full sort: only the first min(kept, nms_pre_max_size) anchors of the stable
+// ascending-key order are ever used.  One 1024-thread workgroup per frame, keys read from global memory (428 KB per
+// KITTI frame: L2 resident): a 3-pass radix SELECT (10-bit LDS histograms) finds the exact cut-off key kc and how
+// many anchors with key == kc still fit; the selected anchors are compacted IN ANCHOR ORDER (wave w owns a
+// contiguous sixteenth of the anchors, ranks by ballot) and sorted as (key, anchor) pairs by a bitonic network --
+// the same total order a stable key sort gives (layer_libs.py:231-233 argsort + [:pre_max_size]).
+constexpr int kSsdTopkThreads = 1024;
+constexpr int kSsdTopkMaxK = 1024;
+
+__global__ __launch_bounds__(kSsdTopkThreads) void ssd_topk_kernel(const uint32_t* __restrict__ keys,
+                                                                   const int* __restrict__ counts, int n, int cap,
+                                                                   uint32_t* __restrict__ sidx) {
+  __shared__ unsigned long long list[kSsdTopkMaxK];
+  __shared__ int hist[1024];
+  __shared__ int scr[kSsdTopkThreads / kWave + 2];
+  __shared__ int pick[2];
+  __shared__ int wless[kSsdTopkThreads / kWave], weq[kSsdTopkThreads / kWave];
+  const int frame = blockIdx.x;
+  const int count = counts[frame];
+  const int K = min(count, cap);
+  if (K <= 0) return;
+  const uint32_t* kg = keys + (int64_t)frame * n;
+  const int t = threadIdx.x, lane = lane_id(), wave = wave_id();
+  list[t] = ~0ull;
+  uint32_t kc = kSsdKeyOut;  // take every key < kc ...
+  int r = 0;                 // ... and the first r anchors with key == kc
+  if (count > K) {
+    uint32_t prefix = 0;
+    int need = K;
+    for (int pass = 0; pass < 3; ++pass) {
+      const int shift = 20 - 10 * pass;
+      hist[t] = 0;
+      __syncthreads();
+#pragma unroll 8
+      for (int i = t; i < n; i += kSsdTopkThreads) {
+        const uint32_t k = kg[i];
+        if (k != kSsdKeyOut && (pass == 0 || (k >> (shift + 10)) == prefix)) atomicAdd(&hist[(k >> shift) & 1023u], 1);
+      }
+      __syncthreads();
+      const int h = hist[t];
+      int total;
+      const int base = block_exclusive_scan<kSsdTopkThreads>(h, scr, total);
+      if (need > base && need <= base + h) {  // exactly one thread
+        pick[0] = t;
+        pick[1] = need - base;
+      }
+      __syncthreads();
+      prefix = (prefix << 10) | (uint32_t)pick[0];
+      need = pick[1];
+      __syncthreads();
+    }
+    kc = prefix;
+    r = need;
+  }
+  // order-preserving compaction: wave w owns anchors [w * per, (w + 1) * per)
+  const int per = (int)ceil_div(ceil_div((int64_t)n, kSsdTopkThreads / kWave), kWave) * kWave;
+  const int i0 = wave * per, i1 = min(i0 + per, n);
+  int nless = 0, neq = 0;
+#pragma unroll 4
+  for (int i = i0 + lane; i < i1; i += kWave) {
+    const uint32_t k = kg[i];
+    nless += k < kc ? 1 : 0;
+    neq += k == kc ? 1 : 0;
+  }
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    nless += __shfl_xor(nless, d, kWave);
+    neq += __shfl_xor(neq, d, kWave);
+  }
+  if (lane == 0) {
+    wless[wave] = nless;
+    weq[wave] = neq;
+  }
+  __syncthreads();
+  int pos_less = 0, pos_eq = 0, tot_less = 0;
+  for (int w = 0; w < kSsdTopkThreads / kWave; ++w) {
+    if (w < wave) {
+      pos_less += wless[w];
+      pos_eq += weq[w];
+    }
+    tot_less += wless[w];
+  }
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int ib = i0; ib < i1; ib += kWave) {  // uniform trip count per wave: the ballots see the whole wave
+    const int i = ib + lane;
+    const uint32_t k = i < i1 ? kg[i] : kSsdKeyOut;
+    const bool isl = k < kc, ise = k == kc && kc != kSsdKeyOut;
+    const unsigned long long bl = __ballot(isl), be = __ballot(ise);
+    if (isl) list[pos_less + __popcll(bl & below)] = ((unsigned long long)k << 32) | (uint32_t)i;
+    const int slot = pos_eq + __popcll(be & below);
+    if (ise && slot < r) list[tot_less + slot] = ((unsigned long long)k << 32) | (uint32_t)i;
+    pos_less += __popcll(bl);
+    pos_eq += __popcll(be);
+  }
+  __syncthreads();
+  int n2 = 64;
+  while (n2 < K) n2 <<= 1;  // uniform
+  for (int size = 2; size <= n2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (t < (n2 >> 1)) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = list[lo], b = list[hi];
+        if ((a > b) == up) {
+          list[lo] = b;
+          list[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (t < K) sidx[(int64_t)frame * n + t] = (uint32_t)(list[t] & 0xffffffffull);
+}
+
 // layer_libs.py:222-229: columns (x, y, z, l, w, h, theta) and theta -> -theta - pi/2 in fp32
 __global__ __launch_bounds__(256) void ssd_nms_boxes_kernel(const float* __restrict__ boxes,
                                                             const uint32_t* __restrict__ sidx,
@@ -298,7 +415,9 @@ extern "C" int pd3_ssd_postprocess(const float* head_map, int64_t batch_stride, 
                                    int grid_y, float anchor_area_threshold, float score_threshold,
                                    const float* center_limit_range, float nms_iou_threshold, int nms_pre_max_size,
                                    int nms_post_max_size, float* out_boxes, float* out_scores, int64_t* out_labels,
-                                   int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream) {
+                                   int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream,
+                                   int selection) {
+  if (selection < 0 || selection > 1) return PD3_EINVAL;
   if (!head_map || !anchors || !anchors_bv || (!coors && num_coors > 0) || !out_boxes || !out_scores ||
       !out_labels || !out_count || !workspace)
     return PD3_EINVAL;
@@ -347,9 +466,15 @@ extern "C" int pd3_ssd_postprocess(const float* head_map, int64_t batch_stride, 
   ssd_integral_cols_kernel<<<dim3((unsigned)ceil_div(grid_x, 256), batch), 256, 0, s>>>(w.occ, grid_y, grid_x);
   ssd_decode_kernel<<<dim3((unsigned)ceil_div(hw, 256), anchors_per_loc, batch), 256, 0, s>>>(
       head_map, c, anchors, anchors_bv, w.occ, w.boxes, w.scores, w.labels, w.keys_a, w.counts);
-  const int where = enqueue_radix_sort(w.keys_a, w.vals_a, w.keys_b, w.vals_b, a, a, batch, plan,
-                                       /*identity_vals=*/true, w.hist, w.partial, s);
-  const uint32_t* sidx = where ? w.vals_b : w.vals_a;
+  const uint32_t* sidx;
+  if (selection == 0 && cap <= kSsdTopkMaxK) {
+    ssd_topk_kernel<<<batch, kSsdTopkThreads, 0, s>>>(w.keys_a, w.counts, (int)a, cap, w.vals_a);
+    sidx = w.vals_a;
+  } else {  // the reference's own selection: a full stable sort of all anchors' keys
+    const int where = enqueue_radix_sort(w.keys_a, w.vals_a, w.keys_b, w.vals_b, a, a, batch, plan,
+                                         /*identity_vals=*/true, w.hist, w.partial, s);
+    sidx = where ? w.vals_b : w.vals_a;
+  }
   ssd_nms_boxes_kernel<<<dim3((cap + 255) / 256, batch), 256, 0, s>>>(w.boxes, sidx, w.counts, (int)a, cap,
                                                                       w.nms_boxes);
   nms_mask_kernel<false><<<dim3(cb, cb, batch), 64, 0, s>>>(w.nms_boxes, w.counts, 0, cap, cb, nms_iou_threshold,

@@ -19,12 +19,13 @@ __all__ = ["ssd_postprocess_device"]
 def ssd_postprocess_device(head_map, cls_channel0, box_channel0, dir_channel0, anchors_per_loc, num_classes,
                            encode_background_as_zeros, anchors, anchors_bv, coors, grid_xy, anchor_area_threshold,
                            score_threshold, center_limit_range, nms_iou_threshold, nms_pre_max_size,
-                           nms_post_max_size):
+                           nms_post_max_size, full_sort=False):
     """head_map [B, C, H, W] fp32 (the head convolutions' NCHW output; a batch-strided view of a wider map is taken
     as it is), anchors [H*W*apl, 7] fp32, anchors_bv [H*W*apl, 4] int32, coors [M, 4] int32 (batch, z, y, x; rows
     with batch < 0 are padding) -> (boxes [B, R, 7], scores [B, R], labels [B, R] int64, counts [B] int32) on the
     device, R = max(nms_post_max_size, 1).  count 0 = the reference's empty result (row 0 then holds its
-    `_box_empty` row: zeros, -1, -1)."""
+    `_box_empty` row: zeros, -1, -1).  full_sort=True forces the reference's own selection (a stable sort of all
+    anchors) instead of the top-K selection kernel (`selection` of the C ABI; identical results)."""
     op = "ssd_postprocess"
     if not isinstance(head_map, torch.Tensor) or not head_map.is_cuda or head_map.dtype != torch.float32:
         raise RuntimeError(f"Unsupported device type for {op} operator.")
@@ -59,5 +60,5 @@ def ssd_postprocess_device(head_map, cls_channel0, box_channel0, dir_channel0, a
                                 C.c_int64(coors.shape[0]), gx, gy, C.c_float(anchor_area_threshold),
                                 C.c_float(score_threshold), ptr(lim), C.c_float(nms_iou_threshold),
                                 int(nms_pre_max_size), int(nms_post_max_size), ptr(out_b), ptr(out_s), ptr(out_l),
-                                ptr(out_n), ptr(ws), ws.numel(), stream_ptr(dev)), op)
+                                ptr(out_n), ptr(ws), ws.numel(), stream_ptr(dev), int(bool(full_sort))), op)
     return out_b, out_s, out_l, out_n

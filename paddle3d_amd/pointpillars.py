@@ -152,7 +152,7 @@ class SSDHead(_InferenceCache, nn.Module):
         return ret
 
     @torch.no_grad()
-    def post_process(self, preds, anchor_generator: AnchorGenerator, coors, device_only=False):
+    def post_process(self, preds, anchor_generator: AnchorGenerator, coors, device_only=False, full_sort=False):
         """pointpillars_head.py:86-196 for the whole batch.  `preds` = forward()'s dict (or the fused head map);
         coors [M, 4] int32 (batch, z, y, x) of the batch's pillars, padding rows with batch -1.
         -> per frame dict(box3d_lidar [K, 7], scores [K], label_preds [K] int64); K = 0 where the reference returns
@@ -168,7 +168,8 @@ class SSDHead(_InferenceCache, nn.Module):
             m, f["cls0"], f["box0"], f["dir0"], self.num_anchor_per_loc, self.num_classes,
             self.encode_background_as_zeros, anchor_generator.anchors, anchor_generator.anchors_bv, coors,
             anchor_generator.grid_size, anchor_generator.anchor_area_threshold, self.nms_score_threshold,
-            self.pred_center_limit_range, self.nms_iou_threshold, self.nms_pre_max_size, self.nms_post_max_size)
+            self.pred_center_limit_range, self.nms_iou_threshold, self.nms_pre_max_size, self.nms_post_max_size,
+            full_sort=full_sort)
         if device_only:
             return b, s, l, n
         counts = n.cpu().tolist()

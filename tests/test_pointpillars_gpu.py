@@ -116,7 +116,11 @@ def test_ssd_postprocess_vs_reference_python(oracle, sg, tag):
     rng = np.random.default_rng(5)
     co = np.concatenate([co, np.full((7, 4), -1, np.int32)])[rng.permutation(co.shape[0] + 7)]
     dets = head.post_process(m, gen, _cuda(co.astype(np.int32)))
+    sorted_dets = head.post_process(m, gen, _cuda(co.astype(np.int32)), full_sort=True)  # the reference's own selection
     assert len(dets) == c["batch"]
+    for d, e in zip(dets, sorted_dets):
+        for k in ("box3d_lidar", "scores", "label_preds"):
+            assert torch.equal(d[k], e[k])
     for b, d in enumerate(dets):
         gb, gs, gl = sg[f"{tag}_out_boxes_{b}"], sg[f"{tag}_out_scores_{b}"], sg[f"{tag}_out_labels_{b}"]
         if gs.tolist() == [-1.0]:
@@ -132,16 +136,17 @@ def test_ssd_postprocess_vs_reference_python(oracle, sg, tag):
         assert int(nn[1]) == 0 and float(ss[1, 0]) == -1.0 and int(ll[1, 0]) == -1 and float(bb[1, 0].abs().sum()) == 0
 
 
-@pytest.mark.parametrize("batch,seed,thr", [(3, 1, 0.05), (2, 2, 0.6)])
-def test_ssd_postprocess_kitti_size_vs_oracle(oracle, batch, seed, thr):
-    """Full KITTI head map (248 x 216 x 2 = 107 136 anchors per frame, the generic sort path) against the oracle
-    restatement on the same inputs: identical rows, labels and order; boxes / scores within an ulp of exp."""
+@pytest.mark.parametrize("batch,seed,thr,pre", [(3, 1, 0.05, 1000), (2, 2, 0.6, 1000), (2, 3, 0.02, 1500)])
+def test_ssd_postprocess_kitti_size_vs_oracle(oracle, batch, seed, thr, pre):
+    """Full KITTI head map (248 x 216 x 2 = 107 136 anchors per frame) against the oracle restatement on the same
+    inputs: identical rows, labels and order; boxes / scores within an ulp of exp.  Top-K selection kernel and full
+    sort; a pre-NMS cap beyond the selection kernel's 1024 (which takes the sort by itself)."""
     from paddle3d_amd.pointpillars import KITTI_CAR_ANCHORS, AnchorGenerator, SSDHead
 
     pcr, vs = list(synth.KITTI_RANGE), list(synth.KITTI_PILLAR)
     gen = AnchorGenerator(2, pcr, vs, KITTI_CAR_ANCHORS, 1).cuda()
     lim = [0.0, -39.68, -5.0, 69.12, 39.68, 5.0]
-    head = SSDHead(1, 64, 2, nms_score_threshold=thr, nms_pre_max_size=1000, nms_post_max_size=300,
+    head = SSDHead(1, 64, 2, nms_score_threshold=thr, nms_pre_max_size=pre, nms_post_max_size=300,
                    nms_iou_threshold=0.5, prediction_center_limit_range=lim).cuda().eval()
     fh, fw = gen.feature_map_size
     assert (fh, fw) == (248, 216) and gen.anchors.shape[0] == 107136
@@ -157,11 +162,14 @@ def test_ssd_postprocess_kitti_size_vs_oracle(oracle, batch, seed, thr):
     co = np.concatenate(coords).astype(np.int32)
     m = _cuda(_map_from_preds(cls, box, dirp, fh, fw, 2))
     dets = head.post_process(m, gen, _cuda(co))
+    for d, e in zip(dets, head.post_process(m, gen, _cuda(co), full_sort=True)):  # both selections, same bytes
+        for k in ("box3d_lidar", "scores", "label_preds"):
+            assert torch.equal(d[k], e[k])
     an, bv = gen.anchors.cpu().numpy(), gen.anchors_bv.cpu().numpy().astype(np.int64)
     for b in range(batch):
         mask = oracle.ssd_anchor_mask_numpy(co[co[:, 0] == b][:, 1:], bv, gen.grid_size, 1.0)
         assert 0 < mask.sum() < a
-        rb, rs, rl = oracle.ssd_post_process_frame_numpy(box[b], cls[b], dirp[b], an, mask, thr, lim, 1000, 300, 0.5)
+        rb, rs, rl = oracle.ssd_post_process_frame_numpy(box[b], cls[b], dirp[b], an, mask, thr, lim, pre, 300, 0.5)
         assert rs.shape[0] > 10
         np.testing.assert_array_equal(dets[b]["label_preds"].cpu().numpy(), rl)
         np.testing.assert_allclose(dets[b]["scores"].cpu().numpy(), rs, rtol=0, atol=3e-7)
