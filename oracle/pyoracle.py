@@ -577,7 +577,7 @@ def ssd_box_decode_numpy(encodings, anchors):
 
 def ssd_post_process_frame_numpy(box_preds, cls_preds, dir_preds, anchors, anchors_mask, score_threshold,
                                  center_limit_range, nms_pre_max_size, nms_post_max_size, nms_iou_threshold,
-                                 kind="port"):
+                                 kind="port", encode_background_as_zeros=True):
     """pointpillars_head.py:86-196 for one frame: decode, anchors_mask, sigmoid / max / argmax, direction argmax,
     score (>=) and centre-range filter, heading flip by the direction bit, bottom -> object centre, rotate_nms_pcdet,
     back to the bottom centre.  Returns (boxes [K, 7], scores [K], labels [K] int64); the reference's `_box_empty`
@@ -588,6 +588,8 @@ def ssd_post_process_frame_numpy(box_preds, cls_preds, dir_preds, anchors, ancho
         return empty
     box = ssd_box_decode_numpy(box_preds, anchors)[anchors_mask]
     cls = np.asarray(cls_preds, f32)[anchors_mask]
+    if not encode_background_as_zeros:
+        cls = cls[..., 1:]  # head.py:147-148: the background logit is dropped before the sigmoid
     conf = (f32(1) / (f32(1) + np.exp(-cls).astype(f32))).astype(f32)
     scores, labels = conf.max(-1), conf.argmax(-1).astype(np.int64)
     kept = scores >= f32(score_threshold)

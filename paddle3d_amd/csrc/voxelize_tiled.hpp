@@ -301,7 +301,7 @@ constexpr int kVgPassSteps = kVgWaves * kVgSteps;   // 160
 static inline size_t vt_group_lds(int cpg, int tiles) {
   const size_t cw = (size_t)std::max(cpg >> 1, 1), bw = (size_t)std::max(cpg >> 2, 1);
   return kVgWaves * cw * 4 + bw * 4 + (size_t)kVgPassSteps * 8 + (size_t)(3 * tiles + 1) * 4 +
-         (kVgWaves + 2) * 4 + 16;
+         (kVgWaves + 2) * 4 + 16 + (size_t)kVgThreads * 4;
 }
 
 // One 256-thread workgroup per group (<= 4096 cells; a nuScenes group receives ~4200 records, ~58 from each
@@ -332,6 +332,7 @@ __global__ __launch_bounds__(kVgThreads, 4) void vt_group_kernel(
   uint32_t* tstep = tdir + tiles;                                    // [tiles + 1] exclusive prefix of steps
   uint32_t* tfirst = tstep + tiles + 1;                              // [tiles] first points seen per tile
   int* scan_tmp = reinterpret_cast<int*>(tfirst + tiles);            // [waves + 2]
+  uint32_t* sink = reinterpret_cast<uint32_t*>(scan_tmp + kVgWaves + 2 + 4) + threadIdx.x;  // a word of its own per lane
   int frame, grp;
   vt_unit(blockIdx.x, (uint32_t)groups, (uint32_t)batch, frame, grp);
   const int lane = lane_id(), wave = wave_id();
@@ -448,17 +449,36 @@ __global__ __launch_bounds__(kVgThreads, 4) void vt_group_kernel(
 #pragma unroll
         for (int c0 = 0; c0 < kVgSteps; c0 += kVgChunk) {
           if (c0 < s_n) {
-            uint32_t old[kVgChunk];
+            // One returning LDS add per RUN of equal cells, not per record: firing-ordered points put runs of
+            // neighbouring lanes into one cell, and lanes that hit one address are served one after the other
+            // (tools/hwcheck/lds_atomic_rate: 4.8 G instr/s chip-wide for one cell against 64 G for distinct ones).
+            // The head lane of a run adds the run's length and hands the returned count to its followers, who add
+            // their distance from the head; lanes without a record and followers add 0 to a word of their own.  A
+            // cell that comes back later in the step is a second run: two adds to one address, served in lane order
+            // like before.
+            uint32_t old[kVgChunk], behind[kVgChunk];
+            int headl[kVgChunk];
 #pragma unroll
             for (int k = 0; k < kVgChunk; ++k) {
-              // ds_add_rtn_u32: lanes in ascending order within the step, steps in order; lanes without a
-              // record add 0 to the last counter
               const uint32_t r = rec[c0 + k], cell = r & cell_mask;
-              old[k] = atomicAdd(&cnt_mine[cell >> 1], (r & kNoRec) ? 0u : 1u << ((cell & 1u) * 16u));
+              const bool valid = !(r & kNoRec);
+              const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, kWave);  // records of a step are lanes 0 .. c-1
+              const bool head = valid && (lane == 0 || prev != cell);
+              const unsigned long long hm = __ballot(head);
+              const unsigned long long upto = hm & ((2ull << lane) - 1ull);        // heads at or before this lane
+              headl[k] = valid ? 63 - __builtin_clzll(upto | 1ull) : lane;
+              const unsigned long long after = hm & ~((2ull << lane) - 1ull);      // heads behind this lane
+              const int cnt_step = __builtin_amdgcn_readlane((int)my_cnt, c0 + k);
+              const int next = after ? __builtin_ctzll(after) : cnt_step;
+              behind[k] = (uint32_t)(lane - headl[k]);
+              uint32_t* addr = head ? &cnt_mine[cell >> 1] : sink;
+              old[k] = atomicAdd(addr, head ? (uint32_t)(next - lane) << ((cell & 1u) * 16u) : 0u);
             }
 #pragma unroll
-            for (int k = 0; k < kVgChunk; ++k)
-              rec[c0 + k] |= ((old[k] >> ((rec[c0 + k] & cell_mask & 1u) * 16u)) & 0xFFFFu) << 12;
+            for (int k = 0; k < kVgChunk; ++k) {
+              const uint32_t from_head = (uint32_t)__shfl((int)old[k], headl[k], kWave);
+              rec[c0 + k] |= ((((from_head >> ((rec[c0 + k] & cell_mask & 1u) * 16u)) & 0xFFFFu) + behind[k]) & 0xFFFFu) << 12;
+            }
           }
         }
         PD3_MARK();

@@ -176,6 +176,58 @@ def test_ssd_postprocess_kitti_size_vs_oracle(oracle, batch, seed, thr, pre):
         np.testing.assert_allclose(dets[b]["box3d_lidar"].cpu().numpy(), rb, rtol=1e-6, atol=4e-6)
 
 
+def test_ssd_postprocess_variants_and_edges(oracle):
+    """Head variants the KITTI config does not use (background logit in front of the classes, no direction
+    classifier, no centre range) against the oracle, and the degenerate inputs: no pillars at all, only padding rows,
+    a zero pre-NMS cap."""
+    from paddle3d_amd.pointpillars import AnchorGenerator, SSDHead
+
+    c = G.CASES["b"]
+    gen = AnchorGenerator(2, c["pcr"], c["vs"], c["anchor_configs"], 1).cuda()
+    fh, fw = gen.feature_map_size
+    apl, a = gen.num_anchors_per_loc, gen.anchors.shape[0]
+    rng = np.random.default_rng(9)
+    nx, ny = gen.grid_size
+    cells = rng.choice(nx * ny, 400, replace=False)
+    co = np.zeros((400, 4), np.int32)
+    co[:, 0], co[:, 2], co[:, 3] = rng.integers(0, 2, 400), cells // nx, cells % nx
+    an, bv = gen.anchors.cpu().numpy(), gen.anchors_bv.cpu().numpy().astype(np.int64)
+    for bg_zero, use_dir, lim in ((False, True, None), (True, False, c["head"]["prediction_center_limit_range"]),
+                                  (False, False, None)):
+        ncls = c["num_classes"]
+        width = ncls if bg_zero else ncls + 1
+        head = SSDHead(ncls, 32, apl, encode_background_as_zeros=bg_zero, use_direction_classifier=use_dir,
+                       nms_score_threshold=0.3, nms_pre_max_size=150, nms_post_max_size=25, nms_iou_threshold=0.3,
+                       prediction_center_limit_range=lim).cuda().eval()
+        cls = rng.normal(-1.0, 2.0, (2, a, width)).astype(np.float32)
+        box = rng.normal(0, 0.35, (2, a, 7)).astype(np.float32)
+        dirp = rng.normal(0, 1, (2, a, 2)).astype(np.float32)
+        groups = [cls, box] + ([dirp] if use_dir else [])
+        m = _cuda(np.ascontiguousarray(np.concatenate(
+            [g.reshape(2, fh, fw, apl * g.shape[2]).transpose(0, 3, 1, 2) for g in groups], 1)))
+        dets = head.post_process(m, gen, _cuda(co))
+        for b in range(2):
+            mask = oracle.ssd_anchor_mask_numpy(co[co[:, 0] == b][:, 1:], bv, gen.grid_size, 1.0)
+            rb, rs, rl = oracle.ssd_post_process_frame_numpy(box[b], cls[b], dirp[b] if use_dir else None, an, mask, 0.3,
+                                                             lim, 150, 25, 0.3, encode_background_as_zeros=bg_zero)
+            assert rs.shape[0] > 3 and rs[0] >= 0
+            np.testing.assert_array_equal(dets[b]["label_preds"].cpu().numpy(), rl)
+            np.testing.assert_allclose(dets[b]["scores"].cpu().numpy(), rs, rtol=0, atol=3e-7)
+            np.testing.assert_allclose(dets[b]["box3d_lidar"].cpu().numpy(), rb, rtol=1e-6, atol=4e-6)
+    head = SSDHead(c["num_classes"], 32, apl, nms_pre_max_size=150, nms_post_max_size=25).cuda().eval()
+    cls = rng.normal(2.0, 1.0, (2, a, c["num_classes"])).astype(np.float32)
+    m = _cuda(_map_from_preds(cls, rng.normal(0, 0.3, (2, a, 7)).astype(np.float32),
+                              rng.normal(0, 1, (2, a, 2)).astype(np.float32), fh, fw, apl))
+    none = torch.zeros((0, 4), dtype=torch.int32, device="cuda")
+    pad = torch.full((5, 4), -1, dtype=torch.int32, device="cuda")
+    for coors in (none, pad):  # no pillar: no anchor passes the area test, every frame is empty
+        dets = head.post_process(m, gen, coors)
+        assert [d["scores"].numel() for d in dets] == [0, 0]
+    assert all(d["scores"].numel() > 0 for d in head.post_process(m, gen, _cuda(co)))
+    head0 = SSDHead(c["num_classes"], 32, apl, nms_pre_max_size=0, nms_post_max_size=25).cuda().eval()
+    assert [d["scores"].numel() for d in head0.post_process(m, gen, _cuda(co))] == [0, 0]  # order[:0]: nothing to keep
+
+
 def _randomise_bn(model, seed=0):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
