@@ -77,26 +77,28 @@ __global__ __launch_bounds__(256) void cp_decode_kernel(CpHeads h, CpCfg c, floa
     // decode_kernel :41-70
     const int xs = i % c.feat_w, ys = i / c.feat_w;
     const float x = regp[i], y = regp[i + c.hw], z = heip[i];
-    float* bx = boxes + ((int64_t)set * c.hw + i) * c.dims;
-    bx[0] = (x + xs) * c.down_ratio * c.vx + c.pc_x;
-    bx[1] = (y + ys) * c.down_ratio * c.vy + c.pc_y;
-    bx[2] = z;
-    bx[3] = exp_rn(dimp[i]);  // :151 exp(dim)
-    bx[4] = exp_rn(dimp[i + c.hw]);
-    bx[5] = exp_rn(dimp[i + 2 * c.hw]);
-    const float ang = atan2_rn(rotp[i], rotp[i + c.hw]);
-    if (c.with_velocity) {
-      bx[6] = velp[i];
-      bx[7] = velp[i + c.hw];
-      bx[8] = ang;
-    } else {
-      bx[6] = ang;
-    }
     // :72-77  mask on the RAW reg / height values
     const bool m = best > c.score_threshold && x <= c.r[3] && y <= c.r[4] && z <= c.r[5] &&
                    x >= c.r[0] && y >= c.r[1] && z >= c.r[2];
-    scores[(int64_t)set * c.hw + i] = best;
-    labels[(int64_t)set * c.hw + i] = arg;
+    if (m) {  // only masked-in cells are ever read back (top-K / sort orders them first): nothing else is stored
+      float* bx = boxes + ((int64_t)set * c.hw + i) * c.dims;
+      bx[0] = (x + xs) * c.down_ratio * c.vx + c.pc_x;
+      bx[1] = (y + ys) * c.down_ratio * c.vy + c.pc_y;
+      bx[2] = z;
+      bx[3] = exp_rn(dimp[i]);  // :151 exp(dim)
+      bx[4] = exp_rn(dimp[i + c.hw]);
+      bx[5] = exp_rn(dimp[i + 2 * c.hw]);
+      const float ang = atan2_rn(rotp[i], rotp[i + c.hw]);
+      if (c.with_velocity) {
+        bx[6] = velp[i];
+        bx[7] = velp[i + c.hw];
+        bx[8] = ang;
+      } else {
+        bx[6] = ang;
+      }
+      scores[(int64_t)set * c.hw + i] = best;
+      labels[(int64_t)set * c.hw + i] = arg;
+    }
     uint32_t key = kKeyOut;
     if (m) {
       const uint32_t bits = __float_as_uint(best);
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void cp_nms_boxes_kernel(const float* __restri
                                                            const uint32_t* __restrict__ sidx,
                                                            const int* __restrict__ counts, int hw,
                                                            int dims, int cap,
-                                                           float* __restrict__ nms_boxes) {
+                                                           float* __restrict__ nms_boxes, BoxPre* __restrict__ pre) {
   const int t = blockIdx.y;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = min(counts[t], cap);
@@ -248,6 +250,8 @@ __global__ __launch_bounds__(256) void cp_nms_boxes_kernel(const float* __restri
   o[4] = bx[3];
   o[5] = bx[5];
   o[6] = (float)(-(double)bx[dims - 1] - 3.141592653589793 / 2);
+  const float nb[7] = {o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
+  pre[(int64_t)t * cap + r] = box_prepare(nb);  // what every tile of the suppression matrix needs of this box
 }
 
 // One workgroup: concatenate tasks in order (postprocess.cu:247-278).
@@ -296,6 +300,7 @@ struct CpWorkspace {
   int *labels, *counts, *hist, *partial;
   uint32_t *keys_a, *vals_a, *keys_b, *vals_b;
   unsigned long long* mask;
+  BoxPre* pre;
   int32_t *keep, *nkeep;
   size_t bytes;
 };
@@ -318,6 +323,7 @@ static CpWorkspace cp_carve(void* base, int tasks, int hw, int pre_max, const Ra
   w.partial = c.take<int>((size_t)tasks * scan_num_tiles((int64_t)radix_hist_ints(plan)));
   w.nms_boxes = c.take<float>((size_t)tasks * cap * 7);
   w.mask = c.take<unsigned long long>((size_t)tasks * cap * cb);
+  w.pre = c.take<BoxPre>((size_t)tasks * cap);
   w.keep = c.take<int32_t>((size_t)tasks * cap);
   w.nkeep = c.take<int32_t>((size_t)tasks);
   w.bytes = c.off;
@@ -411,10 +417,10 @@ static int cp_postprocess_impl(
     sidx = where ? w.vals_b : w.vals_a;
   }
   dim3 bgrid((cap + 255) / 256, sets);
-  cp_nms_boxes_kernel<<<bgrid, 256, 0, s>>>(w.boxes, sidx, w.counts, hw, c.dims, cap, w.nms_boxes);
+  cp_nms_boxes_kernel<<<bgrid, 256, 0, s>>>(w.boxes, sidx, w.counts, hw, c.dims, cap, w.nms_boxes, w.pre);
   dim3 mgrid(cb, cb, sets);
   nms_mask_kernel<false><<<mgrid, 64, 0, s>>>(w.nms_boxes, w.counts, 0, cap, cb, nms_iou_threshold,
-                                              w.mask);
+                                              w.mask, w.pre);
   {
     const size_t lds = nms_sweep_lds(cap);
     if (lds > 48 * 1024) {

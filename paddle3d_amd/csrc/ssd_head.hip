@@ -297,7 +297,8 @@ __global__ __launch_bounds__(kSsdTopkThreads) void ssd_topk_kernel(const uint32_
 __global__ __launch_bounds__(256) void ssd_nms_boxes_kernel(const float* __restrict__ boxes,
                                                             const uint32_t* __restrict__ sidx,
                                                             const int* __restrict__ counts, int num_anchors,
-                                                            int cap, float* __restrict__ nms_boxes) {
+                                                            int cap, float* __restrict__ nms_boxes,
+                                                            BoxPre* __restrict__ pre) {
   const int frame = blockIdx.y;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = min(counts[frame], cap);
@@ -312,6 +313,8 @@ __global__ __launch_bounds__(256) void ssd_nms_boxes_kernel(const float* __restr
   o[4] = bx[3];
   o[5] = bx[5];
   o[6] = (-bx[6]) - 1.57079632679489661923f;
+  const float nb[7] = {o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
+  pre[(int64_t)frame * cap + r] = box_prepare(nb);  // what every tile of the suppression matrix needs of this box
 }
 
 // grid (batch): the kept rows in NMS order; a frame without detections gets the reference's `_box_empty` row
@@ -365,6 +368,7 @@ struct SsdWorkspace {
   float *boxes, *scores, *nms_boxes;
   uint32_t *keys_a, *vals_a, *keys_b, *vals_b;
   unsigned long long* mask;
+  BoxPre* pre;
   int32_t *keep, *nkeep;
   size_t bytes;
 };
@@ -389,6 +393,7 @@ static SsdWorkspace ssd_carve(void* base, int batch, int64_t num_anchors, int nx
   w.partial = c.take<int>((size_t)batch * scan_num_tiles((int64_t)radix_hist_ints(plan)));
   w.nms_boxes = c.take<float>((size_t)batch * cap * 7);
   w.mask = c.take<unsigned long long>((size_t)batch * cap * cb);
+  w.pre = c.take<BoxPre>((size_t)batch * cap);
   w.keep = c.take<int32_t>((size_t)batch * cap);
   w.nkeep = c.take<int32_t>((size_t)batch);
   w.bytes = c.off;
@@ -476,9 +481,9 @@ extern "C" int pd3_ssd_postprocess(const float* head_map, int64_t batch_stride, 
     sidx = where ? w.vals_b : w.vals_a;
   }
   ssd_nms_boxes_kernel<<<dim3((cap + 255) / 256, batch), 256, 0, s>>>(w.boxes, sidx, w.counts, (int)a, cap,
-                                                                      w.nms_boxes);
+                                                                      w.nms_boxes, w.pre);
   nms_mask_kernel<false><<<dim3(cb, cb, batch), 64, 0, s>>>(w.nms_boxes, w.counts, 0, cap, cb, nms_iou_threshold,
-                                                            w.mask);
+                                                            w.mask, w.pre);
   const size_t lds = nms_sweep_lds(cap);
   if (lds > 48 * 1024) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel),
