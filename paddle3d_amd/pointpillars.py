@@ -28,7 +28,8 @@ from .centerpoint import (HardVoxelizer, PillarFeatureNet, PointPillarsScatter, 
 from .ops import conv as _conv
 from .ops import ssd_head as _ssd
 
-__all__ = ["AnchorGenerator", "SSDHead", "PointPillars", "pointpillars_kitti_car"]
+__all__ = ["AnchorGenerator", "SSDHead", "PointPillars", "pointpillars_kitti_car",
+           "pointpillars_kitti_cyclist_pedestrian"]
 
 
 def _limit_period(val, offset=0.5, period=math.pi):
@@ -246,3 +247,28 @@ def pointpillars_kitti_car(max_num_voxels=(16000, 40000)) -> PointPillars:
                      nms_post_max_size=300, nms_iou_threshold=0.5,
                      prediction_center_limit_range=[0.0, -39.68, -5.0, 69.12, 39.68, 5.0]),
         anchor_configs=KITTI_CAR_ANCHORS, anchor_area_threshold=1)
+
+
+KITTI_CYCLIST_PEDESTRIAN_ANCHORS = [
+    dict(sizes=[0.6, 1.76, 1.73], anchor_strides=[0.16, 0.16, 0.0], anchor_offsets=[0.08, -19.76, -1.465],
+         rotations=[0, 1.57], matched_threshold=0.5, unmatched_threshold=0.35),
+    dict(sizes=[0.6, 0.8, 1.73], anchor_strides=[0.16, 0.16, 0.0], anchor_offsets=[0.08, -19.76, -1.465],
+         rotations=[0, 1.57], matched_threshold=0.5, unmatched_threshold=0.35)]
+
+
+def pointpillars_kitti_cyclist_pedestrian(max_num_voxels=(12000, 12000)) -> PointPillars:
+    """configs/pointpillars/pointpillars_xyres16_kitti_cyclist_pedestrian.yml:86-150, random init: 100 points per
+    pillar, a stride-1 first backbone block (the head map has the pillar grid's resolution, 248 x 296), two classes,
+    four anchors per location."""
+    pcr, vs = [0.0, -19.84, -2.5, 47.36, 19.84, 0.5], [0.16, 0.16, 3.0]
+    return PointPillars(
+        voxelizer=HardVoxelizer(vs, pcr, 100, list(max_num_voxels)),
+        pillar_encoder=PillarFeatureNet(4, (64,), False, 100, vs, pcr, legacy=False),
+        middle_encoder=PointPillarsScatter(64, vs, pcr),
+        backbone=SecondBackbone(64, (64, 128, 256), (3, 5, 5), (1, 2, 2)),
+        neck=SecondFPN((64, 128, 256), (128, 128, 128), (1, 2, 4), use_conv_for_no_stride=False),
+        head=SSDHead(num_classes=2, feature_channels=384, num_anchor_per_loc=4, encode_background_as_zeros=True,
+                     use_direction_classifier=True, box_code_size=7, nms_score_threshold=0.05, nms_pre_max_size=1000,
+                     nms_post_max_size=300, nms_iou_threshold=0.5,
+                     prediction_center_limit_range=[0.0, -19.84, -2.5, 47.36, 19.84, 0.5]),
+        anchor_configs=KITTI_CYCLIST_PEDESTRIAN_ANCHORS, anchor_area_threshold=1)

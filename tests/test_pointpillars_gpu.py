@@ -239,60 +239,70 @@ def _randomise_bn(model, seed=0):
                 mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
 
 
-def test_pointpillars_kitti_end_to_end_vs_oracle(oracle):
-    """Config 1 end to end on two frames: device voxelize -> PFN -> scatter -> SECOND -> FPN (1 / 2 / 4 transposed
+@pytest.mark.parametrize("config", ["car", "cyclist_pedestrian"])
+def test_pointpillars_kitti_end_to_end_vs_oracle(oracle, config):
+    """Configs 1 / 2 end to end on two frames: device voxelize -> PFN -> scatter -> SECOND -> FPN (1 / 2 / 4 transposed
     convolutions) -> fused SSD head -> ssd_postprocess, against the oracle pipeline (reference voxelizer, torch-CPU
-    statement of the layers, NumPy post-processing)."""
+    statement of the layers, NumPy post-processing).  The cyclist / pedestrian config has 100 points per pillar, a
+    stride-1 first backbone block (head map = pillar grid, 248 x 296, third stage 62 x 74 in rows of pitch 76), two
+    classes and four anchors per location (a 44-map head: both MFMA row blocks of the 1x1 GEMM)."""
     from paddle3d_amd import pointpillars as ppm
 
     torch.manual_seed(4)
-    model = ppm.pointpillars_kitti_car().cuda().eval()
+    make = ppm.pointpillars_kitti_car if config == "car" else ppm.pointpillars_kitti_cyclist_pedestrian
+    model = make().cuda().eval()
     _randomise_bn(model)
     with torch.no_grad():
         model.head.cls_head.bias.fill_(-1.5)
     pts = np.stack([synth.kitti_frame(500), synth.kitti_frame(501)])
     dets = model.test_forward(torch.from_numpy(pts).cuda())
     assert len(dets) == 2
-    cpu = ppm.pointpillars_kitti_car().eval()
+    cpu = make().eval()
     cpu.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
-    an, bv = cpu.anchor_generator.anchors.numpy(), cpu.anchor_generator.anchors_bv.numpy().astype(np.int64)
-    vs, pcr = list(synth.KITTI_PILLAR), list(synth.KITTI_RANGE)
-    h = cpu.head
+    gen, h = cpu.anchor_generator, cpu.head
+    an, bv = gen.anchors.numpy(), gen.anchors_bv.numpy().astype(np.int64)
+    vs, pcr = cpu.voxelizer.voxel_size, cpu.voxelizer.point_cloud_range
+    p_max, v_max = cpu.voxelizer.max_num_points_in_voxel, cpu.voxelizer.max_num_voxels[1]
+    nx, ny = gen.grid_size
+    fh, fw = gen.feature_map_size
+    apl, ncls = h.num_anchor_per_loc, h.num_classes
+    c_cls, c_box = apl * ncls, apl * 7
     for b in range(2):
-        vox, co, npv, nv = oracle.hard_voxelize(pts[b], vs, pcr, 32, 40000)
+        vox, co, npv, nv = oracle.hard_voxelize(pts[b], vs, pcr, p_max, v_max)
         c4 = np.concatenate([np.zeros((nv, 1), np.int32), co[:nv]], 1)
         params = [dict(weight=l.linear.weight.t().detach().numpy(), gamma=l.norm.weight.detach().numpy(),
                        beta=l.norm.bias.detach().numpy(), mean=l.norm.running_mean.numpy(),
                        var=l.norm.running_var.numpy()) for l in cpu.pillar_encoder.pfn_layers]
         feats = oracle.pfn_forward_torch(vox[:nv], npv[:nv], c4, params, vs, pcr)
-        bev = torch.from_numpy(oracle.pillar_scatter(feats, c4, 1, 496, 432))
+        bev = torch.from_numpy(oracle.pillar_scatter(feats, c4, 1, ny, nx))
         with torch.no_grad():
             x = oracle.second_fpn_torch(cpu.neck, oracle.second_backbone_torch(cpu.backbone, bev))
-            assert x.shape == (1, 384, 248, 216)
+            assert x.shape == (1, 384, fh, fw)
             ref_map = torch.cat([h.cls_head(x), h.box_head(x), h.dir_head(x)], 1)[0].numpy()
         # the device graph's head map for this frame
         voxels, coors, npv_d, _ = model.voxelizer(torch.from_numpy(pts[b:b + 1]).cuda())
         v = voxels.shape[1]
-        f = model.pillar_encoder(voxels.view(v, 32, 4), npv_d.view(v), coors.view(v, 4))
+        f = model.pillar_encoder(voxels.view(v, p_max, 4), npv_d.view(v), coors.view(v, 4))
         gx = model.neck(model.backbone(model.middle_encoder(f, coors.view(v, 4), 1)))
         got_map = model.head.head_map(gx)[0].cpu().numpy()
+        assert got_map.shape == ref_map.shape == (c_cls + c_box + apl * 2, fh, fw)
         assert np.abs(got_map - ref_map).max() < 1e-3  # the north star's bar on fp32 features
         # post-processing of the CPU map by the oracle vs the device detections (maps differ by ~1e-5: compare as
         # sets, every strong reference detection has a twin)
-        mask = oracle.ssd_anchor_mask_numpy(co[:nv], bv, cpu.anchor_generator.grid_size, 1.0)
-        pr = ref_map.reshape(20, -1).T  # [hw, 20]
-        cls = pr[:, 0:2].reshape(-1, 1)
-        box = pr[:, 2:16].reshape(-1, 7)
-        dirp = pr[:, 16:20].reshape(-1, 2)
+        mask = oracle.ssd_anchor_mask_numpy(co[:nv], bv, gen.grid_size, 1.0)
+        pr = ref_map.reshape(ref_map.shape[0], -1).T  # [hw, channels]
+        cls = pr[:, :c_cls].reshape(-1, ncls)
+        box = pr[:, c_cls:c_cls + c_box].reshape(-1, 7)
+        dirp = pr[:, c_cls + c_box:].reshape(-1, 2)
         rb, rs, rl = oracle.ssd_post_process_frame_numpy(box, cls, dirp, an, mask, h.nms_score_threshold,
                                                          h.pred_center_limit_range, h.nms_pre_max_size,
                                                          h.nms_post_max_size, h.nms_iou_threshold)
-        gb, gs = dets[b]["box3d_lidar"].cpu().numpy(), dets[b]["scores"].cpu().numpy()
+        gb, gs, gl = (dets[b][k].cpu().numpy() for k in ("box3d_lidar", "scores", "label_preds"))
         assert rs.shape[0] > 20 and gs.shape[0] > 20
         strong = rs > h.nms_score_threshold + 1e-3
         matched = 0
         for i in np.nonzero(strong)[0]:
-            d = np.abs(gb[:, :2] - rb[i, :2]).sum(1)
+            d = np.abs(gb[:, :2] - rb[i, :2]).sum(1) + (gl != rl[i]) * 1e3
             j = int(np.argmin(d))
             if d[j] < 1e-2 and abs(gs[j] - rs[i]) < 1e-3:
                 matched += 1
