@@ -393,7 +393,7 @@ int pd3_conv3x3_winograd_bias_relu(const float *x, const float *u_packed, const 
  * second_fpn.py:99-157; Conv2D / Conv2DTranspose with kernel = stride, BatchNorm folded) as one fp32-MFMA
  * GEMM with bias + ReLU, written at a channel offset of a wider output tensor (the concat of the FPN levels).
  *   mode 0: Conv2D kernel 2 stride 2      x [batch, cin, h, w] -> out[:, off:off+cout] of [batch, ctot, h/2, w/2]
- *           w_packed = A[co][ci*4 + py*2 + px] from the [cout, cin, 2, 2] weight; needs h % 4 == 0, w % 256 == 0
+ *           w_packed = A[co][ci*4 + py*2 + px] from the [cout, cin, 2, 2] weight; needs h % 4 == 0, w % 4 == 0
  *   mode 1: 1x1 convolution               -> [batch, ctot, h, w];  A[co][ci]; needs (h*w) % 4 == 0
  *   mode 2: Conv2DTranspose kernel 2 stride 2 -> [batch, ctot, 2h, 2 w_valid];  A[co*4 + dy*2 + dx][ci] from the
  *           [cin, cout, 2, 2] weight; needs (h*w) % 4 == 0; w is the row pitch of x, w_valid <= w its real width

@@ -39,7 +39,7 @@ from .ops import voxel_encoder as _ve
 from .ops import voxelize as _vox
 
 __all__ = ["HardVoxelizer", "PillarFeatureNet", "HardVFE", "VoxelMean", "PointPillarsScatter", "SecondBackbone",
-           "SecondFPN", "CenterHead", "CenterPoint", "centerpoint_pillars_nuscenes",
+           "SecondFPN", "CenterHead", "CenterPoint", "centerpoint_pillars_nuscenes", "centerpoint_pillars_kitti",
            "centerpoint_voxels_nuscenes", "load_paddle_state_dict"]
 
 
@@ -579,6 +579,27 @@ def centerpoint_pillars_nuscenes(max_num_voxels=(30000, 60000)) -> CenterPoint:
         neck=SecondFPN((64, 128, 256), (128, 128, 128), (0.5, 1, 2), use_conv_for_no_stride=True),
         bbox_head=CenterHead(384, NUSC_TASKS, dict(reg=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2))),
         test_cfg=test_cfg, box_with_velocity=True)
+
+
+KITTI_TASKS = [dict(num_class=1, class_names=["Car"]), dict(num_class=2, class_names=["Cyclist", "Pedestrian"])]
+
+
+def centerpoint_pillars_kitti(max_num_voxels=(12000, 40000)) -> CenterPoint:
+    """configs/centerpoint/centerpoint_pillars_016voxel_kitti.yml:108-163, random init: 0.16 m pillars on the KITTI
+    range (432 x 496), 100 points per pillar, a stride-1 first backbone block (head map 248 x 216, down_ratio 2), two
+    tasks, boxes without velocity."""
+    pcr, vs = [0.0, -39.68, -3.0, 69.12, 39.68, 1.0], [0.16, 0.16, 4]
+    test_cfg = dict(post_center_limit_range=[-10.0, -50.0, -10.0, 80.0, 50.0, 10.0], max_per_img=500,
+                    nms=dict(nms_pre_max_size=1000, nms_post_max_size=83, nms_iou_threshold=0.1),
+                    score_threshold=0.1, point_cloud_range=pcr[:2], down_ratio=2, voxel_size=[0.16, 0.16])
+    return CenterPoint(
+        voxelizer=HardVoxelizer(vs, pcr, 100, list(max_num_voxels)),
+        voxel_encoder=PillarFeatureNet(4, (64, 64), False, 100, vs, pcr, legacy=False),
+        middle_encoder=PointPillarsScatter(64, vs, pcr),
+        backbone=SecondBackbone(64, (64, 128, 256), (3, 5, 5), (1, 2, 2)),
+        neck=SecondFPN((64, 128, 256), (128, 128, 128), (0.5, 1, 2), use_conv_for_no_stride=True),
+        bbox_head=CenterHead(384, KITTI_TASKS, dict(reg=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2))),
+        test_cfg=test_cfg, box_with_velocity=False)
 
 
 def centerpoint_voxels_nuscenes(max_num_voxels=(120000, 160000), point_cloud_range=None) -> CenterPoint:

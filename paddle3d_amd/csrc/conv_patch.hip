@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(PgArgs a) {
   // pixel tile: mode 0 -> 2 output rows x 128 columns; modes 1, 2 -> 256 consecutive pixels of the input plane
   int n, p0 = 0, oy0 = 0, ox0 = 0;
   if (MODE == 0) {
-    const int tiles_x = a.wo / 128, tiles_y = a.ho / 2;
+    const int tiles_x = (a.wo + 127) / 128, tiles_y = a.ho / 2;  // the last tile of a row may be partial
     n = pt / (tiles_x * tiles_y);
     oy0 = ((pt / tiles_x) % tiles_y) * 2;
     ox0 = (pt % tiles_x) * 128;
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(PgArgs a) {
     const int e = threadIdx.x + i * 256;
     if (MODE == 0) {  // e -> (ci 0..3, row 0..3, c4 0..63) of the 4-channel window
       const int ci = e >> 8, r = (e >> 6) & 3, c4 = e & 63;
-      gofs[i] = (int)(ci * iplane + (int64_t)(2 * oy0 + r) * a.wi + 2 * ox0 + c4 * 4);
+      // columns past the row are clamped to its last float4: they only feed pixels that are never stored
+      gofs[i] = (int)(ci * iplane + (int64_t)(2 * oy0 + r) * a.wi + min(2 * ox0 + c4 * 4, a.wi - 4));
     } else {          // e -> (ci 0..15, c4 0..63)
       const int ci = e >> 6, c4 = e & 63;
       // columns past the plane are clamped to its last float4: they only feed pixels that are never stored
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(PgArgs a) {
   for (int t = 0; t < 2; ++t) {
     const int pj = (wave * 2 + t) * 32 + (lane & 31);
     if (MODE != 0 && (int64_t)p0 + pj >= iplane) continue;  // pixel of a partial tile
+    if (MODE == 0 && ox0 + (pj % 128) >= a.wo) continue;
 #pragma unroll
     for (int m = 0; m < (HALF ? 1 : 2); ++m) {
       if (MODE == 3) {
@@ -250,12 +252,12 @@ extern "C" int pd3_patch_conv_bias_relu(const float* x, const float* w_packed, c
   hipStream_t s = static_cast<hipStream_t>(stream);
   int64_t ptiles;
   if (mode == 0) {  // Conv2D kernel 2 stride 2
-    if (h % 4 != 0 || w % 256 != 0 || (cin * 4) % kPgK != 0 || cout % kPgM != 0) return PD3_EUNSUPPORTED;
+    if (h % 4 != 0 || w % 4 != 0 || (cin * 4) % kPgK != 0 || cout % kPgM != 0) return PD3_EUNSUPPORTED;
     a.m_rows = cout;
     a.m_valid = cout;
     a.ho = h / 2;
     a.wo = w / 2;
-    ptiles = (int64_t)batch * (a.ho / 2) * (a.wo / 128);
+    ptiles = (int64_t)batch * (a.ho / 2) * ceil_div(a.wo, 128);
     a.ptiles = (int)ptiles;
     return launch_patch_gemm<0>(a, ptiles, s);
   }

@@ -131,7 +131,7 @@ def patch_mode(weight: torch.Tensor, stride: int, transpose: bool):
 def patch_supported(mode: int, cin: int, cout: int, h: int, w: int) -> bool:
     """[h, w] = input map, w its row pitch (pitch4 of the valid width for modes 2, 3)."""
     if mode == 0:
-        return h % 4 == 0 and w % 256 == 0 and (cin * 4) % 16 == 0 and cout % 64 == 0
+        return h % 4 == 0 and w % 4 == 0 and (cin * 4) % 16 == 0 and cout % 64 == 0
     if (h * w) % 4 or cin % 16:
         return False
     return {1: cout >= 1, 2: (cout * 4) % 64 == 0, 3: (cout * 16) % 64 == 0}.get(mode, False)

@@ -173,18 +173,18 @@ def test_winograd_shift_taps():
             assert (out - want).abs().max().item() < 1e-3, (ky, kx)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 11, 12])
+@pytest.mark.parametrize("mode", [0, 1, 2, 11, 12, 10])
 def test_patch_conv_matches_torch(mode):
-    """FPN patch convolutions (second_fpn.py:99-157) written at a channel offset of a wider tensor; modes 11 / 12
-    are modes 1 / 2 on planes that are not a multiple of the 256-pixel tile (CenterPoint-Voxel: 180 x 180, 90 x 90)."""
+    """FPN patch convolutions (second_fpn.py:99-157) written at a channel offset of a wider tensor; modes 10 / 11 / 12
+    are modes 0 / 1 / 2 on planes that are not a multiple of the 256-pixel tile (CenterPoint-Voxel: 180 x 180, 90 x 90)."""
     from paddle3d_amd.ops import conv
 
     g = torch.Generator().manual_seed(mode)
     n, off, ctot = 2, 64, 256
     odd = mode > 2
     mode = mode % 10
-    if mode == 0:
-        cin, cout, h, w = 16, 128, 8, 256
+    if mode == 0:  # mode 10: a width that is not a multiple of the 2 x 128 output tile (CenterPoint-KITTI: 496 x 432)
+        cin, cout, h, w = (16, 64, 12, 432) if odd else (16, 128, 8, 256)
         wt = torch.randn(cout, cin, 2, 2, generator=g) / (cin * 4) ** 0.5
         x = torch.randn(n, cin, h, w, generator=g)
         b = torch.randn(cout, generator=g)
