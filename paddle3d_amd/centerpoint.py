@@ -40,7 +40,7 @@ from .ops import voxelize as _vox
 
 __all__ = ["HardVoxelizer", "PillarFeatureNet", "HardVFE", "VoxelMean", "PointPillarsScatter", "SecondBackbone",
            "SecondFPN", "CenterHead", "CenterPoint", "centerpoint_pillars_nuscenes", "centerpoint_pillars_kitti",
-           "centerpoint_voxels_nuscenes", "load_paddle_state_dict"]
+           "centerpoint_voxels_nuscenes", "centerpoint_voxels_kitti", "load_paddle_state_dict"]
 
 
 def _grid(voxel_size, point_cloud_range):
@@ -621,6 +621,26 @@ def centerpoint_voxels_nuscenes(max_num_voxels=(120000, 160000), point_cloud_ran
         neck=SecondFPN((128, 256), (256, 256), (1, 2), use_conv_for_no_stride=True),
         bbox_head=CenterHead(512, NUSC_TASKS, dict(reg=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2))),
         test_cfg=test_cfg, box_with_velocity=True)
+
+
+def centerpoint_voxels_kitti(max_num_voxels=(12000, 40000)) -> CenterPoint:
+    """configs/centerpoint/centerpoint_voxels_008voxel_kitti.yml:108-160, random init: 0.08 m x 0.08 m x 0.1 m voxels
+    on the KITTI range (864 x 992 x 40), 100 points per voxel, SparseResNet3D on 4 input channels, 124 x 108 head maps
+    (down_ratio 8), two tasks, boxes without velocity."""
+    from .sparse import SparseResNet3D
+
+    pcr, vs = [0.0, -39.68, -3.0, 69.12, 39.68, 1.0], [0.08, 0.08, 0.1]
+    test_cfg = dict(post_center_limit_range=[-10.0, -50.0, -10.0, 80.0, 50.0, 10.0], max_per_img=500,
+                    nms=dict(nms_pre_max_size=1000, nms_post_max_size=83, nms_iou_threshold=0.1),
+                    score_threshold=0.1, point_cloud_range=pcr[:2], down_ratio=8, voxel_size=[0.08, 0.08])
+    return CenterPoint(
+        voxelizer=HardVoxelizer(vs, pcr, 100, list(max_num_voxels)),
+        voxel_encoder=VoxelMean(4),
+        middle_encoder=SparseResNet3D(4, vs, pcr),
+        backbone=SecondBackbone(256, (128, 256), (5, 5), (1, 2)),
+        neck=SecondFPN((128, 256), (256, 256), (1, 2), use_conv_for_no_stride=True),
+        bbox_head=CenterHead(512, KITTI_TASKS, dict(reg=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2))),
+        test_cfg=test_cfg, box_with_velocity=False)
 
 
 from .checkpoint import load_paddle_state_dict  # noqa: E402,F401  (re-exported: the models' loader)

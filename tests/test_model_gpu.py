@@ -172,6 +172,40 @@ def test_centerpoint_voxel_forward():
     assert torch.equal(dets[0]["box3d_lidar"], dets2[0]["box3d_lidar"])
 
 
+def test_centerpoint_voxel_kitti_forward():
+    """CenterPoint-Voxel KITTI (configs/centerpoint/centerpoint_voxels_008voxel_kitti.yml): 864 x 992 x 40 grid (sort
+    path of the voxelizer), 100 points per voxel, 4 input channels into the sparse encoder, 124 x 108 head maps with a
+    62 x 54 second stage (rows of pitch 56), boxes without velocity: runs end to end, deterministic, and the sparse
+    encoder's BEV map is where the voxels are."""
+    from paddle3d_amd import centerpoint as cpm
+
+    torch.manual_seed(7)
+    model = cpm.centerpoint_voxels_kitti().cuda().eval()
+    assert model.middle_encoder.sparse_shape == (41, 992, 864)
+    with torch.no_grad():
+        for task in model.bbox_head.tasks:
+            task.hm[-1].bias.fill_(-1.0)
+    pts = torch.from_numpy(np.stack([synth.kitti_frame(530), synth.kitti_frame(531)])).cuda()
+    bev = model.extract_pillars(pts)
+    assert bev.shape == (2, 256, 124, 108) and torch.isfinite(bev).all() and bev.abs().sum() > 0
+    # columns of the BEV map far from every point stay empty (three stride-2 stages + 3x3 kernels reach < 16 cells)
+    xy = pts[0, :, :2].cpu().numpy()
+    occ = np.zeros((124, 108), bool)
+    iy = np.clip(((xy[:, 1] + 39.68) / 0.64).astype(int), 0, 123)
+    ix = np.clip((xy[:, 0] / 0.64).astype(int), 0, 107)
+    inside = (xy[:, 0] >= 0) & (xy[:, 0] < 69.12) & (np.abs(xy[:, 1]) < 39.68)
+    occ[iy[inside], ix[inside]] = True
+    from scipy.ndimage import binary_dilation
+
+    near = binary_dilation(occ, iterations=3)
+    live = (bev[0] != 0).any(0).cpu().numpy()
+    assert live.any() and not (live & ~near).any()
+    dets = model.test_forward(pts)
+    assert len(dets) == 2 and dets[0]["box3d_lidar"].shape[1] == 7
+    dets2 = model.test_forward(pts)
+    assert torch.equal(dets[0]["box3d_lidar"], dets2[0]["box3d_lidar"])
+
+
 def test_centerpoint_voxel_end_to_end_vs_oracle(oracle):
     """CenterPoint-Voxel (config 4) end to end against the oracle pipeline on a quarter-range copy of the config
     (0.075 m voxels, 41 x 256 x 256 sparse grid: the dense statement of the sparse encoder fits a CPU): reference
