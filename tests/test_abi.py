@@ -82,3 +82,43 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     with pytest.raises(_lib.Paddle3DAmdError, match="no CPU / PyTorch fallback"):
         _lib.lib()
     _lib.lib.cache_clear()
+
+
+def test_patch_weight_packers_describe_the_layers():
+    """Host logic of the patch-GEMM layers (no GPU): un-packing pack_patch_weight's [M/64][K/16][16][64] blocks gives
+    the GEMM A matrix whose product with the pixels is the layer -- Conv2D k2 s2 (mode 0), 1x1 with a row count that is
+    not a multiple of 64 (mode 1, zero-padded rows), Conv2DTranspose k2 s2 / k4 s4 (modes 2 / 3: rows (co, dy, dx))."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+
+    from paddle3d_amd.ops import conv
+
+    def unpack(p):
+        mb, kb = p.shape[0], p.shape[1]
+        return p.permute(0, 3, 1, 2).reshape(mb * 64, kb * 16)
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 16, 4, 8, generator=g)
+    # mode 1, 20 rows -> 64 padded
+    w = torch.randn(20, 16, 1, 1, generator=g)
+    a = unpack(conv.pack_patch_weight(w, 1, False))
+    assert a.shape == (64, 16) and not a[20:].any()
+    ref = F.conv2d(x, w)[0].reshape(20, -1)
+    np.testing.assert_allclose((a @ x[0].reshape(16, -1))[:20].numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    # modes 2 / 3: transposed convolutions with kernel = stride
+    for k, mode in ((2, 2), (4, 3)):
+        wt = torch.randn(16, 16, k, k, generator=g)
+        assert conv.patch_mode(wt, k, True) == mode
+        a = unpack(conv.pack_patch_weight(wt, mode, True))            # [co * k * k + dy * k + dx][ci]
+        d = (a @ x[0].reshape(16, -1)).reshape(16, k, k, 4, 8)         # [co, dy, dx, y, x]
+        out = d.permute(0, 3, 1, 4, 2).reshape(16, 4 * k, 8 * k)       # out[co][k y + dy][k x + dx]
+        np.testing.assert_allclose(out.numpy(), F.conv_transpose2d(x, wt, stride=k)[0].numpy(), rtol=1e-5, atol=1e-5)
+    # mode 0: Conv2D k2 s2, K = (ci, py, px)
+    wc = torch.randn(64, 16, 2, 2, generator=g)
+    a = unpack(conv.pack_patch_weight(wc, 0, False))
+    cols = F.unfold(x, 2, stride=2)[0]                                  # [ci * 4 + py * 2 + px][pixels]
+    np.testing.assert_allclose((a @ cols).numpy(), F.conv2d(x, wc, stride=2)[0].reshape(64, -1).numpy(), rtol=1e-5,
+                               atol=1e-5)
+    assert conv.patch_supported(0, 64, 128, 496, 432) and not conv.patch_supported(0, 64, 128, 496, 430)
+    assert conv.patch_supported(3, 256, 128, 62, 56) and conv.patch_supported(1, 384, 20, 248, 216)
