@@ -125,10 +125,18 @@ static __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned lo
   const bool in_lds = n <= kNmsLdsBoxes;
   for (int j = threadIdx.x; j < cbs; j += blockDim.x) remv[j] = 0ull;
   if (in_lds) {
-    if (cbs == cb_cap) {  // full-width rows: one linear copy, four loads in flight per thread
+    if (cbs == cb_cap) {  // full-width rows: one linear copy, 16 bytes per load where the set's block is aligned
       const int total = n * cbs;
+      if ((reinterpret_cast<uintptr_t>(m) & 15u) == 0) {
+        const ulonglong2* m2 = reinterpret_cast<const ulonglong2*>(m);
+        ulonglong2* l2 = reinterpret_cast<ulonglong2*>(mlds);  // mlds = nms_smem + 1024 words: 16-byte aligned
 #pragma unroll 4
-      for (int e = threadIdx.x; e < total; e += blockDim.x) mlds[e] = m[e];
+        for (int e = threadIdx.x; e < (total >> 1); e += blockDim.x) l2[e] = m2[e];
+        if ((total & 1) && threadIdx.x == 0) mlds[total - 1] = m[total - 1];
+      } else {
+#pragma unroll 4
+        for (int e = threadIdx.x; e < total; e += blockDim.x) mlds[e] = m[e];
+      }
     } else {
       for (int e = threadIdx.x; e < n * cbs; e += blockDim.x) {
         const int i = e / cbs, j = e - i * cbs;
@@ -160,15 +168,28 @@ static __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned lo
       kp[kept_total + __popcll(keepbits & ((1ull << lane) - 1ull))] = nb * 64 + lane;
     kept_total += __popcll(keepbits);
     // OR the kept rows' words into the later column blocks
-    for (int j = nb + 1 + lane; j < cbs; j += 64) {
-      unsigned long long acc = remv[j];
-      if (in_lds) {  // every row of the block is read (independent LDS loads, pipelined); kept rows are OR-ed in
+    if (in_lds) {
+      // cbs <= 16 here: lane = (row group g, word jj); every lane ORs 16 of the block's 64 rows (independent LDS loads,
+      // pipelined; rows that were not kept contribute 0), the four groups are combined across the wave
+      const int g = lane >> 4, j = nb + 1 + (lane & 15);
+      unsigned long long acc = 0ull;
+      if (j < cbs) {
 #pragma unroll 8
-        for (int t = 0; t < rows; ++t) {
+        for (int t = g * 16; t < min(g * 16 + 16, rows); ++t) {
           const unsigned long long v = mlds[(nb * 64 + t) * cbs + j];
           acc |= ((keepbits >> t) & 1ull) ? v : 0ull;
         }
-      } else {
+      }
+      unsigned lo = (unsigned)(acc & 0xffffffffull), hi = (unsigned)(acc >> 32);
+      lo |= (unsigned)__shfl_xor((int)lo, 16, 64);
+      hi |= (unsigned)__shfl_xor((int)hi, 16, 64);
+      lo |= (unsigned)__shfl_xor((int)lo, 32, 64);
+      hi |= (unsigned)__shfl_xor((int)hi, 32, 64);
+      if (g == 0 && j < cbs) remv[j] |= ((unsigned long long)hi << 32) | lo;
+    }
+    for (int j = nb + 1 + lane; !in_lds && j < cbs; j += 64) {
+      unsigned long long acc = remv[j];
+      {
         unsigned long long kb = keepbits;
         while (kb) {
           const int t = __ffsll((long long)kb) - 1;
