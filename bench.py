@@ -192,35 +192,83 @@ def measured_ceilings(dev, mb=384):
     return dict(fill_GBps=fill, copy_GBps_read_plus_write=copy, buffer_MB=mb)
 
 
-def _events(names, steps):
+class _HostEvent:
+    """CPU stand-in for torch.cuda.Event (the --stub-ops launch-path test runs without a GPU)."""
+
+    def __init__(self):
+        self.t = 0.0
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def _events(names, steps, dev):
+    if dev.type != "cuda":
+        return [[_HostEvent() for _ in names] for _ in range(steps)]
     return [[torch.cuda.Event(enable_timing=True) for _ in names] for _ in range(steps)]
 
 
 def _timed_loop(step, args, world, dev, names):
+    """The contract: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX
+    over ranks.  Returns (seconds, per-op milliseconds (median over the K steps of the HIP-event intervals), last
+    output, info).  info["repeats_s"]: the same K steps timed `--repeats` more times after the contract block (the
+    0.2 s region of a 20-step run moves by a few per cent from box to box; the spread is reported, `value` is always
+    the first block); info["ranks_seen"]: ranks that answered an all-gather after the timed region."""
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
+    def block(events):
+        sync()
+        barrier()
+        t0 = time.perf_counter()
+        out = None
+        for k in range(args.steps):
+            out = step(events[k] if events is not None else None)
+        sync()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out
+
     with torch.no_grad():
         for _ in range(args.warmup):
             step(None)
-        torch.cuda.synchronize()
-        barrier()
-        events = _events(names, args.steps)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            out = step(events[k])
-        torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
+        events = _events(names, args.steps, dev)
+        dt, out = block(events)
+        sync()
+        per_op_ms = {names[i]: float(np.median([events[k][i - 1].elapsed_time(events[k][i])
+                                                for k in range(args.steps)])) for i in range(1, len(names))}
+        repeats = [block(None)[0] for _ in range(max(0, args.repeats))]
+    seen = 1
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    per_op_ms = {names[i]: float(np.mean([events[k][i - 1].elapsed_time(events[k][i]) for k in range(args.steps)]))
-                 for i in range(1, len(names))}
-    return dt, per_op_ms, out
+        mine = torch.tensor([torch.distributed.get_rank()], dtype=torch.int64, device=dev)
+        allr = torch.empty(world, dtype=torch.int64, device=dev)
+        torch.distributed.all_gather_into_tensor(allr, mine)
+        seen = int(torch.unique(allr).numel())
+    return dt, per_op_ms, out, dict(repeats_s=repeats, ranks_seen=seen)
+
+
+def _dist_fields(line, args, world, info, units_per_step):
+    """Fields every workload's line carries about the launch: ranks that took part, spread over repeated blocks."""
+    line["ranks_seen"] = info["ranks_seen"]
+    line["collective_backend"] = (torch.distributed.get_backend() if world > 1 else None)
+    if info["repeats_s"]:
+        vals = sorted(world * units_per_step * args.steps / t for t in info["repeats_s"])
+        line.setdefault("extras", {})["repeat_blocks"] = dict(
+            blocks=len(vals), steps_each=args.steps, unit=line["unit"], min=vals[0], median=vals[len(vals) // 2],
+            max=vals[-1], note="the same K steps timed again after the contract block; `value` is the contract block")
+    return line
 
 
 def _traffic(batch, v):
@@ -345,7 +393,7 @@ def bench_pillars(args, rank, world, dev):
                 torch.cuda.synchronize()
                 print(f"bench: HIP-graph capture failed ({type(e).__name__}: {e}); running the eager step", file=sys.stderr)
                 step, launch = (lambda ev: run(pts, ev)), "eager (graph capture failed)"
-    dt, per_op_ms, out = _timed_loop(step, args, world, dev, names)
+    dt, per_op_ms, out, info = _timed_loop(step, args, world, dev, names)
     if rank != 0:
         return None
     alg = algorithmic_bytes(V)
@@ -485,7 +533,7 @@ def bench_voxel(args, rank, world, dev):
         mark(5)
         return all_rec, all_cnt
 
-    dt, per_op_ms, out = _timed_loop(run, args, world, dev, names)
+    dt, per_op_ms, out, info = _timed_loop(run, args, world, dev, names)
     if rank != 0:
         return None
     alg = 4 * N_POINTS * DIMS + 4 * V * 10 * DIMS + 16 * V + 4
@@ -557,7 +605,7 @@ def bench_bevfusion_lidar(args, rank, world, dev):
         return canvas, nv
 
     with torch.no_grad():
-        dt, per_op_ms, out = _timed_loop(run, args, world, dev, names)
+        dt, per_op_ms, out, info = _timed_loop(run, args, world, dev, names)
     if rank != 0:
         return None
     alg_v = 4 * N_POINTS * D4 + 4 * V * PV * D4 + 16 * V + 4
@@ -622,7 +670,7 @@ def bench_pointpillars_kitti(args, rank, world, dev):
         return out, nv
 
     with torch.no_grad():
-        dt, per_op_ms, out = _timed_loop(run, args, world, dev, names)
+        dt, per_op_ms, out, info = _timed_loop(run, args, world, dev, names)
     if rank != 0:
         return None
     alg_v = 4 * NK * D4 + 4 * V * PV * D4 + 16 * V + 4
@@ -697,7 +745,7 @@ def bench_bev_pool(args, rank, world, dev):
             events[1].record()
         return out
 
-    dt, per_op_ms, out = _timed_loop(run, args, world, dev, names)
+    dt, per_op_ms, out, info = _timed_loop(run, args, world, dev, names)
     if rank != 0:
         return None
     n_pts, n_int, c = int(t["ranks_bev"].numel()), int(t["interval_lengths"].numel()), int(t["feat"].shape[-1])

@@ -63,11 +63,12 @@ int pd3_hard_voxelize(const float *points, const int32_t *num_points, int batch,
                       int32_t *num_points_per_voxel, int32_t *num_voxels, int32_t *coors_batched,
                       void *workspace, size_t workspace_bytes, void *stream);
 /* Same operator with the implementation chosen by the caller (diagnostics and the parity tests, which run
- * every case on all of them): path 0 = automatic (what pd3_hard_voxelize does: 3 where the grid qualifies, else 1), 1 = generic radix-sort path (any
- * grid below 2^31 cells), 2 = tiled path, payload copied once into a cell-ordered compact array, 3 = tiled path,
- * rows gathered from the points through a cell-ordered index list (2 and 3: BEV-sized grids; PD3_EUNSUPPORTED when
- * the shape does not qualify).
- * All paths produce identical bytes. */
+ * every case on all of them): path 0 = automatic (what pd3_hard_voxelize does: 5 where the grid qualifies, else 3,
+ * else 1), 1 = generic radix-sort path (any grid below 2^31 cells), 2 = tiled path, payload copied once into a
+ * cell-ordered compact array, 3 = tiled path, rows gathered from the points through a cell-ordered index list (2 and
+ * 3: BEV-sized grids up to 2^22 cells), 5 = wave form of the tiled path (one wave per group of 1024 cells, grids up to
+ * 2^20 cells; 6 .. 10 = the same with the route kernel's tile shape forced: 4096 / 8192 / 10240 / 5120 / 5120 points).
+ * PD3_EUNSUPPORTED when the shape does not qualify for a forced path.  Identical bytes out on every path. */
 int pd3_hard_voxelize_path(const float *points, const int32_t *num_points, int batch, int64_t max_points,
                            int num_point_dim, const float *voxel_size, const float *point_cloud_range,
                            int max_num_points_in_voxel, int max_voxels, float *voxels, int32_t *coords,

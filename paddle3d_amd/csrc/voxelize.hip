@@ -23,7 +23,7 @@
 #include "common.hpp"
 #include "radix_sort.hpp"
 #include "scan.hpp"
-#include "voxelize_tiled.hpp"
+#include "voxelize_wave.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -322,6 +322,102 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
   return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wave form of the tiled path (voxelize_wave.hpp)
+// ---------------------------------------------------------------------------------------------------
+struct VwWorkspace {
+  uint32_t *recs, *dir, *clist, *tstate;
+  unsigned char* fmap;
+  uint2 *finfo, *vinfo;
+  int* totals;
+  int64_t cap;
+  size_t bytes;
+};
+
+static VwWorkspace vw_carve(void* base, int batch, int64_t n, int max_voxels, const VwPlan& p) {
+  Carver c(base);
+  VwWorkspace w;
+  w.cap = n;
+  w.recs = c.take<uint32_t>((size_t)batch * p.tiles * p.tile);
+  w.dir = c.take<uint32_t>((size_t)batch * p.tiles * p.groups);
+  w.clist = c.take<uint32_t>((size_t)batch * w.cap + 4);
+  w.fmap = c.take<unsigned char>((size_t)batch * p.fstride);
+  w.finfo = c.take<uint2>((size_t)batch * p.fstride);
+  w.tstate = c.take<uint32_t>((size_t)batch * p.atiles);
+  w.vinfo = c.take<uint2>((size_t)batch * max_voxels);
+  w.totals = c.take<int>((size_t)batch);
+  w.bytes = c.off;
+  return w;
+}
+
+constexpr int kVwShapes = 5;
+
+static bool wave_applicable(const VoxGrid& g, int64_t n, int dim, int max_pts, int max_voxels, int batch, int shape,
+                            VwPlan& plan) {
+  plan = vw_plan(g.ncells, n, max_pts, batch, shape);
+  const int64_t row = (int64_t)max_pts * dim;
+  const int64_t rowq = (row % 4 == 0) ? row / 4 : row;
+  return plan.ok && (int64_t)max_voxels * rowq < ((int64_t)1 << 24) - 4096;
+}
+
+static int run_wave(const float* points, const int32_t* num_points, int batch, int64_t n, int dim, const VoxGrid& g,
+                    int max_pts, int max_voxels, const VwPlan& plan, float* voxels, int32_t* coords,
+                    int32_t* num_pts, int32_t* num_voxels, int32_t* coors4, void* workspace, hipStream_t s) {
+  VwWorkspace w = vw_carve(workspace, batch, n, max_voxels, plan);
+  VtGrid vg{g.min_x, g.min_y, g.min_z, g.size_x, g.size_y, g.size_z,
+            (float)(1.0 / (double)g.size_x), (float)(1.0 / (double)g.size_y), (float)(1.0 / (double)g.size_z),
+            g.gx, g.gy, g.gz, g.ncells};
+  const int waves = plan.threads / kWave;
+  const size_t lds_a = ((size_t)plan.tile + (size_t)waves * plan.groups + waves + 2) * 4;
+  const unsigned tile_grid = (unsigned)(plan.tiles * batch);
+#define PD3_VW_ROUTE(T, R)                                                                                         \
+  vw_route_kernel<T, R><<<tile_grid, T, lds_a, s>>>(points, num_points, n, dim, vg, plan.low, plan.gbits,          \
+                                                    plan.tiles, batch, max_voxels, w.recs, w.dir, w.fmap,          \
+                                                    plan.fstride, w.tstate, plan.atiles, w.vinfo)
+  if (plan.threads == 512 && plan.rounds == 8) PD3_VW_ROUTE(512, 8);
+  else if (plan.threads == 1024 && plan.rounds == 8) PD3_VW_ROUTE(1024, 8);
+  else if (plan.threads == 1024 && plan.rounds == 10) PD3_VW_ROUTE(1024, 10);
+  else if (plan.threads == 512 && plan.rounds == 10) PD3_VW_ROUTE(512, 10);
+  else if (plan.threads == 1024 && plan.rounds == 5) PD3_VW_ROUTE(1024, 5);
+  else return PD3_EINVAL;
+#undef PD3_VW_ROUTE
+  const int tp = vw_pow2_above(plan.tiles);
+  vw_group_kernel<<<(unsigned)(plan.groups * batch), kWave, vw_group_lds(plan.cpg, plan.tiles), s>>>(
+      w.recs, w.dir, plan.low, plan.gbits, plan.tiles, plan.tile, tp, batch, max_pts, w.clist, w.cap, w.fmap,
+      w.finfo, plan.fstride);
+  vw_count_kernel<<<(unsigned)ceil_div((int64_t)plan.atiles * batch, 4), 256, 0, s>>>(w.fmap, plan.fstride, plan.atiles,
+                                                                                       batch, w.tstate);
+  vw_assign_kernel<<<(unsigned)(plan.atiles * batch), kVwAssignThreads, 0, s>>>(
+      w.fmap, w.finfo, plan.fstride, plan.atiles, batch, w.tstate, max_voxels, vg, w.vinfo, w.totals, coords, num_pts,
+      coors4);
+  const int64_t row = (int64_t)max_pts * dim;
+  const bool vec4 = (row % 4 == 0) && (reinterpret_cast<uintptr_t>(voxels) % 16 == 0);
+  const int rowq = (int)(vec4 ? row / 4 : row);
+  const int units = (int)ceil_div((int64_t)max_voxels * rowq, kVtRowsThreads * kVtRowsIlp);
+  const int step_v = kVtRowsThreads / rowq, step_j = kVtRowsThreads % rowq;
+  if (dim == 4 || dim == 5) {
+    const int64_t slots = (int64_t)max_voxels * max_pts;
+    const int sunits = (int)ceil_div(slots, kVwRowsThreads);
+#define PD3_VW_ROWS(D)                                                                                            \
+  vw_rows_kernel<D><<<(unsigned)(sunits * batch), kVwRowsThreads, 0, s>>>(                                   \
+      points, n, w.clist, w.cap, w.vinfo, w.totals, batch, sunits, max_voxels, max_pts, voxels, coords, num_pts,   \
+      num_voxels, coors4)
+    if (dim == 4) PD3_VW_ROWS(4);
+    else PD3_VW_ROWS(5);
+#undef PD3_VW_ROWS
+    return launch_status();
+  }
+  if (vec4)
+    vt_rows_gather_kernel<4><<<(unsigned)(units * batch), kVtRowsThreads, 0, s>>>(
+        points, n, w.clist, w.cap, w.vinfo, w.totals, batch, units, max_voxels, rowq, step_v, step_j, dim, voxels,
+        coords, num_pts, num_voxels, coors4);
+  else
+    vt_rows_gather_kernel<1><<<(unsigned)(units * batch), kVtRowsThreads, 0, s>>>(
+        points, n, w.clist, w.cap, w.vinfo, w.totals, batch, units, max_voxels, rowq, step_v, step_j, dim, voxels,
+        coords, num_pts, num_voxels, coors4);
+  return launch_status();
+}
+
 }  // namespace pd3
 
 using namespace pd3;
@@ -339,6 +435,11 @@ extern "C" size_t pd3_hard_voxelize_workspace(int batch, int64_t max_points, int
   if (tiled_applicable(g, max_points, num_point_dim, max_num_points_in_voxel, max_voxels, vp))
     bytes = std::max(bytes, vt_carve(nullptr, batch, max_points, num_point_dim, max_num_points_in_voxel, max_voxels,
                                      g.ncells, vp).bytes);
+  for (int shape = -1; shape < kVwShapes; ++shape) {
+    VwPlan wp;
+    if (wave_applicable(g, max_points, num_point_dim, max_num_points_in_voxel, max_voxels, batch, shape, wp))
+      bytes = std::max(bytes, vw_carve(nullptr, batch, max_points, max_voxels, wp).bytes);
+  }
   return bytes;
 }
 
@@ -355,13 +456,26 @@ extern "C" int pd3_hard_voxelize_path(const float* points, const int32_t* num_po
   if (batch <= 0 || max_points <= 0 || max_points >= ((int64_t)1 << 31) || num_point_dim < 3 ||
       max_num_points_in_voxel <= 0 || max_voxels <= 0)
     return PD3_EINVAL;
-  if (!make_grid(voxel_size, point_cloud_range, g) || path < 0 || path > 3) return PD3_EINVAL;
+  if (!make_grid(voxel_size, point_cloud_range, g) || path < 0 || path > 5 + kVwShapes) return PD3_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t n = max_points;
   if (workspace_bytes < pd3_hard_voxelize_workspace(batch, max_points, num_point_dim, voxel_size,
                                                     point_cloud_range, max_num_points_in_voxel,
                                                     max_voxels))
     return PD3_EWORKSPACE;
+  if (path >= 5) {  // wave form: 5 = shape chosen from the sizes, 6 .. = route-kernel shape forced (measurement)
+    VwPlan wp;
+    if (!wave_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, batch, path - 6, wp))
+      return PD3_EUNSUPPORTED;
+    return run_wave(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel, max_voxels, wp, voxels,
+                    coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s);
+  }
+  if (path == 0) {  // the library's choice: wave form, else the tiled gather form, else the sort path
+    VwPlan wp;
+    if (wave_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, batch, -1, wp))
+      return run_wave(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel, max_voxels, wp, voxels,
+                      coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s);
+  }
   {
     VtPlan vp;
     const bool can = tiled_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, vp);

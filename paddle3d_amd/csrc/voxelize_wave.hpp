@@ -1,0 +1,555 @@
+// hard_voxelize, "wave" form of the tiled path (path 5): the same order-independent restatement as
+// voxelize_tiled.hpp (voxel id of a cell = rank of its first point among all first points; slot of a point =
+// number of earlier points in its cell), restructured around what the round-2 measurements charged for:
+//
+//   * the group kernel of the tiled path (one 256-thread workgroup per 4096 cells) was one round of workgroups
+//     whose time was a workgroup's latency chain: barriers, a prefix over the four waves' count tables, a step
+//     table in which a step never crossed a run boundary.  Here a group is 1024 cells (or fewer) and belongs to
+//     ONE WAVE: no barrier, no cross-wave prefix, the wave's record stream cut into exact 64-record steps
+//     (the tile a record comes from is found by a binary search over the group's directory column in LDS),
+//     sixteen independent waves per CU hide each other's latency.
+//   * pos16 / cposr (6 bytes per point, written and re-read) are gone: a cell's first point announces itself
+//     by index -- one byte in a per-point map plus an 8-byte record (place of the cell's points in the index
+//     list, count, cell) -- and voxel ids are a prefix over that byte map in point order, taken tile by tile
+//     with a look-back over the earlier tiles' published counts (no atomics, no second launch).
+//
+//   A  vw_route_kernel    as vt_route_kernel (tile of THREADS * R points sorted by group in LDS, one coalesced
+//                         slice + directory row), minus pos16; clears the first-point map, the look-back
+//                         states and vinfo.
+//   B  vw_group_kernel    one wave per group: directory column -> prefix; sweep 1 hands out slots (returning
+//                         LDS adds, lane order = point order) and counts; cells are placed in the group's region
+//                         of the index list; sweep 2 writes clist[place] = point index for the kept points and
+//                         the first-point records.  Groups of up to kVwRegSteps * 64 records keep (record, slot)
+//                         in registers between the sweeps; longer ones walk their records twice.
+//   C  vw_assign_kernel   prefix over the first-point bytes = voxel id; vinfo / coords / counts of the voxels a
+//                         tile opens.
+//   E  vt_rows_gather_kernel (voxelize_tiled.hpp), unchanged: the fixed-shape output written once.
+// Preconditions (else the other paths run): cells <= 2^20, groups <= 1024 per frame, N < 2^22 - 3, P <= 254.
+#pragma once
+#include "voxelize_tiled.hpp"
+
+namespace pd3 {
+
+constexpr int kVwMaxLow = 10;       // cells per group <= 1024: two 4 KB tables per wave, sixteen waves per CU
+constexpr int kVwAssignTile = 4096;  // points per workgroup of the assign kernel (256 threads x 16 bytes)
+constexpr int kVwAssignThreads = 256;
+constexpr uint32_t kVwReady = 0x80000000u;
+
+struct VwPlan {
+  int low, cpg, groups, gbits;
+  int threads, rounds, tile, tiles;  // route kernel shape
+  int atiles;                        // assign tiles per frame
+  int64_t fstride;                   // per-frame length of the per-point arrays (multiple of kVwAssignTile)
+  bool ok;
+};
+
+// Route-kernel shape: the tile is THREADS * R points.  Longer tiles mean longer runs per (tile, group) and a
+// shorter directory column; what decides is how the tile count fills the workgroup slots of the chip
+// (256 CUs x 2048 threads): a last round that is mostly empty costs a whole round.
+static inline VwPlan vw_plan(uint32_t ncells, int64_t n, int max_pts, int batch, int shape) {
+  VwPlan p{};
+  int bits = 0;
+  while (((int64_t)1 << bits) < (int64_t)ncells) ++bits;
+  p.low = std::max(std::min(bits - 2, kVwMaxLow), 0);
+  while (p.low > 0 && n >= ((int64_t)1 << (32 - p.low)) - 1) --p.low;
+  p.gbits = std::max(bits - p.low, 2);
+  p.groups = 1 << p.gbits;
+  p.cpg = 1 << p.low;
+  struct Shape { int threads, rounds; };
+  static const Shape shapes[] = {{512, 8}, {1024, 8}, {1024, 10}, {512, 10}, {1024, 5}};
+  const int nshapes = (int)(sizeof(shapes) / sizeof(shapes[0]));
+  int pick = shape;
+  if (pick < 0 || pick >= nshapes) {
+    // fewest rounds of the chip, then the longer tile
+    double best = 1e30;
+    pick = 0;
+    for (int k = 0; k < 3; ++k) {
+      const int64_t tile = (int64_t)shapes[k].threads * shapes[k].rounds;
+      const int64_t wgs = ceil_div(n, tile) * batch;
+      const int64_t slots = 256 * (2048 / shapes[k].threads);
+      const double cost = (double)ceil_div(wgs, slots) * (double)tile + (wgs < 256 ? 1e-3 * (double)tile : 0.0);
+      if (cost < best) {
+        best = cost;
+        pick = k;
+      }
+    }
+  }
+  p.threads = shapes[pick].threads;
+  p.rounds = shapes[pick].rounds;
+  p.tile = p.threads * p.rounds;
+  p.tiles = (int)ceil_div(n, p.tile);
+  p.fstride = (int64_t)align_up((size_t)p.tiles * p.tile, kVwAssignTile);
+  p.atiles = (int)(p.fstride / kVwAssignTile);
+  p.ok = bits <= 20 && p.gbits <= kVtMaxGbits && p.tiles <= kVtMaxTiles && p.atiles <= 4096 &&
+         n < (int64_t)kVtCpMask - 1 && max_pts <= kVtMaxPts;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------ A
+template <int THREADS, int R>
+__global__ __launch_bounds__(THREADS, 8) void vw_route_kernel(
+    const float* __restrict__ points, const int32_t* __restrict__ num_points, int64_t n, int dim, VtGrid g, int low,
+    int gbits, int tiles, int batch, int max_voxels, uint32_t* __restrict__ recs, uint32_t* __restrict__ dir,
+    unsigned char* __restrict__ fmap, int64_t fstride, uint32_t* __restrict__ tstate, int atiles,
+    uint2* __restrict__ vinfo) {
+  constexpr int kTile = THREADS * R;
+  constexpr int kWaves = THREADS / kWave;
+  extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
+  const int groups = 1 << gbits;
+  uint32_t* stage = reinterpret_cast<uint32_t*>(vt_smem);                      // [kTile]
+  uint32_t* cnt_all = stage + kTile;                                           // [waves][groups]
+  int* scan_tmp = reinterpret_cast<int*>(cnt_all + (size_t)kWaves * groups);   // [waves + 1]
+  int frame, tile;
+  vt_unit(blockIdx.x, (uint32_t)tiles, (uint32_t)batch, frame, tile);
+  const int lane = lane_id(), wave = wave_id();
+  uint32_t* cnt = cnt_all + (size_t)wave * groups;
+  const int64_t nf = num_points ? min((int64_t)num_points[frame], n) : n;
+
+  for (int d = lane; d < groups; d += kWave) cnt[d] = 0u;
+  vt_wave_sync();
+  {  // this tile's share of the arrays the later kernels expect clear
+    const int per = (int)ceil_div(max_voxels, tiles);
+    const int v1 = min((tile + 1) * per, max_voxels);
+    for (int v = tile * per + (int)threadIdx.x; v < v1; v += THREADS)
+      vinfo[(int64_t)frame * max_voxels + v] = make_uint2(0u, 0u);
+    const int64_t q = fstride / 16, perq = ceil_div(q, tiles);
+    uint4* fm = reinterpret_cast<uint4*>(fmap + (int64_t)frame * fstride);
+    const int64_t q1 = min((int64_t)(tile + 1) * perq, q);
+    for (int64_t j = (int64_t)tile * perq + threadIdx.x; j < q1; j += THREADS) fm[j] = make_uint4(0u, 0u, 0u, 0u);
+    const int pera = (int)ceil_div(atiles, tiles);
+    const int a1 = min((tile + 1) * pera, atiles);
+    for (int a = tile * pera + (int)threadIdx.x; a < a1; a += THREADS) tstate[(int64_t)frame * atiles + a] = 0u;
+  }
+
+  // phase 1: keys; rank of a point among the wave's earlier points of its group (returning LDS add, lane order)
+  const float* pf = points + (int64_t)frame * n * dim;
+  const int64_t wave_base = (int64_t)tile * kTile + (int64_t)wave * (R * kWave);
+  VtXyz p[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t i = wave_base + r * kWave + lane;
+    p[r].x = p[r].y = p[r].z = __builtin_nanf("");
+    if (i < nf) __builtin_memcpy(&p[r], pf + i * dim, sizeof(VtXyz));
+  }
+  uint32_t key[R], ord[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    uint32_t cellkey = 0, grp = 0, local = 0;
+    key[r] = 0xFFFFFFFFu;
+    ord[r] = 0;
+    if (vt_cell_key(p[r].x, p[r].y, p[r].z, g, cellkey)) {
+      vt_key_to_group(cellkey, gbits, grp, local);
+      key[r] = (grp << low) | local;
+      ord[r] = atomicAdd(&cnt[grp], 1u);
+    }
+  }
+  __syncthreads();
+  // phase 2: tile-level offsets, groups spread over the threads (two per thread: groups <= 2 * THREADS)
+  int tile_total;
+  {
+    const int d0 = threadIdx.x * 2;
+    int c0 = 0, c1 = 0;
+    if (d0 < groups) {
+      for (int w = 0; w < kWaves; ++w) c0 += (int)cnt_all[(size_t)w * groups + d0];
+      for (int w = 0; w < kWaves; ++w) c1 += (int)cnt_all[(size_t)w * groups + d0 + 1];
+    }
+    const int ex = block_exclusive_scan<THREADS>(c0 + c1, scan_tmp, tile_total);
+    if (d0 < groups) {
+      *reinterpret_cast<uint2*>(dir + ((int64_t)frame * tiles + tile) * groups + d0) =
+          make_uint2((uint32_t)ex | ((uint32_t)c0 << 16), (uint32_t)(ex + c0) | ((uint32_t)c1 << 16));
+      uint32_t acc = (uint32_t)ex;
+      for (int w = 0; w < kWaves; ++w) {
+        const uint32_t c = cnt_all[(size_t)w * groups + d0];
+        cnt_all[(size_t)w * groups + d0] = acc;
+        acc += c;
+      }
+      for (int w = 0; w < kWaves; ++w) {
+        const uint32_t c = cnt_all[(size_t)w * groups + d0 + 1];
+        cnt_all[(size_t)w * groups + d0 + 1] = acc;
+        acc += c;
+      }
+    }
+  }
+  __syncthreads();
+  // phase 3: records into the LDS slice, grouped and stable
+  const uint32_t low_mask = (1u << low) - 1u;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t k = key[r];
+    const int64_t i = wave_base + r * kWave + lane;
+    if (k != 0xFFFFFFFFu) stage[cnt[k >> low] + ord[r]] = ((uint32_t)i << low) | (k & low_mask);
+  }
+  __syncthreads();
+  // phase 4: the slice leaves as one coalesced run
+  uint32_t* out = recs + ((int64_t)frame * tiles + tile) * kTile;
+  for (int j = threadIdx.x; j < tile_total; j += THREADS) out[j] = stage[j];
+}
+
+// ------------------------------------------------------------------------------------------------ B
+constexpr int kVwRegSteps = 40;  // groups of up to 2560 records keep (record, slot) in registers between the sweeps
+constexpr int kVwChunk = 8;      // steps whose searches, loads and LDS adds are issued back to back
+
+static inline int vw_pow2_above(int tiles) {  // entries of the padded directory prefix: a power of two > tiles
+  int tp = 2;
+  while (tp < tiles + 1) tp <<= 1;
+  return tp;
+}
+static inline size_t vw_group_lds(int cpg, int tiles) { return ((size_t)2 * cpg + (size_t)2 * vw_pow2_above(tiles)) * 4; }
+
+// the tile whose run holds record r of the group's stream: the last t with pre[t] <= r (pre is padded with
+// 0xFFFFFFFF up to a power of two; empty tiles repeat their successor's value and are skipped by "last")
+__device__ __forceinline__ uint32_t vw_tile_of(const uint32_t* pre, int tp, uint32_t r) {
+  uint32_t t = 0;
+  for (int st = tp >> 1; st > 0; st >>= 1) {
+    const uint32_t c = t + (uint32_t)st;
+    if (pre[c] <= r) t = c;
+  }
+  return t;
+}
+
+// A wave's time here is a chain of latencies (LDS search -> global load -> returning LDS add), and the kernel lasts
+// as long as its heaviest group (about twice the mean on a nuScenes frame), so everything that does not depend on
+// each other is issued together: the searches of eight steps, then their loads, then their adds (which the LDS
+// executes in program order: that order is the slot order).
+__global__ __launch_bounds__(kWave) void vw_group_kernel(
+    const uint32_t* __restrict__ recs, const uint32_t* __restrict__ dir, int low, int gbits, int tiles, int tile_len,
+    int tp, int batch, int max_pts, uint32_t* __restrict__ clist, int64_t cap, unsigned char* __restrict__ fmap,
+    uint2* __restrict__ finfo, int64_t fstride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
+  const int cpg = 1 << low, groups = 1 << gbits;
+  uint32_t* A = reinterpret_cast<uint32_t*>(vt_smem);  // [cpg] (kept << 24) | place of the cell in the region
+  uint32_t* B = A + cpg;                               // [cpg] records of the cell so far
+  uint32_t* pre = B + cpg;                             // [tp]  records of the group before tile t
+  uint32_t* tsrc = pre + tp;                           // [tp]  routed position of the group's run in tile t
+  int frame, grp;
+  vt_unit(blockIdx.x, (uint32_t)groups, (uint32_t)batch, frame, grp);
+  const int lane = threadIdx.x;
+
+  // directory column -> prefix of the run lengths; the group's region of the index list is sized by its record
+  // count and starts at the sum of its offsets inside the tiles' slices (no global counter)
+  const uint32_t* dcol = dir + (int64_t)frame * tiles * groups + grp;
+  uint32_t d0 = lane < tiles ? dcol[(int64_t)lane * groups] : 0u;  // in flight while the tables are cleared
+  for (int c = lane; c < cpg; c += kWave) {
+    A[c] = 0u;
+    B[c] = 0u;
+  }
+  uint32_t total = 0, region = 0;
+  for (int t0 = 0; t0 < tp; t0 += kWave) {
+    const int t = t0 + lane;
+    const uint32_t d = t0 == 0 ? d0 : (t < tiles ? dcol[(int64_t)t * groups] : 0u);
+    const uint32_t c = d >> 16, off = d & 0xFFFFu;
+    const uint32_t inc = (uint32_t)wave_inclusive_scan((int)c);
+    if (t < tp) {
+      pre[t] = t <= tiles ? total + inc - c : 0xFFFFFFFFu;
+      tsrc[t] = (uint32_t)t * (uint32_t)tile_len + off;
+    }
+    total += (uint32_t)__shfl((int)inc, kWave - 1, kWave);
+    uint32_t o = off;
+#pragma unroll
+    for (int dd = 1; dd < kWave; dd <<= 1) o += (uint32_t)__shfl_xor((int)o, dd, kWave);
+    region += o;
+  }
+  vt_wave_sync();
+  if (total == 0u) return;
+
+  const uint32_t* rf = recs + (int64_t)frame * tiles * tile_len;
+  uint32_t* cl = clist + (int64_t)frame * cap + region;
+  unsigned char* fm = fmap + (int64_t)frame * fstride;
+  uint2* fi = finfo + (int64_t)frame * fstride;
+  const uint32_t cell_mask = (uint32_t)cpg - 1u;
+  const int nsteps = (int)((total + 63u) >> 6);
+  const bool in_regs = nsteps <= kVwRegSteps;
+  const uint32_t P = (uint32_t)max_pts;
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+  // records 64 s .. 64 s + 63 of the group's stream (input order), one per lane: where they lie in the routed
+  // slices.  Lanes past the end name record 0 of the frame (a mapped address; they are masked by `slot`).
+  auto source = [&](int s) -> uint32_t {
+    const uint32_t r = (uint32_t)s * kWave + (uint32_t)lane;
+    const uint32_t t = vw_tile_of(pre, tp, r);
+    return r < total ? tsrc[t] + (r - pre[t]) : 0u;
+  };
+  // what a kept / first point leaves behind (direct form: the walk of a group too long for the registers)
+  auto emit = [&](uint32_t rec, uint32_t slot) {
+    const uint32_t cell = rec & cell_mask, info = A[cell];
+    const uint32_t place = info & 0xFFFFFFu, idx = rec >> low;
+    if (slot < P) cl[place + slot] = idx;  // (a lane without a record carries slot = kNone)
+    if (slot == 0u) {
+      fm[idx] = (unsigned char)1;
+      fi[idx] = make_uint2((region + place) | (info & 0xFF000000u), vt_group_to_key((uint32_t)grp, cell, gbits));
+    }
+  };
+  // eight steps: sources, records, slots (or only the counts) -- the walk of a group too long for the registers
+  auto chunk = [&](int s0, uint32_t* rec, uint32_t* slot, bool want_slots) {
+#pragma unroll
+    for (int k = 0; k < kVwChunk; ++k) rec[k] = source(s0 + k);
+#pragma unroll
+    for (int k = 0; k < kVwChunk; ++k) rec[k] = rf[rec[k]];
+#pragma unroll
+    for (int k = 0; k < kVwChunk; ++k) {
+      const bool valid = (uint32_t)(s0 + k) * kWave + (uint32_t)lane < total;
+      // lanes without a record add 0 to the cell of the record they re-read (a word of the table: harmless)
+      if (want_slots) {
+        const uint32_t old = atomicAdd(&B[rec[k] & cell_mask], valid ? 1u : 0u);
+        slot[k] = valid ? old : kNone;
+      } else {
+        atomicAdd(&B[rec[k] & cell_mask], valid ? 1u : 0u);
+      }
+    }
+  };
+
+  uint32_t rec[kVwRegSteps], slot[kVwRegSteps];
+  // sweep 1: slots and counts.  In registers: ALL searches (level by level across the steps: a search loop per
+  // step would be forty chains of dependent LDS reads one after the other), then ALL loads, then ALL adds.
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < kVwRegSteps; ++k) rec[k] = 0u;
+    for (int st = tp >> 1; st > 0; st >>= 1) {
+#pragma unroll
+      for (int s0 = 0; s0 < kVwRegSteps; s0 += kVwChunk) {
+        if (s0 < nsteps) {
+          uint32_t pv[kVwChunk];
+#pragma unroll
+          for (int k = 0; k < kVwChunk; ++k) pv[k] = pre[rec[s0 + k] + (uint32_t)st];
+#pragma unroll
+          for (int k = 0; k < kVwChunk; ++k)
+            if (pv[k] <= (uint32_t)(s0 + k) * kWave + (uint32_t)lane) rec[s0 + k] += (uint32_t)st;
+        }
+      }
+    }
+#pragma unroll
+    for (int s0 = 0; s0 < kVwRegSteps; s0 += kVwChunk) {
+      if (s0 < nsteps) {
+        uint32_t ts[kVwChunk], pt[kVwChunk];
+#pragma unroll
+        for (int k = 0; k < kVwChunk; ++k) {
+          ts[k] = tsrc[rec[s0 + k]];
+          pt[k] = pre[rec[s0 + k]];
+        }
+#pragma unroll
+        for (int k = 0; k < kVwChunk; ++k) {
+          const uint32_t r = (uint32_t)(s0 + k) * kWave + (uint32_t)lane;
+          rec[s0 + k] = rf[r < total ? ts[k] + (r - pt[k]) : 0u];
+        }
+      }
+    }
+#pragma unroll
+    for (int s0 = 0; s0 < kVwRegSteps; s0 += kVwChunk) {
+      if (s0 < nsteps) {
+#pragma unroll
+        for (int k = 0; k < kVwChunk; ++k) {
+          const bool valid = (uint32_t)(s0 + k) * kWave + (uint32_t)lane < total;
+          const uint32_t old = atomicAdd(&B[rec[s0 + k] & cell_mask], valid ? 1u : 0u);
+          slot[s0 + k] = valid ? old : kNone;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < kVwChunk; ++k) slot[s0 + k] = kNone;
+      }
+    }
+  } else {
+    for (int s0 = 0; s0 < nsteps; s0 += kVwChunk) {
+      uint32_t r8[kVwChunk], s8[kVwChunk];
+      chunk(s0, r8, s8, false);
+    }
+  }
+  vt_wave_sync();
+  // cells -> places in the group's region (any order will do: the list is scratch).  Lane l takes cells l, l + 64, ...
+  uint32_t kept_total;
+  {
+    uint32_t cnt[1 << (kVwMaxLow - 6)];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < (1 << (kVwMaxLow - 6)); ++j) {
+      const int c = lane + j * kWave;
+      cnt[j] = c < cpg ? min(B[c], P) : 0u;
+      sum += cnt[j];
+    }
+    const uint32_t inc = (uint32_t)wave_inclusive_scan((int)sum);
+    kept_total = (uint32_t)__shfl((int)inc, kWave - 1, kWave);
+    uint32_t at = inc - sum;
+#pragma unroll
+    for (int j = 0; j < (1 << (kVwMaxLow - 6)); ++j) {
+      const int c = lane + j * kWave;
+      if (c < cpg) {
+        A[c] = (cnt[j] << 24) | at;
+        B[c] = 0u;
+      }
+      at += cnt[j];
+    }
+  }
+  vt_wave_sync();
+  // sweep 2: the index list and the first-point records.  From registers, the list is first put together in LDS
+  // (B is free now: a scattered 4-byte store to memory costs as much as streaming 40 bytes) and leaves coalesced;
+  // what does not fit B goes to memory directly.
+  if (in_regs) {
+#pragma unroll
+    for (int s0 = 0; s0 < kVwRegSteps; s0 += kVwChunk) {
+      if (s0 < nsteps) {
+        uint32_t info[kVwChunk];
+#pragma unroll
+        for (int k = 0; k < kVwChunk; ++k) info[k] = A[rec[s0 + k] & cell_mask];
+#pragma unroll
+        for (int k = 0; k < kVwChunk; ++k) {
+          const uint32_t sl = slot[s0 + k], idx = rec[s0 + k] >> low;
+          const uint32_t pos = (info[k] & 0xFFFFFFu) + sl;
+          if (sl < P) {
+            if (pos < (uint32_t)cpg) B[pos] = idx;
+            else cl[pos] = idx;
+          }
+          if (sl == 0u) {
+            fm[idx] = (unsigned char)1;
+            fi[idx] = make_uint2((region + (info[k] & 0xFFFFFFu)) | (info[k] & 0xFF000000u),
+                                 vt_group_to_key((uint32_t)grp, rec[s0 + k] & cell_mask, gbits));
+          }
+        }
+      }
+    }
+    vt_wave_sync();
+    const uint32_t staged = min(kept_total, (uint32_t)cpg);
+    for (uint32_t i = (uint32_t)lane; i < staged; i += kWave) cl[i] = B[i];
+  } else {
+    for (int s0 = 0; s0 < nsteps; s0 += kVwChunk) {
+      uint32_t r8[kVwChunk], s8[kVwChunk];
+      chunk(s0, r8, s8, true);
+#pragma unroll
+      for (int k = 0; k < kVwChunk; ++k) emit(r8[k], s8[k]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ C
+// Voxel id of a first point = number of first points before it = (first points of the earlier 4096-point tiles)
+// + (earlier ones in its tile).  Two small launches: vw_count_kernel (one wave per tile: 64 bytes of the map per lane)
+// and vw_assign_kernel (one workgroup per tile: 16 bytes per thread, a workgroup scan, the earlier tiles' counts
+// summed by the lanes).  Tried first and dropped: a look-back over counts published by the earlier tiles' workgroups
+// (49 us: a thousand workgroups polling a few cache lines keep the publishing stores waiting), and every workgroup
+// counting the bytes in front of its tile itself (16-25 us: the loop's registers halve the occupancy and the last
+// tiles read the whole map).
+__global__ __launch_bounds__(256) void vw_count_kernel(const unsigned char* __restrict__ fmap, int64_t fstride,
+                                                       int atiles, int batch, uint32_t* __restrict__ tcount) {
+  const int w = (int)blockIdx.x * 4 + wave_id();  // tile number over the whole batch
+  if (w >= atiles * batch) return;
+  const int frame = w / atiles, tile = w - frame * atiles;
+  const uint4* fq = reinterpret_cast<const uint4*>(fmap + (int64_t)frame * fstride + (int64_t)tile * kVwAssignTile);
+  uint4 a[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a[k] = fq[lane_id() + k * kWave];
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c += __popc(a[k].x) + __popc(a[k].y) + __popc(a[k].z) + __popc(a[k].w);  // bytes are 0 or 1
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) c += __shfl_xor(c, d, kWave);
+  if (lane_id() == 0) tcount[w] = (uint32_t)c;
+}
+
+__global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
+    const unsigned char* __restrict__ fmap, const uint2* __restrict__ finfo, int64_t fstride, int atiles,
+    int batch, const uint32_t* __restrict__ tcount, int max_voxels, VtGrid g, uint2* __restrict__ vinfo,
+    int* __restrict__ totals, int32_t* __restrict__ coords, int32_t* __restrict__ num_pts,
+    int32_t* __restrict__ coors4) {
+  __shared__ int scan_tmp[kVwAssignThreads / kWave + 2];
+  __shared__ int s_before[kVwAssignThreads / kWave];
+  int frame, tile;
+  vt_unit(blockIdx.x, (uint32_t)atiles, (uint32_t)batch, frame, tile);
+  const int64_t base_i = (int64_t)tile * kVwAssignTile + (int64_t)threadIdx.x * 16;
+  const uint4 w = *reinterpret_cast<const uint4*>(fmap + (int64_t)frame * fstride + base_i);
+  int before = 0;
+  for (int t = threadIdx.x; t < tile; t += kVwAssignThreads) before += (int)tcount[(int64_t)frame * atiles + t];
+  const uint32_t word[4] = {w.x, w.y, w.z, w.w};
+  const int mine = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+  int tile_new;
+  int local = block_exclusive_scan<kVwAssignThreads>(mine, scan_tmp, tile_new);
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) before += __shfl_xor(before, d, kWave);
+  if (lane_id() == 0) s_before[wave_id()] = before;
+  __syncthreads();
+  int vid = local;
+#pragma unroll
+  for (int k = 0; k < kVwAssignThreads / kWave; ++k) vid += s_before[k];
+  if (tile == atiles - 1 && threadIdx.x == kVwAssignThreads - 1) totals[frame] = vid + mine;
+  if (mine == 0 || vid >= max_voxels) return;
+  // the thread's flagged points: predicated loads of their records, all sixteen in flight together (a load inside
+  // the loop that hands out the ids is a chain of dependent round trips), then their rows (consecutive ids;
+  // neighbouring threads continue them)
+  const uint2* fi = finfo + (int64_t)frame * fstride + base_i;
+  uint2 fr[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    fr[b] = make_uint2(0u, 0u);
+    if ((word[b >> 2] >> (8 * (b & 3))) & 1u) fr[b] = fi[b];
+  }
+  const float inv_gx = 1.0f / (float)g.gx, inv_gy = 1.0f / (float)g.gy;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    if (((word[b >> 2] >> (8 * (b & 3))) & 1u) && vid < max_voxels) {
+      const int64_t row = (int64_t)frame * max_voxels + vid;
+      const uint32_t kept = fr[b].x >> 24, key = fr[b].y;
+      vinfo[row] = make_uint2(fr[b].x & 0xFFFFFFu, kept);
+      const uint32_t t = vt_div(key, (uint32_t)g.gx, inv_gx);
+      const int cx = (int)(key - t * (uint32_t)g.gx);
+      const uint32_t cz = vt_div(t, (uint32_t)g.gy, inv_gy);
+      const int cy = (int)(t - cz * (uint32_t)g.gy);
+      const VtInt3 c3{(int)cz, cy, cx};
+      __builtin_memcpy(coords + row * 3, &c3, sizeof(c3));
+      num_pts[row] = (int)kept;
+      if (coors4) *reinterpret_cast<int4*>(coors4 + row * 4) = make_int4(frame, (int)cz, cy, cx);
+      ++vid;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ E
+// Row writer of the wave form.  vt_rows_gather_kernel gives a lane four consecutive floats of the flat output and
+// spends ~170 instructions per float4 on finding out whose they are (the row writer was instruction bound: 1370
+// issued instructions per eight float4s, wave64 instructions issue over several cycles); here a lane owns one
+// (voxel, point slot): one index load, the point's D floats as one 16-byte + one 4-byte load (4-byte aligned, which
+// is all global_load_dwordx4 asks for), the same two stores into the row -- lanes of consecutive slots write
+// consecutive pieces, a wave writes one contiguous 64 * D * 4 bytes.  D = 4 / 5 (else the float4 form runs).
+// 51 -> 47 us: what is left is the gather itself, 2.15 M random 20-byte reads at the ~57 G/s this machine serves
+// them at (tools/hwcheck/memrates).  Tried on top and dropped: clearing the tensor with a fill on a second stream
+// while the ranking kernels run and storing only the slots that hold a point (the row writer alone 47 -> 39 us, but
+// the fill slows the kernels it runs beside by more than that: 125 -> 136 us).
+constexpr int kVwRowsThreads = 256;
+
+template <int D>
+__global__ __launch_bounds__(kVwRowsThreads) void vw_rows_kernel(
+    const float* __restrict__ points, int64_t n, const uint32_t* __restrict__ clist, int64_t cap,
+    const uint2* __restrict__ vinfo, const int* __restrict__ totals, int batch, int units, int max_voxels, int max_pts,
+    float* __restrict__ voxels, int32_t* __restrict__ coords, int32_t* __restrict__ num_pts,
+    int32_t* __restrict__ num_voxels, int32_t* __restrict__ coors4) {
+  int frame, unit;
+  vt_unit(blockIdx.x, (uint32_t)units, (uint32_t)batch, frame, unit);
+  const uint32_t total_q = (uint32_t)max_voxels * (uint32_t)max_pts;
+  const uint32_t q = (uint32_t)unit * kVwRowsThreads + threadIdx.x;
+  if (q >= total_q) return;
+  const uint32_t v = vt_div(q, (uint32_t)max_pts, 1.0f / (float)max_pts);
+  const uint32_t slot = q - v * (uint32_t)max_pts;
+  const uint2 info = vinfo[(int64_t)frame * max_voxels + v];
+  const bool live = slot < info.y;
+  if (slot == 0u) {
+    const int nv = min(totals[frame], max_voxels);
+    if (v == 0u) num_voxels[frame] = nv;
+    if ((int)v >= nv) {  // padding rows of coords / count / coors4 (batch = -1)
+      const int64_t row = (int64_t)frame * max_voxels + v;
+      const VtInt3 z3{0, 0, 0};
+      __builtin_memcpy(coords + row * 3, &z3, sizeof(z3));
+      num_pts[row] = 0;
+      if (coors4) *reinterpret_cast<int4*>(coors4 + row * 4) = make_int4(-1, 0, 0, 0);
+    }
+  }
+  const uint32_t idx = live ? clist[(int64_t)frame * cap + info.x + slot] : 0u;
+  const float* src = points + ((int64_t)frame * n + idx) * D;
+  vt_f32x4u a = *reinterpret_cast<const vt_f32x4u*>(src);
+  float e = 0.f;
+  if (D == 5) e = src[4];
+  if (!live) {
+    a = vt_f32x4u{0.f, 0.f, 0.f, 0.f};
+    e = 0.f;
+  }
+  float* dst = voxels + ((int64_t)frame * total_q + q) * D;
+  __builtin_nontemporal_store(a, reinterpret_cast<vt_f32x4u*>(dst));
+  if (D == 5) __builtin_nontemporal_store(e, dst + 4);
+}
+
+}  // namespace pd3

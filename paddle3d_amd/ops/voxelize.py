@@ -23,8 +23,8 @@ def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max
     Returns voxels [B,V,P,D], coords [B,V,3], num_points_per_voxel [B,V], num_voxels [B] -- the
     reference's per-sample op results stacked (HardVoxelizer's python loop, voxelize.py:60-82).
     with_batch_coors=True additionally returns coors [B,V,4] = (batch, z, y, x), batch -1 on padding rows.
-    path: 0 automatic, 1 generic sort path, 2 tiled path (compact payload array), 3 tiled path (gathered rows)
-    (pd3_hard_voxelize_path; the tests run all of them).
+    path: 0 automatic, 1 generic sort path, 2 tiled path (compact payload array), 3 tiled path (gathered rows),
+    5 wave form of the tiled path (6 .. 10: route tile shape forced) (pd3_hard_voxelize_path; the tests run them).
     """
     pts = require_gpu(points, "hard_voxelize")
     if pts.dim() != 3:

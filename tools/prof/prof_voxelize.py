@@ -15,7 +15,8 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 v = int(sys.argv[2]) if len(sys.argv) > 2 else 30000
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 paths = [int(p) for p in sys.argv[4].split(",")] if len(sys.argv) > 4 else [2, 3]
-pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(100 + i) for i in range(batch)])).cuda()
+shuffle = len(sys.argv) > 5 and sys.argv[5] == "shuffle"
+pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(100 + i, shuffle=shuffle) for i in range(batch)])).cuda()
 args = (list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20, v)
 ref = voxelize.hard_voxelize_batch(pts, *args, with_batch_coors=True, path=1)
 alg = (4 * 300000 * 5 + 4 * v * 20 * 5 + 16 * v + 4) * batch
