@@ -256,15 +256,22 @@ def _timed_loop(step, args, world, dev, names):
         allr = torch.empty(world, dtype=torch.int64, device=dev)
         torch.distributed.all_gather_into_tensor(allr, mine)
         seen = int(torch.unique(allr).numel())
-    return dt, per_op_ms, out, dict(repeats_s=repeats, ranks_seen=seen)
+    info = dict(dt=dt, repeats_s=repeats, ranks_seen=seen)
+    _LAST_LOOP.clear()
+    _LAST_LOOP.update(info)
+    return dt, per_op_ms, out, info
 
 
-def _dist_fields(line, args, world, info, units_per_step):
+_LAST_LOOP = {}  # what the last _timed_loop saw (contract-block seconds, repeated blocks, ranks): main() adds it to the line
+
+
+def _dist_fields(line, args, world):
     """Fields every workload's line carries about the launch: ranks that took part, spread over repeated blocks."""
-    line["ranks_seen"] = info["ranks_seen"]
+    info = _LAST_LOOP
+    line["ranks_seen"] = info.get("ranks_seen", 1)
     line["collective_backend"] = (torch.distributed.get_backend() if world > 1 else None)
-    if info["repeats_s"]:
-        vals = sorted(world * units_per_step * args.steps / t for t in info["repeats_s"])
+    if info.get("repeats_s"):
+        vals = sorted(line["value"] * info["dt"] / t for t in info["repeats_s"])
         line.setdefault("extras", {})["repeat_blocks"] = dict(
             blocks=len(vals), steps_each=args.steps, unit=line["unit"], min=vals[0], median=vals[len(vals) // 2],
             max=vals[-1], note="the same K steps timed again after the contract block; `value` is the contract block")
@@ -764,7 +771,68 @@ def bench_bev_pool(args, rank, world, dev):
     }
 
 
-def main():
+def bench_stub(args, rank, world, dev):
+    """--stub-ops: the launch / timing / collective path of the default workload with the GPU ops replaced by a fixed
+    synthetic detection set on the CPU, so that `bench.py --gpus N` (self-launch, gloo, barriers, MAX over ranks,
+    all-gather inside the step) can be exercised without a GPU (tests/test_bench_dist_cpu.py).  The line it prints is
+    marked `stub` and is not a measurement."""
+    from paddle3d_amd import dist as pdist
+
+    B, max_per_img = args.batch, 500
+    g = torch.Generator().manual_seed(1234 + rank)
+    bx = torch.randn(B, 498, 9, generator=g)
+    sc = torch.rand(B, 498, generator=g)
+    lb = torch.randint(0, 10, (B, 498), generator=g)
+    cnt = torch.randint(1, 498, (B,), generator=g, dtype=torch.int32)
+    names = ["start", "ops_stub", "gather"]
+
+    def run(events):
+        if events is not None:
+            events[0].record()
+        time.sleep(0.002)  # stands for the device work of a step
+        if events is not None:
+            events[1].record()
+        rec = pdist.pack_records(bx, sc, lb, cnt, max_per_img)
+        out = pdist.gather_detections(rec, cnt)
+        if events is not None:
+            events[2].record()
+        return out
+
+    dt, per_op_ms, out, _info = _timed_loop(run, args, world, dev, names)
+    assert out[0].shape[0] == world * B and out[1].shape[0] == world * B
+    if rank != 0:
+        return None
+    return {"metric": "scenes/sec CenterPoint-Pillars nuScenes 300k-pt sweeps", "stub": True,
+            "value": world * B * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "STUB: no device ops; launch / collective path only", "frames_per_gpu_per_step": B,
+                       "parallelism": f"dp{world} (frames)"},
+            "per_op_ms": per_op_ms, "frames_gathered": int(out[1].shape[0])}
+
+
+def _self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script through torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1) and hand back its exit status."""
+    import socket
+    import subprocess
+
+    if not args.stub_ops:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node; refusing to "
+                             f"report a {args.gpus}-GPU number from fewer devices")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -775,34 +843,51 @@ def main():
                     choices=["centerpoint_pillars", "centerpoint_voxel", "bev_pool_v2", "bevfusion_lidar",
                              "pointpillars_kitti"])
     ap.add_argument("--vox-path", type=int, default=0, help="pd3_hard_voxelize_path selector (0 = library default, "
-                    "1 generic sort, 2 tiled with a compact payload array, 3 tiled with gathered rows)")
+                    "1 generic sort, 2 tiled with a compact payload array, 3 tiled with gathered rows, 5 wave form)")
     ap.add_argument("--graph", action="store_true", help="replay the step as five captured HIP graphs (one per op) "
                     "instead of launching every kernel from the host (centerpoint_pillars; same kernels and buffers)")
+    ap.add_argument("--repeats", type=int, default=None, help="time the same K steps this many more times after the "
+                    "contract block and report min / median / max (default 4 at N=1, 0 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the h2d-inclusive / batch-1 / ceiling measurements "
-                    "(profiling runs: only warm-up + timed steps are launched)")
-    args = ap.parse_args()
+                    "and the other workloads (profiling runs: only warm-up + timed steps are launched)")
+    ap.add_argument("--stub-ops", action="store_true", help="test hook: no device ops, launch / collective path only "
+                    "(CPU, gloo); the line is marked stub")
+    args = ap.parse_args(argv)
     if args.batch is None:
         args.batch = 2 if args.workload == "centerpoint_voxel" else 16
+    if args.repeats is None:
+        args.repeats = 4 if args.gpus == 1 else 0
+
+    # `python bench.py --gpus N` with no launcher around it: become the launcher
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_launch(args, argv))
 
     from paddle3d_amd import dist as pdist
-    from paddle3d_amd._lib import lib
 
-    rank, world, local = pdist.init_from_env()
-    if world != args.gpus and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP ops have no CPU path")
-    lib()  # fail loudly if libpaddle3d_amd.so is missing
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    torch.manual_seed(0)
+    rank, world, local = pdist.init_from_env("gloo" if args.stub_ops else None)
+    if world != args.gpus:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing "
+                         "to print a line whose n_gpus would not be what was asked for")
+    if args.stub_ops:
+        dev = torch.device("cpu")
+        line = bench_stub(args, rank, world, dev)
+    else:
+        from paddle3d_amd._lib import lib
 
-    fn = dict(centerpoint_pillars=bench_pillars, centerpoint_voxel=bench_voxel, bev_pool_v2=bench_bev_pool,
-              bevfusion_lidar=bench_bevfusion_lidar, pointpillars_kitti=bench_pointpillars_kitti)[args.workload]
-    line = fn(args, rank, world, dev)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP ops have no CPU path")
+        lib()  # fail loudly if libpaddle3d_amd.so is missing
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        torch.manual_seed(0)
+        fn = dict(centerpoint_pillars=bench_pillars, centerpoint_voxel=bench_voxel, bev_pool_v2=bench_bev_pool,
+                  bevfusion_lidar=bench_bevfusion_lidar, pointpillars_kitti=bench_pointpillars_kitti)[args.workload]
+        line = fn(args, rank, world, dev)
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(_dist_fields(line, args, world)))
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -147,6 +147,10 @@ int pd3_boxes_iou_bev(const float *boxes_a, int num_a, const float *boxes_b, int
                       float *ans_iou, void *stream);
 int pd3_boxes_overlap_bev(const float *boxes_a, int num_a, const float *boxes_b, int num_b,
                           float *ans_overlap, void *stream);
+/* Diagnostic: the float math routines the geometry / decode kernels use, over an array -- glibc's sinf / cosf / expf /
+ * atanf / atan2f bit for bit (csrc/libm_exact.hpp; what the reference's cos / sin / atan2 on floats call,
+ * iou3d_cpu.cpp:77-79,128-129).  op: 0 sinf(x), 1 cosf(x), 2 expf(x), 3 atanf(x), 4 atan2f(x, y).  x, y, out device. */
+int pd3_libm_eval(int op, const float *x, const float *y, float *out, int64_t n, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * centerpoint_postprocess -- replaces PD_BUILD_OP(centerpoint_postprocess),

@@ -409,3 +409,18 @@ void port_bev_pool_v2_bkwd(int c, int n_intervals, const float *out_grad, const 
     }
   }
 }
+
+/* the host libm's float routines over an array (what the reference's cos / sin / atan2 / exp on floats call):
+ * the tests hold the device's restatement (csrc/libm_exact.hpp) to them.  op as pd3_libm_eval. */
+void port_libm_eval(int op, const float *x, const float *y, float *out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    volatile float a = x[i];
+    switch (op) {
+      case 0: out[i] = sinf(a); break;
+      case 1: out[i] = cosf(a); break;
+      case 2: out[i] = expf(a); break;
+      case 3: out[i] = atanf(a); break;
+      default: out[i] = atan2f(a, y[i]); break;
+    }
+  }
+}

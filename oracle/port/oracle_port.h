@@ -49,6 +49,8 @@ void port_bev_pool_v2_bkwd(int c, int n_intervals, const float *out_grad, const 
                            const int32_t *interval_starts, const int32_t *interval_lengths,
                            float *depth_grad, float *feat_grad);
 
+void port_libm_eval(int op, const float *x, const float *y, float *out, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,15 @@ def boxes_overlap_bev(a, b, kind="port"):
     return out
 
 
+def libm_eval(op, x, y=None):
+    """The host libm's sinf / cosf / expf / atanf / atan2f (op 0..4) over float32 arrays."""
+    x = _c(x, _f)
+    y = _c(y if y is not None else x, _f)
+    out = np.empty_like(x)
+    _lib("port").port_libm_eval(C.c_int(op), _p(x), _p(y), _p(out), C.c_int64(x.size))
+    return out
+
+
 def nms(boxes, thresh, normal=False, kind="port"):
     """Greedy NMS over score-sorted boxes [N,7]; returns keep indices (int32 [num])."""
     bx = _c(boxes, _f)

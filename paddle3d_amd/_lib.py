@@ -45,6 +45,7 @@ _SIGNATURES = {
     "pd3_boxes_iou_bev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "pd3_boxes_overlap_bev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p]),
+    "pd3_libm_eval": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "pd3_centerpoint_postprocess_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pd3_centerpoint_postprocess": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

@@ -4,8 +4,9 @@
 // Arithmetic contract (what makes the keep indices match the CPU reference):
 //   * identical fp32 operation order for every product / sum (the library is built with
 //     -ffp-contract=off, so nothing below is fused into FMA);
-//   * sin / cos / atan2 are evaluated in fp64 and rounded to fp32 once, which reproduces the
-//     correctly rounded fp32 value -- what glibc's sinf/cosf return in all but ~1e-3 of arguments;
+//   * sin / cos / atan2 are glibc's cosf / sinf / atan2f bit for bit (libm_exact.hpp: the Arm Optimized Routines
+//     fp64 polynomials with the fused operations of glibc's x86-64 FMA build, fdlibm's float atan2f), which is
+//     what the reference's `cos(-box[6])` etc. on floats call (iou3d_cpu.cpp:77-79,128-129);
 //   * per-box quantities (corners, cos/sin of -heading, half extents + MARGIN) are computed once per
 //     box instead of once per pair: they are pure functions of the box, so the values are the same;
 //   * the centroid-angle bubble sort keeps the reference's comparison order (angles are computed once
@@ -14,6 +15,7 @@
 // disjoint: the reference finds no vertex for them and returns exactly 0.
 #pragma once
 #include "common.hpp"
+#include "libm_exact.hpp"
 
 namespace pd3 {
 
@@ -34,9 +36,10 @@ struct BoxPre {
   Pt c[4];           // rotated corners                            (:139-160)
 };
 
-__device__ __forceinline__ float cos_rn(float a) { return (float)cos((double)a); }
-__device__ __forceinline__ float sin_rn(float a) { return (float)sin((double)a); }
-__device__ __forceinline__ float atan2_rn(float y, float x) { return (float)atan2((double)y, (double)x); }
+// glibc's bits, not the correctly rounded value (libm_exact.hpp): the reference's cos / sin / atan2 on floats
+__device__ __forceinline__ float cos_rn(float a) { return lm::cosf(a); }
+__device__ __forceinline__ float sin_rn(float a) { return lm::sinf(a); }
+__device__ __forceinline__ float atan2_rn(float y, float x) { return lm::atan2f(y, x); }
 
 __device__ __forceinline__ BoxPre box_prepare(const float* b) {
   BoxPre p;

@@ -97,3 +97,29 @@ extern "C" int pd3_boxes_overlap_bev(const float* boxes_a, int num_a, const floa
                                      int num_b, float* ans_overlap, void* stream) {
   return run_pairwise<false>(boxes_a, num_a, boxes_b, num_b, ans_overlap, stream);
 }
+
+// Diagnostic entry point: the device's sinf / cosf / expf / atanf / atan2f (libm_exact.hpp) over an array, so that
+// the tests can hold them to glibc bit for bit on the GPU too.  op: 0 sinf, 1 cosf, 2 expf, 3 atanf, 4 atan2f(x, y).
+namespace pd3 {
+static __global__ void libm_eval_kernel(int op, const float* __restrict__ x, const float* __restrict__ y,
+                                        float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r;
+  switch (op) {
+    case 0: r = lm::sinf(x[i]); break;
+    case 1: r = lm::cosf(x[i]); break;
+    case 2: r = lm::expf(x[i]); break;
+    case 3: r = lm::atanf(x[i]); break;
+    default: r = lm::atan2f(x[i], y[i]); break;
+  }
+  out[i] = r;
+}
+}  // namespace pd3
+
+extern "C" int pd3_libm_eval(int op, const float* x, const float* y, float* out, int64_t n, void* stream) {
+  if (op < 0 || op > 4 || n < 0 || (n > 0 && (!x || !out || (op == 4 && !y)))) return PD3_EINVAL;
+  if (n == 0) return 0;
+  libm_eval_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(op, x, y, out, n);
+  return launch_status();
+}

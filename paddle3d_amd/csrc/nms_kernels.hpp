@@ -205,11 +205,12 @@ static __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned lo
   if (lane == 0) num_keep[set] = kept_total;
 }
 
-// dynamic LDS bytes for nms_sweep_kernel given the largest set size
+// dynamic LDS bytes for nms_sweep_kernel given the capacity of a set.  The kernel takes the LDS path for every
+// set of <= kNmsLdsBoxes boxes whatever the capacity (a launch with nms_pre_max_size = 4096 still has sets of a
+// few hundred candidates), so the matrix area is sized for min(cap, kNmsLdsBoxes) boxes.
 static inline size_t nms_sweep_lds(int cap) {
-  size_t b = (size_t)kNmsMaxWords * 8;
-  if (cap <= kNmsLdsBoxes) b += (size_t)cap * ((cap + 63) / 64) * 8;
-  return b;
+  const int c = cap < kNmsLdsBoxes ? cap : kNmsLdsBoxes;
+  return (size_t)kNmsMaxWords * 8 + (size_t)c * ((c + 63) / 64) * 8;
 }
 
 }  // namespace pd3

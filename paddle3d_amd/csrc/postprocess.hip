@@ -45,7 +45,7 @@ struct CpCfg {
   float score_threshold;
 };
 
-__device__ __forceinline__ float exp_rn(float x) { return (float)exp((double)x); }
+__device__ __forceinline__ float exp_rn(float x) { return lm::expf(x); }  // glibc's bits (libm_exact.hpp)
 
 __global__ __launch_bounds__(256) void cp_decode_kernel(CpHeads h, CpCfg c, float* __restrict__ boxes,
                                                         float* __restrict__ scores,

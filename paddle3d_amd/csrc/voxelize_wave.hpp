@@ -44,8 +44,7 @@ struct VwPlan {
 };
 
 // Route-kernel shape: the tile is THREADS * R points.  Longer tiles mean longer runs per (tile, group) and a
-// shorter directory column; what decides is how the tile count fills the workgroup slots of the chip
-// (256 CUs x 2048 threads): a last round that is mostly empty costs a whole round.
+// shorter directory column.
 static inline VwPlan vw_plan(uint32_t ncells, int64_t n, int max_pts, int batch, int shape) {
   VwPlan p{};
   int bits = 0;
@@ -60,19 +59,13 @@ static inline VwPlan vw_plan(uint32_t ncells, int64_t n, int max_pts, int batch,
   const int nshapes = (int)(sizeof(shapes) / sizeof(shapes[0]));
   int pick = shape;
   if (pick < 0 || pick >= nshapes) {
-    // fewest rounds of the chip, then the longer tile
-    double best = 1e30;
+    // the longest tile that still leaves a workgroup and a half per CU: long tiles mean long runs per (tile,
+    // group), which is what the group kernel's 64-record steps and the directory search want (measured on 16
+    // nuScenes frames: 10240-point tiles 119 us, 4096-point tiles 127 us for the whole operator); small batches
+    // keep the short tile so that the route kernel still covers the chip
     pick = 0;
-    for (int k = 0; k < 3; ++k) {
-      const int64_t tile = (int64_t)shapes[k].threads * shapes[k].rounds;
-      const int64_t wgs = ceil_div(n, tile) * batch;
-      const int64_t slots = 256 * (2048 / shapes[k].threads);
-      const double cost = (double)ceil_div(wgs, slots) * (double)tile + (wgs < 256 ? 1e-3 * (double)tile : 0.0);
-      if (cost < best) {
-        best = cost;
-        pick = k;
-      }
-    }
+    for (int k = 1; k < 3; ++k)
+      if (ceil_div(n, (int64_t)shapes[k].threads * shapes[k].rounds) * batch >= 384) pick = k;
   }
   p.threads = shapes[pick].threads;
   p.rounds = shapes[pick].rounds;

@@ -87,3 +87,14 @@ def boxes_iou_bev_cpu(boxes_a, boxes_b, device=None):
             raise RuntimeError("boxes_iou_bev_cpu: boxes must be CPU float32 tensors of shape [N, 7]")
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     return boxes_iou_bev_gpu(boxes_a.to(dev), boxes_b.to(dev)).cpu()
+
+
+def libm_eval(op: str, x: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:
+    """Diagnostic: the float math routines the geometry / decode kernels use (glibc's sinf / cosf / expf / atanf /
+    atan2f bit for bit, csrc/libm_exact.hpp) over a float32 GPU tensor; `y` only for atan2f(x, y)."""
+    code = {"sinf": 0, "cosf": 1, "expf": 2, "atanf": 3, "atan2f": 4}[op]
+    x = require_gpu(x, "libm_eval")
+    y = require_gpu(y, "libm_eval") if y is not None else None
+    out = torch.empty_like(x)
+    check(lib().pd3_libm_eval(code, ptr(x), ptr(y), ptr(out), x.numel(), stream_ptr(x.device)), "libm_eval")
+    return out
