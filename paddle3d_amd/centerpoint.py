@@ -115,14 +115,6 @@ class PillarFeatureNet(nn.Module):
         self._folded = None
         return super().train(mode)
 
-    def _apply(self, fn, *args, **kwargs):
-        self._folded = None
-        return super()._apply(fn, *args, **kwargs)
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        self._folded = None
-        return super()._load_from_state_dict(*args, **kwargs)
-
     def _fold(self):
         out = []
         for l in self.pfn_layers:
@@ -133,10 +125,11 @@ class PillarFeatureNet(nn.Module):
 
     def forward(self, features, num_points_per_voxel, coors):
         """features [M,P,D], num_points [M] int32, coors [M,4] int32 -> [M, C]."""
-        if self.training or self._folded is None:
-            self._folded = self._fold()
+        sig = _param_signature(self)
+        if self.training or self._folded is None or self._folded[0] != sig:
+            self._folded = (sig, self._fold())
         return _ve.pillar_feature_net(features, num_points_per_voxel, coors, self.vx, self.vy, self.x_offset,
-                                      self.y_offset, *self._folded)
+                                      self.y_offset, *self._folded[1])
 
 
 class HardVFE(nn.Module):
@@ -194,27 +187,36 @@ class PointPillarsScatter(nn.Module):
         return _ps.pointpillars_scatter(voxel_features, coords, batch_size, self.ny, self.nx)
 
 
+def _param_signature(module):
+    """(storage, version, device) of every parameter and buffer below `module`: changes when any of them is
+    reloaded, moved or written in place (load_state_dict on a child, param.data.copy_, an optimizer step)."""
+    return tuple((t.data_ptr(), t._version, str(t.device)) for t in list(module.parameters()) + list(module.buffers()))
+
+
 class _InferenceCache:
     """Mixin of the parameter-holding layers: weights derived for inference (BatchNorm folded, packed in the
-    kernels' layouts) live in ``self._cache`` and are dropped whenever the parameters can have changed
-    (``train()`` / ``eval()``, ``load_state_dict``, ``.to()`` / ``.cuda()``)."""
+    kernels' layouts) live in ``self._cache`` together with the signature of the tensors they were derived from
+    and are rebuilt whenever that signature differs (a reload of this module or of a child, ``.to()``, an in-place
+    write) -- checked on every forward, a few microseconds; ``train()`` drops them outright."""
 
     _cache = None
+    _cache_sig = None
 
     def _drop_cache(self):
         self.__dict__["_cache"] = None
+        self.__dict__["_cache_sig"] = None
+
+    def _cache_valid(self):
+        return self._cache is not None and self._cache_sig == _param_signature(self)
+
+    def _store_cache(self, value):
+        self.__dict__["_cache"] = value
+        self.__dict__["_cache_sig"] = _param_signature(self)
+        return value
 
     def train(self, mode: bool = True):
         self._drop_cache()
         return super().train(mode)
-
-    def _apply(self, fn, *args, **kwargs):
-        self._drop_cache()
-        return super()._apply(fn, *args, **kwargs)
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        self._drop_cache()
-        return super()._load_from_state_dict(*args, **kwargs)
 
     def _require_eval(self):
         if self.training:
@@ -301,12 +303,12 @@ class SecondBackbone(_InferenceCache, nn.Module):
         self.blocks = nn.ModuleList(blocks)
 
     def _plan(self):
-        if self._cache is None:
+        if not self._cache_valid():
             plan = []
             for blk in self.blocks:
                 mods = list(blk)
                 plan.append([_fold_conv3x3(mods[i], mods[i + 1]) for i in range(0, len(mods), 3)])
-            self.__dict__["_cache"] = plan
+            self._store_cache(plan)
         return self._cache
 
     def forward(self, x):
@@ -344,7 +346,7 @@ class SecondFPN(_InferenceCache, nn.Module):
         self.deblocks = nn.ModuleList(deblocks)
 
     def _plan(self):
-        if self._cache is None:
+        if not self._cache_valid():
             plan, off = [], 0
             for blk in self.deblocks:
                 conv, bn = blk[0], blk[1]
@@ -359,7 +361,7 @@ class SecondFPN(_InferenceCache, nn.Module):
                 plan.append(dict(mode=mode, w=_conv.pack_patch_weight(w, mode, tr), b=b, cin=cin, cout=cout, off=off,
                                  scale={0: 0.5, 1: 1, 2: 2, 3: 4}[mode]))
                 off += cout
-            self.__dict__["_cache"] = (plan, off)
+            self._store_cache((plan, off))
         return self._cache
 
     def forward(self, xs):
@@ -430,7 +432,7 @@ class CenterHead(_InferenceCache, nn.Module):
             self.tasks.append(SeparateHead(share_conv_channel, heads, final_kernel=3, init_bias=init_bias))
 
     def _plan(self):
-        if self._cache is None:
+        if not self._cache_valid():
             w0, b0 = _fold_conv_bn(self.shared_conv.conv, self.shared_conv.bn)
             ws, bs, plan, finals = [], [], [], []
             for t, task in enumerate(self.tasks):
@@ -452,10 +454,10 @@ class CenterHead(_InferenceCache, nn.Module):
             for g, (w, b) in enumerate(finals):
                 wf[g * cmax:g * cmax + w.shape[0]] = w
                 bf[g * cmax:g * cmax + w.shape[0]] = b
-            self.__dict__["_cache"] = dict(
+            self._store_cache(dict(
                 shared=_Conv3x3(w0, b0, 1), first=_Conv3x3(torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous(), 1),
                 pf=_conv.pack_grouped_weight(wf, len(finals)), bf=bf, hc=int(hc), plan=plan, cmax=int(cmax),
-                groups=len(finals), ncls=[int(f[0].shape[0]) for f in finals])
+                groups=len(finals), ncls=[int(f[0].shape[0]) for f in finals]))
         return self._cache
 
     def forward(self, x):

@@ -21,10 +21,28 @@ __all__ = ["load_pdparams", "save_pdparams", "load_paddle_state_dict"]
 _STRUCT_KEY = "StructuredToParameterName@@"
 
 
+class _NumpyOnlyUnpickler(pickle.Unpickler):
+    """A `.pdparams` file is a pickle of {name: ndarray}; unpickling it needs numpy's array reconstruction helpers
+    and nothing else.  Everything else is refused, so a downloaded checkpoint cannot run code on load (which
+    `pickle.load` -- and `paddle.load` -- would let it)."""
+
+    _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                ("numpy", "ndarray"), ("numpy", "dtype"), ("collections", "OrderedDict"),
+                ("_codecs", "encode")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"refusing to load {module}.{name} from a checkpoint: a .pdparams file holds "
+                                     "numpy arrays only")
+
+
 def load_pdparams(path: str) -> dict:
-    """What `paddle.load(path)` returns for a `.pdparams` written by `paddle.save(layer.state_dict(), path)`."""
+    """What `paddle.load(path)` returns for a `.pdparams` written by `paddle.save(layer.state_dict(), path)`.
+    Only numpy arrays (and the containers around them) are unpickled, see _NumpyOnlyUnpickler."""
     with open(path, "rb") as f:
-        state = pickle.load(f, encoding="latin1")
+        state = _NumpyOnlyUnpickler(f, encoding="latin1").load()
     if not isinstance(state, dict):
         raise RuntimeError(f"{path}: not a Paddle state dict (got {type(state).__name__})")
     state.pop(_STRUCT_KEY, None)

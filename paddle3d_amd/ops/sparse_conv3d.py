@@ -147,7 +147,7 @@ def plan(coords: torch.Tensor, batch: int, spatial_shape, specs) -> SparsePlan:
         if sp.subm:
             pd = tuple(k // 2 for k in ks)
         kvol = ks[0] * ks[1] * ks[2]
-        tag = (i, o, ks, st, pd, sp.subm) if sp.key is None else (i, o, sp.key, ks)
+        tag = (i, o, sp.key, ks, st, pd, sp.subm)  # a key shared by convolutions of different geometry shares nothing
         if tag not in books:
             n_in, n_out = sets[i]["n"], sets[o]["n"]
             nbr = torch.empty((n_out, kvol), dtype=torch.int32, device=dev)

@@ -54,14 +54,40 @@ def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max
     return voxels, coords, npv, nv
 
 
+def _stage_points(points, op):
+    """The reference dispatches on the place of `points` (voxelize_op.cc:149-166): CPU tensors run
+    hard_voxelize_cpu and get CPU results, GPU and GPU-pinned tensors run the device kernel.  This library has the
+    device kernel only -- bit-identical to hard_voxelize_cpu -- so host tensors are staged through the current
+    GPU: (device tensor, whether the results go back to the host)."""
+    if not isinstance(points, torch.Tensor):
+        raise RuntimeError(f"Unsupported device type for {op} operator.")
+    if points.dtype == torch.float64:
+        raise RuntimeError(f"{op}: float64 points are not supported: the reference instantiates its kernels for "
+                           "float and double (PD_DISPATCH_FLOATING_TYPES, voxelize_op.cc:128), this library "
+                           "computes in float32 only -- cast the points explicitly if that is what you want")
+    if points.is_cuda:
+        return points, False
+    if points.device.type != "cpu":
+        raise RuntimeError(f"Unsupported device type for {op} operator.")
+    if not torch.cuda.is_available():
+        raise RuntimeError(f"{op}: host tensors are staged through the GPU and no GPU is visible "
+                           "(this library has no CPU kernel)")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    return points.to(dev, non_blocking=points.is_pinned()), not points.is_pinned()
+
+
 def hard_voxelize(points: torch.Tensor, voxel_size, point_cloud_range, max_num_points_in_voxel: int,
                   max_voxels: int, path: int = 0):
-    pts = require_gpu(points, "hard_voxelize")
+    """points [N, D] fp32 on the GPU, in pinned host memory (results on the GPU, like the reference's
+    `is_gpu_pinned()` branch) or on the CPU (results on the CPU, like hard_voxelize_cpu; computed on the GPU)."""
+    pts, to_host = _stage_points(points, "hard_voxelize")
+    pts = require_gpu(pts, "hard_voxelize")
     if pts.dim() != 2:
         raise RuntimeError("hard_voxelize expects points of shape [N, D]")
     voxels, coords, npv, nv = hard_voxelize_batch(pts.unsqueeze(0), voxel_size, point_cloud_range,
                                                   max_num_points_in_voxel, max_voxels, path=path)
-    return voxels[0], coords[0], npv[0], nv
+    out = (voxels[0], coords[0], npv[0], nv)
+    return tuple(o.cpu() for o in out) if to_host else out
 
 
 def dynamic_voxelize(points: torch.Tensor, voxel_size, point_cloud_range) -> torch.Tensor:

@@ -116,14 +116,14 @@ class SSDHead(_InferenceCache, nn.Module):
             self.dir_head = nn.Conv2d(feature_channels, self.num_anchor_per_loc * 2, 1)
 
     def _plan(self):
-        if self._cache is None:
+        if not self._cache_valid():
             heads = [self.cls_head, self.box_head] + ([self.dir_head] if self.use_direction_classifier else [])
             w = torch.cat([h.weight.detach() for h in heads], 0).contiguous()
             b = torch.cat([h.bias.detach() for h in heads], 0).contiguous()
             cls_c, box_c = self.cls_head.out_channels, self.box_head.out_channels
-            self.__dict__["_cache"] = dict(w=_conv.pack_patch_weight(w, 1, False), b=b, cout=int(w.shape[0]),
-                                           cin=int(w.shape[1]), cls0=0, box0=cls_c,
-                                           dir0=cls_c + box_c if self.use_direction_classifier else -1)
+            self._store_cache(dict(w=_conv.pack_patch_weight(w, 1, False), b=b, cout=int(w.shape[0]),
+                                   cin=int(w.shape[1]), cls0=0, box0=cls_c,
+                                   dir0=cls_c + box_c if self.use_direction_classifier else -1))
         return self._cache
 
     def head_map(self, features):

@@ -63,13 +63,22 @@ def test_workspace_queries_need_no_gpu(built):
     assert L.pd3_centerpoint_postprocess_workspace(1, 6, 128, 128, 1000, 83) > 0
 
 
-def test_ops_refuse_cpu_tensors(built):
+def test_ops_device_dispatch_without_a_gpu(built):
+    """The reference's hard_voxelize takes CPU, GPU and GPU-pinned points (voxelize_op.cc:149-166); here host tensors
+    are staged through the GPU (tests/test_voxelize_gpu.py), so without one the op says so instead of computing on
+    the CPU.  float64 points get an explicit dtype error.  The other ops are GPU-only in the reference too."""
     import torch
 
     from paddle3d_amd.ops import iou3d_nms, voxelize
 
+    args = ([0.2, 0.2, 8], [-51.2, -51.2, -5, 51.2, 51.2, 3], 20, 100)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="staged through the GPU and no GPU is visible"):
+            voxelize.hard_voxelize(torch.zeros(10, 4), *args)
+    with pytest.raises(RuntimeError, match="PD_DISPATCH_FLOATING_TYPES"):
+        voxelize.hard_voxelize(torch.zeros(10, 4, dtype=torch.float64), *args)
     with pytest.raises(RuntimeError, match="Unsupported device type for hard_voxelize operator"):
-        voxelize.hard_voxelize(torch.zeros(10, 4), [0.2, 0.2, 8], [-51.2, -51.2, -5, 51.2, 51.2, 3], 20, 100)
+        voxelize.hard_voxelize([[0.0, 0.0, 0.0, 0.0]], *args)
     with pytest.raises(RuntimeError, match="Unsupported device type"):
         iou3d_nms.nms_gpu(torch.zeros(4, 7), 0.5)
 

@@ -196,3 +196,50 @@ def test_centerpoint_postprocess_orchestration_vs_reference_python(oracle):
         np.testing.assert_array_equal(rl, gold[f"labels_{b}"])
         np.testing.assert_allclose(rs, gold[f"scores_{b}"], rtol=0, atol=2e-7)
         np.testing.assert_allclose(rb, gold[f"boxes_{b}"], rtol=2e-6, atol=2e-6)
+
+
+def test_pdparams_loader_refuses_code(tmp_path):
+    """A .pdparams is a pickle; the loader unpickles numpy arrays only (a checkpoint from the net cannot run code)."""
+    import pickle
+
+    import numpy as np
+    import pytest
+
+    from paddle3d_amd import checkpoint
+
+    good = tmp_path / "good.pdparams"
+    checkpoint.save_pdparams({"a.weight": np.arange(6, dtype=np.float32).reshape(2, 3)}, str(good))
+    assert checkpoint.load_pdparams(str(good))["a.weight"].shape == (2, 3)
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > /dev/null",))
+
+    bad = tmp_path / "bad.pdparams"
+    with open(bad, "wb") as f:
+        pickle.dump({"a.weight": Evil()}, f, protocol=2)
+    with pytest.raises(pickle.UnpicklingError, match="refusing to load"):
+        checkpoint.load_pdparams(str(bad))
+
+
+def test_packed_weights_follow_in_place_and_child_updates():
+    """The inference caches (folded BatchNorm, packed kernel layouts) are keyed on (storage, version, device) of the
+    module's parameters: an in-place write or a load_state_dict on a CHILD module must not leave stale packed weights
+    behind (round-2 advice: they were only dropped by train() / _apply() / load on the caching module itself)."""
+    import torch
+
+    from paddle3d_amd import centerpoint as cpm
+
+    head = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(100, 100)).bbox_head.eval()
+    first = head._plan()["bf"].clone()
+    assert head._plan() is head._cache  # unchanged parameters: the same plan object
+    task = head.tasks[0]
+    name = list(task.heads)[0]
+    with torch.no_grad():
+        getattr(task, name)[1].bias.add_(1.0)  # in-place write on a grandchild
+    second = head._plan()["bf"]
+    assert not torch.equal(first, second)
+    sd = {k: v + 0.5 if k.endswith("1.bias") else v for k, v in task.state_dict().items()}
+    task.load_state_dict(sd)  # reload of a child, not of the head
+    assert not torch.equal(second, head._plan()["bf"])

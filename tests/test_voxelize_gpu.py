@@ -190,3 +190,24 @@ def test_dynamic_voxelize_agrees_with_hard_voxelize(oracle):
     # and the set of occupied cells equals the coords hard_voxelize reports when nothing is capped
     rv, rc, rn, rnv = oracle.hard_voxelize(pts, synth.NUSC_PILLAR, synth.NUSC_RANGE, 20, 200_000)
     assert set(map(tuple, co[inside])) == set(map(tuple, rc[:rnv]))
+
+
+def test_host_points_are_staged(oracle):
+    """voxelize_op.cc:149-166: CPU points -> hard_voxelize_cpu, results on the CPU; GPU-pinned points -> the device
+    kernel, results on the GPU.  Here both run the device kernel (bit-identical to the CPU kernel)."""
+    from paddle3d_amd.ops import voxelize
+
+    pts = synth.nuscenes_sweep(31, n_points=50_000)
+    args = (list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20, 9000)
+    rv, rc, rn, rnv = oracle.hard_voxelize(pts, synth.NUSC_PILLAR, synth.NUSC_RANGE, 20, 9000)
+    cpu_out = voxelize.hard_voxelize(torch.from_numpy(pts), *args, path=PATH)
+    pin_out = voxelize.hard_voxelize(torch.from_numpy(pts).pin_memory(), *args, path=PATH)
+    assert all(not o.is_cuda for o in cpu_out) and all(o.is_cuda for o in pin_out)
+    for out in (cpu_out, pin_out):
+        vox, co, npv, nv = [o.cpu().numpy() for o in out]
+        assert int(nv[0]) == rnv
+        np.testing.assert_array_equal(co, rc)
+        np.testing.assert_array_equal(npv, rn)
+        np.testing.assert_array_equal(vox.view(np.uint32), rv.view(np.uint32))
+    with pytest.raises(RuntimeError, match="PD_DISPATCH_FLOATING_TYPES"):
+        voxelize.hard_voxelize(torch.from_numpy(pts.astype(np.float64)).cuda(), *args)
