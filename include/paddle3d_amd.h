@@ -197,6 +197,22 @@ int pd3_centerpoint_postprocess_strided(const float *const *hm, const float *con
                                 float *out_bboxes, float *out_scores, int64_t *out_labels,
                                 int32_t *out_count, void *workspace, size_t workspace_bytes,
                                 void *stream, int selection);
+/* Same as the strided form (automatic selection), plus `out_records` [batch, max_per_img, 11] fp32: the rows once
+ * more in the fixed shape of the multi-GPU result hand-off -- box (7 or 9 values, zero padded to 9), score, label as
+ * float, rows >= count zero -- so that the RCCL all-gather of a batch's detections (paddle3d_amd/dist.py; no
+ * counterpart in the reference, whose evaluation is single device, apis/trainer.py:47-51) starts from the operator's
+ * own output.  All four outputs read zero behind the last row; none needs clearing by the caller. */
+int pd3_centerpoint_postprocess_records(const float *const *hm, const float *const *reg,
+                                        const float *const *height, const float *const *dim,
+                                        const float *const *vel, const float *const *rot,
+                                        int64_t head_batch_stride, int batch, int num_tasks,
+                                        const int *hm_channels, int feat_h, int feat_w, const float *voxel_size,
+                                        const float *point_cloud_range, const float *post_center_range,
+                                        const int *label_offsets, int down_ratio, float score_threshold,
+                                        float nms_iou_threshold, int nms_pre_max_size, int nms_post_max_size,
+                                        int with_velocity, float *out_bboxes, float *out_scores,
+                                        int64_t *out_labels, int32_t *out_count, float *out_records,
+                                        int max_per_img, void *workspace, size_t workspace_bytes, void *stream);
 /* selection: how the nms_pre_max_size best cells of a task are found -- 0 automatic (an exact in-LDS top-K
  * selection where the map allows, else a full sort), 1 always the full stable radix sort of all cells (what the
  * reference does; the tests run both and require identical output). */

@@ -57,6 +57,11 @@ _SIGNATURES = {
                                                       C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
+    "pd3_centerpoint_postprocess_records": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pd3_bev_pool_v2": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int64, C.c_void_p,
                                                      C.c_void_p]),
     "pd3_bev_pool_v2_bkwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64,

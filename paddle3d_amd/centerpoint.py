@@ -480,8 +480,9 @@ class CenterHead(_InferenceCache, nn.Module):
         return rets, x
 
     @torch.no_grad()
-    def predict_by_custom_op(self, preds_dicts, test_cfg, device_only=False):
-        """center_head.py:294-339.  Returns per frame dict(box3d_lidar, label_preds, scores)."""
+    def predict_by_custom_op(self, preds_dicts, test_cfg, device_only=False, records=0):
+        """center_head.py:294-339.  Returns per frame dict(box3d_lidar, label_preds, scores); device_only=True the
+        padded device tensors + counts without a host sync (records = max_per_img: plus the hand-off record)."""
         hm, reg, height, dim, vel, rot = [], [], [], [], [], []
         for preds in preds_dicts:
             hm.append(preds["hm"])
@@ -493,13 +494,15 @@ class CenterHead(_InferenceCache, nn.Module):
         # the reference builds a len(tasks)**2 list of running class offsets (:303-309); entry t is task t's
         offsets = np.concatenate([[0], np.cumsum(self.num_classes)[:-1]]).astype(int).tolist()
         num_classes = offsets * len(preds_dicts)
-        b, s, l, n = _cp.centerpoint_postprocess_device(
+        out = _cp.centerpoint_postprocess_device(
             hm, reg, height, dim, vel, rot, test_cfg["voxel_size"], test_cfg["point_cloud_range"],
             test_cfg["post_center_limit_range"], num_classes, test_cfg["down_ratio"], test_cfg["score_threshold"],
             test_cfg["nms"]["nms_iou_threshold"], test_cfg["nms"]["nms_pre_max_size"],
-            test_cfg["nms"]["nms_post_max_size"], self.with_velocity, allow_batch=True)
+            test_cfg["nms"]["nms_post_max_size"], self.with_velocity, allow_batch=True,
+            records=records if device_only else 0)
         if device_only:
-            return b, s, l, n
+            return out
+        b, s, l, n = out
         counts = n.cpu().tolist()
         return [dict(box3d_lidar=b[i, :k], label_preds=l[i, :k], scores=s[i, :k]) for i, k in enumerate(counts)]
 

@@ -261,12 +261,18 @@ __global__ __launch_bounds__(256) void cp_output_kernel(
     const int* __restrict__ counts, const int32_t* __restrict__ keep,
     const int32_t* __restrict__ nkeep, CpHeads h, int num_tasks, int hw, int dims, int cap, int pre_max,
     int post_max, float* __restrict__ out_boxes, float* __restrict__ out_scores,
-    int64_t* __restrict__ out_labels, int32_t* __restrict__ out_count) {
+    int64_t* __restrict__ out_labels, int32_t* __restrict__ out_count, float* __restrict__ out_records,
+    int max_per_img) {
   const int frame = blockIdx.x;
   const int rows_cap = num_tasks * max(post_max, 1);
   out_boxes += (int64_t)frame * rows_cap * dims;
   out_scores += (int64_t)frame * rows_cap;
   out_labels += (int64_t)frame * rows_cap;
+  // optional second form of the same rows: the fixed-shape record of the multi-GPU result hand-off
+  // (paddle3d_amd/dist.py: [max_per_img, 11] = box (zero padded to 9 values), score, label), written here instead
+  // of by a handful of tensor-library kernels after the fact
+  constexpr int kRec = 11;
+  float* rec = out_records ? out_records + (int64_t)frame * max_per_img * kRec : nullptr;
   int offset = 0;
   for (int task = 0; task < num_tasks; ++task) {
     const int t = frame * num_tasks + task;  // set index
@@ -277,6 +283,8 @@ __global__ __launch_bounds__(256) void cp_output_kernel(
         out_scores[offset] = -1.f;
         out_labels[offset] = 0;
       }
+      if (rec && offset < max_per_img && (int)threadIdx.x < kRec)
+        rec[(int64_t)offset * kRec + threadIdx.x] = threadIdx.x == 9 ? -1.f : 0.f;
       offset += 1;
       continue;
     }
@@ -287,11 +295,27 @@ __global__ __launch_bounds__(256) void cp_output_kernel(
       const uint32_t cell = sidx[(int64_t)t * hw + pos];   // selected_score_idx[sorted_index[keep]]
       const float* bx = boxes + ((int64_t)t * hw + cell) * dims;
       for (int k = 0; k < dims; ++k) out_boxes[(int64_t)(offset + r) * dims + k] = bx[k];
-      out_scores[offset + r] = scores[(int64_t)t * hw + cell];
-      out_labels[offset + r] = (int64_t)labels[(int64_t)t * hw + cell] + h.label_offset[task];
+      const float sc = scores[(int64_t)t * hw + cell];
+      const int lb = labels[(int64_t)t * hw + cell] + h.label_offset[task];
+      out_scores[offset + r] = sc;
+      out_labels[offset + r] = (int64_t)lb;
+      if (rec && offset + r < max_per_img) {
+        float* q = rec + (int64_t)(offset + r) * kRec;
+        for (int k = 0; k < 9; ++k) q[k] = k < dims ? bx[k] : 0.f;
+        q[9] = sc;
+        q[10] = (float)lb;
+      }
     }
     offset += rows;
   }
+  // rows behind the last one read zero (the outputs need no clearing by the caller)
+  for (int r = offset + (int)threadIdx.x; r < rows_cap; r += blockDim.x) {
+    for (int k = 0; k < dims; ++k) out_boxes[(int64_t)r * dims + k] = 0.f;
+    out_scores[r] = 0.f;
+    out_labels[r] = 0;
+  }
+  if (rec)
+    for (int e = min(offset, max_per_img) * kRec + (int)threadIdx.x; e < max_per_img * kRec; e += blockDim.x) rec[e] = 0.f;
   if (threadIdx.x == 0) out_count[frame] = offset;
 }
 
@@ -352,7 +376,7 @@ static int cp_postprocess_impl(
     int down_ratio, float score_threshold, float nms_iou_threshold, int nms_pre_max_size,
     int nms_post_max_size, int with_velocity, float* out_bboxes, float* out_scores,
     int64_t* out_labels, int32_t* out_count, void* workspace, size_t workspace_bytes,
-    void* stream) {
+    void* stream, float* out_records = nullptr, int max_per_img = 0) {
   if (!hm || !reg || !height || !dim || !vel || !rot || !hm_channels || !label_offsets ||
       !voxel_size || !point_cloud_range || !post_center_range || !out_bboxes || !out_scores ||
       !out_labels || !out_count || !workspace)
@@ -432,7 +456,7 @@ static int cp_postprocess_impl(
   }
   cp_output_kernel<<<batch, 256, 0, s>>>(w.boxes, w.scores, w.labels, sidx, w.counts, w.keep, w.nkeep, h,
                                      num_tasks, hw, c.dims, cap, nms_pre_max_size, nms_post_max_size, out_bboxes,
-                                     out_scores, out_labels, out_count);
+                                     out_scores, out_labels, out_count, out_records, max_per_img);
   return launch_status();
 }
 
@@ -467,4 +491,21 @@ extern "C" int pd3_centerpoint_postprocess_strided(
                              down_ratio, score_threshold, nms_iou_threshold, nms_pre_max_size,
                              nms_post_max_size, with_velocity, out_bboxes, out_scores, out_labels, out_count,
                              workspace, workspace_bytes, stream);
+}
+
+extern "C" int pd3_centerpoint_postprocess_records(
+    const float* const* hm, const float* const* reg, const float* const* height,
+    const float* const* dim, const float* const* vel, const float* const* rot, int64_t head_batch_stride,
+    int batch, int num_tasks, const int* hm_channels, int feat_h, int feat_w, const float* voxel_size,
+    const float* point_cloud_range, const float* post_center_range, const int* label_offsets,
+    int down_ratio, float score_threshold, float nms_iou_threshold, int nms_pre_max_size,
+    int nms_post_max_size, int with_velocity, float* out_bboxes, float* out_scores,
+    int64_t* out_labels, int32_t* out_count, float* out_records, int max_per_img, void* workspace,
+    size_t workspace_bytes, void* stream) {
+  if (head_batch_stride <= 0 || !out_records || max_per_img <= 0) return PD3_EINVAL;
+  return cp_postprocess_impl(head_batch_stride, 0, hm, reg, height, dim, vel, rot, batch, num_tasks, hm_channels,
+                             feat_h, feat_w, voxel_size, point_cloud_range, post_center_range, label_offsets,
+                             down_ratio, score_threshold, nms_iou_threshold, nms_pre_max_size,
+                             nms_post_max_size, with_velocity, out_bboxes, out_scores, out_labels, out_count,
+                             workspace, workspace_bytes, stream, out_records, max_per_img);
 }

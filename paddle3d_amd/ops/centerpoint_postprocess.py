@@ -57,11 +57,13 @@ def _require_view(t: torch.Tensor, op: str) -> torch.Tensor:
 def centerpoint_postprocess_device(hm, reg, height, dim, vel, rot, voxel_size, point_cloud_range,
                                    post_center_range, num_classes, down_ratio, score_threshold,
                                    nms_iou_threshold, nms_pre_max_size, nms_post_max_size, with_velocity,
-                                   allow_batch=False, full_sort=False):
+                                   allow_batch=False, full_sort=False, records=0):
     """No-sync variant: returns padded (bboxes [B,R,dims], scores [B,R], labels [B,R]; rows >= count are zero)
     plus the device int32 row counts [B].  allow_batch=True lifts the reference's batch-1 restriction (frames
     are processed independently in one launch sequence).  full_sort=True forces the reference's own selection
-    (a full stable sort of all cells) instead of the in-LDS top-K selection (`selection` of the C ABI)."""
+    (a full stable sort of all cells) instead of the in-LDS top-K selection (`selection` of the C ABI).
+    records = max_per_img > 0 additionally returns the rows as the [B, max_per_img, 11] record of the multi-GPU
+    hand-off (paddle3d_amd/dist.py), written by the operator itself (heads must be views of one fused map)."""
     op = "centerpoint postprocess"
     t_n = len(hm)
     groups = (hm, reg, height, dim, vel, rot)
@@ -83,9 +85,10 @@ def centerpoint_postprocess_device(hm, reg, height, dim, vel, rot, voxel_size, p
     dev = hm0.device
     dims = 9 if with_velocity else 7
     rows = t_n * max(int(nms_post_max_size), 1)
-    out_b = torch.zeros((batch, rows, dims), dtype=torch.float32, device=dev)
-    out_s = torch.zeros((batch, rows), dtype=torch.float32, device=dev)
-    out_l = torch.zeros((batch, rows), dtype=torch.int64, device=dev)
+    # (rows behind the last one are zeroed by the operator)
+    out_b = torch.empty((batch, rows, dims), dtype=torch.float32, device=dev)
+    out_s = torch.empty((batch, rows), dtype=torch.float32, device=dev)
+    out_l = torch.empty((batch, rows), dtype=torch.int64, device=dev)
     out_n = torch.empty((batch,), dtype=torch.int32, device=dev)
     ncls = np.ascontiguousarray([int(t.shape[1]) for t in lists[0]], dtype=np.int32)
     offs = np.ascontiguousarray([int(num_classes[t]) for t in range(t_n)], dtype=np.int32)
@@ -100,6 +103,18 @@ def centerpoint_postprocess_device(hm, reg, height, dim, vel, rot, voxel_size, p
         if batch != 1:
             raise RuntimeError("centerpoint_postprocess: full_sort needs batch 1 or heads with one common batch stride")
         bstride = 1  # never applied with a single frame
+    if records:
+        if full_sort or (not bstride and batch != 1):
+            raise RuntimeError("centerpoint_postprocess: records need batch 1 or heads with one common batch stride")
+        bstride = bstride or 1  # never applied with a single frame
+        out_r = torch.empty((batch, int(records), 11), dtype=torch.float32, device=dev)
+        check(L.pd3_centerpoint_postprocess_records(
+            *[C.cast(a, C.c_void_p) for a in arrays], C.c_int64(bstride), batch, t_n, ptr(ncls), h, w, ptr(vs),
+            ptr(pr), ptr(pcr), ptr(offs), int(down_ratio), C.c_float(score_threshold),
+            C.c_float(nms_iou_threshold), int(nms_pre_max_size), int(nms_post_max_size), int(bool(with_velocity)),
+            ptr(out_b), ptr(out_s), ptr(out_l), ptr(out_n), ptr(out_r), int(records), ptr(ws), ws.numel(),
+            stream_ptr(dev)), op)
+        return out_b, out_s, out_l, out_n, out_r
     if bstride:
         check(L.pd3_centerpoint_postprocess_strided(
             *[C.cast(a, C.c_void_p) for a in arrays], C.c_int64(bstride), batch, t_n, ptr(ncls), h, w, ptr(vs),

@@ -346,3 +346,25 @@ def test_packed_weights_follow_the_parameters(oracle):
     assert not torch.equal(first, got)
     assert torch.equal(got, want)
     assert (got - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_postprocess_records_equal_pack_records():
+    """The [B, 500, 11] hand-off record written by the postprocess operator itself equals dist.pack_records over its
+    ordinary outputs, and the ordinary outputs read zero behind the last row although the caller no longer clears them."""
+    from paddle3d_amd import centerpoint as cpm
+    from paddle3d_amd import dist as pdist
+
+    torch.manual_seed(3)
+    model = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(8000, 8000)).cuda().eval()
+    pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(40 + i, n_points=60_000) for i in range(3)])).cuda()
+    with torch.no_grad():
+        x = model.dense_forward(model.extract_pillars(pts))
+        preds, _ = model.bbox_head(x)
+        bx, sc, lb, cnt, rec = model.bbox_head.predict_by_custom_op(preds, model.test_cfg, device_only=True,
+                                                                     records=500)
+        bx2, sc2, lb2, cnt2 = model.bbox_head.predict_by_custom_op(preds, model.test_cfg, device_only=True)
+    assert torch.equal(cnt, cnt2) and torch.equal(bx, bx2) and torch.equal(sc, sc2) and torch.equal(lb, lb2)
+    assert torch.equal(rec, pdist.pack_records(bx, sc, lb, cnt, 500))
+    for i, k in enumerate(cnt.tolist()):
+        assert k > 0 and float(bx[i, k:].abs().sum()) == 0 and float(sc[i, k:].abs().sum()) == 0
+        assert int(lb[i, k:].abs().sum()) == 0
