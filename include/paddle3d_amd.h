@@ -396,6 +396,13 @@ int pd3_conv3x3_winograd43_bias_relu(const float *x, const float *u_packed, cons
  */
 int pd3_grouped_conv3x3_small(const float *x, const float *w_grouped, const float *bias, int batch, int groups,
                               int cin_per_group, int cout_per_group, int h, int w, float *out, void *stream);
+/* The same over a SLICE of the groups: x, w_grouped and bias describe `groups` consecutive groups, whose outputs land
+ * at groups [out_group0, out_group0 + groups) of out [batch, out_groups*cout_per_group, h, w].  CenterHead runs its
+ * 36 branches a few at a time this way, so that a slice's first-stage map (67 MB per branch and 16 frames) is read
+ * back while it is still in the last-level cache instead of after 2.4 GB have gone by. */
+int pd3_grouped_conv3x3_small_slice(const float *x, const float *w_grouped, const float *bias, int batch, int groups,
+                                    int cin_per_group, int cout_per_group, int h, int w, float *out, int out_groups,
+                                    int out_group0, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * conv3x3_winograd_bias_relu -- the same stride-1 convolution as conv3x3_bias_relu computed by Winograd

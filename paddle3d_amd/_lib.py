@@ -113,6 +113,9 @@ _SIGNATURES = {
                                       C.c_void_p, C.c_int]),
     "pd3_grouped_conv3x3_small": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_grouped_conv3x3_small_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                  C.c_void_p]),
 }
 
 SYMBOLS = tuple(_SIGNATURES)

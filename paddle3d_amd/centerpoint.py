@@ -425,6 +425,9 @@ class CenterHead(_InferenceCache, nn.Module):
         self.with_velocity = "vel" in common_heads
         self.box_n_dim = 9 if self.with_velocity else 7
         self.shared_conv = ConvModule(in_channels, share_conv_channel, 3, padding=1)
+        # branches per slice of the head (0 = automatic: see forward)
+        self.head_chunk = 0
+        self.head_chunk_bytes = 1 << 30
         self.tasks = nn.ModuleList()
         for ncls in self.num_classes:
             heads = dict(common_heads)
@@ -468,11 +471,38 @@ class CenterHead(_InferenceCache, nn.Module):
             raise Paddle3DAmdError(f"CenterHead: unsupported configuration (map width {x.shape[3]} is not a multiple "
                                    "of 4) (status -3)")
         x, _ = f["shared"](x)
-        y, _ = f["first"](x)
-        if not _conv.grouped_small_supported(f["hc"], f["cmax"], int(y.shape[2]), int(y.shape[3])):
+        n, _, h, w = (int(v) for v in x.shape)
+        if not _conv.grouped_small_supported(f["hc"], f["cmax"], h, w):
             raise Paddle3DAmdError(f"grouped_conv3x3_small: unsupported configuration ({f['hc']} -> {f['cmax']} "
-                                   f"channels per group, map {tuple(y.shape[2:])}) (status -3)")
-        z = _conv.grouped_conv3x3_small(y, f["pf"], f["bf"], f["groups"])
+                                   f"channels per group, map {(h, w)}) (status -3)")
+        first, groups = f["first"], f["groups"]
+        # The branches in slices: a slice's first-stage map goes through ONE reused buffer and is read back by the
+        # slice's final convolutions right away.  Measured at 16 frames of 128 x 128 (tools/prof/prof_head_chunk.py;
+        # bit-identical results): all 36 branches at once (2.4 GB map) 3.60 ms, two slices of 18 3.43 ms, slices of
+        # 1 / 2 / 4 branches (67 MB each, inside the last-level cache) 4.60 / 3.93 / 3.55 ms -- the short launches
+        # lose more than the cache gives, so a map above head_chunk_bytes is cut in two and no further.
+        full = n * f["hc"] * h * w * 4 * groups
+        k = self.head_chunk if self.head_chunk else ((groups + 1) // 2 if full > self.head_chunk_bytes else groups)
+        chunked = (k < groups and f["hc"] == 64 and first.stride == 1 and _conv.winograd43_supported(first.cin, first.cout, h, w)
+                   and w % 4 == 0)
+        if chunked:
+            if "w43" not in first.packed:
+                first.packed["w43"] = _conv.pack_winograd43_weight(first.w)
+            u = first.packed["w43"]
+            chunked = int(u.shape[2]) * 16 == 64
+        if chunked:
+            z = torch.empty((n, groups * f["cmax"], h, w), dtype=torch.float32, device=x.device)
+            buf = torch.empty((n * k * 64 * h * w,), dtype=torch.float32, device=x.device)
+            for c0 in range(0, groups, k):
+                c1 = min(c0 + k, groups)
+                y = buf[: n * (c1 - c0) * 64 * h * w].view(n, (c1 - c0) * 64, h, w)
+                _conv.conv3x3_winograd43_bias_relu(x, u[c0:c1], first.b[c0 * 64:c1 * 64], (c1 - c0) * 64, relu=True,
+                                                   out=y)
+                _conv.grouped_conv3x3_small(y, f["pf"][c0:c1], f["bf"][c0 * f["cmax"]:c1 * f["cmax"]], c1 - c0, out=z,
+                                            out_groups=groups, out_group0=c0)
+        else:
+            y, _ = first(x)
+            z = _conv.grouped_conv3x3_small(y, f["pf"], f["bf"], groups)
         rets = [dict() for _ in self.tasks]
         for g, (t, head) in enumerate(f["plan"]):
             # channel slices of z stay views: the postprocess op takes them with their common batch stride

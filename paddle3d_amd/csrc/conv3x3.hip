@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_kernel(const float*
                                                                     const float* __restrict__ wg,
                                                                     const float* __restrict__ bias,
                                                                     float* __restrict__ out, int groups,
-                                                                    int cg, int h, int w) {
+                                                                    int cg, int h, int w, int out_groups,
+                                                                    int out_group0) {
   __shared__ __attribute__((aligned(16))) float Xs[kGcCi * kGcXR * kGcXW];
   const int tiles_x = (w + kGcW - 1) / kGcW, tiles_y = (h + kGcR - 1) / kGcR;
   const int pt = blockIdx.x;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_kernel(const float*
     const float b = bias ? bias[g * CO + c] : 0.f;
     cv_f32x4 v = {acc[c][0] + b, acc[c][1] + b, acc[c][2] + b, acc[c][3] + b};
     if (y0 + tr < h && x0 + tc < w)  // partial tiles at the border (w % 4 == 0: a quad is in or out)
-      *reinterpret_cast<cv_f32x4*>(out + ((int64_t)n * groups * CO + g * CO + c) * plane +
+      *reinterpret_cast<cv_f32x4*>(out + ((int64_t)n * out_groups * CO + (out_group0 + g) * CO + c) * plane +
                                    (int64_t)(y0 + tr) * w + x0 + tc) = v;
   }
 }
@@ -352,21 +353,40 @@ extern "C" int pd3_conv3x3_bias_relu(const float* x, const float* w_packed, cons
 #undef PD3_CV
 }
 
-extern "C" int pd3_grouped_conv3x3_small(const float* x, const float* w_grouped, const float* bias, int batch,
-                                         int groups, int cin_per_group, int cout_per_group, int h, int w,
-                                         float* out, void* stream) {
-  if (!x || !w_grouped || !out || batch <= 0 || groups <= 0 || cin_per_group <= 0 || h <= 0 || w <= 0)
+static int grouped_small_launch(const float* x, const float* w_grouped, const float* bias, int batch, int groups,
+                                int cin_per_group, int cout_per_group, int h, int w, float* out, int out_groups,
+                                int out_group0, void* stream) {
+  if (!x || !w_grouped || !out || batch <= 0 || groups <= 0 || cin_per_group <= 0 || h <= 0 || w <= 0 ||
+      out_group0 < 0 || out_group0 + groups > out_groups)
     return PD3_EINVAL;
   if (cout_per_group < 1 || cout_per_group > 4 || cin_per_group % kGcCi != 0 || w % 4 != 0)
     return PD3_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return PD3_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid((unsigned)((int64_t)batch * ceil_div(h, kGcR) * ceil_div(w, kGcW)), (unsigned)groups);
+#define PD3_GC(CO)                                                                                                  \
+  grouped_conv3x3_small_kernel<CO><<<grid, 256, 0, s>>>(x, w_grouped, bias, out, groups, cin_per_group, h, w,        \
+                                                        out_groups, out_group0)
   switch (cout_per_group) {
-    case 1: grouped_conv3x3_small_kernel<1><<<grid, 256, 0, s>>>(x, w_grouped, bias, out, groups, cin_per_group, h, w); break;
-    case 2: grouped_conv3x3_small_kernel<2><<<grid, 256, 0, s>>>(x, w_grouped, bias, out, groups, cin_per_group, h, w); break;
-    case 3: grouped_conv3x3_small_kernel<3><<<grid, 256, 0, s>>>(x, w_grouped, bias, out, groups, cin_per_group, h, w); break;
-    default: grouped_conv3x3_small_kernel<4><<<grid, 256, 0, s>>>(x, w_grouped, bias, out, groups, cin_per_group, h, w); break;
+    case 1: PD3_GC(1); break;
+    case 2: PD3_GC(2); break;
+    case 3: PD3_GC(3); break;
+    default: PD3_GC(4); break;
   }
+#undef PD3_GC
   return launch_status();
+}
+
+extern "C" int pd3_grouped_conv3x3_small(const float* x, const float* w_grouped, const float* bias, int batch,
+                                         int groups, int cin_per_group, int cout_per_group, int h, int w,
+                                         float* out, void* stream) {
+  return grouped_small_launch(x, w_grouped, bias, batch, groups, cin_per_group, cout_per_group, h, w, out, groups, 0,
+                              stream);
+}
+
+extern "C" int pd3_grouped_conv3x3_small_slice(const float* x, const float* w_grouped, const float* bias, int batch,
+                                               int groups, int cin_per_group, int cout_per_group, int h, int w,
+                                               float* out, int out_groups, int out_group0, void* stream) {
+  return grouped_small_launch(x, w_grouped, bias, batch, groups, cin_per_group, cout_per_group, h, w, out, out_groups,
+                              out_group0, stream);
 }

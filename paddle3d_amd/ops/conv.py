@@ -179,14 +179,20 @@ def pack_grouped_weight(weight: torch.Tensor, groups: int) -> torch.Tensor:
 
 
 def grouped_conv3x3_small(x: torch.Tensor, w_grouped: torch.Tensor, bias, groups: int,
-                          out: torch.Tensor | None = None) -> torch.Tensor:
-    """Grouped 3x3 convolution + bias with 1..4 output channels per group (the final SeparateHead convolutions)."""
+                          out: torch.Tensor | None = None, out_groups: int | None = None,
+                          out_group0: int = 0) -> torch.Tensor:
+    """Grouped 3x3 convolution + bias with 1..4 output channels per group (the final SeparateHead convolutions).
+    out_groups / out_group0: x, w_grouped and bias describe a slice of `groups` consecutive groups whose outputs land
+    at groups [out_group0, out_group0 + groups) of `out` [n, out_groups * co, h, w]."""
     xx = require_gpu(x, "grouped_conv3x3_small")
     n, c, h, w = xx.shape
     cg, co = w_grouped.shape[1], w_grouped.shape[2]
     assert c == groups * cg
+    total = groups if out_groups is None else int(out_groups)
     if out is None:
-        out = torch.empty((n, groups * co, h, w), dtype=torch.float32, device=xx.device)
-    check(lib().pd3_grouped_conv3x3_small(ptr(xx), ptr(w_grouped), ptr(bias), n, groups, cg, co, h, w, ptr(out),
-                                          stream_ptr(xx.device)), "grouped_conv3x3_small")
+        out = torch.empty((n, total * co, h, w), dtype=torch.float32, device=xx.device)
+    assert out.is_contiguous() and tuple(out.shape) == (n, total * co, h, w)
+    check(lib().pd3_grouped_conv3x3_small_slice(ptr(xx), ptr(w_grouped), ptr(bias), n, groups, cg, co, h, w, ptr(out),
+                                                total, int(out_group0), stream_ptr(xx.device)),
+          "grouped_conv3x3_small")
     return out
