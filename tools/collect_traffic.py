@@ -15,7 +15,8 @@ import sys
 from collections import defaultdict
 
 OPS = {
-    "hard_voxelize": ("vt_route", "vt_group", "vt_assign", "vt_rows", "cell_key", "seg_head",
+    "hard_voxelize": ("vw_route", "vw_group", "vw_count", "vw_assign", "vw_rows",
+                      "vt_route", "vt_group", "vt_assign", "vt_rows", "cell_key", "seg_head",
                       "gather_voxels", "voxel_meta", "EpiVoxelStart", "LoadNonNegative"),
     "pillar_feature_net": ("pfn_",),
     "pointpillars_scatter": ("fill_i32", "inverse_map", "canvas_write"),
@@ -26,18 +27,25 @@ SHARED = ("rs_hist", "rs_scatter", "scan_reduce", "scan_partials", "scan_apply")
 
 
 def load(path):
-    acc = defaultdict(float)
+    """kernel -> (sum of the counter over its dispatches, dispatches).  A dispatch appears once per counter row;
+    with a derived counter rocprofv3 may write several rows per dispatch (one per dimension), so dispatches are
+    told apart by Dispatch_Id."""
+    acc, ids = defaultdict(float), defaultdict(set)
     for r in csv.DictReader(open(path)):
         acc[r["Kernel_Name"]] += float(r["Counter_Value"])
-    return acc
+        ids[r["Kernel_Name"]].add(r.get("Dispatch_Id", len(ids[r["Kernel_Name"]])))
+    return acc, {k: len(v) for k, v in ids.items()}
 
 
 def main():
-    fetch, write = load(sys.argv[1]), load(sys.argv[2])
-    launches = int(sys.argv[3])  # steps + warmup of the profiled bench run
+    (fetch, nf), (write, _nw) = load(sys.argv[1]), load(sys.argv[2])
+    # steps of the profiled run = dispatches of a kernel that runs once per step (the route kernel of hard_voxelize);
+    # the command-line count (steps + warmup) is only the fallback: bench.py also runs a few untimed set-up steps
+    once = [n for k, n in nf.items() if "route_kernel" in k]
+    launches = once[0] if once else int(sys.argv[3])
     out = {"batch": int(sys.argv[5]), "max_voxels": int(sys.argv[6]), "launches_profiled": launches,
            "note": "bytes per launch (= per bench step) ; fetch corrected x2 (gfx950 FETCH_SIZE), write uncorrected"}
-    tiled = any("vt_route" in k for k in fetch)
+    tiled = any("vt_route" in k or "vw_route" in k for k in fetch)
     ops = dict(OPS)
     owner = "centerpoint_postprocess" if tiled else "hard_voxelize"
     ops[owner] = ops[owner] + SHARED
@@ -48,7 +56,7 @@ def main():
                    "bytes_per_launch": (2.0 * f + w) * 1024.0 / launches}
     out["kernels"] = {k[:60]: {"fetch_bytes_x2": 2.0 * fetch.get(k, 0.0) * 1024.0 / launches,
                                "write_bytes": write.get(k, 0.0) * 1024.0 / launches}
-                      for k in sorted(set(fetch) | set(write)) if "pd3" in k or "vt_" in k}
+                      for k in sorted(set(fetch) | set(write)) if "pd3" in k or "vt_" in k or "vw_" in k}
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "kernels"}, indent=1))
 

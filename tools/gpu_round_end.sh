@@ -1,17 +1,22 @@
 #!/bin/bash
-# round-2 measurement run (GPU box): kernel splits, bench lines, PMC traffic.  Outputs under gpurun_out/.
+# round-end measurement run (GPU box): the whole GPU suite, the default bench line, the step's kernel list, PMC
+# traffic, hard_voxelize alone on every path.  Outputs under gpurun_out/<tag>_*; copy what is to be judged to profiles/.
+tag=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-cd $R
-python tools/prof/prof_voxelize.py 16 30000 20 2,3 2>&1 | grep -v amdgpu > gpurun_out/r2z_voxpaths.txt
-PROF_FILTER=vt_ tools/gpu_prof.sh r2z_vox_path2 $R/tools/prof/prof_voxelize.py 16 30000 20 2 > gpurun_out/r2z_prof2.log 2>&1
-PROF_FILTER=vt_ tools/gpu_prof.sh r2z_vox_path3 $R/tools/prof/prof_voxelize.py 16 30000 20 3 > gpurun_out/r2z_prof3.log 2>&1
-PROF_TOP=40 tools/gpu_prof.sh r2z_kitti $R/bench.py --workload pointpillars_kitti --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r2z_prof_kitti.log 2>&1
-python bench.py > gpurun_out/r2z_bench_b16.json 2> gpurun_out/r2z_bench_b16.err
-PROF_TOP=60 tools/gpu_prof.sh r2z_bench_b16 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/r2z_prof_b16.log 2>&1
-cp /tmp/prof_r2z_bench_b16/r2z_bench_b16_kernel_stats.csv gpurun_out/ 2>/dev/null
-tools/gpu_traffic.sh r2z_b16 16 30000 > gpurun_out/r2z_traffic.log 2>&1
-for w in pointpillars_kitti bevfusion_lidar centerpoint_voxel bev_pool_v2; do
-  python bench.py --workload $w --no-cpu-baseline > gpurun_out/r2z_bench_$w.json 2> gpurun_out/r2z_bench_$w.err
-done
-cat gpurun_out/r2z_voxpaths.txt gpurun_out/r2z_vox_path3_kernels.txt
-head -c 600 gpurun_out/r2z_bench_b16.json
+cd $R; mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/${tag}_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1
+python bench.py > gpurun_out/${tag}_bench_b32.json 2> gpurun_out/${tag}_bench.err
+PROF_TOP=90 tools/gpu_prof.sh ${tag}_bench_b32 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --repeats 0 > gpurun_out/${tag}_prof.log 2>&1
+cp /tmp/prof_${tag}_bench_b32/${tag}_bench_b32_kernel_stats.csv gpurun_out/ 2>/dev/null
+tools/gpu_traffic.sh ${tag}_b32 32 30000 > gpurun_out/${tag}_traffic.log 2>&1
+tools/gpu_vox.sh 3,5,6,7,8 0 > /dev/null 2>&1
+cp gpurun_out/vox_paths.txt gpurun_out/${tag}_vox_paths.txt
+cat gpurun_out/${tag}_tests.log gpurun_out/${tag}_smoke.log
+python - <<PY
+import json
+d=json.load(open("gpurun_out/${tag}_bench_b32.json"))
+print("value", d["value"], "ms_per_step", d["ms_per_step"], "vox frac", d["roofline"]["frac"], "traffic", d["roofline"]["traffic"])
+print(d["per_op_ms"]); print(d["extras"]["repeat_blocks"])
+print({k: (v.get("value"), v.get("error")) for k, v in d["extras"]["other_workloads"].items()})
+PY

@@ -7,6 +7,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p /tmp/tr_$tag $R/gpurun_out
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d /tmp/tr_$tag -o ${tag}_$c -- python $R/bench.py --steps 3 --warmup 2 --batch $batch --max-voxels $mv --no-cpu-baseline --no-extras > /tmp/tr_$tag/run_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d /tmp/tr_$tag -o ${tag}_$c -- python $R/bench.py --steps 3 --warmup 2 --batch $batch --max-voxels $mv --no-cpu-baseline --no-extras --repeats 0 > /tmp/tr_$tag/run_$c.log 2>&1
 done
 python $R/tools/collect_traffic.py /tmp/tr_$tag/${tag}_FETCH_SIZE_counter_collection.csv /tmp/tr_$tag/${tag}_WRITE_SIZE_counter_collection.csv 5 $R/gpurun_out/${tag}_traffic.json $batch $mv
