@@ -170,6 +170,61 @@ def cpu_baseline(model_cpu, max_voxels, frames=6):
     return out
 
 
+class NodeSampler:
+    """What else the node is doing while the bench runs: the pool's boxes are 8-GPU nodes shared with other jobs, and
+    the ops next to the step boundary have run 1.2x slower on some of them (round 2 called it the "slow box").  A
+    thread reads the amdgpu sysfs files every 20 ms: every card's gpu_busy_percent and current sclk level.  Recorded
+    in `extras.node_state`, so that a slow line can be told from a loaded node by data instead of by guess."""
+
+    def __init__(self, period=0.02):
+        import glob
+        import threading
+
+        self.cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/gpu_busy_percent"))
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(path):
+        try:
+            return open(path).read()
+        except OSError:
+            return ""
+
+    def _run(self):
+        while not self._stop.is_set():
+            row = []
+            for c in self.cards:
+                busy = self._read(c).strip()
+                cur = [l for l in self._read(c.replace("gpu_busy_percent", "pp_dpm_sclk")).splitlines() if "*" in l]
+                mhz = "".join(ch for ch in (cur[0].split(":")[1] if cur else "") if ch.isdigit())
+                row.append((int(busy) if busy.isdigit() else -1, int(mhz) if mhz else -1))
+            self.samples.append(row)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.cards:
+            self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self.cards:
+            self._t.join(timeout=1.0)
+
+    def summary(self):
+        if not self.samples:
+            return dict(note="no amdgpu sysfs on this host")
+        a = np.asarray(self.samples)  # [samples, cards, (busy, sclk MHz)]
+        busy_mean = a[:, :, 0].mean(0)
+        return dict(cards=len(self.cards), samples=int(a.shape[0]), period_s=self.period,
+                    gpu_busy_percent_mean=[round(float(v), 1) for v in busy_mean],
+                    sclk_mhz_median=[int(np.median(a[:, k, 1])) for k in range(a.shape[1])],
+                    cards_busy_over_50_percent=int((busy_mean > 50).sum()),
+                    note="all cards of the node, sampled while the repeated blocks ran (this process drives one of "
+                         "them; the others belong to other jobs)")
+
+
 def measured_ceilings(dev, mb=384):
     """Device copy / fill rates of this box (GB/s), the practical ceilings next to the 8 TB/s spec."""
     n = mb * (1 << 20) // 4
@@ -249,14 +304,16 @@ def _timed_loop(step, args, world, dev, names):
         sync()
         per_op_ms = {names[i]: float(np.median([events[k][i - 1].elapsed_time(events[k][i])
                                                 for k in range(args.steps)])) for i in range(1, len(names))}
-        repeats = [block(None)[0] for _ in range(max(0, args.repeats))]
+        with NodeSampler() as sampler:
+            repeats = [block(None)[0] for _ in range(max(0, args.repeats))]
+        node = sampler.summary() if args.repeats > 0 else None
     seen = 1
     if world > 1:
         mine = torch.tensor([torch.distributed.get_rank()], dtype=torch.int64, device=dev)
         allr = torch.empty(world, dtype=torch.int64, device=dev)
         torch.distributed.all_gather_into_tensor(allr, mine)
         seen = int(torch.unique(allr).numel())
-    info = dict(dt=dt, repeats_s=repeats, ranks_seen=seen)
+    info = dict(dt=dt, repeats_s=repeats, ranks_seen=seen, node=node)
     _LAST_LOOP.clear()
     _LAST_LOOP.update(info)
     return dt, per_op_ms, out, info
@@ -275,6 +332,8 @@ def _dist_fields(line, args, world):
         line.setdefault("extras", {})["repeat_blocks"] = dict(
             blocks=len(vals), steps_each=args.steps, unit=line["unit"], min=vals[0], median=vals[len(vals) // 2],
             max=vals[-1], note="the same K steps timed again after the contract block; `value` is the contract block")
+    if info.get("node"):
+        line.setdefault("extras", {})["node_state"] = info["node"]
     return line
 
 
