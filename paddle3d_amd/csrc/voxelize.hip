@@ -326,7 +326,7 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
 // wave form of the tiled path (voxelize_wave.hpp)
 // ---------------------------------------------------------------------------------------------------
 struct VwWorkspace {
-  uint32_t *recs, *dir, *clist, *tstate;
+  uint32_t *recs, *dir, *clist, *tcount;
   unsigned char* fmap;
   uint2 *finfo, *vinfo;
   int* totals;
@@ -343,7 +343,7 @@ static VwWorkspace vw_carve(void* base, int batch, int64_t n, int max_voxels, co
   w.clist = c.take<uint32_t>((size_t)batch * w.cap + 4);
   w.fmap = c.take<unsigned char>((size_t)batch * p.fstride);
   w.finfo = c.take<uint2>((size_t)batch * p.fstride);
-  w.tstate = c.take<uint32_t>((size_t)batch * p.atiles);
+  w.tcount = c.take<uint32_t>((size_t)batch * p.atiles);
   w.vinfo = c.take<uint2>((size_t)batch * max_voxels);
   w.totals = c.take<int>((size_t)batch);
   w.bytes = c.off;
@@ -373,7 +373,7 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
 #define PD3_VW_ROUTE(T, R)                                                                                         \
   vw_route_kernel<T, R><<<tile_grid, T, lds_a, s>>>(points, num_points, n, dim, vg, plan.low, plan.gbits,          \
                                                     plan.tiles, batch, max_voxels, w.recs, w.dir, w.fmap,          \
-                                                    plan.fstride, w.tstate, plan.atiles, w.vinfo)
+                                                    plan.fstride, w.vinfo)
   if (plan.threads == 512 && plan.rounds == 8) PD3_VW_ROUTE(512, 8);
   else if (plan.threads == 1024 && plan.rounds == 8) PD3_VW_ROUTE(1024, 8);
   else if (plan.threads == 1024 && plan.rounds == 10) PD3_VW_ROUTE(1024, 10);
@@ -386,9 +386,9 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
       w.recs, w.dir, plan.low, plan.gbits, plan.tiles, plan.tile, tp, batch, max_pts, w.clist, w.cap, w.fmap,
       w.finfo, plan.fstride);
   vw_count_kernel<<<(unsigned)ceil_div((int64_t)plan.atiles * batch, 4), 256, 0, s>>>(w.fmap, plan.fstride, plan.atiles,
-                                                                                       batch, w.tstate);
+                                                                                       batch, w.tcount);
   vw_assign_kernel<<<(unsigned)(plan.atiles * batch), kVwAssignThreads, 0, s>>>(
-      w.fmap, w.finfo, plan.fstride, plan.atiles, batch, w.tstate, max_voxels, vg, w.vinfo, w.totals, coords, num_pts,
+      w.fmap, w.finfo, plan.fstride, plan.atiles, batch, w.tcount, max_voxels, vg, w.vinfo, w.totals, coords, num_pts,
       coors4);
   const int64_t row = (int64_t)max_pts * dim;
   const bool vec4 = (row % 4 == 0) && (reinterpret_cast<uintptr_t>(voxels) % 16 == 0);

@@ -10,20 +10,26 @@
 //     sixteen independent waves per CU hide each other's latency.
 //   * pos16 / cposr (6 bytes per point, written and re-read) are gone: a cell's first point announces itself
 //     by index -- one byte in a per-point map plus an 8-byte record (place of the cell's points in the index
-//     list, count, cell) -- and voxel ids are a prefix over that byte map in point order, taken tile by tile
-//     with a look-back over the earlier tiles' published counts (no atomics, no second launch).
+//     list, count, cell) -- and voxel ids are a prefix over that byte map in point order, tile by tile.
+//   * the row writer maps a lane to a (voxel, point slot) instead of to four floats of the flat output: ~170
+//     instructions per float4 went into finding out whose floats they were.
+// What sets the pace of these kernels is instruction issue (a wave64 instruction occupies its SIMD for several
+// cycles: 4.8 M points x ~150 instructions are 20+ us whatever the memory does) and the NUMBER of scattered memory
+// accesses, not bytes and rarely latency; DESIGN.md section 4.1 has the measurements each choice below rests on.
 //
 //   A  vw_route_kernel    as vt_route_kernel (tile of THREADS * R points sorted by group in LDS, one coalesced
-//                         slice + directory row), minus pos16; clears the first-point map, the look-back
-//                         states and vinfo.
+//                         slice + directory row), minus pos16; clears the first-point map and vinfo.
 //   B  vw_group_kernel    one wave per group: directory column -> prefix; sweep 1 hands out slots (returning
 //                         LDS adds, lane order = point order) and counts; cells are placed in the group's region
-//                         of the index list; sweep 2 writes clist[place] = point index for the kept points and
-//                         the first-point records.  Groups of up to kVwRegSteps * 64 records keep (record, slot)
-//                         in registers between the sweeps; longer ones walk their records twice.
-//   C  vw_assign_kernel   prefix over the first-point bytes = voxel id; vinfo / coords / counts of the voxels a
+//                         of the index list; sweep 2 puts the list together in LDS (clist[place] = point index of
+//                         the kept points, written as one coalesced run) and stores the first-point records.
+//                         Groups of up to kVwRegSteps * 64 records keep (record, slot) in registers between the
+//                         sweeps; longer ones walk their records twice.
+//   C  vw_count_kernel    first points per 4096-point tile (a wave per tile);
+//      vw_assign_kernel   prefix over the first-point bytes = voxel id; vinfo / coords / counts of the voxels a
 //                         tile opens.
-//   E  vt_rows_gather_kernel (voxelize_tiled.hpp), unchanged: the fixed-shape output written once.
+//   E  vw_rows_kernel     the fixed-shape output written once, a lane per (voxel, point slot) (D = 4 / 5; other
+//                         point widths take vt_rows_gather_kernel of voxelize_tiled.hpp).
 // Preconditions (else the other paths run): cells <= 2^20, groups <= 1024 per frame, N < 2^22 - 3, P <= 254.
 #pragma once
 #include "voxelize_tiled.hpp"
@@ -33,7 +39,6 @@ namespace pd3 {
 constexpr int kVwMaxLow = 10;       // cells per group <= 1024: two 4 KB tables per wave, sixteen waves per CU
 constexpr int kVwAssignTile = 4096;  // points per workgroup of the assign kernel (256 threads x 16 bytes)
 constexpr int kVwAssignThreads = 256;
-constexpr uint32_t kVwReady = 0x80000000u;
 
 struct VwPlan {
   int low, cpg, groups, gbits;
@@ -83,8 +88,7 @@ template <int THREADS, int R>
 __global__ __launch_bounds__(THREADS, 8) void vw_route_kernel(
     const float* __restrict__ points, const int32_t* __restrict__ num_points, int64_t n, int dim, VtGrid g, int low,
     int gbits, int tiles, int batch, int max_voxels, uint32_t* __restrict__ recs, uint32_t* __restrict__ dir,
-    unsigned char* __restrict__ fmap, int64_t fstride, uint32_t* __restrict__ tstate, int atiles,
-    uint2* __restrict__ vinfo) {
+    unsigned char* __restrict__ fmap, int64_t fstride, uint2* __restrict__ vinfo) {
   constexpr int kTile = THREADS * R;
   constexpr int kWaves = THREADS / kWave;
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
@@ -109,9 +113,6 @@ __global__ __launch_bounds__(THREADS, 8) void vw_route_kernel(
     uint4* fm = reinterpret_cast<uint4*>(fmap + (int64_t)frame * fstride);
     const int64_t q1 = min((int64_t)(tile + 1) * perq, q);
     for (int64_t j = (int64_t)tile * perq + threadIdx.x; j < q1; j += THREADS) fm[j] = make_uint4(0u, 0u, 0u, 0u);
-    const int pera = (int)ceil_div(atiles, tiles);
-    const int a1 = min((tile + 1) * pera, atiles);
-    for (int a = tile * pera + (int)threadIdx.x; a < a1; a += THREADS) tstate[(int64_t)frame * atiles + a] = 0u;
   }
 
   // phase 1: keys; rank of a point among the wave's earlier points of its group (returning LDS add, lane order)

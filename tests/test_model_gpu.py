@@ -368,3 +368,41 @@ def test_postprocess_records_equal_pack_records():
     for i, k in enumerate(cnt.tolist()):
         assert k > 0 and float(bx[i, k:].abs().sum()) == 0 and float(sc[i, k:].abs().sum()) == 0
         assert int(lb[i, k:].abs().sum()) == 0
+
+
+def test_whole_graph_rows_at_c3_size(oracle):
+    """The whole CenterPoint-Pillars graph at the C3 size (300 k points, V = 30 000, 128 x 128 head maps), pinned row
+    for row where the stages allow it: voxels / coords exact against the reference voxelizer, BEV canvas within 1e-3 of
+    the oracle front end, and the detections EQUAL, bit for bit and in order, to the oracle's post-processing of the
+    head maps the device produced (the decode and NMS arithmetic is glibc-exact, so nothing may flip)."""
+    from paddle3d_amd import centerpoint as cpm
+
+    torch.manual_seed(5)
+    model = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(30000, 30000)).cuda().eval()
+    _randomise_bn(model)
+    with torch.no_grad():
+        for task in model.bbox_head.tasks:
+            task.hm[-1].bias.fill_(-1.0)
+    pts = np.stack([synth.nuscenes_sweep(170), synth.nuscenes_sweep(171)])
+    dev = torch.from_numpy(pts).cuda()
+    cfg = model.test_cfg
+    with torch.no_grad():
+        voxels, coors, npv, nv = model.voxelizer(dev)
+        canvas = model.extract_pillars(dev)
+        preds, _ = model.bbox_head(model.dense_forward(canvas))
+        dets = model.bbox_head.predict_by_custom_op(preds, cfg)
+    for b in range(2):
+        rv, rc, rn, rnv = oracle.hard_voxelize(pts[b], synth.NUSC_PILLAR, synth.NUSC_RANGE, 20, 30000,
+                                               "ref" if oracle.have_ref() else "port")
+        assert int(nv[b]) == rnv == 30000
+        np.testing.assert_array_equal(voxels[b].cpu().numpy().view(np.uint32), rv.view(np.uint32))
+        np.testing.assert_array_equal(coors[b, :, 1:].cpu().numpy(), rc)
+        tasks = [{k: v[b:b + 1].contiguous().cpu().numpy() for k, v in p.items()} for p in preds]
+        rb, rs, rl = oracle.centerpoint_postprocess(
+            tasks, cfg["voxel_size"] + [8.0], cfg["point_cloud_range"] + [0.0] * 4, cfg["post_center_limit_range"],
+            [0, 1, 3, 5, 6, 8], cfg["down_ratio"], cfg["score_threshold"], cfg["nms"]["nms_iou_threshold"],
+            cfg["nms"]["nms_pre_max_size"], cfg["nms"]["nms_post_max_size"], True)
+        assert rb.shape[0] > 50
+        np.testing.assert_array_equal(dets[b]["label_preds"].cpu().numpy(), rl)
+        np.testing.assert_array_equal(dets[b]["scores"].cpu().numpy().view(np.uint32), rs.view(np.uint32))
+        np.testing.assert_array_equal(dets[b]["box3d_lidar"].cpu().numpy().view(np.uint32), rb.view(np.uint32))

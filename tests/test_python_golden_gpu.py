@@ -63,6 +63,10 @@ def test_lss_voxel_pooling_vs_reference_python(pg):
                                np.array([-9.75, -9.75, 0.0], np.float32), [40, 40, 1]).cpu().numpy()
     assert out.shape == pg["lss_out"].shape
     # the reference's cumsum trick carries the rounding of one global running total; per-cell sums do not
+    # 5e-3, not the 1e-3 of the other feature checks: the noisy side is the reference.  Its cumsum trick
+    # (cam_stream_lss.py:111-121) takes differences of an fp32 running sum over ALL points, whose magnitude is the
+    # total, not the cell's sum; against exact per-cell sums the device result is within 1e-4 (tests below), and so
+    # is the reference's trick within 5e-3 of them.
     assert np.abs(out - pg["lss_out"]).max() < 5e-3
     np.testing.assert_array_equal(out != 0, pg["lss_out"] != 0)
 
