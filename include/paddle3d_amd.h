@@ -98,6 +98,21 @@ int pd3_pointpillars_scatter(const float *voxel_features, const int32_t *coords,
                              int64_t num_pillars, int channels, int batch, int ny, int nx,
                              float *canvas, void *workspace, size_t workspace_bytes, void *stream);
 
+/* PointPillarsScatter fused into the convolution that consumes it (round 3): the canvas is never written.
+ *   pd3_pointpillars_inverse_map: inv [batch, ny*nx] int32 = the pillar row (index into voxel_features) whose coords
+ *     name the cell, -1 for an empty cell; on duplicates the highest row wins (paddle.scatter(overwrite=True),
+ *     pillar_scatter.py:83-90).
+ *   pd3_scatter_conv3x3_bias_relu: conv3x3 / pad 1 / stride 2 + bias + ReLU (a SECOND block's first convolution,
+ *     second_backbone.py:84-98, BatchNorm folded) over the canvas those two arguments describe; the kernel stages the
+ *     occupied cells' channels straight from voxel_features [pillars, cin].  w_packed as pd3_conv3x3_bias_relu;
+ *     out [batch, cout, ny/2, out_w] (out_w % 4 == 0, columns >= nx/2 written as zeros).  Results are bit-identical to
+ *     pd3_pointpillars_scatter followed by pd3_conv3x3_bias_relu.  cin % 8 == 0, cout % 64 == 0, ny, nx even. */
+int pd3_pointpillars_inverse_map(const int32_t *coords, int64_t num_pillars, int batch, int ny, int nx,
+                                 int32_t *inv, void *stream);
+int pd3_scatter_conv3x3_bias_relu(const float *voxel_features, const int32_t *inv, const float *w_packed,
+                                  const float *bias, int batch, int cin, int cout, int ny, int nx, int stride,
+                                  int relu, float *out, int out_w, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * pillar feature net (PFN) -- replaces PillarFeatureNet.forward / PFNLayer.forward in eval mode,
  * paddle3d/models/voxel_encoders/pillar_encoder.py:156-210 / :81-105 (decorate with cluster and

@@ -182,8 +182,11 @@ class PointPillarsScatter(nn.Module):
         self.in_channels = in_channels
         g = _grid(voxel_size, point_cloud_range)
         self.nx, self.ny = int(g[0]), int(g[1])
+        self.lazy = False  # True: return a SparseCanvas (set by the model constructors whose backbone takes one)
 
     def forward(self, voxel_features, coords, batch_size):
+        if self.lazy:  # the consumer (SecondBackbone) gathers from the pillar features itself: no canvas is written
+            return _ps.SparseCanvas(voxel_features, coords, batch_size, self.ny, self.nx)
         return _ps.pointpillars_scatter(voxel_features, coords, batch_size, self.ny, self.nx)
 
 
@@ -315,13 +318,27 @@ class SecondBackbone(_InferenceCache, nn.Module):
         """-> the block outputs.  A stage whose width is not a multiple of 4 (CenterPoint-Voxel: 90) comes back in
         zero-padded rows, tagged with its real width (_valid_w); SecondFPN reads the tag."""
         self._require_eval()
-        if x.shape[3] % 4:
+        plan = self._plan()
+        first = None
+        if isinstance(x, _ps.SparseCanvas):
+            # PointPillarsScatter fused into the first convolution where the kernel takes it (stride 2), else written out
+            c0 = plan[0][0]
+            if _conv.scatter_conv_supported(c0.cin, c0.cout, x.ny, x.nx, c0.stride) and x.shape[1] == c0.cin:
+                if "direct" not in c0.packed:
+                    c0.packed["direct"] = _conv.pack_conv3x3_weight(c0.w)
+                first = (_conv.scatter_conv3x3_bias_relu(x, c0.packed["direct"], c0.b, c0.cout), x.nx // 2)
+            else:
+                x = x.dense()
+        if first is None and x.shape[3] % 4:
             raise Paddle3DAmdError(f"SecondBackbone: unsupported configuration (input width {x.shape[3]} is not a "
                                    "multiple of 4) (status -3)")
-        outs, wv = [], int(x.shape[3])
-        for layers in self._plan():
-            for conv in layers:
-                x, wv = conv(x, wv)
+        outs, wv = [], (0 if first is not None else int(x.shape[3]))
+        for bi, layers in enumerate(plan):
+            for li, conv in enumerate(layers):
+                if first is not None and bi == 0 and li == 0:
+                    x, wv = first
+                else:
+                    x, wv = conv(x, wv)
             outs.append(_tag_valid_w(x, wv))
         return tuple(outs)
 
@@ -552,6 +569,8 @@ class CenterPoint(nn.Module):
         self.bbox_head = bbox_head
         self.test_cfg = test_cfg
         self.box_with_velocity = box_with_velocity
+        if isinstance(middle_encoder, PointPillarsScatter) and isinstance(backbone, SecondBackbone):
+            middle_encoder.lazy = True  # the scatter is fused into the backbone's first convolution where it can be
 
     def _pack(self, points):
         if isinstance(points, torch.Tensor):
@@ -564,8 +583,9 @@ class CenterPoint(nn.Module):
         lens = torch.tensor([p.shape[0] for p in points], dtype=torch.int32, device=points[0].device)
         return out, lens
 
-    def extract_pillars(self, points, num_points=None):
-        """voxelize -> voxel encoder -> middle encoder: the LiDAR front half (dense BEV features)."""
+    def extract_pillars(self, points, num_points=None, dense=True):
+        """voxelize -> voxel encoder -> middle encoder: the LiDAR front half (dense BEV features; dense=False leaves a
+        PointPillarsScatter result as the SparseCanvas the backbone consumes without writing the pseudo image)."""
         voxels, coors, npv, nv = self.voxelizer(points, num_points)
         b, v, p, d = voxels.shape
         voxels, coors, npv = voxels.view(b * v, p, d), coors.view(b * v, 4), npv.view(b * v)
@@ -577,7 +597,8 @@ class CenterPoint(nn.Module):
             keep = coors[:, 0] >= 0
             voxels, coors, npv = voxels[keep], coors[keep].contiguous(), npv[keep]
         feats = self.voxel_encoder(voxels, npv, coors)
-        return self.middle_encoder(feats, coors, b)
+        x = self.middle_encoder(feats, coors, b)
+        return x.dense() if dense and isinstance(x, _ps.SparseCanvas) else x
 
     def dense_forward(self, x):
         """SecondBackbone -> SecondFPN (centerpoint.py:133-137)."""
@@ -586,7 +607,7 @@ class CenterPoint(nn.Module):
     @torch.no_grad()
     def test_forward(self, points, device_only=False):
         pts, lens = self._pack(points)
-        x = self.extract_pillars(pts, lens)
+        x = self.extract_pillars(pts, lens, dense=False)
         x = self.dense_forward(x)
         preds, _ = self.bbox_head(x)
         return self.bbox_head.predict_by_custom_op(preds, self.test_cfg, device_only=device_only)

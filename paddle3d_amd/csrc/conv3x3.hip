@@ -34,12 +34,18 @@ constexpr int kCvK = kCvCi * 9;
 
 // XB = number of X buffers: 2 (one barrier per trip), or 1 for the 256-pixel stride-2 tile whose staged input
 // (42 KB) would not leave room for two workgroups per CU if doubled -- one more barrier per trip instead.
-template <int R, int WT, int S, int XB>
+// FUSED: the input map is never materialised -- `x` is the pillar feature matrix [pillars, cin] and `imap` the
+// inverse map cell -> pillar row (-1: empty) of PointPillarsScatter (pillar_scatter.py:57-93); the staging of a
+// chunk gathers the 8 channels of the tile's occupied cells (32 contiguous bytes of a pillar's row each) straight
+// into the LDS image, whose empty cells were zeroed once.  A nuScenes canvas is 11 % occupied: the first backbone
+// convolution stages less than it did from the dense canvas, and the 67 MB per frame the scatter wrote are gone.
+template <int R, int WT, int S, int XB, bool FUSED = false>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ wp,
                                                            const float* __restrict__ bias,
                                                            float* __restrict__ out, int cin, int cout,
-                                                           int h, int w, int wi, int wv, int relu, int ptiles) {
+                                                           int h, int w, int wi, int wv, int relu, int ptiles,
+                                                           const int* __restrict__ imap) {
   // h, w: OUTPUT rows and row pitch; the input map has S*h rows of pitch wi, S = stride (1 or 2), padding 1.
   // Output columns >= wv (the valid width) are written as zeros: a map whose width is not a multiple of 4 lives
   // in rows padded with zeros, which the next layer reads as its own zero padding.
@@ -91,6 +97,24 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
   // of the image repeat its last float4 (same value to the same address).
   int gofs[XPT], ldst[XPT];
   unsigned live = 0;
+  // FUSED: thread t owns cells t, t + 256, ... of the staged [XR][XW] window; cpid = pillar row of the cell or -1
+  constexpr int NCELL = XR * XW, CPT = (NCELL + 255) / 256;
+  int cpid[FUSED ? CPT : 1], cdst[FUSED ? CPT : 1];
+  if (FUSED) {
+    const int* im = imap + (int64_t)n * iplane;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int e = (int)threadIdx.x + i * 256;
+      const int r = e / XW, c = e - r * XW;
+      const int gy = S * y0 - 1 + r, gx = S * x0 - 4 + c;
+      const bool ok = e < NCELL && gy >= 0 && gy < hi && gx >= 0 && gx < wi;
+      cpid[i] = ok ? im[(int64_t)gy * wi + gx] : -1;
+      cdst[i] = min(e, NCELL - 1);
+    }
+    for (int e = threadIdx.x; e < XB * XSZ / 4; e += 256)
+      reinterpret_cast<cv_f32x4*>(cv_smem)[e] = (cv_f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
     const int e = min((int)threadIdx.x + i * 256, XN4 - 1);
@@ -106,13 +130,22 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < WPT; ++i) wofs[i] = min((int)threadIdx.x + i * 256, WN4 - 1);
   const cv_f32x4* wsrc = reinterpret_cast<const cv_f32x4*>(wp) + (int64_t)ct * chunks * WN4;
-  cv_f32x4 xr[XPT], wr[WPT];
+  cv_f32x4 xr[FUSED ? 2 * CPT : XPT], wr[WPT];
 
 #define CV_FETCH(cc)                                                                     \
   {                                                                                      \
-    const float* xc_ = xin + (int64_t)(cc) * kCvCi * iplane;                             \
-    _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                      \
-        xr[i] = *reinterpret_cast<const cv_f32x4*>(xc_ + gofs[i]);                         \
+    if (FUSED) {                                                                         \
+      _Pragma("unroll") for (int i = 0; i < CPT; ++i)                                    \
+        if (cpid[i] >= 0) {                                                              \
+          const float* f_ = x + (int64_t)cpid[i] * cin + (cc) * kCvCi;                   \
+          xr[2 * i] = *reinterpret_cast<const cv_f32x4*>(f_);                            \
+          xr[2 * i + 1] = *reinterpret_cast<const cv_f32x4*>(f_ + 4);                    \
+        }                                                                                \
+    } else {                                                                             \
+      const float* xc_ = xin + (int64_t)(cc) * kCvCi * iplane;                           \
+      _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                    \
+          xr[i] = *reinterpret_cast<const cv_f32x4*>(xc_ + gofs[i]);                     \
+    }                                                                                    \
     const cv_f32x4* wc_ = wsrc + (int64_t)(cc) * WN4;                                      \
     _Pragma("unroll") for (int i = 0; i < WPT; ++i) wr[i] = wc_[wofs[i]];                \
   }
@@ -120,10 +153,21 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
   {                                                                                      \
     float* xd_ = cv_smem + (XB == 2 ? (buf) : 0) * XSZ;                                  \
     float* wd_ = cv_smem + XB * XSZ + (buf) * WSZ;                                       \
-    _Pragma("unroll") for (int i = 0; i < XPT; ++i) {                                    \
-      const bool on_ = (live >> i) & 1u;                                                 \
-      const cv_f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                          \
-      *reinterpret_cast<cv_f32x4*>(xd_ + ldst[i]) = on_ ? xr[i] : z_;                    \
+    if (FUSED) {                                                                         \
+      _Pragma("unroll") for (int i = 0; i < CPT; ++i)                                    \
+        if (cpid[i] >= 0) {                                                              \
+          float* d_ = xd_ + cdst[i];                                                     \
+          _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                             \
+            d_[k_ * XPL] = xr[2 * i][k_];                                                \
+            d_[(4 + k_) * XPL] = xr[2 * i + 1][k_];                                      \
+          }                                                                              \
+        }                                                                                \
+    } else {                                                                             \
+      _Pragma("unroll") for (int i = 0; i < XPT; ++i) {                                  \
+        const bool on_ = (live >> i) & 1u;                                               \
+        const cv_f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                        \
+        *reinterpret_cast<cv_f32x4*>(xd_ + ldst[i]) = on_ ? xr[i] : z_;                  \
+      }                                                                                  \
     }                                                                                    \
     _Pragma("unroll") for (int i = 0; i < WPT; ++i)                                      \
         *reinterpret_cast<cv_f32x4*>(wd_ + wofs[i] * 4) = wr[i];                         \
@@ -201,18 +245,19 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(const float* __restri
   }
 }
 
-template <int R, int WT, int S, int XB = 2>
+template <int R, int WT, int S, int XB = 2, bool FUSED = false>
 static int launch_conv3x3(int64_t tiles, hipStream_t s, const float* x, const float* wp, const float* bias,
-                          float* out, int cin, int cout, int h, int w, int wi, int wv, int relu) {
+                          float* out, int cin, int cout, int h, int w, int wi, int wv, int relu,
+                          const int* imap = nullptr) {
   constexpr size_t lds = (size_t)(XB * kCvCi * ((R - 1) * S + 3) * (S * WT + 8) + 2 * kCvK * kCvCo) * sizeof(float);
   // raise the dynamic-LDS cap (per device and per instantiation: set on every launch, it is a host-side table write)
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<R, WT, S, XB>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<R, WT, S, XB, FUSED>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int64_t nwg = (tiles + 7) / 8 * 8 * (cout / kCvCo);
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
-  conv3x3_mfma_kernel<R, WT, S, XB><<<(unsigned)nwg, 256, lds, s>>>(x, wp, bias, out, cin, cout, h, w, wi, wv, relu,
-                                                                    (int)tiles);
+  conv3x3_mfma_kernel<R, WT, S, XB, FUSED><<<(unsigned)nwg, 256, lds, s>>>(x, wp, bias, out, cin, cout, h, w, wi, wv,
+                                                                           relu, (int)tiles, imap);
   return launch_status();
 }
 
@@ -351,6 +396,32 @@ extern "C" int pd3_conv3x3_bias_relu(const float* x, const float* w_packed, cons
     return PD3_CV(4, 32, 2);  // any size
   }
 #undef PD3_CV
+}
+
+// PointPillarsScatter fused into a stride-2 3x3 convolution (the first SECOND block of the pillar models): see FUSED
+// above.  feats [pillars, cin], imap [batch, ny * nx] (pd3_pointpillars_inverse_map), out [batch, cout, ny/2, out_w].
+extern "C" int pd3_scatter_conv3x3_bias_relu(const float* feats, const int32_t* imap, const float* w_packed,
+                                             const float* bias, int batch, int cin, int cout, int ny, int nx,
+                                             int stride, int relu, float* out, int out_w, void* stream) {
+  if (!feats || !imap || !w_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || ny <= 0 || nx <= 0 || out_w <= 0)
+    return PD3_EINVAL;
+  if (stride != 2) return PD3_EUNSUPPORTED;
+  if (cin % kCvCi != 0 || cout % kCvCo != 0 || ny % 2 != 0 || nx % 2 != 0 || out_w % 4 != 0 || out_w < nx / 2)
+    return PD3_EUNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(w_packed) % 16 != 0 || reinterpret_cast<uintptr_t>(feats) % 16 != 0 || cin % 4 != 0)
+    return PD3_EINVAL;
+  if ((int64_t)ny * nx >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int ho = ny / 2, wo = out_w, wv = nx / 2;
+  const int* im = reinterpret_cast<const int*>(imap);
+  if (wo % 128 == 0 && ho % 2 == 0)
+    return launch_conv3x3<2, 128, 2, 1, true>((int64_t)batch * ho * wo / 256, s, feats, w_packed, bias, out, cin, cout, ho,
+                                              wo, nx, wv, relu, im);
+  if (wo % 64 == 0 && ho % 2 == 0)
+    return launch_conv3x3<2, 64, 2, 2, true>((int64_t)batch * ceil_div(ho, 2) * ceil_div(wo, 64), s, feats, w_packed, bias,
+                                             out, cin, cout, ho, wo, nx, wv, relu, im);
+  return launch_conv3x3<4, 32, 2, 2, true>((int64_t)batch * ceil_div(ho, 4) * ceil_div(wo, 32), s, feats, w_packed, bias,
+                                           out, cin, cout, ho, wo, nx, wv, relu, im);
 }
 
 static int grouped_small_launch(const float* x, const float* w_grouped, const float* bias, int batch, int groups,

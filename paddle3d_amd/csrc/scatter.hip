@@ -79,6 +79,21 @@ extern "C" size_t pd3_pointpillars_scatter_workspace(int batch, int ny, int nx) 
   return align_up((size_t)batch * ny * nx * sizeof(int), 256);
 }
 
+// The inverse map alone (cell -> pillar row, -1 for an empty cell): what pd3_scatter_conv3x3_bias_relu reads instead of
+// a materialised canvas.  inv [batch, ny * nx] int32.
+extern "C" int pd3_pointpillars_inverse_map(const int32_t* coords, int64_t num_pillars, int batch, int ny, int nx,
+                                            int32_t* inv, void* stream) {
+  if (!inv || batch <= 0 || ny <= 0 || nx <= 0 || num_pillars < 0 || (num_pillars > 0 && !coords)) return PD3_EINVAL;
+  if (num_pillars >= ((int64_t)1 << 31)) return PD3_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t cells = (int64_t)ny * nx * batch;
+  fill_i32_kernel<<<(unsigned)ceil_div(cells, 256), 256, 0, s>>>(reinterpret_cast<int*>(inv), cells, -1);
+  if (num_pillars > 0)
+    inverse_map_kernel<<<(unsigned)ceil_div(num_pillars, 256), 256, 0, s>>>(coords, num_pillars, batch, ny, nx,
+                                                                            reinterpret_cast<int*>(inv));
+  return launch_status();
+}
+
 extern "C" int pd3_pointpillars_scatter(const float* voxel_features, const int32_t* coords,
                                         int64_t num_pillars, int channels, int batch, int ny,
                                         int nx, float* canvas, void* workspace,

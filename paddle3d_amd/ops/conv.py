@@ -49,6 +49,23 @@ def conv3x3_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, 
     return out
 
 
+def scatter_conv_supported(cin: int, cout: int, ny: int, nx: int, stride: int) -> bool:
+    return stride == 2 and cin % 8 == 0 and cout % 64 == 0 and ny % 2 == 0 and nx % 2 == 0
+
+
+def scatter_conv3x3_bias_relu(canvas, w_packed: torch.Tensor, bias, cout: int, relu: bool = True) -> torch.Tensor:
+    """conv3x3 / pad 1 / stride 2 + bias + ReLU over a SparseCanvas (ops.pointpillars_scatter) without writing the
+    canvas: -> [B, cout, ny/2, pitch4(nx/2)] (columns >= nx/2 zero).  Bit-identical to scatter + conv3x3_bias_relu."""
+    f, inv = canvas.features, canvas.inv
+    n, cin, ny, nx = canvas.shape
+    wo = pitch4(nx // 2)
+    out = torch.empty((n, cout, ny // 2, wo), dtype=torch.float32, device=f.device)
+    check(lib().pd3_scatter_conv3x3_bias_relu(ptr(f), ptr(inv), ptr(w_packed), ptr(bias), n, cin, cout, ny, nx, 2,
+                                              int(bool(relu)), ptr(out), wo, stream_ptr(f.device)),
+          "scatter_conv3x3_bias_relu")
+    return out
+
+
 def winograd_supported(cin: int, cout: int, h: int, w: int) -> bool:
     return cin % 8 == 0 and cout % 32 == 0 and w % 4 == 0
 

@@ -188,6 +188,8 @@ class PointPillars(nn.Module):
         self.voxelizer = voxelizer
         self.pillar_encoder = pillar_encoder
         self.middle_encoder = middle_encoder
+        if isinstance(middle_encoder, PointPillarsScatter) and isinstance(backbone, SecondBackbone):
+            middle_encoder.lazy = True  # the scatter is fused into the backbone's first convolution where it can be
         self.backbone = backbone
         self.neck = neck
         self.head = head

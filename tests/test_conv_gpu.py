@@ -251,3 +251,33 @@ def test_winograd43_shift_taps():
             out = conv.conv3x3_winograd43_bias_relu(x.cuda(), conv.pack_winograd43_weight(wt.cuda()), None, cout, False).cpu()
             want = F.conv2d(x, wt, None, padding=1)
             assert (out - want).abs().max().item() < 5e-3, (ky, kx, (out - want).abs().max().item())
+
+
+@pytest.mark.parametrize("ny,nx,batch", [(512, 512, 2), (496, 432, 2), (64, 96, 3), (40, 24, 1)])
+def test_scatter_fused_into_stride2_conv(ny, nx, batch):
+    """PointPillarsScatter fused into the first backbone convolution (pd3_scatter_conv3x3_bias_relu): bit-identical
+    to the canvas written out and convolved (every stride-2 tile shape: 128-, 64- and 32-pixel-wide output tiles,
+    partial tiles, duplicate coordinates = the highest pillar row wins, padding rows with batch -1)."""
+    import torch
+
+    from paddle3d_amd.ops import conv
+    from paddle3d_amd.ops import pointpillars_scatter as ps
+
+    torch.manual_seed(ny + nx)
+    cin, cout = 64, 64
+    m = min(6000, ny * nx // 3) * batch
+    coords = torch.stack([torch.randint(0, batch, (m,)), torch.zeros(m, dtype=torch.long),
+                          torch.randint(0, ny, (m,)), torch.randint(0, nx, (m,))], 1).int()
+    coords[::97, 0] = -1                     # padding rows of a fixed-shape voxelizer output
+    coords[5] = coords[3]                    # a duplicate cell
+    feats = torch.randn(m, cin)
+    w = torch.randn(cout, cin, 3, 3) * 0.05
+    b = torch.randn(cout)
+    feats, coords, w, b = feats.cuda(), coords.cuda(), w.cuda(), b.cuda()
+    wp = conv.pack_conv3x3_weight(w)
+    canvas = ps.pointpillars_scatter(feats, coords, batch, ny, nx)
+    want = conv.conv3x3_bias_relu(canvas, wp, b, cout, relu=True, stride=2)
+    got = conv.scatter_conv3x3_bias_relu(ps.SparseCanvas(feats, coords, batch, ny, nx), wp, b, cout)
+    assert got.shape == want.shape
+    assert torch.equal(got, want)
+    assert torch.equal(ps.SparseCanvas(feats, coords, batch, ny, nx).dense(), canvas)
