@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void pfn_single64_kernel(PfnArgs a) {
 typedef float pfn_f32x4 __attribute__((ext_vector_type(4)));
 
 template <int D, int CD, int C1, int MAXP, int LINE>
-__global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_two_mfma_kernel(PfnArgs a) {
+__global__ __launch_bounds__(256, C1 == 32 ? 4 : 2) void pfn_two_mfma_kernel(PfnArgs a) {
   constexpr int IN = D + 3 + CD;
   static_assert(IN <= 12, "layer-1 K is padded to 12");
   constexpr int NB1 = C1 / 16;   // layer-1 column blocks
@@ -305,7 +305,12 @@ __global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_two_mfma_kernel(Pfn
   float* bases = m1s + C1;                  // [64]
   float* part = bases + 64;                 // [4][64]
   // ---- weights and folded BatchNorm in registers ------------------------------------------------
-  float w1r[3][NB1], w2a[KS2][4], w2b[C1];
+  // W2's second half (the weights of the max-pooled concat half) in registers for the wide variant; for C1 = 32 it
+  // lives in LDS, shared by the four waves: the kernel is a chain of dependent LDS / MFMA steps per pillar, and the 32
+  // registers decide between three and four waves per SIMD to hide it behind
+  constexpr bool kW2bLds = C1 == 32;
+  float* w2bs = smem + 4 * kWaveFloats;  // [C1][64] (kW2bLds)
+  float w1r[3][NB1], w2a[KS2][4], w2b[kW2bLds ? 1 : C1];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
@@ -317,8 +322,13 @@ __global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_two_mfma_kernel(Pfn
   for (int ks = 0; ks < KS2; ++ks)
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) w2a[ks][cb] = a.w2[(ks * 4 + g) * 64 + cb * 16 + r16];
+  if (kW2bLds) {
+    for (int i = threadIdx.x; i < C1 * 64; i += 256) w2bs[i] = a.w2[C1 * 64 + i];
+    __syncthreads();
+  } else {
 #pragma unroll
-  for (int i = 0; i < C1; ++i) w2b[i] = a.w2[(C1 + i) * 64 + lane];
+    for (int i = 0; i < (kW2bLds ? 1 : C1); ++i) w2b[i] = a.w2[(C1 + i) * 64 + lane];
+  }
   float sc1[NB1], sh1[NB1], sc2[4], sh2[4];
 #pragma unroll
   for (int cb = 0; cb < NB1; ++cb) {
@@ -431,10 +441,17 @@ __global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_two_mfma_kernel(Pfn
 #pragma unroll
     for (int i4 = 0; i4 < C1; i4 += 4) {
       const pfn_f32x4 mv = *reinterpret_cast<const pfn_f32x4*>(m1s + i4);
-      base = fmaf(mv[0], w2b[i4 + 0], base);
-      base = fmaf(mv[1], w2b[i4 + 1], base);
-      base = fmaf(mv[2], w2b[i4 + 2], base);
-      base = fmaf(mv[3], w2b[i4 + 3], base);
+      if (kW2bLds) {
+        base = fmaf(mv[0], w2bs[(i4 + 0) * 64 + lane], base);
+        base = fmaf(mv[1], w2bs[(i4 + 1) * 64 + lane], base);
+        base = fmaf(mv[2], w2bs[(i4 + 2) * 64 + lane], base);
+        base = fmaf(mv[3], w2bs[(i4 + 3) * 64 + lane], base);
+      } else {
+        base = fmaf(mv[0], w2b[kW2bLds ? 0 : i4 + 0], base);
+        base = fmaf(mv[1], w2b[kW2bLds ? 0 : i4 + 1], base);
+        base = fmaf(mv[2], w2b[kW2bLds ? 0 : i4 + 2], base);
+        base = fmaf(mv[3], w2b[kW2bLds ? 0 : i4 + 3], base);
+      }
     }
     bases[lane] = base;
     wave_lds_order();
@@ -539,7 +556,8 @@ extern "C" int pd3_pillar_feature_net(const float* voxels, const int32_t* num_po
   }
 #define PD3_PFN_MFMA(DD, CDV, C1V, MAXPV, LINEV)                                                                \
   do {                                                                                                        \
-    constexpr size_t lds_ = (size_t)4 * (LINEV + MAXPV * (C1V + 2) + C1V + 64 + 4 * 64) * sizeof(float);       \
+    constexpr size_t lds_ = ((size_t)4 * (LINEV + MAXPV * (C1V + 2) + C1V + 64 + 4 * 64) +                     \
+                             (C1V == 32 ? C1V * 64 : 0)) * sizeof(float);                                      \
     if (lds_ > 48 * 1024) {                                                                                    \
       hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(pfn_two_mfma_kernel<DD, CDV, C1V, MAXPV, LINEV>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);              \
