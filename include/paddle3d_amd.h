@@ -75,6 +75,16 @@ int pd3_hard_voxelize_path(const float *points, const int32_t *num_points, int b
                            int32_t *num_points_per_voxel, int32_t *num_voxels, int32_t *coors_batched,
                            void *workspace, size_t workspace_bytes, void *stream, int path);
 
+/* hard_voxelize for double points: PD_DISPATCH_FLOATING_TYPES (voxelize_op.cc:128) instantiates the reference's CPU
+ * kernel for float and double; with T = double the cell index is floor((p - (double)range_min) / (double)voxel_size)
+ * (:37-45) and `voxels` is double.  Generic sort path (any grid below 2^31 cells); the workspace of
+ * pd3_hard_voxelize_workspace suffices.  points / voxels fp64 device, everything else as pd3_hard_voxelize. */
+int pd3_hard_voxelize_f64(const double *points, const int32_t *num_points, int batch, int64_t max_points,
+                          int num_point_dim, const float *voxel_size, const float *point_cloud_range,
+                          int max_num_points_in_voxel, int max_voxels, double *voxels, int32_t *coords,
+                          int32_t *num_points_per_voxel, int32_t *num_voxels, int32_t *coors_batched,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* dynamic_voxelize -- per-point voxel coordinates without the per-voxel cap.  The reference has no such
  * operator (only a "dynamic voxelization" comment at transforms/ for num_points == -1);
  * BASELINE.json's north star names it, so it is provided with hard_voxelize's own cell rule

@@ -62,6 +62,49 @@ int port_hard_voxelize(const float *points, int64_t n, int d, const float *voxel
   return 0;
 }
 
+/* the same scan with T = double (PD_DISPATCH_FLOATING_TYPES, voxelize_op.cc:128): the float attributes are promoted,
+ * the cell index is floor((p - (double)min) / (double)size) in double (:37-45) */
+int port_hard_voxelize_f64(const double *points, int64_t n, int d, const float *voxel_size,
+                           const float *pc_range, int max_pts, int max_voxels, double *voxels,
+                           int32_t *coords, int32_t *num_pts, int32_t *num_voxels) {
+  const int gx = grid_extent(pc_range[0], pc_range[3], voxel_size[0]);
+  const int gy = grid_extent(pc_range[1], pc_range[4], voxel_size[1]);
+  const int gz = grid_extent(pc_range[2], pc_range[5], voxel_size[2]);
+  const size_t cells = (size_t)gx * gy * gz;
+  int32_t *cell_to_voxel = (int32_t *)malloc(cells * sizeof(int32_t));
+  if (!cell_to_voxel) return -1;
+  for (size_t i = 0; i < cells; ++i) cell_to_voxel[i] = -1;
+  memset(voxels, 0, sizeof(double) * (size_t)max_voxels * max_pts * d);
+  memset(coords, 0, sizeof(int32_t) * (size_t)max_voxels * 3);
+  memset(num_pts, 0, sizeof(int32_t) * (size_t)max_voxels);
+  int made = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double *p = points + i * d;
+    const int cx = (int)floor((p[0] - pc_range[0]) / voxel_size[0]);
+    const int cy = (int)floor((p[1] - pc_range[1]) / voxel_size[1]);
+    const int cz = (int)floor((p[2] - pc_range[2]) / voxel_size[2]);
+    if (cx < 0 || cx >= gx || cy < 0 || cy >= gy || cz < 0 || cz >= gz) continue;
+    const size_t cell = ((size_t)cz * gy + cy) * gx + cx;
+    int v = cell_to_voxel[cell];
+    if (v < 0) {
+      if (made >= max_voxels) continue;
+      v = made++;
+      cell_to_voxel[cell] = v;
+      coords[v * 3 + 0] = cz;
+      coords[v * 3 + 1] = cy;
+      coords[v * 3 + 2] = cx;
+    }
+    const int k = num_pts[v];
+    if (k < max_pts) {
+      memcpy(voxels + ((size_t)v * max_pts + k) * d, p, sizeof(double) * d);
+      num_pts[v] = k + 1;
+    }
+  }
+  num_voxels[0] = made;
+  free(cell_to_voxel);
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * rotated BEV IoU  (iou3d_nms/iou3d_cpu.cpp:36-239)
  * ---------------------------------------------------------------------------------------------- */

@@ -49,6 +49,9 @@ void port_bev_pool_v2_bkwd(int c, int n_intervals, const float *out_grad, const 
                            const int32_t *interval_starts, const int32_t *interval_lengths,
                            float *depth_grad, float *feat_grad);
 
+int port_hard_voxelize_f64(const double *points, int64_t n, int d, const float *voxel_size,
+                           const float *pc_range, int max_pts, int max_voxels, double *voxels,
+                           int32_t *coords, int32_t *num_pts, int32_t *num_voxels);
 void port_libm_eval(int op, const float *x, const float *y, float *out, int64_t n);
 
 #ifdef __cplusplus

@@ -65,14 +65,16 @@ def have_ref() -> bool:
 # ------------------------------------------------------------------------------------------------
 def hard_voxelize(points, voxel_size, pc_range, max_pts, max_voxels, kind="port"):
     """Returns (voxels [V,P,D] f32, coords [V,3] i32 (z,y,x), num_points [V] i32, num_voxels int)."""
-    pts = _c(points, _f)
+    f64 = np.asarray(points).dtype == np.float64  # the reference's kernel instantiated for double
+    pts = _c(points, np.float64 if f64 else _f)
     n, d = pts.shape
     vs, pr = _c(voxel_size, _f), _c(pc_range, _f)
-    voxels = np.empty((max_voxels, max_pts, d), _f)
+    voxels = np.empty((max_voxels, max_pts, d), pts.dtype)
     coords = np.empty((max_voxels, 3), _i)
     npts = np.empty((max_voxels,), _i)
     nv = np.zeros((1,), _i)
-    fn = _lib(kind).port_hard_voxelize if kind == "port" else _lib(kind).ref_hard_voxelize
+    name = ("port" if kind == "port" else "ref") + "_hard_voxelize" + ("_f64" if f64 else "")
+    fn = getattr(_lib(kind), name)
     fn.restype = C.c_int
     fn(_p(pts), C.c_int64(n), C.c_int(d), _p(vs), _p(pr), C.c_int(max_pts), C.c_int(max_voxels),
        _p(voxels), _p(coords), _p(npts), _p(nv))

@@ -71,6 +71,27 @@ int ref_hard_voxelize(const float *points, int64_t num_points, int num_point_dim
   return 0;
 }
 
+// The same with the kernel instantiated for double (PD_DISPATCH_FLOATING_TYPES, voxelize_op.cc:128).
+int ref_hard_voxelize_f64(const double *points, int64_t num_points, int num_point_dim,
+                          const float *voxel_size, const float *point_cloud_range,
+                          int max_num_points_in_voxel, int max_voxels, double *voxels, int *coords,
+                          int *num_points_per_voxel, int *num_voxels) {
+  const float voxel_size_x = voxel_size[0], voxel_size_y = voxel_size[1], voxel_size_z = voxel_size[2];
+  int grid_size_x = static_cast<int>(round((point_cloud_range[3] - point_cloud_range[0]) / voxel_size_x));
+  int grid_size_y = static_cast<int>(round((point_cloud_range[4] - point_cloud_range[1]) / voxel_size_y));
+  int grid_size_z = static_cast<int>(round((point_cloud_range[5] - point_cloud_range[2]) / voxel_size_z));
+  std::fill(coords, coords + (size_t)max_voxels * 3, 0);
+  std::fill(num_points_per_voxel, num_points_per_voxel + max_voxels, 0);
+  num_voxels[0] = 0;
+  std::vector<int> grid((size_t)grid_size_x * grid_size_y * grid_size_z, -1);
+  ref_vox::hard_voxelize_cpu_kernel<double, int>(
+      points, point_cloud_range[0], point_cloud_range[1], point_cloud_range[2], voxel_size_x,
+      voxel_size_y, voxel_size_z, grid_size_x, grid_size_y, grid_size_z, num_points, num_point_dim,
+      max_num_points_in_voxel, max_voxels, voxels, coords, num_points_per_voxel, grid.data(),
+      num_voxels);
+  return 0;
+}
+
 // boxes_iou_bev_cpu loop (iou3d_cpu.cpp:257-262) over the extracted iou_bev.
 void ref_boxes_iou_bev(const float *boxes_a, int num_a, const float *boxes_b, int num_b,
                        float *ans_iou) {

@@ -50,7 +50,17 @@ __device__ __forceinline__ bool axis_cell(float p, float lo, float size, int ext
   return c < extent;
 }
 
-__global__ __launch_bounds__(256) void cell_key_kernel(const float* __restrict__ points,
+// The same for double points (PD_DISPATCH_FLOATING_TYPES, voxelize_op.cc:128, instantiates the CPU kernel for double
+// too): `points[i] - range_min` and the division promote the float attributes to double (:37-45 with T = double).
+__device__ __forceinline__ bool axis_cell(double p, float lo, float size, int extent, int& c) {
+  const double q = floor((p - (double)lo) / (double)size);
+  if (!(q >= 0.0 && q < (double)extent)) return false;  // also false for NaN
+  c = (int)q;
+  return c < extent;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cell_key_kernel(const T* __restrict__ points,
                                                        const int32_t* __restrict__ num_points,
                                                        int64_t max_points, int dim, VoxGrid g,
                                                        uint32_t* __restrict__ keys) {
@@ -60,7 +70,7 @@ __global__ __launch_bounds__(256) void cell_key_kernel(const float* __restrict__
   const int64_t n = num_points ? (int64_t)num_points[frame] : max_points;
   uint32_t key = g.ncells;
   if (i < n) {
-    const float* p = points + ((int64_t)frame * max_points + i) * dim;
+    const T* p = points + ((int64_t)frame * max_points + i) * dim;
     int cx, cy, cz;
     if (axis_cell(p[0], g.min_x, g.size_x, g.gx, cx) && axis_cell(p[1], g.min_y, g.size_y, g.gy, cy) &&
         axis_cell(p[2], g.min_z, g.size_z, g.gz, cz)) {
@@ -112,11 +122,12 @@ struct EpiVoxelStart {
 };
 
 // One thread per output float of `voxels` (coalesced 4-byte lanes over the contiguous [V,P,D] block).
+template <typename T>
 __global__ __launch_bounds__(256) void gather_voxels_kernel(
-    const float* __restrict__ points, const uint32_t* __restrict__ skey,
+    const T* __restrict__ points, const uint32_t* __restrict__ skey,
     const uint32_t* __restrict__ sidx, const int* __restrict__ vox_start,
     const int* __restrict__ totals, int64_t n, int dim, int max_pts, int max_voxels,
-    float* __restrict__ voxels) {
+    T* __restrict__ voxels) {
   const int frame = blockIdx.y;
   const int64_t per_frame = (int64_t)max_voxels * max_pts * dim;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(256) void gather_voxels_kernel(
   const int r = (int)(e - (int64_t)v * row);
   const int k = r / dim, c = r - k * dim;
   const int nv = min(totals[frame], max_voxels);
-  float out = 0.0f;
+  T out = (T)0;
   if (v < nv) {
     const int64_t s = vox_start[(int64_t)frame * max_voxels + v];
     const uint32_t* keyp = skey + (int64_t)frame * n;
@@ -418,6 +429,37 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
   return launch_status();
 }
 
+// generic path: stable radix sort of (cell, index), segment heads, flag scan in point order, voxel-parallel gather
+template <typename T>
+static int run_sort_path(const T* points, const int32_t* num_points, int batch, int64_t n, int num_point_dim,
+                         const VoxGrid& g, int max_num_points_in_voxel, int max_voxels, T* voxels, int32_t* coords,
+                         int32_t* num_points_per_voxel, int32_t* num_voxels, int32_t* coors_batched, void* workspace,
+                         hipStream_t s) {
+  const int64_t max_points = n;
+  const RadixPlan plan = radix_plan(g.ncells, max_points);
+  VoxWorkspace w = carve(workspace, batch, max_points, max_voxels, plan);
+
+  dim3 pgrid((unsigned)ceil_div(n, 256), batch);
+  cell_key_kernel<T><<<pgrid, 256, 0, s>>>(points, num_points, n, num_point_dim, g, w.keys_a);
+  const int where = enqueue_radix_sort(w.keys_a, w.vals_a, w.keys_b, w.vals_b, n, n, batch, plan,
+                                       /*identity_vals=*/true, w.hist, w.partial, s);
+  const uint32_t* skey = where ? w.keys_b : w.keys_a;
+  const uint32_t* sidx = where ? w.vals_b : w.vals_a;
+  seg_head_kernel<<<pgrid, 256, 0, s>>>(skey, sidx, n, g.ncells, w.mark);
+  EpiVoxelStart epi{w.mark, w.vox_start, n, max_voxels};
+  enqueue_exclusive_scan(w.mark, n, n, batch, w.partial, w.totals, (int*)nullptr, LoadNonNegative{},
+                         epi, s);
+  const int64_t per_frame = (int64_t)max_voxels * max_num_points_in_voxel * num_point_dim;
+  dim3 ggrid((unsigned)ceil_div(per_frame, 256), batch);
+  gather_voxels_kernel<T><<<ggrid, 256, 0, s>>>(points, skey, sidx, w.vox_start, w.totals, n,
+                                                num_point_dim, max_num_points_in_voxel, max_voxels,
+                                                voxels);
+  dim3 mgrid((unsigned)ceil_div(max_voxels, 256), batch);
+  voxel_meta_kernel<<<mgrid, 256, 0, s>>>(skey, w.vox_start, w.totals, n, max_num_points_in_voxel,
+                                          max_voxels, g, coords, num_points_per_voxel, num_voxels, coors_batched);
+  return launch_status();
+}
+
 }  // namespace pd3
 
 using namespace pd3;
@@ -485,28 +527,8 @@ extern "C" int pd3_hard_voxelize_path(const float* points, const int32_t* num_po
                        max_voxels, vp, voxels, coords, num_points_per_voxel, num_voxels, coors_batched,
                        workspace, s, path != 2);  // the library's choice (path 0) is the gather form
   }
-  const RadixPlan plan = radix_plan(g.ncells, max_points);
-  VoxWorkspace w = carve(workspace, batch, max_points, max_voxels, plan);
-
-  dim3 pgrid((unsigned)ceil_div(n, 256), batch);
-  cell_key_kernel<<<pgrid, 256, 0, s>>>(points, num_points, n, num_point_dim, g, w.keys_a);
-  const int where = enqueue_radix_sort(w.keys_a, w.vals_a, w.keys_b, w.vals_b, n, n, batch, plan,
-                                       /*identity_vals=*/true, w.hist, w.partial, s);
-  const uint32_t* skey = where ? w.keys_b : w.keys_a;
-  const uint32_t* sidx = where ? w.vals_b : w.vals_a;
-  seg_head_kernel<<<pgrid, 256, 0, s>>>(skey, sidx, n, g.ncells, w.mark);
-  EpiVoxelStart epi{w.mark, w.vox_start, n, max_voxels};
-  enqueue_exclusive_scan(w.mark, n, n, batch, w.partial, w.totals, (int*)nullptr, LoadNonNegative{},
-                         epi, s);
-  const int64_t per_frame = (int64_t)max_voxels * max_num_points_in_voxel * num_point_dim;
-  dim3 ggrid((unsigned)ceil_div(per_frame, 256), batch);
-  gather_voxels_kernel<<<ggrid, 256, 0, s>>>(points, skey, sidx, w.vox_start, w.totals, n,
-                                             num_point_dim, max_num_points_in_voxel, max_voxels,
-                                             voxels);
-  dim3 mgrid((unsigned)ceil_div(max_voxels, 256), batch);
-  voxel_meta_kernel<<<mgrid, 256, 0, s>>>(skey, w.vox_start, w.totals, n, max_num_points_in_voxel,
-                                          max_voxels, g, coords, num_points_per_voxel, num_voxels, coors_batched);
-  return launch_status();
+  return run_sort_path<float>(points, num_points, batch, max_points, num_point_dim, g, max_num_points_in_voxel,
+                              max_voxels, voxels, coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s);
 }
 
 extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points, int batch,
@@ -520,6 +542,28 @@ extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points,
                                 point_cloud_range, max_num_points_in_voxel, max_voxels, voxels, coords,
                                 num_points_per_voxel, num_voxels, coors_batched, workspace, workspace_bytes,
                                 stream, 0);
+}
+
+// double points (the reference's CPU kernel instantiated for double): always the generic sort path
+extern "C" int pd3_hard_voxelize_f64(const double* points, const int32_t* num_points, int batch,
+                                     int64_t max_points, int num_point_dim, const float* voxel_size,
+                                     const float* point_cloud_range, int max_num_points_in_voxel,
+                                     int max_voxels, double* voxels, int32_t* coords,
+                                     int32_t* num_points_per_voxel, int32_t* num_voxels,
+                                     int32_t* coors_batched, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  VoxGrid g;
+  if (!points || !voxels || !coords || !num_points_per_voxel || !num_voxels || !workspace) return PD3_EINVAL;
+  if (batch <= 0 || max_points <= 0 || max_points >= ((int64_t)1 << 31) || num_point_dim < 3 ||
+      max_num_points_in_voxel <= 0 || max_voxels <= 0)
+    return PD3_EINVAL;
+  if (!make_grid(voxel_size, point_cloud_range, g)) return PD3_EINVAL;
+  if (workspace_bytes < pd3_hard_voxelize_workspace(batch, max_points, num_point_dim, voxel_size, point_cloud_range,
+                                                    max_num_points_in_voxel, max_voxels))
+    return PD3_EWORKSPACE;
+  return run_sort_path<double>(points, num_points, batch, max_points, num_point_dim, g, max_num_points_in_voxel,
+                               max_voxels, voxels, coords, num_points_per_voxel, num_voxels, coors_batched, workspace,
+                               static_cast<hipStream_t>(stream));
 }
 
 extern "C" int pd3_version(void) { return 200; }

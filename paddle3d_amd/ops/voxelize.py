@@ -26,14 +26,17 @@ def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max
     path: 0 automatic, 1 generic sort path, 2 tiled path (compact payload array), 3 tiled path (gathered rows),
     5 wave form of the tiled path (6 .. 10: route tile shape forced) (pd3_hard_voxelize_path; the tests run them).
     """
-    pts = require_gpu(points, "hard_voxelize")
+    f64 = isinstance(points, torch.Tensor) and points.dtype == torch.float64
+    pts = require_gpu(points, "hard_voxelize", torch.float64 if f64 else torch.float32)
     if pts.dim() != 3:
         raise RuntimeError("hard_voxelize_batch expects points of shape [B, N, D]")
+    if f64 and path not in (0, 1):
+        raise RuntimeError("hard_voxelize: float64 points run the generic sort path only (path 0 or 1)")
     b, n, d = pts.shape
     dev = pts.device
     vs, pr = host_f32(voxel_size, 3), host_f32(point_cloud_range, 6)
     p, v = int(max_num_points_in_voxel), int(max_voxels)
-    voxels = torch.empty((b, v, p, d), dtype=torch.float32, device=dev)
+    voxels = torch.empty((b, v, p, d), dtype=pts.dtype, device=dev)  # HardInferDtype: voxels take the points' dtype
     coords = torch.empty((b, v, 3), dtype=torch.int32, device=dev)
     npv = torch.empty((b, v), dtype=torch.int32, device=dev)
     nv = torch.empty((b,), dtype=torch.int32, device=dev)
@@ -45,10 +48,15 @@ def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max
     if ws_bytes == 0:
         raise RuntimeError("hard_voxelize: invalid voxel_size / point_cloud_range / sizes")
     ws = workspace(ws_bytes, dev)
-    check(L.pd3_hard_voxelize_path(ptr(pts), ptr(num_points), b, n, d, ptr(vs), ptr(pr), p, v, ptr(voxels),
-                                   ptr(coords), ptr(npv), ptr(nv), ptr(coors4), ptr(ws), ws.numel(),
-                                   stream_ptr(dev), int(path)),
-          "hard_voxelize")
+    if f64:  # the reference's CPU kernel instantiated for double (PD_DISPATCH_FLOATING_TYPES, voxelize_op.cc:128)
+        check(L.pd3_hard_voxelize_f64(ptr(pts), ptr(num_points), b, n, d, ptr(vs), ptr(pr), p, v, ptr(voxels),
+                                      ptr(coords), ptr(npv), ptr(nv), ptr(coors4), ptr(ws), ws.numel(),
+                                      stream_ptr(dev)), "hard_voxelize")
+    else:
+        check(L.pd3_hard_voxelize_path(ptr(pts), ptr(num_points), b, n, d, ptr(vs), ptr(pr), p, v, ptr(voxels),
+                                       ptr(coords), ptr(npv), ptr(nv), ptr(coors4), ptr(ws), ws.numel(),
+                                       stream_ptr(dev), int(path)),
+              "hard_voxelize")
     if with_batch_coors:
         return voxels, coords, npv, nv, coors4
     return voxels, coords, npv, nv
@@ -61,10 +69,9 @@ def _stage_points(points, op):
     GPU: (device tensor, whether the results go back to the host)."""
     if not isinstance(points, torch.Tensor):
         raise RuntimeError(f"Unsupported device type for {op} operator.")
-    if points.dtype == torch.float64:
-        raise RuntimeError(f"{op}: float64 points are not supported: the reference instantiates its kernels for "
-                           "float and double (PD_DISPATCH_FLOATING_TYPES, voxelize_op.cc:128), this library "
-                           "computes in float32 only -- cast the points explicitly if that is what you want")
+    if points.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f"{op}: points must be float32 or float64 (PD_DISPATCH_FLOATING_TYPES, "
+                           f"voxelize_op.cc:128), got {points.dtype}")
     if points.is_cuda:
         return points, False
     if points.device.type != "cpu":
@@ -78,10 +85,11 @@ def _stage_points(points, op):
 
 def hard_voxelize(points: torch.Tensor, voxel_size, point_cloud_range, max_num_points_in_voxel: int,
                   max_voxels: int, path: int = 0):
-    """points [N, D] fp32 on the GPU, in pinned host memory (results on the GPU, like the reference's
-    `is_gpu_pinned()` branch) or on the CPU (results on the CPU, like hard_voxelize_cpu; computed on the GPU)."""
+    """points [N, D] fp32 or fp64 on the GPU, in pinned host memory (results on the GPU, like the reference's
+    `is_gpu_pinned()` branch) or on the CPU (results on the CPU, like hard_voxelize_cpu; computed on the GPU).
+    float64 points give float64 voxels (the reference's kernel instantiated for double)."""
     pts, to_host = _stage_points(points, "hard_voxelize")
-    pts = require_gpu(pts, "hard_voxelize")
+    pts = require_gpu(pts, "hard_voxelize", pts.dtype)
     if pts.dim() != 2:
         raise RuntimeError("hard_voxelize expects points of shape [N, D]")
     voxels, coords, npv, nv = hard_voxelize_batch(pts.unsqueeze(0), voxel_size, point_cloud_range,

@@ -66,7 +66,7 @@ def test_workspace_queries_need_no_gpu(built):
 def test_ops_device_dispatch_without_a_gpu(built):
     """The reference's hard_voxelize takes CPU, GPU and GPU-pinned points (voxelize_op.cc:149-166); here host tensors
     are staged through the GPU (tests/test_voxelize_gpu.py), so without one the op says so instead of computing on
-    the CPU.  float64 points get an explicit dtype error.  The other ops are GPU-only in the reference too."""
+    the CPU.  float32 and float64 points are taken (PD_DISPATCH_FLOATING_TYPES), other dtypes refused by name.  The other ops are GPU-only in the reference too."""
     import torch
 
     from paddle3d_amd.ops import iou3d_nms, voxelize
@@ -76,7 +76,9 @@ def test_ops_device_dispatch_without_a_gpu(built):
         with pytest.raises(RuntimeError, match="staged through the GPU and no GPU is visible"):
             voxelize.hard_voxelize(torch.zeros(10, 4), *args)
     with pytest.raises(RuntimeError, match="PD_DISPATCH_FLOATING_TYPES"):
-        voxelize.hard_voxelize(torch.zeros(10, 4, dtype=torch.float64), *args)
+        voxelize.hard_voxelize(torch.zeros(10, 4, dtype=torch.float16), *args)
+    with pytest.raises(RuntimeError, match="PD_DISPATCH_FLOATING_TYPES"):
+        voxelize.hard_voxelize(torch.zeros(10, 4, dtype=torch.int32), *args)
     with pytest.raises(RuntimeError, match="Unsupported device type for hard_voxelize operator"):
         voxelize.hard_voxelize([[0.0, 0.0, 0.0, 0.0]], *args)
     with pytest.raises(RuntimeError, match="Unsupported device type"):

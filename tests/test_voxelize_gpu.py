@@ -210,4 +210,32 @@ def test_host_points_are_staged(oracle):
         np.testing.assert_array_equal(npv, rn)
         np.testing.assert_array_equal(vox.view(np.uint32), rv.view(np.uint32))
     with pytest.raises(RuntimeError, match="PD_DISPATCH_FLOATING_TYPES"):
-        voxelize.hard_voxelize(torch.from_numpy(pts.astype(np.float64)).cuda(), *args)
+        voxelize.hard_voxelize(torch.from_numpy(pts.astype(np.float16)).cuda(), *args)
+
+
+@pytest.mark.parametrize("name", ["c1_kitti", "c3_nusc_train_cap"])
+def test_float64_points(oracle, name):
+    """PD_DISPATCH_FLOATING_TYPES (voxelize_op.cc:128): the reference's CPU kernel also exists for double points --
+    cell = floor((p - (double)min) / (double)size) in double, voxels in double.  Bit-exact against that instantiation
+    (compiled from /root/reference when it was present at build time, else the port, which test_oracle.py holds to
+    it); points are placed on cell boundaries of the fp32 rule and a hair beside them, where fp32 and fp64 disagree."""
+    from paddle3d_amd.ops import voxelize
+
+    if PATH not in (0, 1):
+        pytest.skip("float64 points take the generic sort path")
+    gen, vs, pr, p, v = CONFIGS[name]
+    pts = gen(11).astype(np.float64)
+    rng = np.random.default_rng(3)
+    k = rng.choice(len(pts), 2000, replace=False)
+    pts[k[:1000], 0] = pr[0] + np.float64(vs[0]) * rng.integers(0, 300, 1000)          # on the fp64 boundary
+    pts[k[1000:], 1] = np.float32(pr[1]) + np.float32(vs[1]) * rng.integers(0, 300, 1000).astype(np.float32)
+    pts[k[1000:], 1] += rng.choice([-1e-12, 0.0, 1e-12], 1000)                           # a hair beside the fp32 one
+    kind = "ref" if oracle.have_ref() else "port"
+    rv, rc, rn, rnv = oracle.hard_voxelize(pts, vs, pr, p, v, kind)
+    vox, co, npv, nv = voxelize.hard_voxelize(torch.from_numpy(pts).cuda(), list(vs), list(pr), p, v, path=PATH)
+    assert vox.dtype == torch.float64 and int(nv[0]) == rnv and rnv > 1000
+    np.testing.assert_array_equal(co.cpu().numpy(), rc)
+    np.testing.assert_array_equal(npv.cpu().numpy(), rn)
+    np.testing.assert_array_equal(vox.cpu().numpy().view(np.uint64), rv.view(np.uint64))
+    cpu_out = voxelize.hard_voxelize(torch.from_numpy(pts), list(vs), list(pr), p, v, path=PATH)  # CPU in -> CPU out
+    assert not cpu_out[0].is_cuda and torch.equal(cpu_out[0], vox.cpu())
