@@ -337,9 +337,8 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
 // wave form of the tiled path (voxelize_wave.hpp)
 // ---------------------------------------------------------------------------------------------------
 struct VwWorkspace {
-  uint32_t *recs, *dir, *clist, *tcount;
-  unsigned char* fmap;
-  uint2 *finfo, *vinfo;
+  uint32_t *recs, *dir, *clist, *fcnt;
+  uint2 *vinfo, *flist;
   int* totals;
   int64_t cap;
   size_t bytes;
@@ -352,11 +351,10 @@ static VwWorkspace vw_carve(void* base, int batch, int64_t n, int max_voxels, co
   w.recs = c.take<uint32_t>((size_t)batch * p.tiles * p.tile);
   w.dir = c.take<uint32_t>((size_t)batch * p.tiles * p.groups);
   w.clist = c.take<uint32_t>((size_t)batch * w.cap + 4);
-  w.fmap = c.take<unsigned char>((size_t)batch * p.fstride);
-  w.finfo = c.take<uint2>((size_t)batch * p.fstride);
-  w.tcount = c.take<uint32_t>((size_t)batch * p.atiles);
   w.vinfo = c.take<uint2>((size_t)batch * max_voxels);
   w.totals = c.take<int>((size_t)batch);
+  w.flist = c.take<uint2>((size_t)batch * p.groups * p.cpg);
+  w.fcnt = c.take<uint32_t>((size_t)batch * vw_pow2_above(p.tiles) * p.groups);
   w.bytes = c.off;
   return w;
 }
@@ -383,8 +381,7 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
   const unsigned tile_grid = (unsigned)(plan.tiles * batch);
 #define PD3_VW_ROUTE(T, R)                                                                                         \
   vw_route_kernel<T, R><<<tile_grid, T, lds_a, s>>>(points, num_points, n, dim, vg, plan.low, plan.gbits,          \
-                                                    plan.tiles, batch, max_voxels, w.recs, w.dir, w.fmap,          \
-                                                    plan.fstride, w.vinfo)
+                                                    plan.tiles, batch, max_voxels, w.recs, w.dir, w.vinfo)
   if (plan.threads == 512 && plan.rounds == 8) PD3_VW_ROUTE(512, 8);
   else if (plan.threads == 1024 && plan.rounds == 8) PD3_VW_ROUTE(1024, 8);
   else if (plan.threads == 1024 && plan.rounds == 10) PD3_VW_ROUTE(1024, 10);
@@ -394,13 +391,11 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
 #undef PD3_VW_ROUTE
   const int tp = vw_pow2_above(plan.tiles);
   vw_group_kernel<<<(unsigned)(plan.groups * batch), kWave, vw_group_lds(plan.cpg, plan.tiles), s>>>(
-      w.recs, w.dir, plan.low, plan.gbits, plan.tiles, plan.tile, tp, batch, max_pts, w.clist, w.cap, w.fmap,
-      w.finfo, plan.fstride);
-  vw_count_kernel<<<(unsigned)ceil_div((int64_t)plan.atiles * batch, 4), 256, 0, s>>>(w.fmap, plan.fstride, plan.atiles,
-                                                                                       batch, w.tcount);
-  vw_assign_kernel<<<(unsigned)(plan.atiles * batch), kVwAssignThreads, 0, s>>>(
-      w.fmap, w.finfo, plan.fstride, plan.atiles, batch, w.tcount, max_voxels, vg, w.vinfo, w.totals, coords, num_pts,
-      coors4);
+      w.recs, w.dir, plan.low, plan.gbits, plan.tiles, plan.tile, tp, batch, max_pts, w.clist, w.cap, w.flist, w.fcnt);
+  const size_t lds_c = (size_t)2 * (((size_t)plan.tile + 31) / 32) * 4 + (size_t)kVwAssignCap * 8;
+  vw_assign_kernel<<<(unsigned)(plan.tiles * batch), kVwAssignThreads, lds_c, s>>>(
+      w.flist, w.fcnt, plan.low, plan.gbits, plan.tiles, plan.tile, tp, batch, max_voxels, vg, w.vinfo, w.totals, coords,
+      num_pts, coors4);
   const int64_t row = (int64_t)max_pts * dim;
   const bool vec4 = (row % 4 == 0) && (reinterpret_cast<uintptr_t>(voxels) % 16 == 0);
   const int rowq = (int)(vec4 ? row / 4 : row);

@@ -8,9 +8,8 @@
 //     ONE WAVE: no barrier, no cross-wave prefix, the wave's record stream cut into exact 64-record steps
 //     (the tile a record comes from is found by a binary search over the group's directory column in LDS),
 //     sixteen independent waves per CU hide each other's latency.
-//   * pos16 / cposr (6 bytes per point, written and re-read) are gone: a cell's first point announces itself
-//     by index -- one byte in a per-point map plus an 8-byte record (place of the cell's points in the index
-//     list, count, cell) -- and voxel ids are a prefix over that byte map in point order, tile by tile.
+//   * pos16 / cposr (6 bytes per point, written and re-read) are gone: a cell's first point leaves an 8-byte
+//     record in its group's list; voxel ids come from merging the lists tile by tile through an LDS bitmap.
 //   * the row writer maps a lane to a (voxel, point slot) instead of to four floats of the flat output: ~170
 //     instructions per float4 went into finding out whose floats they were.
 // What sets the pace of these kernels is instruction issue (a wave64 instruction occupies its SIMD for several
@@ -18,16 +17,15 @@
 // accesses, not bytes and rarely latency; DESIGN.md section 4.1 has the measurements each choice below rests on.
 //
 //   A  vw_route_kernel    as vt_route_kernel (tile of THREADS * R points sorted by group in LDS, one coalesced
-//                         slice + directory row), minus pos16; clears the first-point map and vinfo.
+//                         slice + directory row), minus pos16; clears vinfo.
 //   B  vw_group_kernel    one wave per group: directory column -> prefix; sweep 1 hands out slots (returning
 //                         LDS adds, lane order = point order) and counts; cells are placed in the group's region
 //                         of the index list; sweep 2 puts the list together in LDS (clist[place] = point index of
-//                         the kept points, written as one coalesced run) and stores the first-point records.
+//                         the kept points, written as one coalesced run) and appends the first-point records.
 //                         Groups of up to kVwRegSteps * 64 records keep (record, slot) in registers between the
 //                         sweeps; longer ones walk their records twice.
-//   C  vw_count_kernel    first points per 4096-point tile (a wave per tile);
-//      vw_assign_kernel   prefix over the first-point bytes = voxel id; vinfo / coords / counts of the voxels a
-//                         tile opens.
+//   C  vw_assign_kernel   per route tile: bitmap of its first points = voxel ids; vinfo / coords / counts of the
+//                         voxels the tile opens.
 //   E  vw_rows_kernel     the fixed-shape output written once, a lane per (voxel, point slot) (D = 4 / 5; other
 //                         point widths take vt_rows_gather_kernel of voxelize_tiled.hpp).
 // Preconditions (else the other paths run): cells <= 2^20, groups <= 1024 per frame, N < 2^22 - 3, P <= 254.
@@ -37,14 +35,10 @@
 namespace pd3 {
 
 constexpr int kVwMaxLow = 10;       // cells per group <= 1024: two 4 KB tables per wave, sixteen waves per CU
-constexpr int kVwAssignTile = 4096;  // points per workgroup of the assign kernel (256 threads x 16 bytes)
-constexpr int kVwAssignThreads = 256;
 
 struct VwPlan {
   int low, cpg, groups, gbits;
   int threads, rounds, tile, tiles;  // route kernel shape
-  int atiles;                        // assign tiles per frame
-  int64_t fstride;                   // per-frame length of the per-point arrays (multiple of kVwAssignTile)
   bool ok;
 };
 
@@ -76,9 +70,7 @@ static inline VwPlan vw_plan(uint32_t ncells, int64_t n, int max_pts, int batch,
   p.rounds = shapes[pick].rounds;
   p.tile = p.threads * p.rounds;
   p.tiles = (int)ceil_div(n, p.tile);
-  p.fstride = (int64_t)align_up((size_t)p.tiles * p.tile, kVwAssignTile);
-  p.atiles = (int)(p.fstride / kVwAssignTile);
-  p.ok = bits <= 20 && p.gbits <= kVtMaxGbits && p.tiles <= kVtMaxTiles && p.atiles <= 4096 &&
+  p.ok = bits <= 20 && p.gbits <= kVtMaxGbits && p.tiles <= kVtMaxTiles &&
          n < (int64_t)kVtCpMask - 1 && max_pts <= kVtMaxPts;
   return p;
 }
@@ -88,7 +80,7 @@ template <int THREADS, int R>
 __global__ __launch_bounds__(THREADS, 8) void vw_route_kernel(
     const float* __restrict__ points, const int32_t* __restrict__ num_points, int64_t n, int dim, VtGrid g, int low,
     int gbits, int tiles, int batch, int max_voxels, uint32_t* __restrict__ recs, uint32_t* __restrict__ dir,
-    unsigned char* __restrict__ fmap, int64_t fstride, uint2* __restrict__ vinfo) {
+    uint2* __restrict__ vinfo) {
   constexpr int kTile = THREADS * R;
   constexpr int kWaves = THREADS / kWave;
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
@@ -109,10 +101,6 @@ __global__ __launch_bounds__(THREADS, 8) void vw_route_kernel(
     const int v1 = min((tile + 1) * per, max_voxels);
     for (int v = tile * per + (int)threadIdx.x; v < v1; v += THREADS)
       vinfo[(int64_t)frame * max_voxels + v] = make_uint2(0u, 0u);
-    const int64_t q = fstride / 16, perq = ceil_div(q, tiles);
-    uint4* fm = reinterpret_cast<uint4*>(fmap + (int64_t)frame * fstride);
-    const int64_t q1 = min((int64_t)(tile + 1) * perq, q);
-    for (int64_t j = (int64_t)tile * perq + threadIdx.x; j < q1; j += THREADS) fm[j] = make_uint4(0u, 0u, 0u, 0u);
   }
 
   // phase 1: keys; rank of a point among the wave's earlier points of its group (returning LDS add, lane order)
@@ -188,7 +176,7 @@ static inline int vw_pow2_above(int tiles) {  // entries of the padded directory
   while (tp < tiles + 1) tp <<= 1;
   return tp;
 }
-static inline size_t vw_group_lds(int cpg, int tiles) { return ((size_t)2 * cpg + (size_t)2 * vw_pow2_above(tiles)) * 4; }
+static inline size_t vw_group_lds(int cpg, int tiles) { return ((size_t)2 * cpg + (size_t)3 * vw_pow2_above(tiles)) * 4; }
 
 // the tile whose run holds record r of the group's stream: the last t with pre[t] <= r (pre is padded with
 // 0xFFFFFFFF up to a power of two; empty tiles repeat their successor's value and are skipped by "last")
@@ -205,19 +193,27 @@ __device__ __forceinline__ uint32_t vw_tile_of(const uint32_t* pre, int tp, uint
 // as long as its heaviest group (about twice the mean on a nuScenes frame), so everything that does not depend on
 // each other is issued together: the searches of eight steps, then their loads, then their adds (which the LDS
 // executes in program order: that order is the slot order).
+// How a cell's first point reaches the kernel that hands out voxel ids: the wave appends a record (index inside its
+// tile, cell, place of the cell's points in the index list, kept count) to its OWN list in stream order -- first points
+// come in increasing index, so the records of one route tile are a contiguous piece of the list -- and counts them
+// per tile; vw_assign_kernel merges the lists of a tile through an LDS bitmap.  (The first form of this round stored
+// one byte in a per-point map + an 8-byte record at the point's own index and read both back in point order: two
+// scattered stores and a scattered load per first point, a count kernel and a 17 us assign kernel; 122 -> 117 us.)
 __global__ __launch_bounds__(kWave) void vw_group_kernel(
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ dir, int low, int gbits, int tiles, int tile_len,
-    int tp, int batch, int max_pts, uint32_t* __restrict__ clist, int64_t cap, unsigned char* __restrict__ fmap,
-    uint2* __restrict__ finfo, int64_t fstride) {
+    int tp, int batch, int max_pts, uint32_t* __restrict__ clist, int64_t cap, uint2* __restrict__ flist,
+    uint32_t* __restrict__ fcnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
   const int cpg = 1 << low, groups = 1 << gbits;
   uint32_t* A = reinterpret_cast<uint32_t*>(vt_smem);  // [cpg] (kept << 24) | place of the cell in the region
   uint32_t* B = A + cpg;                               // [cpg] records of the cell so far
   uint32_t* pre = B + cpg;                             // [tp]  records of the group before tile t
   uint32_t* tsrc = pre + tp;                           // [tp]  routed position of the group's run in tile t
+  uint32_t* cntT = tsrc + tp;                          // [tp]  first points of the group per tile
   int frame, grp;
   vt_unit(blockIdx.x, (uint32_t)groups, (uint32_t)batch, frame, grp);
   const int lane = threadIdx.x;
+  uint32_t* fcol = fcnt + (int64_t)frame * tp * groups + grp;  // this group's column of [tp][groups]
 
   // directory column -> prefix of the run lengths; the group's region of the index list is sized by its record
   // count and starts at the sum of its offsets inside the tiles' slices (no global counter)
@@ -227,6 +223,7 @@ __global__ __launch_bounds__(kWave) void vw_group_kernel(
     A[c] = 0u;
     B[c] = 0u;
   }
+  for (int t = lane; t < tp; t += kWave) cntT[t] = 0u;
   uint32_t total = 0, region = 0;
   for (int t0 = 0; t0 < tp; t0 += kWave) {
     const int t = t0 + lane;
@@ -244,17 +241,32 @@ __global__ __launch_bounds__(kWave) void vw_group_kernel(
     region += o;
   }
   vt_wave_sync();
-  if (total == 0u) return;
+  if (total == 0u) {
+    for (int t = lane; t < tiles; t += kWave) fcol[(int64_t)t * groups] = 0u;
+    return;
+  }
 
   const uint32_t* rf = recs + (int64_t)frame * tiles * tile_len;
   uint32_t* cl = clist + (int64_t)frame * cap + region;
-  unsigned char* fm = fmap + (int64_t)frame * fstride;
-  uint2* fi = finfo + (int64_t)frame * fstride;
   const uint32_t cell_mask = (uint32_t)cpg - 1u;
   const int nsteps = (int)((total + 63u) >> 6);
   const bool in_regs = nsteps <= kVwRegSteps;
   const uint32_t P = (uint32_t)max_pts;
   constexpr uint32_t kNone = 0xFFFFFFFFu;
+  uint2* fl = flist + ((int64_t)frame * groups + grp) * cpg;  // <= one first point per cell
+  const float inv_tile = 1.0f / (float)tile_len;
+  uint32_t nfirst = 0;  // first points written so far (wave-uniform)
+  // a first point's record, appended in stream order; x = index inside its tile | cell in group << 14
+  auto announce = [&](bool first, uint32_t idx, uint32_t cell, uint32_t word) {
+    const unsigned long long m = __ballot(first);
+    if (first) {
+      const uint32_t t = vt_div(idx, (uint32_t)tile_len, inv_tile);
+      atomicAdd(&cntT[t], 1u);
+      fl[nfirst + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] =
+          make_uint2((idx - t * (uint32_t)tile_len) | (cell << 14), word);
+    }
+    nfirst += (uint32_t)__popcll(m);
+  };
 
   // records 64 s .. 64 s + 63 of the group's stream (input order), one per lane: where they lie in the routed
   // slices.  Lanes past the end name record 0 of the frame (a mapped address; they are masked by `slot`).
@@ -268,10 +280,7 @@ __global__ __launch_bounds__(kWave) void vw_group_kernel(
     const uint32_t cell = rec & cell_mask, info = A[cell];
     const uint32_t place = info & 0xFFFFFFu, idx = rec >> low;
     if (slot < P) cl[place + slot] = idx;  // (a lane without a record carries slot = kNone)
-    if (slot == 0u) {
-      fm[idx] = (unsigned char)1;
-      fi[idx] = make_uint2((region + place) | (info & 0xFF000000u), vt_group_to_key((uint32_t)grp, cell, gbits));
-    }
+    announce(slot == 0u, idx, cell, (region + place) | (info & 0xFF000000u));
   };
   // eight steps: sources, records, slots (or only the counts) -- the walk of a group too long for the registers
   auto chunk = [&](int s0, uint32_t* rec, uint32_t* slot, bool want_slots) {
@@ -391,11 +400,7 @@ __global__ __launch_bounds__(kWave) void vw_group_kernel(
             if (pos < (uint32_t)cpg) B[pos] = idx;
             else cl[pos] = idx;
           }
-          if (sl == 0u) {
-            fm[idx] = (unsigned char)1;
-            fi[idx] = make_uint2((region + (info[k] & 0xFFFFFFu)) | (info[k] & 0xFF000000u),
-                                 vt_group_to_key((uint32_t)grp, rec[s0 + k] & cell_mask, gbits));
-          }
+          announce(sl == 0u, idx, rec[s0 + k] & cell_mask, (region + (info[k] & 0xFFFFFFu)) | (info[k] & 0xFF000000u));
         }
       }
     }
@@ -410,86 +415,159 @@ __global__ __launch_bounds__(kWave) void vw_group_kernel(
       for (int k = 0; k < kVwChunk; ++k) emit(r8[k], s8[k]);
     }
   }
+  vt_wave_sync();
+  for (int t = lane; t < tiles; t += kWave) fcol[(int64_t)t * groups] = cntT[t];
 }
 
 // ------------------------------------------------------------------------------------------------ C
-// Voxel id of a first point = number of first points before it = (first points of the earlier 4096-point tiles)
-// + (earlier ones in its tile).  Two small launches: vw_count_kernel (one wave per tile: 64 bytes of the map per lane)
-// and vw_assign_kernel (one workgroup per tile: 16 bytes per thread, a workgroup scan, the earlier tiles' counts
-// summed by the lanes).  Tried first and dropped: a look-back over counts published by the earlier tiles' workgroups
-// (49 us: a thousand workgroups polling a few cache lines keep the publishing stores waiting), and every workgroup
-// counting the bytes in front of its tile itself (16-25 us: the loop's registers halve the occupancy and the last
-// tiles read the whole map).
-__global__ __launch_bounds__(256) void vw_count_kernel(const unsigned char* __restrict__ fmap, int64_t fstride,
-                                                       int atiles, int batch, uint32_t* __restrict__ tcount) {
-  const int w = (int)blockIdx.x * 4 + wave_id();  // tile number over the whole batch
-  if (w >= atiles * batch) return;
-  const int frame = w / atiles, tile = w - frame * atiles;
-  const uint4* fq = reinterpret_cast<const uint4*>(fmap + (int64_t)frame * fstride + (int64_t)tile * kVwAssignTile);
-  uint4 a[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) a[k] = fq[lane_id() + k * kWave];
-  int c = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) c += __popc(a[k].x) + __popc(a[k].y) + __popc(a[k].z) + __popc(a[k].w);  // bytes are 0 or 1
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) c += __shfl_xor(c, d, kWave);
-  if (lane_id() == 0) tcount[w] = (uint32_t)c;
-}
+// vw_assign_kernel: one workgroup per (frame, route tile).  The tile's first points lie in the groups' lists as one
+// contiguous piece each (thread g: its offset = the group's counts of the earlier tiles, summed on the way to the
+// tile's base = first points of the frame before it).  A first point sets its bit in an LDS bitmap of the tile;
+// voxel id = base + bits before it; the records are put in voxel order in LDS and the rows leave coalesced.
+// No per-point map, no scattered global access: ~0.4 M small contiguous reads instead of 2 M scattered accesses.
+constexpr int kVwAssignThreads = 512;  // with 256 groups two threads share a group's piece of the list
+constexpr int kVwAssignCap = 4096;  // records staged in voxel order (a tile that opens more voxels stores the rest directly)
 
 __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
-    const unsigned char* __restrict__ fmap, const uint2* __restrict__ finfo, int64_t fstride, int atiles,
-    int batch, const uint32_t* __restrict__ tcount, int max_voxels, VtGrid g, uint2* __restrict__ vinfo,
-    int* __restrict__ totals, int32_t* __restrict__ coords, int32_t* __restrict__ num_pts,
-    int32_t* __restrict__ coors4) {
+    const uint2* __restrict__ flist, const uint32_t* __restrict__ fcnt, int low, int gbits, int tiles, int tile_len,
+    int tp, int batch, int max_voxels, VtGrid g, uint2* __restrict__ vinfo, int* __restrict__ totals,
+    int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ coors4) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
+  const int groups = 1 << gbits, cpg = 1 << low;
+  const int words = (tile_len + 31) >> 5;
+  uint32_t* bits = reinterpret_cast<uint32_t*>(vt_smem);     // [words]
+  uint32_t* wpre = bits + words;                             // [words] first points of the tile before word w
+  uint2* recv = reinterpret_cast<uint2*>(wpre + words);      // [kVwAssignCap] (place | kept << 24, cell key) by rank
   __shared__ int scan_tmp[kVwAssignThreads / kWave + 2];
   __shared__ int s_before[kVwAssignThreads / kWave];
   int frame, tile;
-  vt_unit(blockIdx.x, (uint32_t)atiles, (uint32_t)batch, frame, tile);
-  const int64_t base_i = (int64_t)tile * kVwAssignTile + (int64_t)threadIdx.x * 16;
-  const uint4 w = *reinterpret_cast<const uint4*>(fmap + (int64_t)frame * fstride + base_i);
+  vt_unit(blockIdx.x, (uint32_t)tiles, (uint32_t)batch, frame, tile);
+  const uint32_t* fc = fcnt + (int64_t)frame * tp * groups;
+  for (int w = threadIdx.x; w < words; w += kVwAssignThreads) bits[w] = 0u;
+  __syncthreads();
+  // per group (thread g, g + 256, ...: at most four with 1024 groups): offset of the tile's piece in the group's
+  // list = its counts of the earlier tiles; loads eight tiles at a time, all in flight (one at a time was a chain
+  // of up to 29 round trips)
+  constexpr int kGpt = (1 << kVtMaxGbits) / kVwAssignThreads;  // groups per thread, at most
+  uint32_t goff[kGpt], gcnt[kGpt];
   int before = 0;
-  for (int t = threadIdx.x; t < tile; t += kVwAssignThreads) before += (int)tcount[(int64_t)frame * atiles + t];
-  const uint32_t word[4] = {w.x, w.y, w.z, w.w};
-  const int mine = __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
-  int tile_new;
-  int local = block_exclusive_scan<kVwAssignThreads>(mine, scan_tmp, tile_new);
+  // fewer groups than threads: tpg threads share a group, each takes a contiguous share of its piece
+  const int tpg = groups < kVwAssignThreads ? kVwAssignThreads / groups : 1;
+  const int sub = tpg > 1 ? (int)threadIdx.x / groups : 0;
+#pragma unroll
+  for (int q = 0; q < kGpt; ++q) {
+    const int gi = tpg > 1 ? (int)threadIdx.x % groups : (int)threadIdx.x + q * kVwAssignThreads;
+    goff[q] = 0u;
+    gcnt[q] = 0u;
+    if (gi < groups && (tpg == 1 || q == 0)) {
+      uint32_t off = 0;
+      for (int t0 = 0; t0 < tile; t0 += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fc[(int64_t)min(t0 + k, tile) * groups + gi];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) off += t0 + k < tile ? v[k] : 0u;
+      }
+      const uint32_t c = fc[(int64_t)tile * groups + gi];
+      if (sub == 0) before += (int)off;
+      const uint32_t lo = c * (uint32_t)sub / (uint32_t)tpg, hi = c * (uint32_t)(sub + 1) / (uint32_t)tpg;
+      goff[q] = off + lo;
+      gcnt[q] = hi - lo;
+    }
+  }
+  auto group_of = [&](int q) { return tpg > 1 ? (int)threadIdx.x % groups : (int)threadIdx.x + q * kVwAssignThreads; };
+  // pass A: bits of the tile's first points.  The first eight records of a group's piece (its mean is 5.5) stay in
+  // registers for pass B; both passes issue their loads eight at a time.
+  constexpr int kHold = 8;
+  uint2 held[kGpt][kHold];
+#pragma unroll
+  for (int q = 0; q < kGpt; ++q) {
+    const int gi = group_of(q);
+    const uint32_t c = gi < groups ? gcnt[q] : 0u;
+    const uint2* fl = flist + ((int64_t)frame * groups + min(gi, groups - 1)) * cpg + goff[q];
+#pragma unroll
+    for (int k = 0; k < kHold; ++k) held[q][k] = c ? fl[min((uint32_t)k, c - 1u)] : make_uint2(0u, 0u);
+#pragma unroll
+    for (int k = 0; k < kHold; ++k)
+      if ((uint32_t)k < c) {
+        const uint32_t pos = held[q][k].x & 0x3FFFu;
+        atomicOr(&bits[pos >> 5], 1u << (pos & 31u));
+      }
+    for (uint32_t k0 = kHold; k0 < c; k0 += 8) {
+      uint32_t x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = fl[min(k0 + k, c - 1u)].x;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k0 + k < c) {
+          const uint32_t pos = x[k] & 0x3FFFu;
+          atomicOr(&bits[pos >> 5], 1u << (pos & 31u));
+        }
+    }
+  }
 #pragma unroll
   for (int d = 1; d < kWave; d <<= 1) before += __shfl_xor(before, d, kWave);
   if (lane_id() == 0) s_before[wave_id()] = before;
   __syncthreads();
-  int vid = local;
+  int base = 0;
 #pragma unroll
-  for (int k = 0; k < kVwAssignThreads / kWave; ++k) vid += s_before[k];
-  if (tile == atiles - 1 && threadIdx.x == kVwAssignThreads - 1) totals[frame] = vid + mine;
-  if (mine == 0 || vid >= max_voxels) return;
-  // the thread's flagged points: predicated loads of their records, all sixteen in flight together (a load inside
-  // the loop that hands out the ids is a chain of dependent round trips), then their rows (consecutive ids;
-  // neighbouring threads continue them)
-  const uint2* fi = finfo + (int64_t)frame * fstride + base_i;
-  uint2 fr[16];
-#pragma unroll
-  for (int b = 0; b < 16; ++b) {
-    fr[b] = make_uint2(0u, 0u);
-    if ((word[b >> 2] >> (8 * (b & 3))) & 1u) fr[b] = fi[b];
+  for (int k = 0; k < kVwAssignThreads / kWave; ++k) base += s_before[k];
+  // prefix over the bitmap words (words <= 2 * threads: two per thread)
+  int tile_new;
+  {
+    const int w0 = threadIdx.x * 2;  // (words <= 512 <= 2 * threads)
+    const int c0 = w0 < words ? __popc(bits[w0]) : 0, c1 = w0 + 1 < words ? __popc(bits[w0 + 1]) : 0;
+    const int ex = block_exclusive_scan<kVwAssignThreads>(c0 + c1, scan_tmp, tile_new);
+    if (w0 < words) wpre[w0] = (uint32_t)ex;
+    if (w0 + 1 < words) wpre[w0 + 1] = (uint32_t)(ex + c0);
   }
+  __syncthreads();
+  if (tile == tiles - 1 && threadIdx.x == 0) totals[frame] = base + tile_new;
   const float inv_gx = 1.0f / (float)g.gx, inv_gy = 1.0f / (float)g.gy;
+  auto write_row = [&](int vid, uint32_t word, uint32_t key) {
+    const int64_t row = (int64_t)frame * max_voxels + vid;
+    const uint32_t kept = word >> 24;
+    vinfo[row] = make_uint2(word & 0xFFFFFFu, kept);
+    const uint32_t t = vt_div(key, (uint32_t)g.gx, inv_gx);
+    const int cx = (int)(key - t * (uint32_t)g.gx);
+    const uint32_t cz = vt_div(t, (uint32_t)g.gy, inv_gy);
+    const int cy = (int)(t - cz * (uint32_t)g.gy);
+    const VtInt3 c3{(int)cz, cy, cx};
+    __builtin_memcpy(coords + row * 3, &c3, sizeof(c3));
+    num_pts[row] = (int)kept;
+    if (coors4) *reinterpret_cast<int4*>(coors4 + row * 4) = make_int4(frame, (int)cz, cy, cx);
+  };
+  // pass B: records to their rank
+  auto place = [&](int gi, uint2 e) {
+    const uint32_t pos = e.x & 0x3FFFu;
+    const uint32_t rank = wpre[pos >> 5] + (uint32_t)__popc(bits[pos >> 5] & ((1u << (pos & 31u)) - 1u));
+    const uint32_t key = vt_group_to_key((uint32_t)gi, e.x >> 14, gbits);
+    if (rank < (uint32_t)kVwAssignCap) recv[rank] = make_uint2(e.y, key);
+    else if (base + (int)rank < max_voxels) write_row(base + (int)rank, e.y, key);
+  };
 #pragma unroll
-  for (int b = 0; b < 16; ++b) {
-    if (((word[b >> 2] >> (8 * (b & 3))) & 1u) && vid < max_voxels) {
-      const int64_t row = (int64_t)frame * max_voxels + vid;
-      const uint32_t kept = fr[b].x >> 24, key = fr[b].y;
-      vinfo[row] = make_uint2(fr[b].x & 0xFFFFFFu, kept);
-      const uint32_t t = vt_div(key, (uint32_t)g.gx, inv_gx);
-      const int cx = (int)(key - t * (uint32_t)g.gx);
-      const uint32_t cz = vt_div(t, (uint32_t)g.gy, inv_gy);
-      const int cy = (int)(t - cz * (uint32_t)g.gy);
-      const VtInt3 c3{(int)cz, cy, cx};
-      __builtin_memcpy(coords + row * 3, &c3, sizeof(c3));
-      num_pts[row] = (int)kept;
-      if (coors4) *reinterpret_cast<int4*>(coors4 + row * 4) = make_int4(frame, (int)cz, cy, cx);
-      ++vid;
+  for (int q = 0; q < kGpt; ++q) {
+    const int gi = group_of(q);
+    if (gi >= groups) break;
+    const uint32_t c = gcnt[q];
+#pragma unroll
+    for (int k = 0; k < kHold; ++k)
+      if ((uint32_t)k < c) place(gi, held[q][k]);
+    const uint2* fl = flist + ((int64_t)frame * groups + gi) * cpg + goff[q];
+    for (uint32_t k0 = kHold; k0 < c; k0 += 8) {
+      uint2 e[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = fl[min(k0 + k, c - 1u)];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k0 + k < c) place(gi, e[k]);
     }
+  }
+  __syncthreads();
+  const int staged = min(tile_new, kVwAssignCap);
+  for (int j = threadIdx.x; j < staged; j += kVwAssignThreads) {
+    if (base + j >= max_voxels) break;
+    write_row(base + j, recv[j].x, recv[j].y);
   }
 }
 

@@ -15,7 +15,7 @@ import sys
 from collections import defaultdict
 
 OPS = {
-    "hard_voxelize": ("vw_route", "vw_group", "vw_count", "vw_assign", "vw_rows",
+    "hard_voxelize": ("vw_route", "vw_group", "vw_assign", "vw_rows",
                       "vt_route", "vt_group", "vt_assign", "vt_rows", "cell_key", "seg_head",
                       "gather_voxels", "voxel_meta", "EpiVoxelStart", "LoadNonNegative"),
     "pillar_feature_net": ("pfn_",),
