@@ -376,6 +376,7 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
   VtGrid vg{g.min_x, g.min_y, g.min_z, g.size_x, g.size_y, g.size_z,
             (float)(1.0 / (double)g.size_x), (float)(1.0 / (double)g.size_y), (float)(1.0 / (double)g.size_z),
             g.gx, g.gy, g.gz, g.ncells};
+  if (g.gz == 1 && !vt_single_cell_bounds(g.size_z, vg.z1_lo, vg.z1_hi)) vg.z1_lo = 0.f, vg.z1_hi = -1.f;
   const int waves = plan.threads / kWave;
   const size_t lds_a = ((size_t)plan.tile + (size_t)waves * plan.groups + waves + 2) * 4;
   const unsigned tile_grid = (unsigned)(plan.tiles * batch);

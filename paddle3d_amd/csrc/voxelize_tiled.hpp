@@ -49,6 +49,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cmath>
 
 namespace pd3 {
 
@@ -72,7 +73,34 @@ struct VtGrid {  // mirror of VoxGrid (kept separate so this header stands alone
   float inv_x, inv_y, inv_z;  // fp32(1 / size): the fast path of vt_axis_cell
   int gx, gy, gz;
   uint32_t ncells;
+  // pillar grids (gz == 1): z - min_z lies in cell 0 exactly when it lies in [z1_lo, z1_hi], the fp32 values whose
+  // correctly rounded quotient by size_z floors to 0 (found on the host with the same fp32 divide, vt_single_cell_bounds);
+  // z1_lo > z1_hi: not used
+  float z1_lo = 0.f, z1_hi = -1.f;
 };
+
+// [lo, hi] = { t : floor(RN(t / size)) == 0 } for fp32 t, by walking the neighbours of -0 and of `size` with the
+// host's correctly rounded fp32 divide (the operation the reference performs, voxelize_op.cc:43-45)
+static inline bool vt_single_cell_bounds(float size, float& lo, float& hi) {
+  if (!(size > 0.f) || !std::isfinite(size)) return false;
+  volatile float s = size;
+  float h = size;
+  int it = 0;
+  while (!((float)(h / s) < 1.0f)) {
+    h = std::nextafterf(h, -INFINITY);
+    if (++it > 64) return false;
+  }
+  float l = -0.0f;
+  for (it = 0; it < 64; ++it) {
+    const float n = std::nextafterf(l, -INFINITY);
+    if ((float)(n / s) == 0.0f) l = n;
+    else break;
+  }
+  if (it == 64) return false;
+  lo = l;
+  hi = h;
+  return true;
+}
 
 struct VtPlan {
   int low;      // log2(cells per group)
@@ -151,11 +179,16 @@ __device__ __forceinline__ bool vt_axis_cell(float p, float lo, float size, floa
 }
 
 __device__ __forceinline__ bool vt_cell_key(float x, float y, float z, const VtGrid& g, uint32_t& key) {
-  int cx, cy, cz;
+  int cx, cy, cz = 0;
   if (!(vt_axis_cell(x, g.min_x, g.size_x, g.inv_x, g.gx, cx) &&
-        vt_axis_cell(y, g.min_y, g.size_y, g.inv_y, g.gy, cy) &&
-        vt_axis_cell(z, g.min_z, g.size_z, g.inv_z, g.gz, cz)))
+        vt_axis_cell(y, g.min_y, g.size_y, g.inv_y, g.gy, cy)))
     return false;
+  if (g.z1_hi >= g.z1_lo) {  // one cell along z: two comparisons instead of the exact cell index
+    const float t = z - g.min_z;
+    if (!(t >= g.z1_lo && t <= g.z1_hi)) return false;  // also false for NaN
+  } else if (!vt_axis_cell(z, g.min_z, g.size_z, g.inv_z, g.gz, cz)) {
+    return false;
+  }
   key = ((uint32_t)cz * (uint32_t)g.gy + (uint32_t)cy) * (uint32_t)g.gx + (uint32_t)cx;
   return true;
 }
