@@ -445,9 +445,9 @@ __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
   const uint32_t* fc = fcnt + (int64_t)frame * tp * groups;
   for (int w = threadIdx.x; w < words; w += kVwAssignThreads) bits[w] = 0u;
   __syncthreads();
-  // per group (thread g, g + 256, ...: at most four with 1024 groups): offset of the tile's piece in the group's
-  // list = its counts of the earlier tiles; loads eight tiles at a time, all in flight (one at a time was a chain
-  // of up to 29 round trips)
+  // per group (thread g, g + 512 with 1024 groups; with fewer groups than threads several threads share one):
+  // offset of the tile's piece in the group's list = its counts of the earlier tiles; loads eight tiles at a time,
+  // all in flight (one at a time was a chain of up to 29 round trips)
   constexpr int kGpt = (1 << kVtMaxGbits) / kVwAssignThreads;  // groups per thread, at most
   uint32_t goff[kGpt], gcnt[kGpt];
   int before = 0;
