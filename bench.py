@@ -71,11 +71,25 @@ def dense_flops():
     return s1 + s2 + other, s1 / 4 + s2 + other
 
 
-def pfn_flops(v):
+def pfn_flops(v, blocks_per_scene=None):
     """(direct-form, executed) flops per scene of the two-layer PFN: direct = per real-or-padded point
-    2*(10*32 + 64*64); executed = one wave per pillar slot issues 38 v_mfma_f32_16x16x4_f32
-    (2048 flops each) whatever the pillar's fill level."""
-    return v * P * 2 * (10 * 32 + 64 * 64), v * 38 * 2048
+    2*(10*32 + 64*64); executed = 38 v_mfma_f32_16x16x4_f32 (2048 flops each) per 16-row block the
+    kernel issues: the packed form (round 3) packs the rows of 8 consecutive pillars into blocks, so the count
+    depends on the fill levels and is taken from the batch; without it, the per-pillar form's
+    one-or-two blocks per pillar slot are assumed."""
+    blocks = blocks_per_scene if blocks_per_scene is not None else v
+    return v * P * 2 * (10 * 32 + 64 * 64), blocks * 38 * 2048
+
+
+def pfn_packed_blocks(npv, p, chunk=8):
+    """16-row MFMA blocks the packed PFN kernel issues for num_points_per_voxel `npv` [B, V] (csrc/pfn.hip:
+    rows = stored points + one representative padded row of a pillar that is not full, chunks of 8 pillars)."""
+    n = npv.reshape(-1).to(torch.int64)
+    rows = (n.clamp(max=p) + (n < p).to(torch.int64)) * (n > 0).to(torch.int64)
+    pad = (-rows.numel()) % chunk
+    if pad:
+        rows = torch.cat([rows, rows.new_zeros(pad)])
+    return int(((rows.reshape(-1, chunk).sum(1) + 15) // 16).sum().item())
 
 
 def make_batch(batch, seed0, device=None, pin=False):
@@ -479,7 +493,9 @@ def bench_pillars(args, rank, world, dev):
                     direct_form_tflops=direct * B / (ms * 1e-3) / 1e12, note=note)
 
     d_direct, d_exec = dense_flops()
-    p_direct, p_exec = pfn_flops(V)
+    with torch.no_grad():
+        pfn_blocks = pfn_packed_blocks(model.voxelizer(pts)[2], P) / B
+    p_direct, p_exec = pfn_flops(V, pfn_blocks)
     rooflines = dict(
         hard_voxelize=hbm("hard_voxelize", "hard_voxelize"),
         pointpillars_scatter=(dict(bound="hbm", fused_into="dense_backbone_fpn_head", achieved=None,
@@ -498,8 +514,10 @@ def bench_pillars(args, rank, world, dev):
                                           "fraction is for completeness (6 tasks x up to 1000 candidates per "
                                           "frame: random-init heads fill the NMS cap)"),
         pillar_feature_net=mfma(per_op_ms["pillar_feature_net"], p_direct, p_exec,
-                                "achieved / frac = executed MFMA flops (38 v_mfma_f32_16x16x4_f32 per pillar slot, "
-                                "~11 of 16 rows live); direct_form_tflops = the layer's own multiply-adds / time"),
+                                "achieved / frac = executed MFMA flops: 38 v_mfma_f32_16x16x4_f32 per 16-row block of "
+                                f"the packed form, {pfn_blocks:.0f} blocks per scene counted on this batch (rows = "
+                                "stored points + one padded row per pillar that is not full, packed per 8 pillars); "
+                                "direct_form_tflops = the layer's own multiply-adds over all P slots / time"),
         dense_backbone_fpn_head=mfma(per_op_ms["dense"], d_direct, d_exec,
                                      "achieved / frac = executed flops: the 52 stride-1 3x3 layers run Winograd "
                                      "F(4x4,3x3) (a quarter of the direct multiplies), the 3 stride-2 layers and the "

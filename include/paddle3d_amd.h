@@ -149,6 +149,17 @@ int pd3_pillar_feature_net(const float *voxels, const int32_t *num_points, const
                            const float *shift1, int c1, const float *w2, const float *scale2,
                            const float *shift2, int c2, float *out, void *stream);
 
+/* Same operator with the kernel form named by the caller (diagnostics and the parity tests, which run every form on
+ * one input; there is no environment switch): path 0 = what pd3_pillar_feature_net picks, 1 = the per-pillar forms
+ * (one wave per pillar), 2 = the packed form (a wave packs the rows of 8 consecutive pillars into 16-row MFMA blocks;
+ * two-layer C1 = 32, C2 = 64 nets with P <= 32 only, PD3_EUNSUPPORTED otherwise). */
+int pd3_pillar_feature_net_path(const float *voxels, const int32_t *num_points, const int32_t *coors,
+                                int64_t num_pillars, int max_points, int num_point_dim,
+                                int voxel_center_dims, float vx, float vy, float vz, float x_offset,
+                                float y_offset, float z_offset, const float *w1, const float *scale1,
+                                const float *shift1, int c1, const float *w2, const float *scale2,
+                                const float *shift2, int c2, float *out, int path, void *stream);
+
 /* VoxelMean.forward, paddle3d/models/voxel_encoders/voxel_encoder.py:44-57: sum over P / count. */
 int pd3_voxel_mean(const float *voxels, const int32_t *num_points, int64_t num_voxels,
                    int max_points, int num_point_dim, float *out, void *stream);

@@ -38,6 +38,11 @@ _SIGNATURES = {
                                          C.c_float, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_pillar_feature_net_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                              C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                              C.c_float, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pd3_voxel_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                  C.c_void_p]),
     "pd3_nms_workspace": (C.c_size_t, [C.c_int]),

@@ -486,6 +486,244 @@ __global__ __launch_bounds__(256, C1 == 32 ? 4 : 2) void pfn_two_mfma_kernel(Pfn
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Packed form of the two-layer fast path (C1 = 32, C2 = 64).  The form above spends one wave and one or two
+// 16-row MFMA blocks on every pillar, whatever its fill level; a nuScenes sweep has 4.5 points per pillar
+// on average (half of the pillars hold one), so two thirds of the rows it multiplies are padding and, worse,
+// every pillar pays the full stage -> mean -> layer 1 -> max -> base -> layer 2 -> max chain of dependent
+// LDS / MFMA steps.  Here a wave takes a CHUNK of 8 consecutive pillars, packs their rows (real points + the
+// one representative padded row of a pillar that is not full) back to back into 16-row blocks, and runs both
+// layers block by block:
+//   * a pillar's maximum over the rows of layer 2 commutes with everything that follows the GEMM: with
+//     t_r = y1_r W2[0:32], the output is max_r relu(bn2(t_r + base)) = relu(bn2(ext_r t_r + base)) where
+//     ext is the maximum for a non-negative folded scale and the minimum for a negative one (fp32 add, fma
+//     and max are monotone, so this is exact, not approximate).  The sign is folded into the columns of the
+//     B operand, so the walk below only takes maxima.  base = max_r(y1_r) W2[32:64] therefore is needed once
+//     per pillar, AFTER its last row, and a block can run layer 2 right behind layer 1 without knowing the
+//     pillar's maximum yet: no row tile survives a block, and pillars may straddle blocks;
+//   * the segmented maxima are taken by lane = channel walking the 16 rows of the block's two LDS tiles; the
+//     rows that end a pillar are a wave-uniform 16-bit mask (one ballot), so the walk is scalar control flow.
+// Per chunk (8 pillars, 43 rows on average) that is 3.2 blocks x 38 MFMAs where the per-pillar form issues
+// 8.9 x 38, and one latency chain per chunk instead of eight.
+constexpr int kPkPillars = 8;
+
+template <int D, int CD, int NV>
+__global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
+  constexpr int IN = D + 3 + CD;
+  static_assert(IN <= 12, "layer-1 K is padded to 12");
+  constexpr int PC = kPkPillars, YS = 34, AS = 68;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = lane_id(), wave = wave_id();
+  const int r16 = lane & 15, g = lane >> 4;
+  const int pd = a.p * D;  // PC * pd <= NV * 64 (dispatch)
+  const int rcap = (PC * (a.p + 1) + 15) & ~15;
+  const int wave_floats = NV * 64 + 16 * YS + 16 * AS + 32 + PC * 8 + rcap + 16;
+  float* ln = smem + wave * wave_floats;            // the chunk's raw pillars, [pillar][k][D]
+  float* y1T = ln + NV * 64;                        // [16 rows][YS]: layer-1 output of the current block
+  float* accT = y1T + 16 * YS;                      // [16 rows][AS]: y1 W2[0:32] (sign-folded) of the block
+  float* m1s = accT + 16 * AS;                      // [32]: a finished pillar's max over y1
+  float* sub = m1s + 32;                            // [PC][8]: cluster mean xyz, pillar centre xyz, 0, count
+  int* rinfo = reinterpret_cast<int*>(sub + PC * 8);  // [rcap]: pillar | k << 4 | real << 12 | last row << 13
+  int* ends = rinfo + rcap;                         // [PC] inclusive row prefix, [PC] stored points
+  float* w2bs = smem + 4 * wave_floats;             // [32][64]: W2[32:64], shared by the four waves
+  // ---- weights and folded BatchNorm in registers ------------------------------------------------
+  float w1r[3][2], w2a[8][4], sc1[2], sh1[2];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int k = ks * 4 + g;
+      w1r[ks][cb] = k < IN ? a.w1[k * 32 + cb * 16 + r16] : 0.f;
+    }
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) {
+    const float sg = a.scale2[cb * 16 + r16] < 0.f ? -1.f : 1.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) w2a[ks][cb] = a.w2[(ks * 4 + g) * 64 + cb * 16 + r16] * sg;
+  }
+  for (int i = threadIdx.x; i < 32 * 64; i += 256) w2bs[i] = a.w2[32 * 64 + i];
+  __syncthreads();
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    sc1[cb] = a.scale1[cb * 16 + r16];
+    sh1[cb] = a.shift1[cb * 16 + r16];
+  }
+  const float sc2 = a.scale2[lane], sh2 = a.shift2[lane], sg2 = sc2 < 0.f ? -1.f : 1.f;
+  // this lane's A-operand features: k-step ks carries decorated feature i = 4 ks + g of the row lane & 15
+  int fsrc[3], fsub[3];  // source coordinate; slot of `sub` that is subtracted (6 = the zero slot)
+  bool fzero[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    const int i = ks * 4 + g;
+    fzero[ks] = i >= IN;
+    fsrc[ks] = i >= IN ? 0 : (i < D ? i : (i < D + 3 ? i - D : i - D - 3));
+    fsub[ks] = (i >= IN || i < D) ? 6 : (i < D + 3 ? i - D : 3 + (i - D - 3));
+  }
+  const int64_t nchunks = (a.m + PC - 1) / PC;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t ch = (int64_t)blockIdx.x * 4 + wave;
+  if (ch >= nchunks) return;
+  float vreg[NV];
+  int npn = 0, c1 = 0, c2 = 0, c3 = 0;
+  auto fetch = [&](int64_t c) {
+    const int64_t q0 = c * PC;
+    const int cntp = (int)(a.m - q0 < PC ? a.m - q0 : PC);
+    const int lim = cntp * pd;
+    const float* src = a.voxels + q0 * pd;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) vreg[q] = lane + 64 * q < lim ? src[lane + 64 * q] : 0.f;
+    npn = c1 = c2 = c3 = 0;
+    if (lane < cntp) {
+      npn = a.num_points[q0 + lane];
+      c1 = a.coors[(q0 + lane) * 4 + 1];
+      c2 = a.coors[(q0 + lane) * 4 + 2];
+      c3 = a.coors[(q0 + lane) * 4 + 3];
+    }
+  };
+  fetch(ch);
+  for (; ch < nchunks; ch += stride) {
+    const int64_t p0 = ch * PC;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) ln[64 * q + lane] = vreg[q];
+    const int np_raw = npn;
+    const float pcx = (float)c3 * a.vx + a.x_off, pcy = (float)c2 * a.vy + a.y_off;
+    const float pcz = (float)c1 * a.vz + a.z_off;  // HardVFE-style centres only (CD == 3)
+    wave_lds_order();
+    if (ch + stride < nchunks) fetch(ch + stride);  // the next chunk's loads fly while this one is evaluated
+    // ---- the chunk's row layout: lane q < PC is pillar p0 + q -------------------------------------
+    const int np = np_raw > 0 ? min(np_raw, a.p) : 0;     // a padding row of a fixed-shape batch has no rows
+    const int rows = np > 0 ? np + (np < a.p ? 1 : 0) : 0;  // + one representative padded (all-zero) row
+    int end = rows;
+#pragma unroll
+    for (int dlt = 1; dlt < PC; dlt <<= 1) {
+      const int t = __shfl_up(end, dlt, PC);
+      if ((lane & (PC - 1)) >= dlt) end += t;
+    }
+    const int R = __builtin_amdgcn_readlane(end, PC - 1);
+    unsigned long long live = __ballot(lane < PC && rows > 0);
+    unsigned long long empty = __ballot(lane < PC && rows == 0 && p0 + lane < a.m);
+    if (lane < PC) {
+      ends[lane] = end;
+      ends[PC + lane] = np;
+      sub[lane * 8 + 3] = pcx;
+      sub[lane * 8 + 4] = pcy;
+      sub[lane * 8 + 5] = pcz;
+      sub[lane * 8 + 6] = 0.f;
+      sub[lane * 8 + 7] = (float)np_raw;
+    }
+    while (empty) {
+      const int q = __builtin_ctzll(empty);
+      empty &= empty - 1;
+      a.out[(p0 + q) * 64 + lane] = 0.f;
+    }
+    wave_lds_order();
+    // cluster means (pillar_encoder.py:166-176; the reference divides by num_points without epsilon): lane =
+    // (pillar, axis), the stored points summed in their order
+    if (lane < 3 * PC) {
+      const int q = lane & (PC - 1), ax = lane / PC;
+      const int npl = ends[PC + q];
+      const float* src = ln + q * pd + ax;
+      float s = 0.f;
+      for (int k = 0; k < npl; ++k) s += src[k * D];
+      if (npl > 0) sub[q * 8 + ax] = s / sub[q * 8 + 7];
+    }
+    const int rb = (R + 15) & ~15;
+    for (int r = lane; r < rb; r += 64) {
+      int q = 0;
+#pragma unroll
+      for (int j = 0; j < PC; ++j) q += ends[j] <= r ? 1 : 0;
+      int info = 0;  // rows past the chunk's last one: a zero row of pillar 0 that no walk reads
+      if (r < R) {
+        const int st = q > 0 ? ends[q - 1] : 0;
+        const int k = r - st;
+        info = q | (k << 4) | ((k < ends[PC + q] ? 1 : 0) << 12) | ((r + 1 == ends[q] ? 1 : 0) << 13);
+      }
+      rinfo[r] = info;
+    }
+    wave_lds_order();
+    float m1 = -INFINITY, m2 = -INFINITY;  // running maxima of the pillar the walk is in; lane = channel
+    const int nblk = rb >> 4;
+    for (int b = 0; b < nblk; ++b) {
+      const int info = rinfo[b * 16 + r16];
+      const unsigned endmask = (unsigned)(__ballot((info >> 13) & 1) & 0xffffull);
+      const int q = info & 15, k = (info >> 4) & 255;
+      const bool real = (info >> 12) & 1;
+      // ---- layer 1 on the matrix cores; Y1 = relu(bn1(X W1)) -> y1T --------------------------------
+      pfn_f32x4 acc1[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) acc1[cb] = (pfn_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        float av = ln[q * pd + k * D + fsrc[ks]] - sub[q * 8 + fsub[ks]];
+        av = (real && !fzero[ks]) ? av : 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1r[ks][cb], acc1[cb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          y1T[(4 * g + r) * YS + cb * 16 + r16] = fmaxf(fmaf(acc1[cb][r], sc1[cb], sh1[cb]), 0.f);
+      wave_lds_order();
+      // ---- layer 2, point-wise half of the concat: T = Y1 W2[0:32] (columns sign-folded) -> accT ------
+      pfn_f32x4 acc2[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc2[cb] = (pfn_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const float av = y1T[r16 * YS + ks * 4 + g];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2a[ks][cb], acc2[cb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accT[(4 * g + r) * AS + cb * 16 + r16] = acc2[cb][r];
+      wave_lds_order();
+      // ---- walk the block's rows: lane = channel; a pillar's last row finishes it ----------------------
+#pragma unroll
+      for (int h = 0; h < 16; h += 8) {
+      float tv[8], yv[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        tv[r] = accT[(h + r) * AS + lane];
+        yv[r] = y1T[(h + r) * YS + (lane & 31)];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        m2 = fmaxf(m2, tv[r]);
+        m1 = fmaxf(m1, yv[r]);
+        if ((endmask >> (h + r)) & 1u) {
+          const int fin = __builtin_ctzll(live);
+          live &= live - 1;
+          if (lane < 32) m1s[lane] = m1;
+          wave_lds_order();
+          // base = max_rows(Y1) W2[32:64], the row-independent half of the concat (PFNLayer :100-104)
+          float bp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i4 = 0; i4 < 32; i4 += 4) {
+            const pfn_f32x4 mv = *reinterpret_cast<const pfn_f32x4*>(m1s + i4);
+            bp[0] = fmaf(mv[0], w2bs[(i4 + 0) * 64 + lane], bp[0]);
+            bp[1] = fmaf(mv[1], w2bs[(i4 + 1) * 64 + lane], bp[1]);
+            bp[2] = fmaf(mv[2], w2bs[(i4 + 2) * 64 + lane], bp[2]);
+            bp[3] = fmaf(mv[3], w2bs[(i4 + 3) * 64 + lane], bp[3]);
+            if ((i4 & 4) != 0) wave_lds_order();  // keeps at most eight weights in flight (register pressure)
+          }
+          const float base = (bp[0] + bp[1]) + (bp[2] + bp[3]);
+          a.out[(p0 + fin) * 64 + lane] = fmaxf(fmaf(sg2 * m2 + base, sc2, sh2), 0.f);
+          m1 = -INFINITY;
+          m2 = -INFINITY;
+          wave_lds_order();  // m1s is rewritten by the next pillar that ends
+        }
+      }
+      }
+      wave_lds_order();  // the next block overwrites the tiles
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict__ voxels,
                                                          const int32_t* __restrict__ num_points,
                                                          int64_t m, int p, int d,
@@ -504,14 +742,13 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict
 
 using namespace pd3;
 
-extern "C" int pd3_pillar_feature_net(const float* voxels, const int32_t* num_points,
-                                      const int32_t* coors, int64_t num_pillars, int max_points,
-                                      int num_point_dim, int voxel_center_dims, float vx, float vy,
-                                      float vz, float x_offset, float y_offset, float z_offset,
-                                      const float* w1, const float* scale1,
-                                      const float* shift1, int c1, const float* w2,
-                                      const float* scale2, const float* shift2, int c2, float* out,
-                                      void* stream) {
+static int pfn_dispatch(const float* voxels, const int32_t* num_points, const int32_t* coors,
+                        int64_t num_pillars, int max_points, int num_point_dim, int voxel_center_dims,
+                        float vx, float vy, float vz, float x_offset, float y_offset, float z_offset,
+                        const float* w1, const float* scale1, const float* shift1, int c1, const float* w2,
+                        const float* scale2, const float* shift2, int c2, float* out, int path,
+                        void* stream) {
+  if (path < 0 || path > 2) return PD3_EINVAL;
   if (num_pillars < 0 || max_points <= 0 || num_point_dim < 3) return PD3_EINVAL;
   if (voxel_center_dims != 2 && voxel_center_dims != 3) return PD3_EINVAL;
   if (num_pillars == 0) return 0;
@@ -565,6 +802,39 @@ extern "C" int pd3_pillar_feature_net(const float* voxels, const int32_t* num_po
     }                                                                                                          \
     pfn_two_mfma_kernel<DD, CDV, C1V, MAXPV, LINEV><<<blocks, 256, lds_, s>>>(a);                              \
   } while (0)
+  // packed form (path 0 picks it where it applies; path 1 = the per-pillar forms below; path 2 = this or nothing)
+  const bool packed_ok = w2 && c1 == 32 && c2 == 64 && max_points <= 32 && (num_point_dim == 4 || num_point_dim == 5) &&
+                         a.in_dim <= 12 && kPkPillars * max_points * num_point_dim <= 20 * 64;
+  if (path == 2 && !packed_ok) return PD3_EUNSUPPORTED;
+  if (packed_ok && path != 1) {
+    const int64_t nchunks = ceil_div(num_pillars, (int64_t)kPkPillars);
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(nchunks, 4), 256 * 3);
+    const int nv = (kPkPillars * max_points * num_point_dim + 63) / 64 <= 13 ? 13 : 20;
+    const int rcap = (kPkPillars * (max_points + 1) + 15) & ~15;
+    const size_t lds = ((size_t)4 * (nv * 64 + 16 * 34 + 16 * 68 + 32 + kPkPillars * 8 + rcap + 16) + 32 * 64) * sizeof(float);
+#define PD3_PFN_PACKED(DD, CDV, NVV)                                                                               \
+  do {                                                                                                            \
+    if (lds > 48 * 1024) {                                                                                        \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(pfn_packed_kernel<DD, CDV, NVV>),         \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+      if (e_ != hipSuccess) return (int)e_;                                                                       \
+    }                                                                                                             \
+    pfn_packed_kernel<DD, CDV, NVV><<<blocks, 256, lds, s>>>(a);                                                  \
+  } while (0)
+    if (nv == 13) {
+      if (num_point_dim == 4 && voxel_center_dims == 2) PD3_PFN_PACKED(4, 2, 13);
+      else if (num_point_dim == 4) PD3_PFN_PACKED(4, 3, 13);
+      else if (voxel_center_dims == 2) PD3_PFN_PACKED(5, 2, 13);
+      else PD3_PFN_PACKED(5, 3, 13);
+    } else {
+      if (num_point_dim == 4 && voxel_center_dims == 2) PD3_PFN_PACKED(4, 2, 20);
+      else if (num_point_dim == 4) PD3_PFN_PACKED(4, 3, 20);
+      else if (voxel_center_dims == 2) PD3_PFN_PACKED(5, 2, 20);
+      else PD3_PFN_PACKED(5, 3, 20);
+    }
+#undef PD3_PFN_PACKED
+    return launch_status();
+  }
   if (w2 && c1 == 32 && c2 == 64 && max_points * num_point_dim <= 128 && max_points <= 32 &&
       (num_point_dim == 4 || num_point_dim == 5) && a.in_dim <= 12) {
     const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(num_pillars, 4), 256 * 8);
@@ -595,6 +865,32 @@ extern "C" int pd3_pillar_feature_net(const float* voxels, const int32_t* num_po
   const int64_t blocks = std::min<int64_t>(ceil_div(num_pillars, waves), 256 * 8);
   pfn_kernel<<<(unsigned)blocks, waves * 64, bytes, s>>>(a);
   return launch_status();
+}
+
+extern "C" int pd3_pillar_feature_net(const float* voxels, const int32_t* num_points,
+                                      const int32_t* coors, int64_t num_pillars, int max_points,
+                                      int num_point_dim, int voxel_center_dims, float vx, float vy,
+                                      float vz, float x_offset, float y_offset, float z_offset,
+                                      const float* w1, const float* scale1,
+                                      const float* shift1, int c1, const float* w2,
+                                      const float* scale2, const float* shift2, int c2, float* out,
+                                      void* stream) {
+  return pfn_dispatch(voxels, num_points, coors, num_pillars, max_points, num_point_dim, voxel_center_dims, vx, vy,
+                      vz, x_offset, y_offset, z_offset, w1, scale1, shift1, c1, w2, scale2, shift2, c2, out, 0,
+                      stream);
+}
+
+extern "C" int pd3_pillar_feature_net_path(const float* voxels, const int32_t* num_points,
+                                           const int32_t* coors, int64_t num_pillars, int max_points,
+                                           int num_point_dim, int voxel_center_dims, float vx, float vy,
+                                           float vz, float x_offset, float y_offset, float z_offset,
+                                           const float* w1, const float* scale1,
+                                           const float* shift1, int c1, const float* w2,
+                                           const float* scale2, const float* shift2, int c2, float* out,
+                                           int path, void* stream) {
+  return pfn_dispatch(voxels, num_points, coors, num_pillars, max_points, num_point_dim, voxel_center_dims, vx, vy,
+                      vz, x_offset, y_offset, z_offset, w1, scale1, shift1, c1, w2, scale2, shift2, c2, out, path,
+                      stream);
 }
 
 extern "C" int pd3_voxel_mean(const float* voxels, const int32_t* num_points, int64_t num_voxels,

@@ -20,9 +20,10 @@ def fold_batchnorm(gamma, beta, mean, var, eps):
 
 
 def pillar_feature_net(voxels, num_points, coors, vx, vy, x_offset, y_offset, w1, scale1, shift1,
-                       w2=None, scale2=None, shift2=None, vz=0.0, z_offset=0.0, voxel_center_dims=2):
+                       w2=None, scale2=None, shift2=None, vz=0.0, z_offset=0.0, voxel_center_dims=2, path=0):
     """voxels [M,P,D], num_points [M] i32, coors [M,4] i32 (b,z,y,x); w* in Paddle Linear layout [in,out].
-    voxel_center_dims=3 (+ vz, z_offset) is the HardVFE decoration (voxel_encoder.py:252-266)."""
+    voxel_center_dims=3 (+ vz, z_offset) is the HardVFE decoration (voxel_encoder.py:252-266).
+    path: 0 = the library's choice, 1 = per-pillar kernels, 2 = packed kernel (tests run all of them)."""
     v = require_gpu(voxels, "pillar_feature_net")
     n = require_gpu(num_points, "pillar_feature_net", torch.int32)
     c = require_gpu(coors, "pillar_feature_net", torch.int32)
@@ -40,13 +41,13 @@ def pillar_feature_net(voxels, num_points, coors, vx, vy, x_offset, y_offset, w1
     else:
         c2 = 0
     out = torch.empty((m, c2 if two else c1), dtype=torch.float32, device=v.device)
-    check(lib().pd3_pillar_feature_net(ptr(v), ptr(n), ptr(c), m, p, d, int(voxel_center_dims), C.c_float(vx),
-                                       C.c_float(vy), C.c_float(vz), C.c_float(x_offset),
-                                       C.c_float(y_offset), C.c_float(z_offset), ptr(w1),
-                                       ptr(scale1.contiguous()), ptr(shift1.contiguous()), c1,
-                                       ptr(w2), ptr(scale2.contiguous() if two else None),
-                                       ptr(shift2.contiguous() if two else None), c2, ptr(out),
-                                       stream_ptr(v.device)), "pillar_feature_net")
+    check(lib().pd3_pillar_feature_net_path(ptr(v), ptr(n), ptr(c), m, p, d, int(voxel_center_dims), C.c_float(vx),
+                                            C.c_float(vy), C.c_float(vz), C.c_float(x_offset),
+                                            C.c_float(y_offset), C.c_float(z_offset), ptr(w1),
+                                            ptr(scale1.contiguous()), ptr(shift1.contiguous()), c1,
+                                            ptr(w2), ptr(scale2.contiguous() if two else None),
+                                            ptr(shift2.contiguous() if two else None), c2, ptr(out), int(path),
+                                            stream_ptr(v.device)), "pillar_feature_net")
     return out
 
 

@@ -50,10 +50,14 @@ def test_scatter_odd_shapes(oracle):
     assert not out.cpu().numpy().any()
 
 
-def _pfn_params(rng, d, c1, c2):
+def _pfn_params(rng, d, c1, c2, signed=False):
     def layer(i, o):
+        gamma = rng.uniform(0.5, 1.5, o).astype(np.float32)
+        if signed:  # trained BatchNorm scales can be negative or exactly zero: max over points must not assume a sign
+            gamma *= rng.choice([-1.0, 1.0], o).astype(np.float32)
+            gamma[:2] = 0.0
         return dict(weight=(rng.uniform(-1, 1, (i, o)) / np.sqrt(i)).astype(np.float32),
-                    gamma=rng.uniform(0.5, 1.5, o).astype(np.float32), beta=rng.normal(0, 0.2, o).astype(np.float32),
+                    gamma=gamma, beta=rng.normal(0, 0.2, o).astype(np.float32),
                     mean=rng.normal(0, 0.2, o).astype(np.float32), var=rng.uniform(0.5, 1.5, o).astype(np.float32))
 
     ps = [layer(d + 5, c1)]
@@ -62,8 +66,11 @@ def _pfn_params(rng, d, c1, c2):
     return ps
 
 
-@pytest.mark.parametrize("two_layers", [True, False])
-def test_pfn(oracle, two_layers):
+_PFN_FORMS = [(True, 0), (True, 1), (True, 2), (False, 0)]  # (two layers, kernel form: 1 per pillar, 2 packed)
+
+
+@pytest.mark.parametrize("two_layers,path", _PFN_FORMS)
+def test_pfn(oracle, two_layers, path):
     from paddle3d_amd.ops import voxel_encoder as ve
 
     rng = np.random.default_rng(2)
@@ -82,26 +89,30 @@ def test_pfn(oracle, two_layers):
     args = [t(vox), t(npv), t(c4), vx, vy, vx / 2 + synth.NUSC_RANGE[0], vy / 2 + synth.NUSC_RANGE[1], *folded[0]]
     if two_layers:
         args += list(folded[1])
-    out = ve.pillar_feature_net(*args).cpu().numpy()
+    out = ve.pillar_feature_net(*args, path=path).cpu().numpy()
     assert out.shape == ref.shape
     assert np.abs(out - ref).max() < 1e-3, np.abs(out - ref).max()
 
 
-@pytest.mark.parametrize("two_layers", [True, False])
-@pytest.mark.parametrize("p,d", [(32, 4), (20, 5), (7, 4)])
-def test_pfn_random_pillars(oracle, two_layers, p, d):
-    """Random pillars with every fill level 0..P (empty, partial, full) through the fast PFN kernels."""
+@pytest.mark.parametrize("two_layers,path", _PFN_FORMS)
+@pytest.mark.parametrize("p,d,m", [(32, 4, 500), (20, 5, 500), (7, 4, 500), (20, 5, 3), (32, 5, 1001)])
+def test_pfn_random_pillars(oracle, two_layers, path, p, d, m):
+    """Random pillars with every fill level 0..P (empty, partial, full) through the fast PFN kernels; BatchNorm
+    scales of both signs and zero; pillar counts that are not a multiple of the packed form's chunk of 8."""
     from paddle3d_amd.ops import voxel_encoder as ve
 
     rng = np.random.default_rng(p * 10 + d)
-    m = 500
     npv = rng.integers(0, p + 1, m).astype(np.int32)
     npv[:3] = [0, p, 1]
+    if m > 100:
+        npv[40:72] = p      # chunks of full pillars: 8 x P rows, no padded row
+        npv[80:100] = 0     # a chunk without any row
+        npv[100:108] = 1
     vox = rng.uniform(-3, 3, (m, p, d)).astype(np.float32)
     vox *= (np.arange(p)[None, :, None] < npv[:, None, None])
     c4 = np.concatenate([np.zeros((m, 2), np.int32), rng.integers(0, 400, (m, 2)).astype(np.int32)], 1)
     c1, c2 = (32, 64) if two_layers else (64, 0)
-    params = _pfn_params(rng, d, c1, c2)
+    params = _pfn_params(rng, d, c1, c2, signed=True)
     keep = npv > 0
     ref = oracle.pfn_forward_torch(vox[keep], npv[keep], c4[keep], params, synth.NUSC_PILLAR, synth.NUSC_RANGE)
     dev = torch.device("cuda")
@@ -114,7 +125,7 @@ def test_pfn_random_pillars(oracle, two_layers, p, d):
     args = [t(vox), t(npv), t(c4), vx, vy, vx / 2 + synth.NUSC_RANGE[0], vy / 2 + synth.NUSC_RANGE[1], *folded[0]]
     if two_layers:
         args += list(folded[1])
-    out = ve.pillar_feature_net(*args).cpu().numpy()
+    out = ve.pillar_feature_net(*args, path=path).cpu().numpy()
     assert np.all(out[~keep] == 0)
     assert np.abs(out[keep] - ref).max() < 1e-3, np.abs(out[keep] - ref).max()
 
