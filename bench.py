@@ -71,25 +71,26 @@ def dense_flops():
     return s1 + s2 + other, s1 / 4 + s2 + other
 
 
-def pfn_flops(v, blocks_per_scene=None):
+def pfn_flops(v, mfma_per_scene=None):
     """(direct-form, executed) flops per scene of the two-layer PFN: direct = per real-or-padded point
-    2*(10*32 + 64*64); executed = 38 v_mfma_f32_16x16x4_f32 (2048 flops each) per 16-row block the
-    kernel issues: the packed form (round 3) packs the rows of 8 consecutive pillars into blocks, so the count
-    depends on the fill levels and is taken from the batch; without it, the per-pillar form's
-    one-or-two blocks per pillar slot are assumed."""
-    blocks = blocks_per_scene if blocks_per_scene is not None else v
-    return v * P * 2 * (10 * 32 + 64 * 64), blocks * 38 * 2048
+    2*(10*32 + 64*64); executed = the v_mfma_f32_16x16x4_f32 (2048 flops each) the kernel issues.
+    The packed form (round 3) packs the stored points of 8 consecutive pillars into 16-row blocks, so the count depends
+    on the fill levels and is taken from the batch (`pfn_packed_mfma`); without it, the per-pillar
+    form's 38 per pillar slot are assumed."""
+    mf = mfma_per_scene if mfma_per_scene is not None else v * 38
+    return v * P * 2 * (10 * 32 + 64 * 64), mf * 2048
 
 
-def pfn_packed_blocks(npv, p, chunk=8):
-    """16-row MFMA blocks the packed PFN kernel issues for num_points_per_voxel `npv` [B, V] (csrc/pfn.hip:
-    rows = stored points + one representative padded row of a pillar that is not full, chunks of 8 pillars)."""
-    n = npv.reshape(-1).to(torch.int64)
-    rows = (n.clamp(max=p) + (n < p).to(torch.int64)) * (n > 0).to(torch.int64)
-    pad = (-rows.numel()) % chunk
+def pfn_packed_mfma(npv, p, chunk=8):
+    """MFMA instructions the packed PFN kernel issues for num_points_per_voxel `npv` [B, V] (csrc/pfn.hip): 38 per
+    16-row block of a chunk's stored points (6 layer 1 + 32 layer 2) and 32 per chunk that holds a pillar (the
+    row-independent half of layer 2 for the chunk's 8 pillars)."""
+    n = npv.reshape(-1).to(torch.int64).clamp(min=0, max=p)
+    pad = (-n.numel()) % chunk
     if pad:
-        rows = torch.cat([rows, rows.new_zeros(pad)])
-    return int(((rows.reshape(-1, chunk).sum(1) + 15) // 16).sum().item())
+        n = torch.cat([n, n.new_zeros(pad)])
+    rows = n.reshape(-1, chunk).sum(1)
+    return int((((rows + 15) // 16) * 38 + (rows > 0).to(torch.int64) * 32).sum().item())
 
 
 def make_batch(batch, seed0, device=None, pin=False):
@@ -494,8 +495,8 @@ def bench_pillars(args, rank, world, dev):
 
     d_direct, d_exec = dense_flops()
     with torch.no_grad():
-        pfn_blocks = pfn_packed_blocks(model.voxelizer(pts)[2], P) / B
-    p_direct, p_exec = pfn_flops(V, pfn_blocks)
+        pfn_mfma = pfn_packed_mfma(model.voxelizer(pts)[2], P) / B
+    p_direct, p_exec = pfn_flops(V, pfn_mfma)
     rooflines = dict(
         hard_voxelize=hbm("hard_voxelize", "hard_voxelize"),
         pointpillars_scatter=(dict(bound="hbm", fused_into="dense_backbone_fpn_head", achieved=None,
@@ -514,9 +515,10 @@ def bench_pillars(args, rank, world, dev):
                                           "fraction is for completeness (6 tasks x up to 1000 candidates per "
                                           "frame: random-init heads fill the NMS cap)"),
         pillar_feature_net=mfma(per_op_ms["pillar_feature_net"], p_direct, p_exec,
-                                "achieved / frac = executed MFMA flops: 38 v_mfma_f32_16x16x4_f32 per 16-row block of "
-                                f"the packed form, {pfn_blocks:.0f} blocks per scene counted on this batch (rows = "
-                                "stored points + one padded row per pillar that is not full, packed per 8 pillars); "
+                                "achieved / frac = executed MFMA flops: the packed form issues 38 "
+                                "v_mfma_f32_16x16x4_f32 per 16-row block of stored points (packed per 8 pillars) + 32 "
+                                f"per chunk, {pfn_mfma:.0f} per scene counted on this batch; the kernel is bound by "
+                                "VALU / LDS instruction issue next to the MFMAs, not by the matrix pipe (DESIGN 4.3); "
                                 "direct_form_tflops = the layer's own multiply-adds over all P slots / time"),
         dense_backbone_fpn_head=mfma(per_op_ms["dense"], d_direct, d_exec,
                                      "achieved / frac = executed flops: the 52 stride-1 3x3 layers run Winograd "

@@ -39,22 +39,18 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   const int row_size = min(n - row_blk * 64, 64);
   const int lane = threadIdx.x;
 
-  __shared__ BoxPre col_pre[64];
-  __shared__ BoxPre row_pre[64];
-  __shared__ float col_raw[64 * 7];
+  // LDS per single-wave workgroup decides how many of them a CU holds (the kernel is a serial candidate walk per
+  // wave: occupancy is its throughput): the arrays of the other variant are not declared, and the candidate list is
+  // built and consumed per half of the column tile (2048 entries instead of 4096): 12.8 KB, 12 workgroups per CU
   __shared__ unsigned long long bits_s[64];
-  __shared__ unsigned short pairs[64 * 64];
   bits_s[lane] = 0ull;
-  if (lane < col_size) {
-    const float* b = bx + (int64_t)(col_blk * 64 + lane) * 7;
-    if (NORMAL) {
+  if constexpr (NORMAL) {
+    __shared__ float col_raw[64 * 7];
+    if (lane < col_size) {
+      const float* b = bx + (int64_t)(col_blk * 64 + lane) * 7;
 #pragma unroll
       for (int k = 0; k < 7; ++k) col_raw[lane * 7 + k] = b[k];
-    } else {
-      col_pre[lane] = pre ? pre[(int64_t)set * cap + col_blk * 64 + lane] : box_prepare(b);
     }
-  }
-  if (NORMAL) {
     __syncthreads();
     if (lane < row_size) {
       const float* b = bx + (int64_t)(row_blk * 64 + lane) * 7;
@@ -67,38 +63,45 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
         if (iou_normal(me, col_raw + i * 7) > thresh) bits |= 1ull << i;
       mask[((int64_t)set * cap + row_blk * 64 + lane) * cb_cap + col_blk] = bits;
     }
-    return;
-  }
-  if (lane < row_size)
-    row_pre[lane] = pre ? pre[(int64_t)set * cap + row_blk * 64 + lane]
-                        : box_prepare(bx + (int64_t)(row_blk * 64 + lane) * 7);
-  __syncthreads();
-  // phase 1: candidate pairs
-  int npairs = 0;
-  {
+  } else {
+    __shared__ BoxPre col_pre[64];
+    __shared__ BoxPre row_pre[64];
+    __shared__ unsigned short pairs[64 * 32];
+    if (lane < col_size)
+      col_pre[lane] = pre ? pre[(int64_t)set * cap + col_blk * 64 + lane]
+                          : box_prepare(bx + (int64_t)(col_blk * 64 + lane) * 7);
+    if (lane < row_size)
+      row_pre[lane] = pre ? pre[(int64_t)set * cap + row_blk * 64 + lane]
+                          : box_prepare(bx + (int64_t)(row_blk * 64 + lane) * 7);
+    __syncthreads();
     const bool live = lane < row_size;
     const float mx = live ? row_pre[lane].cx : 0.f, my = live ? row_pre[lane].cy : 0.f;
     const float mr = live ? row_pre[lane].rad : 0.f;
     const int start = (row_blk == col_blk) ? lane + 1 : 0;
-    for (int i = 0; i < col_size; ++i) {
-      bool cand = false;
-      if (live && i >= start) {
-        const float dx = mx - col_pre[i].cx, dy = my - col_pre[i].cy, r = mr + col_pre[i].rad + 0.25f;
-        cand = !(dx * dx + dy * dy > r * r);  // the same test box_overlap starts with
+    for (int c0 = 0; c0 < col_size; c0 += 32) {
+      // phase 1: candidate pairs of this half of the columns
+      int npairs = 0;
+      const int c1 = min(col_size, c0 + 32);
+      for (int i = c0; i < c1; ++i) {
+        bool cand = false;
+        if (live && i >= start) {
+          const float dx = mx - col_pre[i].cx, dy = my - col_pre[i].cy, r = mr + col_pre[i].rad + 0.25f;
+          cand = !(dx * dx + dy * dy > r * r);  // the same test box_overlap starts with
+        }
+        const unsigned long long m = __ballot(cand);
+        if (cand) pairs[npairs + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((lane << 6) | i);
+        npairs += __popcll(m);
       }
-      const unsigned long long m = __ballot(cand);
-      if (cand) pairs[npairs + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((lane << 6) | i);
-      npairs += __popcll(m);
+      __syncthreads();
+      // phase 2: one candidate pair per lane
+      for (int p = lane; p < npairs; p += 64) {
+        const int r = pairs[p] >> 6, i = pairs[p] & 63;
+        if (iou_bev(row_pre[r], col_pre[i]) > thresh) atomicOr(&bits_s[r], 1ull << i);
+      }
+      __syncthreads();
     }
+    if (lane < row_size) mask[((int64_t)set * cap + row_blk * 64 + lane) * cb_cap + col_blk] = bits_s[lane];
   }
-  __syncthreads();
-  // phase 2: one candidate pair per lane
-  for (int p = lane; p < npairs; p += 64) {
-    const int r = pairs[p] >> 6, i = pairs[p] & 63;
-    if (iou_bev(row_pre[r], col_pre[i]) > thresh) atomicOr(&bits_s[r], 1ull << i);
-  }
-  __syncthreads();
-  if (lane < row_size) mask[((int64_t)set * cap + row_blk * 64 + lane) * cb_cap + col_blk] = bits_s[lane];
 }
 
 // One workgroup per set.  keep [set][cap] receives kept indices in order; num_keep[set] their number.

@@ -489,11 +489,10 @@ __global__ __launch_bounds__(256, C1 == 32 ? 4 : 2) void pfn_two_mfma_kernel(Pfn
 // ---------------------------------------------------------------------------------------------------
 // Packed form of the two-layer fast path (C1 = 32, C2 = 64).  The form above spends one wave and one or two
 // 16-row MFMA blocks on every pillar, whatever its fill level; a nuScenes sweep has 4.5 points per pillar
-// on average (half of the pillars hold one), so two thirds of the rows it multiplies are padding and, worse,
-// every pillar pays the full stage -> mean -> layer 1 -> max -> base -> layer 2 -> max chain of dependent
-// LDS / MFMA steps.  Here a wave takes a CHUNK of 8 consecutive pillars, packs their rows (real points + the
-// one representative padded row of a pillar that is not full) back to back into 16-row blocks, and runs both
-// layers block by block:
+// on average (half of the pillars hold one), so most of the rows it multiplies are padding and, worse, every
+// pillar pays the full stage -> mean -> layer 1 -> max -> base -> layer 2 -> max chain of dependent LDS / MFMA
+// steps.  Here a wave takes a CHUNK of 8 consecutive pillars, packs their stored points back to back into 16-row
+// blocks, and runs both layers block by block:
 //   * a pillar's maximum over the rows of layer 2 commutes with everything that follows the GEMM: with
 //     t_r = y1_r W2[0:32], the output is max_r relu(bn2(t_r + base)) = relu(bn2(ext_r t_r + base)) where
 //     ext is the maximum for a non-negative folded scale and the minimum for a negative one (fp32 add, fma
@@ -501,11 +500,25 @@ __global__ __launch_bounds__(256, C1 == 32 ? 4 : 2) void pfn_two_mfma_kernel(Pfn
 //     B operand, so the walk below only takes maxima.  base = max_r(y1_r) W2[32:64] therefore is needed once
 //     per pillar, AFTER its last row, and a block can run layer 2 right behind layer 1 without knowing the
 //     pillar's maximum yet: no row tile survives a block, and pillars may straddle blocks;
+//   * the padded rows of a pillar that is not full are all the same row whatever the pillar (zero input ->
+//     y1 = relu(shift1), t = relu(shift1) W2[0:32]): two per-kernel constant vectors that the running maxima
+//     of such a pillar START from, so no padded row is ever multiplied;
 //   * the segmented maxima are taken by lane = channel walking the 16 rows of the block's two LDS tiles; the
 //     rows that end a pillar are a wave-uniform 16-bit mask (one ballot), so the walk is scalar control flow.
-// Per chunk (8 pillars, 43 rows on average) that is 3.2 blocks x 38 MFMAs where the per-pillar form issues
+//     A finished pillar parks its two maxima in the LDS slot of its own raw points (dead by then);
+//   * after the chunk's last block, base for all 8 pillars is ONE more 16-row MFMA block (rows = pillars),
+//     and BatchNorm 2 + ReLU are applied once per pillar and channel.
+// Per chunk (8 pillars, 36 points on average) that is 2.8 blocks x 38 + 32 MFMAs where the per-pillar form issues
 // 8.9 x 38, and one latency chain per chunk instead of eight.
 constexpr int kPkPillars = 8;
+
+// v_max_f32 as it is: fmaxf() first canonicalises both operands (two more v_max per call) because it cannot
+// know that they are not signalling NaNs; the walk below is nothing but maxima.
+__device__ __forceinline__ float pk_max(float x, float y) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
 
 template <int D, int CD, int NV>
 __global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
@@ -516,18 +529,20 @@ __global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
   const int lane = lane_id(), wave = wave_id();
   const int r16 = lane & 15, g = lane >> 4;
   const int pd = a.p * D;  // PC * pd <= NV * 64 (dispatch)
-  const int rcap = (PC * (a.p + 1) + 15) & ~15;
-  const int wave_floats = NV * 64 + 16 * YS + 16 * AS + 32 + PC * 8 + rcap + 16;
+  const int rcap = (PC * a.p + 15) & ~15;
+  const bool park_in_ln = pd >= 96;  // a pillar's 32 + 64 maxima fit the slot of its raw points
+  const int wave_floats = NV * 64 + 16 * YS + 16 * AS + PC * 8 + rcap + 16 + (park_in_ln ? 0 : PC * 96);
   float* ln = smem + wave * wave_floats;            // the chunk's raw pillars, [pillar][k][D]
   float* y1T = ln + NV * 64;                        // [16 rows][YS]: layer-1 output of the current block
   float* accT = y1T + 16 * YS;                      // [16 rows][AS]: y1 W2[0:32] (sign-folded) of the block
-  float* m1s = accT + 16 * AS;                      // [32]: a finished pillar's max over y1
-  float* sub = m1s + 32;                            // [PC][8]: cluster mean xyz, pillar centre xyz, 0, count
-  int* rinfo = reinterpret_cast<int*>(sub + PC * 8);  // [rcap]: pillar | k << 4 | real << 12 | last row << 13
+  float* sub = accT + 16 * AS;                      // [PC][8]: cluster mean xyz, pillar centre xyz, 0, count
+  int* rinfo = reinterpret_cast<int*>(sub + PC * 8);  // [rcap]: pillar | k << 4 | last row << 13
   int* ends = rinfo + rcap;                         // [PC] inclusive row prefix, [PC] stored points
+  float* park = park_in_ln ? ln : reinterpret_cast<float*>(ends + 16);  // [PC][pst]: max y1 (32), max t (64)
+  const int pst = park_in_ln ? pd : 96;
   float* w2bs = smem + 4 * wave_floats;             // [32][64]: W2[32:64], shared by the four waves
   // ---- weights and folded BatchNorm in registers ------------------------------------------------
-  float w1r[3][2], w2a[8][4], sc1[2], sh1[2];
+  float w1r[3][2], w2a[8][4], sc1[2], sh1[2], sc2m[2], sh2m[2];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
@@ -547,8 +562,17 @@ __global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
   for (int cb = 0; cb < 2; ++cb) {
     sc1[cb] = a.scale1[cb * 16 + r16];
     sh1[cb] = a.shift1[cb * 16 + r16];
+    // the finishing step: lanes of row groups 0, 1 take column blocks 0, 1, those of groups 2, 3 blocks 2, 3
+    sc2m[cb] = a.scale2[((g >> 1) * 2 + cb) * 16 + r16];
+    sh2m[cb] = a.shift2[((g >> 1) * 2 + cb) * 16 + r16];
   }
-  const float sc2 = a.scale2[lane], sh2 = a.shift2[lane], sg2 = sc2 < 0.f ? -1.f : 1.f;
+  // the padded row (lane = channel): y1 = relu(bn1(0)), t = y1 W2[0:32] with the column's sign folded in
+  const float y1pad = fmaxf(a.shift1[lane & 31], 0.f);
+  float tpad = 0.f;
+  {
+    const float sg = a.scale2[lane] < 0.f ? -1.f : 1.f;
+    for (int c = 0; c < 32; ++c) tpad = fmaf(fmaxf(a.shift1[c], 0.f), a.w2[c * 64 + lane] * sg, tpad);
+  }
   // this lane's A-operand features: k-step ks carries decorated feature i = 4 ks + g of the row lane & 15
   int fsrc[3], fsub[3];  // source coordinate; slot of `sub` that is subtracted (6 = the zero slot)
   bool fzero[3];
@@ -571,14 +595,13 @@ __global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
     const int lim = cntp * pd;
     const float* src = a.voxels + q0 * pd;
 #pragma unroll
-    for (int q = 0; q < NV; ++q) vreg[q] = lane + 64 * q < lim ? src[lane + 64 * q] : 0.f;
-    npn = c1 = c2 = c3 = 0;
-    if (lane < cntp) {
-      npn = a.num_points[q0 + lane];
-      c1 = a.coors[(q0 + lane) * 4 + 1];
-      c2 = a.coors[(q0 + lane) * 4 + 2];
-      c3 = a.coors[(q0 + lane) * 4 + 3];
-    }
+    for (int q = 0; q < NV; ++q) vreg[q] = src[min(lane + 64 * q, lim - 1)];  // clamped, not predicated: no branches;
+    const int ql = min(lane, cntp - 1);                                         // floats past `lim` belong to no pillar
+    npn = a.num_points[q0 + ql];
+    c1 = a.coors[(q0 + ql) * 4 + 1];
+    c2 = a.coors[(q0 + ql) * 4 + 2];
+    c3 = a.coors[(q0 + ql) * 4 + 3];
+    npn = lane < cntp ? npn : 0;
   };
   fetch(ch);
   for (; ch < nchunks; ch += stride) {
@@ -591,17 +614,17 @@ __global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
     wave_lds_order();
     if (ch + stride < nchunks) fetch(ch + stride);  // the next chunk's loads fly while this one is evaluated
     // ---- the chunk's row layout: lane q < PC is pillar p0 + q -------------------------------------
-    const int np = np_raw > 0 ? min(np_raw, a.p) : 0;     // a padding row of a fixed-shape batch has no rows
-    const int rows = np > 0 ? np + (np < a.p ? 1 : 0) : 0;  // + one representative padded (all-zero) row
-    int end = rows;
+    const int np = np_raw > 0 ? min(np_raw, a.p) : 0;  // a padding row of a fixed-shape batch has no rows
+    int end = np;
 #pragma unroll
     for (int dlt = 1; dlt < PC; dlt <<= 1) {
       const int t = __shfl_up(end, dlt, PC);
       if ((lane & (PC - 1)) >= dlt) end += t;
     }
     const int R = __builtin_amdgcn_readlane(end, PC - 1);
-    unsigned long long live = __ballot(lane < PC && rows > 0);
-    unsigned long long empty = __ballot(lane < PC && rows == 0 && p0 + lane < a.m);
+    const unsigned live0 = (unsigned)__ballot(lane < PC && np > 0);
+    const unsigned notfull = (unsigned)__ballot(lane < PC && np < a.p);
+    unsigned long long empty = __ballot(lane < PC && np == 0 && p0 + lane < a.m);
     if (lane < PC) {
       ends[lane] = end;
       ends[PC + lane] = np;
@@ -617,48 +640,65 @@ __global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
       a.out[(p0 + q) * 64 + lane] = 0.f;
     }
     wave_lds_order();
-    // cluster means (pillar_encoder.py:166-176; the reference divides by num_points without epsilon): lane =
-    // (pillar, axis), the stored points summed in their order
-    if (lane < 3 * PC) {
-      const int q = lane & (PC - 1), ax = lane / PC;
+    // cluster means (pillar_encoder.py:166-176; the reference divides by num_points without epsilon): eight lanes
+    // per pillar sum every eighth stored point, a three-step butterfly adds the partial sums
+    {
+      const int q = lane >> 3, j = lane & 7;
       const int npl = ends[PC + q];
-      const float* src = ln + q * pd + ax;
-      float s = 0.f;
-      for (int k = 0; k < npl; ++k) s += src[k * D];
-      if (npl > 0) sub[q * 8 + ax] = s / sub[q * 8 + 7];
+      const float* src = ln + q * pd;
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      for (int k = j; k < npl; k += 8) {
+        sx += src[k * D + 0];
+        sy += src[k * D + 1];
+        sz += src[k * D + 2];
+      }
+#pragma unroll
+      for (int dlt = 1; dlt < 8; dlt <<= 1) {
+        sx += __shfl_xor(sx, dlt, 8);
+        sy += __shfl_xor(sy, dlt, 8);
+        sz += __shfl_xor(sz, dlt, 8);
+      }
+      if (j < 3 && npl > 0) sub[q * 8 + j] = (j == 0 ? sx : (j == 1 ? sy : sz)) / sub[q * 8 + 7];
     }
     const int rb = (R + 15) & ~15;
     for (int r = lane; r < rb; r += 64) {
       int q = 0;
 #pragma unroll
       for (int j = 0; j < PC; ++j) q += ends[j] <= r ? 1 : 0;
-      int info = 0;  // rows past the chunk's last one: a zero row of pillar 0 that no walk reads
+      int info = 0;  // rows past the chunk's last one: zero rows that no walk reads
       if (r < R) {
         const int st = q > 0 ? ends[q - 1] : 0;
-        const int k = r - st;
-        info = q | (k << 4) | ((k < ends[PC + q] ? 1 : 0) << 12) | ((r + 1 == ends[q] ? 1 : 0) << 13);
+        info = q | ((r - st) << 4) | ((r + 1 == ends[q] ? 1 : 0) << 13);
       }
       rinfo[r] = info;
     }
     wave_lds_order();
-    float m1 = -INFINITY, m2 = -INFINITY;  // running maxima of the pillar the walk is in; lane = channel
+    // running maxima of the pillar the walk is in (lane = channel); they start from the padded row's values
+    // where the pillar has padded rows
+    unsigned live = live0;
+    int cur = live ? __builtin_ctz(live) : 0;
+    float m1 = (notfull >> cur) & 1u ? y1pad : -INFINITY;
+    float m2 = (notfull >> cur) & 1u ? tpad : -INFINITY;
     const int nblk = rb >> 4;
     for (int b = 0; b < nblk; ++b) {
       const int info = rinfo[b * 16 + r16];
       const unsigned endmask = (unsigned)(__ballot((info >> 13) & 1) & 0xffffull);
       const int q = info & 15, k = (info >> 4) & 255;
-      const bool real = (info >> 12) & 1;
       // ---- layer 1 on the matrix cores; Y1 = relu(bn1(X W1)) -> y1T --------------------------------
       pfn_f32x4 acc1[2];
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) acc1[cb] = (pfn_f32x4){0.f, 0.f, 0.f, 0.f};
+      // rows past the chunk's last one (info = 0) read pillar 0's slot: whatever they hold stays in their own rows of
+      // the products (MFMA rows are independent) and no walk reads those rows, so the loads need no predicate
+      float av[3];
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) av[ks] = ln[q * pd + k * D + fsrc[ks]] - sub[q * 8 + fsub[ks]];
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
-        float av = ln[q * pd + k * D + fsrc[ks]] - sub[q * 8 + fsub[ks]];
-        av = (real && !fzero[ks]) ? av : 0.f;
+        const float v = fzero[ks] ? 0.f : av[ks];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
-          acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1r[ks][cb], acc1[cb], 0, 0, 0);
+          acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, w1r[ks][cb], acc1[cb], 0, 0, 0);
       }
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
@@ -682,45 +722,60 @@ __global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) accT[(4 * g + r) * AS + cb * 16 + r16] = acc2[cb][r];
       wave_lds_order();
-      // ---- walk the block's rows: lane = channel; a pillar's last row finishes it ----------------------
+      // ---- walk the block's rows: lane = channel; a pillar's last row parks its maxima ------------------
+      float tv[16], yv[16];
 #pragma unroll
-      for (int h = 0; h < 16; h += 8) {
-      float tv[8], yv[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        tv[r] = accT[(h + r) * AS + lane];
-        yv[r] = y1T[(h + r) * YS + (lane & 31)];
+      for (int r = 0; r < 16; ++r) {
+        tv[r] = accT[r * AS + lane];
+        yv[r] = y1T[r * YS + (lane & 31)];
       }
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        m2 = fmaxf(m2, tv[r]);
-        m1 = fmaxf(m1, yv[r]);
-        if ((endmask >> (h + r)) & 1u) {
-          const int fin = __builtin_ctzll(live);
+      for (int r = 0; r < 16; ++r) {
+        m2 = pk_max(m2, tv[r]);
+        m1 = pk_max(m1, yv[r]);
+        if ((endmask >> r) & 1u) {
+          if (lane < 32) park[cur * pst + lane] = m1;
+          park[cur * pst + 32 + lane] = m2;
           live &= live - 1;
-          if (lane < 32) m1s[lane] = m1;
-          wave_lds_order();
-          // base = max_rows(Y1) W2[32:64], the row-independent half of the concat (PFNLayer :100-104)
-          float bp[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int i4 = 0; i4 < 32; i4 += 4) {
-            const pfn_f32x4 mv = *reinterpret_cast<const pfn_f32x4*>(m1s + i4);
-            bp[0] = fmaf(mv[0], w2bs[(i4 + 0) * 64 + lane], bp[0]);
-            bp[1] = fmaf(mv[1], w2bs[(i4 + 1) * 64 + lane], bp[1]);
-            bp[2] = fmaf(mv[2], w2bs[(i4 + 2) * 64 + lane], bp[2]);
-            bp[3] = fmaf(mv[3], w2bs[(i4 + 3) * 64 + lane], bp[3]);
-            if ((i4 & 4) != 0) wave_lds_order();  // keeps at most eight weights in flight (register pressure)
-          }
-          const float base = (bp[0] + bp[1]) + (bp[2] + bp[3]);
-          a.out[(p0 + fin) * 64 + lane] = fmaxf(fmaf(sg2 * m2 + base, sc2, sh2), 0.f);
-          m1 = -INFINITY;
-          m2 = -INFINITY;
-          wave_lds_order();  // m1s is rewritten by the next pillar that ends
+          cur = live ? __builtin_ctz(live) : 0;
+          m1 = (notfull >> cur) & 1u ? y1pad : -INFINITY;
+          m2 = (notfull >> cur) & 1u ? tpad : -INFINITY;
         }
-      }
       }
       wave_lds_order();  // the next block overwrites the tiles
     }
+    if (live0 == 0u) continue;
+    // ---- base = max_rows(Y1) W2[32:64] (the row-independent half of the concat, PFNLayer :100-104) for the
+    // chunk's pillars as one more MFMA block: row = pillar (rows 8..15 repeat 0..7), then bn2 + ReLU once per
+    // pillar and channel: rows 0..7 (lane groups 0, 1) finish column blocks 0, 1, their repeats blocks 2, 3
+    {
+      pfn_f32x4 accb[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) accb[cb] = (pfn_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const float av = park[(r16 & 7) * pst + ks * 4 + g];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+          accb[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2bs[(ks * 4 + g) * 64 + cb * 16 + r16], accb[cb], 0, 0, 0);
+      }
+      const int half = g >> 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = (4 * g + r) & 7;
+        if ((live0 >> q) & 1u) {
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            const int c = (half * 2 + cb) * 16 + r16;
+            const float bs = half ? accb[2 + cb][r] : accb[cb][r];
+            const float t = park[q * pst + 32 + c];
+            const float x = (sc2m[cb] < 0.f ? -t : t) + bs;
+            a.out[(p0 + q) * 64 + c] = fmaxf(fmaf(x, sc2m[cb], sh2m[cb]), 0.f);
+          }
+        }
+      }
+    }
+    wave_lds_order();  // the next chunk's raw points overwrite the parked maxima
   }
 }
 
@@ -810,8 +865,9 @@ static int pfn_dispatch(const float* voxels, const int32_t* num_points, const in
     const int64_t nchunks = ceil_div(num_pillars, (int64_t)kPkPillars);
     const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(nchunks, 4), 256 * 3);
     const int nv = (kPkPillars * max_points * num_point_dim + 63) / 64 <= 13 ? 13 : 20;
-    const int rcap = (kPkPillars * (max_points + 1) + 15) & ~15;
-    const size_t lds = ((size_t)4 * (nv * 64 + 16 * 34 + 16 * 68 + 32 + kPkPillars * 8 + rcap + 16) + 32 * 64) * sizeof(float);
+    const int rcap = (kPkPillars * max_points + 15) & ~15;
+    const size_t lds = ((size_t)4 * (nv * 64 + 16 * 34 + 16 * 68 + kPkPillars * 8 + rcap + 16 +
+                                     (max_points * num_point_dim >= 96 ? 0 : kPkPillars * 96)) + 32 * 64) * sizeof(float);
 #define PD3_PFN_PACKED(DD, CDV, NVV)                                                                               \
   do {                                                                                                            \
     if (lds > 48 * 1024) {                                                                                        \

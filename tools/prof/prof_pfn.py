@@ -26,10 +26,11 @@ w2 = torch.randn(64, 64, device=dev, generator=g) / 8
 s1, b1 = torch.rand(32, device=dev, generator=g) + 0.5, torch.randn(32, device=dev, generator=g) * 0.1
 s2, b2 = torch.rand(64, device=dev, generator=g) + 0.5, torch.randn(64, device=dev, generator=g) * 0.1
 args = (vox, npv, c4, 0.2, 0.2, -51.1, -51.1, w1, s1, b1, w2, s2, b2)
-rows = (npv.clamp(max=20) + (npv < 20).int()) * (npv > 0).int()
-print(f"pillars {vox.shape[0]}, live {(npv > 0).sum().item()}, rows {rows.sum().item()}, "
-      f"per-pillar blocks {((rows + 15) // 16).sum().item()}, "
-      f"packed blocks {((rows.reshape(-1, 8).sum(1) + 15) // 16).sum().item()}")
+rows1 = (npv.clamp(max=20) + (npv < 20).int()) * (npv > 0).int()  # per-pillar form: + one padded row
+rows2 = npv.clamp(min=0, max=20)                                    # packed form: stored points only
+print(f"pillars {vox.shape[0]}, live {(npv > 0).sum().item()}, stored points {rows2.sum().item()}, "
+      f"per-pillar blocks {((rows1 + 15) // 16).sum().item()}, "
+      f"packed blocks {((rows2.reshape(-1, 8).sum(1) + 15) // 16).sum().item()} (+ one base block per chunk)")
 outs = {}
 for path in (1, 2, 0):
     for _ in range(3):
