@@ -103,14 +103,22 @@ __device__ __forceinline__ bool inside(const BoxPre& box, Pt p) {
   return fabsf(rx) < box.lim_x && fabsf(ry) < box.lim_y;
 }
 
+// The vertex list of box_overlap (iou3d_cpu.cpp: `Point cross_points[16]`) lives in LDS, not in a private array: a
+// dynamically indexed private array is scratch memory on this machine (every append, every compare of the bubble
+// sort a round trip through the vector memory path), and an overlap evaluation was a ~90 k-cycle latency chain.
+// Layout of one wave's region: [x | y | angle][16 vertices][64 lanes] floats; a lane passes `region + lane`.
+constexpr int kPolyCap = 16;
+constexpr int kPolyWaveFloats = 3 * kPolyCap * 64;
+
 // box_overlap :134-229
-__device__ inline float box_overlap(const BoxPre& a, const BoxPre& b) {
+__device__ inline float box_overlap(const BoxPre& a, const BoxPre& b, float* __restrict__ st) {
   {
     const float dx = a.cx - b.cx, dy = a.cy - b.cy, r = a.rad + b.rad + 0.25f;
     if (dx * dx + dy * dy > r * r) return 0.0f;  // exact: the reference builds an empty polygon
   }
-  Pt poly[24];
-  float ang[24];
+  float* vx = st;
+  float* vy = st + kPolyCap * 64;
+  float* va = st + 2 * kPolyCap * 64;
   int cnt = 0;
   float sx = 0.f, sy = 0.f;
   for (int i = 0; i < 4; ++i) {
@@ -120,7 +128,9 @@ __device__ inline float box_overlap(const BoxPre& a, const BoxPre& b) {
       if (seg_hit(a1, a0, b.c[(j + 1) & 3], b.c[j], hit)) {
         sx = sx + hit.x;
         sy = sy + hit.y;
-        poly[cnt++] = hit;
+        vx[cnt * 64] = hit.x;
+        vy[cnt * 64] = hit.y;
+        ++cnt;
       }
     }
   }
@@ -128,41 +138,83 @@ __device__ inline float box_overlap(const BoxPre& a, const BoxPre& b) {
     if (inside(a, b.c[k])) {
       sx = sx + b.c[k].x;
       sy = sy + b.c[k].y;
-      poly[cnt++] = b.c[k];
+      vx[cnt * 64] = b.c[k].x;
+      vy[cnt * 64] = b.c[k].y;
+      ++cnt;
     }
     if (inside(b, a.c[k])) {
       sx = sx + a.c[k].x;
       sy = sy + a.c[k].y;
-      poly[cnt++] = a.c[k];
+      vx[cnt * 64] = a.c[k].x;
+      vy[cnt * 64] = a.c[k].y;
+      ++cnt;
     }
   }
   if (cnt == 0) return 0.0f;
   sx /= cnt;  // :197-198
   sy /= cnt;
-  for (int k = 0; k < cnt; ++k) ang[k] = atan2_rn(poly[k].y - sy, poly[k].x - sx);  // point_cmp :129-132
-  for (int j = 0; j < cnt - 1; ++j)  // :201-210
-    for (int i = 0; i < cnt - j - 1; ++i) {
-      if (ang[i] > ang[i + 1]) {
-        const Pt tp = poly[i];
-        poly[i] = poly[i + 1];
-        poly[i + 1] = tp;
-        const float ta = ang[i];
-        ang[i] = ang[i + 1];
-        ang[i + 1] = ta;
+  for (int k = 0; k < cnt; ++k) va[k * 64] = atan2_rn(vy[k * 64] - sy, vx[k * 64] - sx);  // point_cmp :129-132
+  float area = 0.f;
+  if (cnt <= 8) {
+    // two convex quadrilaterals in general position meet in at most eight vertices: sort and sum in registers.  The
+    // fixed eight-element bubble network does the reference's compare-swaps (:201-210) in the reference's order; the
+    // extra ones only ever look at an element that is already in its final place or at a +inf pad, and never swap.
+    float px[8], py[8], an[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool in = k < cnt;
+      px[k] = in ? vx[k * 64] : 0.f;
+      py[k] = in ? vy[k * 64] : 0.f;
+      an[k] = in ? va[k * 64] : INFINITY;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+      for (int i = 0; i < 7 - j; ++i) {
+        const bool sw = an[i] > an[i + 1];
+        const float tx = px[i], ty = py[i], ta = an[i];
+        px[i] = sw ? px[i + 1] : tx;
+        py[i] = sw ? py[i + 1] : ty;
+        an[i] = sw ? an[i + 1] : ta;
+        px[i + 1] = sw ? tx : px[i + 1];
+        py[i + 1] = sw ? ty : py[i + 1];
+        an[i + 1] = sw ? ta : an[i + 1];
+      }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {  // :213-217
+      if (k < cnt - 1) {
+        const float ux = px[k] - px[0], uy = py[k] - py[0];
+        const float wx = px[k + 1] - px[0], wy = py[k + 1] - py[0];
+        area += ux * wy - uy * wx;
       }
     }
-  float area = 0.f;  // :213-217
-  for (int k = 0; k < cnt - 1; ++k) {
-    const float ux = poly[k].x - poly[0].x, uy = poly[k].y - poly[0].y;
-    const float wx = poly[k + 1].x - poly[0].x, wy = poly[k + 1].y - poly[0].y;
-    area += ux * wy - uy * wx;
+  } else {
+    for (int j = 0; j < cnt - 1; ++j)  // :201-210
+      for (int i = 0; i < cnt - j - 1; ++i) {
+        const float a0 = va[i * 64], a1 = va[(i + 1) * 64];
+        if (a0 > a1) {
+          const float x0 = vx[i * 64], y0 = vy[i * 64];
+          vx[i * 64] = vx[(i + 1) * 64];
+          vy[i * 64] = vy[(i + 1) * 64];
+          va[i * 64] = a1;
+          vx[(i + 1) * 64] = x0;
+          vy[(i + 1) * 64] = y0;
+          va[(i + 1) * 64] = a0;
+        }
+      }
+    const float x0 = vx[0], y0 = vy[0];
+    for (int k = 0; k < cnt - 1; ++k) {  // :213-217
+      const float ux = vx[k * 64] - x0, uy = vy[k * 64] - y0;
+      const float wx = vx[(k + 1) * 64] - x0, wy = vy[(k + 1) * 64] - y0;
+      area += ux * wy - uy * wx;
+    }
   }
   return fabsf(area) / 2.0f;  // :219 (the fp64 division by 2 is exact)
 }
 
 // iou_bev :222-229
-__device__ __forceinline__ float iou_bev(const BoxPre& a, const BoxPre& b) {
-  const float so = box_overlap(a, b);
+__device__ __forceinline__ float iou_bev(const BoxPre& a, const BoxPre& b, float* __restrict__ st) {
+  const float so = box_overlap(a, b, st);
   return so / fmaxf(a.area + b.area - so, kGeomEps);
 }
 

@@ -14,6 +14,8 @@ __global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__
   const int b_idx = blockIdx.x * 16 + (threadIdx.x & 15);
   const int a_idx = blockIdx.y * 16 + (threadIdx.x >> 4);
   __shared__ BoxPre pa[16], pb[16];
+  __shared__ float poly_s[4 * kPolyWaveFloats];
+  float* st = poly_s + wave_id() * kPolyWaveFloats + lane_id();
   if (threadIdx.x < 16) {
     const int a = blockIdx.y * 16 + threadIdx.x;
     if (a < num_a) pa[threadIdx.x] = box_prepare(boxes_a + (int64_t)a * 7);
@@ -25,7 +27,7 @@ __global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__
   if (a_idx >= num_a || b_idx >= num_b) return;
   const BoxPre& A = pa[threadIdx.x >> 4];
   const BoxPre& B = pb[threadIdx.x & 15];
-  ans[(int64_t)a_idx * num_b + b_idx] = IOU ? iou_bev(A, B) : box_overlap(A, B);
+  ans[(int64_t)a_idx * num_b + b_idx] = IOU ? iou_bev(A, B, st) : box_overlap(A, B, st);
 }
 
 template <bool NORMAL>

@@ -8,6 +8,8 @@
 #include "common.hpp"
 #include "iou3d_geom.hpp"
 
+#include <algorithm>
+
 namespace pd3 {
 
 constexpr int kNmsMaxWords = 1024;  // sweep supports up to 65536 boxes per set
@@ -41,7 +43,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 
   // LDS per single-wave workgroup decides how many of them a CU holds (the kernel is a serial candidate walk per
   // wave: occupancy is its throughput): the arrays of the other variant are not declared, and the candidate list is
-  // built and consumed per half of the column tile (2048 entries instead of 4096): 12.8 KB, 12 workgroups per CU
+  // built and consumed per half of the column tile (2048 entries instead of 4096): 25 KB with the vertex lists of
+  // box_overlap, six workgroups per CU
   __shared__ unsigned long long bits_s[64];
   bits_s[lane] = 0ull;
   if constexpr (NORMAL) {
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     __shared__ BoxPre col_pre[64];
     __shared__ BoxPre row_pre[64];
     __shared__ unsigned short pairs[64 * 32];
+    __shared__ float poly_s[kPolyWaveFloats];
     if (lane < col_size)
       col_pre[lane] = pre ? pre[(int64_t)set * cap + col_blk * 64 + lane]
                           : box_prepare(bx + (int64_t)(col_blk * 64 + lane) * 7);
@@ -96,12 +100,164 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
       // phase 2: one candidate pair per lane
       for (int p = lane; p < npairs; p += 64) {
         const int r = pairs[p] >> 6, i = pairs[p] & 63;
-        if (iou_bev(row_pre[r], col_pre[i]) > thresh) atomicOr(&bits_s[r], 1ull << i);
+        if (iou_bev(row_pre[r], col_pre[i], poly_s + lane) > thresh) atomicOr(&bits_s[r], 1ull << i);
       }
       __syncthreads();
     }
     if (lane < row_size) mask[((int64_t)set * cap + row_blk * 64 + lane) * cb_cap + col_blk] = bits_s[lane];
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pooled form of the rotated-box bit matrix for the batched callers (all sets of a call, BoxPre records prepared).
+// A tile of the matrix holds 4096 pairs of which 10-20 pass the circle test on typical inputs, so the tile form
+// above spends its polygon clip -- a few thousand instructions -- on a wave with a quarter of its lanes alive, 136
+// times per set.  Here the cheap test and the clip are separate launches:
+//   nms_cand_kernel   one wave per tile: lane = row keeps the tile's candidates as a 64-bit word (columns arrive
+//                     by v_readlane), zeroes the tile's words of the matrix and appends its candidate pairs
+//                     (row, column) to the set's pool: one atomic per tile on the SET's counter (one counter for
+//                     the whole call made 13 k same-address atomics of them: 10 ns each, 136 us);
+//   nms_pairs_kernel  one lane per pooled pair, full waves: clip, compare with the threshold, OR the bit into the
+//                     matrix (bits are independent, so the order of the pool does not matter: same matrix).
+// A tile whose pairs do not fit what is left of its set's pool is put on the set's list of unpooled tiles instead,
+// and the pair kernel walks those tiles pair by pair; the pool holds 32 candidates per box.
+constexpr uint32_t kNmsPoolHole = 0xffffffffu;  // row = col = 65535: not a pair (col > row in every real entry)
+constexpr int kNmsPoolPerBox = 32;
+constexpr int kNmsPairWgs = 8;  // workgroups of the pair kernel per set
+constexpr int kNmsCtrStride = 64;  // ints between two counters (256 bytes)
+
+struct NmsPool {
+  float4* xyr;       // [sets][cap]: centre x, y and circumscribed radius of every box (BoxPre's, packed: the candidate
+                     // pass reads 16 contiguous bytes per box instead of three floats out of a 64-byte record)
+  uint32_t* pairs;   // [sets][per_set]: row << 16 | col
+  int* counts;       // [sets] pairs appended, then [sets] unpooled tiles, one counter per kNmsCtrStride ints (counters of
+                     // different sets in one cache line serialise in one L2 atomic unit): zeroed before every call
+  uint32_t* tiles;   // [sets][cb * cb]: row block << 16 | column block of the unpooled tiles
+  int per_set;
+};
+
+static inline int nms_pool_per_set(int cap) {
+  return (int)std::min<int64_t>(std::max<int64_t>((int64_t)cap * kNmsPoolPerBox, 4096), (int64_t)1 << 24);
+}
+
+static __global__ __launch_bounds__(64) void nms_cand_kernel(const int* __restrict__ counts, int sets, int cap,
+                                                             int cb_cap, unsigned long long* __restrict__ mask,
+                                                             NmsPool pl) {
+  const int set = blockIdx.z;
+  const int n = min(counts[set], cap);
+  const int row_blk = blockIdx.y, col_blk = blockIdx.x;
+  if (col_blk < row_blk) return;
+  if (row_blk * 64 >= n || col_blk * 64 >= n) return;
+  const int lane = threadIdx.x;
+  const float4* ps = pl.xyr + (int64_t)set * cap;
+  const int row = row_blk * 64 + lane, col0 = col_blk * 64;
+  const int col_size = min(n - col0, 64);
+  const bool live = row < n;
+  const float4 me = live ? ps[row] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float mx = me.x, my = me.y, mr = me.z;
+  // lane i holds column i's centre and radius; the walk reads them with v_readlane (no branch, no memory access
+  // inside the loop): all 64 columns are tested, the columns past the set's last box and, in a
+  // diagonal tile, the columns up to the row itself are masked off afterwards
+  const float4 cc = lane < col_size ? ps[col0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ccx = __float_as_int(cc.x), ccy = __float_as_int(cc.y), ccr = __float_as_int(cc.z);
+  unsigned long long bits = 0ull;
+#pragma unroll 1
+  for (int g8 = 0; g8 < 64; g8 += 8) {  // eight columns per trip: their 24 scalars fit the SGPR file without spills
+    unsigned byte = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float cx = __int_as_float(__builtin_amdgcn_readlane(ccx, g8 + j));
+      const float cy = __int_as_float(__builtin_amdgcn_readlane(ccy, g8 + j));
+      const float cr = __int_as_float(__builtin_amdgcn_readlane(ccr, g8 + j));
+      const float dx = mx - cx, dy = my - cy, r = mr + cr + 0.25f;
+      const bool cand = !(dx * dx + dy * dy > r * r);  // the same test box_overlap starts with
+      byte |= cand ? 1u << j : 0u;
+    }
+    bits |= (unsigned long long)byte << g8;
+  }
+  if (col_size < 64) bits &= (1ull << col_size) - 1ull;
+  if (row_blk == col_blk) bits &= lane < 63 ? ~0ull << (lane + 1) : 0ull;
+  if (!live) bits = 0ull;
+  if (live && row_blk == col_blk) {  // the diagonal tile clears its rows of the matrix (contiguous words per lane)
+    unsigned long long* mrow = mask + ((int64_t)set * cap + row) * cb_cap;
+    for (int k = 0; k < cb_cap; ++k) mrow[k] = 0ull;
+  }
+  const int mine = __popcll(bits);
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  const int total = __shfl(incl, 63, 64);
+  if (total == 0) return;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(&pl.counts[set * kNmsCtrStride], total);
+  base = __shfl(base, 0, 64);
+  uint32_t* pool = pl.pairs + (int64_t)set * pl.per_set;
+  int pos = base + incl - mine;
+  if (base + total <= pl.per_set) {
+    const uint32_t head = (uint32_t)row << 16;
+    while (bits) {
+      const int i = __builtin_ctzll(bits);
+      bits &= bits - 1;
+      pool[pos++] = head | (uint32_t)(col0 + i);
+    }
+  } else {
+    // what was reserved inside the pool stays without pairs: mark it (the pair kernel skips holes) and hand the
+    // tile over as a whole
+    for (int k = 0; k < mine; ++k, ++pos)
+      if (pos < pl.per_set) pool[pos] = kNmsPoolHole;
+    if (lane == 0) {
+      const int k = atomicAdd(&pl.counts[(sets + set) * kNmsCtrStride], 1);
+      pl.tiles[(int64_t)set * cb_cap * cb_cap + k] = ((uint32_t)row_blk << 16) | (uint32_t)col_blk;
+    }
+  }
+}
+
+// grid (kNmsPairWgs, sets)
+static __global__ __launch_bounds__(256) void nms_pairs_kernel(const BoxPre* __restrict__ pre,
+                                                               const int* __restrict__ counts, int sets, int cap,
+                                                               int cb_cap, float thresh,
+                                                               unsigned long long* __restrict__ mask, NmsPool pl) {
+  __shared__ float poly_s[4 * kPolyWaveFloats];
+  float* st = poly_s + wave_id() * kPolyWaveFloats + lane_id();
+  const int set = blockIdx.y;
+  const BoxPre* ps = pre + (int64_t)set * cap;
+  unsigned long long* ms = mask + (int64_t)set * cap * cb_cap;
+  const int total = min(pl.counts[set * kNmsCtrStride], pl.per_set);
+  const uint32_t* pool = pl.pairs + (int64_t)set * pl.per_set;
+  const int stride = gridDim.x * 256, first = blockIdx.x * 256 + threadIdx.x;
+  for (int p = first; p < total; p += stride) {
+    const uint32_t e = pool[p];
+    if (e == kNmsPoolHole) continue;
+    const int row = (int)(e >> 16), col = (int)(e & 0xffffu);
+    const BoxPre a = ps[row], b = ps[col];
+    if (iou_bev(a, b, st) > thresh) atomicOr(&ms[(int64_t)row * cb_cap + (col >> 6)], 1ull << (col & 63));
+  }
+  // tiles that did not fit the pool: every pair of the tile through the same circle test, then the clip
+  const int ntiles = pl.counts[(sets + set) * kNmsCtrStride];
+  if (ntiles == 0) return;
+  const int n = min(counts[set], cap);
+  for (int t = 0; t < ntiles; ++t) {
+    const uint32_t tile = pl.tiles[(int64_t)set * cb_cap * cb_cap + t];
+    const int r0 = (int)(tile >> 16) * 64, c0 = (int)(tile & 0xffffu) * 64;
+    for (int idx = first; idx < 4096; idx += stride) {
+      const int row = r0 + (idx >> 6), col = c0 + (idx & 63);
+      if (row >= n || col >= n || col <= row) continue;
+      const BoxPre a = ps[row], b = ps[col];
+      const float dx = a.cx - b.cx, dy = a.cy - b.cy, r = a.rad + b.rad + 0.25f;
+      if (dx * dx + dy * dy > r * r) continue;
+      if (iou_bev(a, b, st) > thresh) atomicOr(&ms[(int64_t)row * cb_cap + (col >> 6)], 1ull << (col & 63));
+    }
+  }
+}
+
+// The rotated-box bit matrix of `sets` sets (counts on the device): candidate pass, then the pooled pairs.
+static inline void nms_enqueue_mask_pooled(const BoxPre* pre, const int* counts, int sets, int cap, int cb, float thresh,
+                                           unsigned long long* mask, const NmsPool& pl, hipStream_t s) {
+  nms_cand_kernel<<<dim3(cb, cb, sets), 64, 0, s>>>(counts, sets, cap, cb, mask, pl);
+  nms_pairs_kernel<<<dim3(kNmsPairWgs, sets), 256, 0, s>>>(pre, counts, sets, cap, cb, thresh, mask, pl);
 }
 
 // One workgroup per set.  keep [set][cap] receives kept indices in order; num_keep[set] their number.

@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256) void cp_nms_boxes_kernel(const float* __restri
                                                            const uint32_t* __restrict__ sidx,
                                                            const int* __restrict__ counts, int hw,
                                                            int dims, int cap,
-                                                           float* __restrict__ nms_boxes, BoxPre* __restrict__ pre) {
+                                                           float* __restrict__ nms_boxes, BoxPre* __restrict__ pre,
+                                                           float4* __restrict__ xyr) {
   const int t = blockIdx.y;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = min(counts[t], cap);
@@ -251,7 +252,9 @@ __global__ __launch_bounds__(256) void cp_nms_boxes_kernel(const float* __restri
   o[5] = bx[5];
   o[6] = (float)(-(double)bx[dims - 1] - 3.141592653589793 / 2);
   const float nb[7] = {o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
-  pre[(int64_t)t * cap + r] = box_prepare(nb);  // what every tile of the suppression matrix needs of this box
+  const BoxPre bp = box_prepare(nb);  // what the suppression matrix needs of this box
+  pre[(int64_t)t * cap + r] = bp;
+  xyr[(int64_t)t * cap + r] = make_float4(bp.cx, bp.cy, bp.rad, 0.f);
 }
 
 // One workgroup: concatenate tasks in order (postprocess.cu:247-278).
@@ -325,6 +328,7 @@ struct CpWorkspace {
   uint32_t *keys_a, *vals_a, *keys_b, *vals_b;
   unsigned long long* mask;
   BoxPre* pre;
+  NmsPool pool;
   int32_t *keep, *nkeep;
   size_t bytes;
 };
@@ -339,6 +343,7 @@ static CpWorkspace cp_carve(void* base, int tasks, int hw, int pre_max, const Ra
   w.scores = c.take<float>(th);
   w.labels = c.take<int>(th);
   w.counts = c.take<int>((size_t)tasks);
+  w.pool.counts = c.take<int>((size_t)tasks * 2 * kNmsCtrStride);  // directly behind `counts`: one memset clears both
   w.keys_a = c.take<uint32_t>(th);
   w.vals_a = c.take<uint32_t>(th);
   w.keys_b = c.take<uint32_t>(th);
@@ -348,6 +353,10 @@ static CpWorkspace cp_carve(void* base, int tasks, int hw, int pre_max, const Ra
   w.nms_boxes = c.take<float>((size_t)tasks * cap * 7);
   w.mask = c.take<unsigned long long>((size_t)tasks * cap * cb);
   w.pre = c.take<BoxPre>((size_t)tasks * cap);
+  w.pool.xyr = c.take<float4>((size_t)tasks * cap);
+  w.pool.per_set = nms_pool_per_set(cap);
+  w.pool.pairs = c.take<uint32_t>((size_t)tasks * w.pool.per_set);
+  w.pool.tiles = c.take<uint32_t>((size_t)tasks * cb * cb);
   w.keep = c.take<int32_t>((size_t)tasks * cap);
   w.nkeep = c.take<int32_t>((size_t)tasks);
   w.bytes = c.off;
@@ -422,7 +431,7 @@ static int cp_postprocess_impl(
   for (int k = 0; k < 6; ++k) c.r[k] = post_center_range[k];
   c.score_threshold = score_threshold;
 
-  hipError_t e = hipMemsetAsync(w.counts, 0, sizeof(int) * sets, s);
+  hipError_t e = hipMemsetAsync(w.counts, 0, (size_t)((char*)(w.pool.counts + (size_t)sets * 2 * kNmsCtrStride) - (char*)w.counts), s);
   if (e != hipSuccess) return (int)e;
   dim3 dgrid((hw + 255) / 256, sets);
   cp_decode_kernel<<<dgrid, 256, 0, s>>>(h, c, w.boxes, w.scores, w.labels, w.keys_a, w.counts);
@@ -441,10 +450,8 @@ static int cp_postprocess_impl(
     sidx = where ? w.vals_b : w.vals_a;
   }
   dim3 bgrid((cap + 255) / 256, sets);
-  cp_nms_boxes_kernel<<<bgrid, 256, 0, s>>>(w.boxes, sidx, w.counts, hw, c.dims, cap, w.nms_boxes, w.pre);
-  dim3 mgrid(cb, cb, sets);
-  nms_mask_kernel<false><<<mgrid, 64, 0, s>>>(w.nms_boxes, w.counts, 0, cap, cb, nms_iou_threshold,
-                                              w.mask, w.pre);
+  cp_nms_boxes_kernel<<<bgrid, 256, 0, s>>>(w.boxes, sidx, w.counts, hw, c.dims, cap, w.nms_boxes, w.pre, w.pool.xyr);
+  nms_enqueue_mask_pooled(w.pre, w.counts, sets, cap, cb, nms_iou_threshold, w.mask, w.pool, s);
   {
     const size_t lds = nms_sweep_lds(cap);
     if (lds > 48 * 1024) {

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void ssd_nms_boxes_kernel(const float* __restr
                                                             const uint32_t* __restrict__ sidx,
                                                             const int* __restrict__ counts, int num_anchors,
                                                             int cap, float* __restrict__ nms_boxes,
-                                                            BoxPre* __restrict__ pre) {
+                                                            BoxPre* __restrict__ pre, float4* __restrict__ xyr) {
   const int frame = blockIdx.y;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = min(counts[frame], cap);
@@ -314,7 +314,9 @@ __global__ __launch_bounds__(256) void ssd_nms_boxes_kernel(const float* __restr
   o[5] = bx[5];
   o[6] = (-bx[6]) - 1.57079632679489661923f;
   const float nb[7] = {o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
-  pre[(int64_t)frame * cap + r] = box_prepare(nb);  // what every tile of the suppression matrix needs of this box
+  const BoxPre bp = box_prepare(nb);  // what the suppression matrix needs of this box
+  pre[(int64_t)frame * cap + r] = bp;
+  xyr[(int64_t)frame * cap + r] = make_float4(bp.cx, bp.cy, bp.rad, 0.f);
 }
 
 // grid (batch): the kept rows in NMS order; a frame without detections gets the reference's `_box_empty` row
@@ -369,6 +371,7 @@ struct SsdWorkspace {
   uint32_t *keys_a, *vals_a, *keys_b, *vals_b;
   unsigned long long* mask;
   BoxPre* pre;
+  NmsPool pool;
   int32_t *keep, *nkeep;
   size_t bytes;
 };
@@ -382,6 +385,7 @@ static SsdWorkspace ssd_carve(void* base, int batch, int64_t num_anchors, int nx
   const size_t cb = ((size_t)cap + 63) / 64;
   w.occ = c.take<int>((size_t)batch * ny * nx);
   w.counts = c.take<int>((size_t)batch);
+  w.pool.counts = c.take<int>((size_t)batch * 2 * kNmsCtrStride);  // inside the span the set-up memset clears
   w.boxes = c.take<float>(ba * 7);
   w.scores = c.take<float>(ba);
   w.labels = c.take<int>(ba);
@@ -394,6 +398,10 @@ static SsdWorkspace ssd_carve(void* base, int batch, int64_t num_anchors, int nx
   w.nms_boxes = c.take<float>((size_t)batch * cap * 7);
   w.mask = c.take<unsigned long long>((size_t)batch * cap * cb);
   w.pre = c.take<BoxPre>((size_t)batch * cap);
+  w.pool.xyr = c.take<float4>((size_t)batch * cap);
+  w.pool.per_set = nms_pool_per_set(cap);
+  w.pool.pairs = c.take<uint32_t>((size_t)batch * w.pool.per_set);
+  w.pool.tiles = c.take<uint32_t>((size_t)batch * cb * cb);
   w.keep = c.take<int32_t>((size_t)batch * cap);
   w.nkeep = c.take<int32_t>((size_t)batch);
   w.bytes = c.off;
@@ -481,9 +489,8 @@ extern "C" int pd3_ssd_postprocess(const float* head_map, int64_t batch_stride, 
     sidx = where ? w.vals_b : w.vals_a;
   }
   ssd_nms_boxes_kernel<<<dim3((cap + 255) / 256, batch), 256, 0, s>>>(w.boxes, sidx, w.counts, (int)a, cap,
-                                                                      w.nms_boxes, w.pre);
-  nms_mask_kernel<false><<<dim3(cb, cb, batch), 64, 0, s>>>(w.nms_boxes, w.counts, 0, cap, cb, nms_iou_threshold,
-                                                            w.mask, w.pre);
+                                                                      w.nms_boxes, w.pre, w.pool.xyr);
+  nms_enqueue_mask_pooled(w.pre, w.counts, batch, cap, cb, nms_iou_threshold, w.mask, w.pool, s);
   const size_t lds = nms_sweep_lds(cap);
   if (lds > 48 * 1024) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel),

@@ -148,6 +148,23 @@ def test_centerpoint_postprocess_large_cap(oracle, pre):
     np.testing.assert_array_equal(b.view(np.uint32), rb.view(np.uint32))
 
 
+def test_centerpoint_postprocess_crowded(oracle):
+    """Boxes 20 m long on the 0.8 m grid: every pair of the 1000 candidates per task passes the circle test, far more
+    than the pair pool of the rotated NMS holds (32 per box) -- its tiles fall back to the per-tile evaluation; 6 m
+    boxes fill the pool part of the way through the call (pooled and per-tile tiles side by side); 1.4 m boxes fit
+    it whole.  Keep lists equal the reference's in all three."""
+    for dim_bias, hm_bias in ((3.0, 6.0), (1.1, 6.0), (0.3, 6.0)):
+        tasks = synth.center_head_outputs(6, feat_h=64, feat_w=64, n_peaks=0)
+        for t in tasks:
+            t["hm"] += hm_bias
+            t["dim"] += dim_bias
+        (b, s, l), (rb, rs, rl), margins = _post(oracle, tasks, nms_pre_max_size=1000, nms_post_max_size=83)
+        assert b.shape == rb.shape, (b.shape, rb.shape, margins)
+        np.testing.assert_array_equal(l, rl)
+        np.testing.assert_array_equal(s.view(np.uint32), rs.view(np.uint32))
+        np.testing.assert_array_equal(b.view(np.uint32), rb.view(np.uint32))
+
+
 def test_centerpoint_postprocess_edges(oracle):
     # a task with no candidate -> the reference's fake row (zeros, -1, 0); small pre/post caps
     tasks = synth.center_head_outputs(3, feat_h=32, feat_w=48, n_peaks=20)
