@@ -47,58 +47,42 @@ struct CpCfg {
 
 __device__ __forceinline__ float exp_rn(float x) { return lm::expf(x); }  // glibc's bits (libm_exact.hpp)
 
-__global__ __launch_bounds__(256) void cp_decode_kernel(CpHeads h, CpCfg c, float* __restrict__ boxes,
-                                                        float* __restrict__ scores,
-                                                        int* __restrict__ labels,
-                                                        uint32_t* __restrict__ keys,
-                                                        int* __restrict__ counts) {
+// postprocess.cu:145-149  sigmoid, then max / argmax over the class axis (first maximum wins)
+__device__ __forceinline__ float cp_best_class(const CpHeads& h, const CpCfg& c, int t, int frame, int i, int& arg) {
+  const int64_t bs = h.batch_stride;
+  const float* hm = h.hm[t] + (int64_t)frame * (bs ? bs : (int64_t)h.ncls[t] * c.hw);
+  float best = 0.f;
+  arg = 0;
+  for (int k = 0; k < h.ncls[t]; ++k) {
+    const float s = 1.0f / (1.0f + exp_rn(-hm[(int64_t)k * c.hw + i]));
+    if (k == 0 || s > best) {
+      best = s;
+      arg = k;
+    }
+  }
+  return best;
+}
+
+// First pass over all cells: score, the mask of postprocess.cu:72-77 on the RAW reg / height values, the sort key
+// of the masked-in cells and their number per set.  Nothing else is written: a cell's box is only ever read if the
+// cell is among the nms_pre_max_size best of its set, and those are decoded by the kernel that lays out the NMS
+// boxes (cp_nms_boxes_kernel) -- a few hundred to a thousand cells per set instead of all 16 k (the box, three exp
+// and an atan2 each, and its 36-byte row were 90 MB of writes per 16 frames).
+__global__ __launch_bounds__(256) void cp_score_kernel(CpHeads h, CpCfg c, uint32_t* __restrict__ keys,
+                                                       int* __restrict__ counts) {
   const int set = blockIdx.y;  // frame * num_tasks + task
   const int t = set % c.num_tasks, frame = set / c.num_tasks;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int selected = 0;
   if (i < c.hw) {
-    // postprocess.cu:145-149  sigmoid, then max / argmax over the class axis (first maximum wins)
     const int64_t bs = h.batch_stride;
-    const float* hm = h.hm[t] + (int64_t)frame * (bs ? bs : (int64_t)h.ncls[t] * c.hw);
     const float* regp = h.reg[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
     const float* heip = h.height[t] + (int64_t)frame * (bs ? bs : (int64_t)c.hw);
-    const float* dimp = h.dim[t] + (int64_t)frame * (bs ? bs : (int64_t)3 * c.hw);
-    const float* velp = h.vel[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
-    const float* rotp = h.rot[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
-    float best = 0.f;
-    int arg = 0;
-    for (int k = 0; k < h.ncls[t]; ++k) {
-      const float s = 1.0f / (1.0f + exp_rn(-hm[(int64_t)k * c.hw + i]));
-      if (k == 0 || s > best) {
-        best = s;
-        arg = k;
-      }
-    }
-    // decode_kernel :41-70
-    const int xs = i % c.feat_w, ys = i / c.feat_w;
+    int arg;
+    const float best = cp_best_class(h, c, t, frame, i, arg);
     const float x = regp[i], y = regp[i + c.hw], z = heip[i];
-    // :72-77  mask on the RAW reg / height values
     const bool m = best > c.score_threshold && x <= c.r[3] && y <= c.r[4] && z <= c.r[5] &&
                    x >= c.r[0] && y >= c.r[1] && z >= c.r[2];
-    if (m) {  // only masked-in cells are ever read back (top-K / sort orders them first): nothing else is stored
-      float* bx = boxes + ((int64_t)set * c.hw + i) * c.dims;
-      bx[0] = (x + xs) * c.down_ratio * c.vx + c.pc_x;
-      bx[1] = (y + ys) * c.down_ratio * c.vy + c.pc_y;
-      bx[2] = z;
-      bx[3] = exp_rn(dimp[i]);  // :151 exp(dim)
-      bx[4] = exp_rn(dimp[i + c.hw]);
-      bx[5] = exp_rn(dimp[i + 2 * c.hw]);
-      const float ang = atan2_rn(rotp[i], rotp[i + c.hw]);
-      if (c.with_velocity) {
-        bx[6] = velp[i];
-        bx[7] = velp[i + c.hw];
-        bx[8] = ang;
-      } else {
-        bx[6] = ang;
-      }
-      scores[(int64_t)set * c.hw + i] = best;
-      labels[(int64_t)set * c.hw + i] = arg;
-    }
     uint32_t key = kKeyOut;
     if (m) {
       const uint32_t bits = __float_as_uint(best);
@@ -230,37 +214,64 @@ static inline size_t cp_topk_lds(int hw) {
   return (size_t)hw * 4 + (size_t)kTopkMaxK * 8 + 1024 * 4 + 8 * 4;
 }
 
-// iou3d_nms_kernel.cu:294-308 remap of the top-n boxes (sorted order) into NMS layout
-__global__ __launch_bounds__(256) void cp_nms_boxes_kernel(const float* __restrict__ boxes,
-                                                           const uint32_t* __restrict__ sidx,
-                                                           const int* __restrict__ counts, int hw,
-                                                           int dims, int cap,
-                                                           float* __restrict__ nms_boxes, BoxPre* __restrict__ pre,
-                                                           float4* __restrict__ xyr) {
-  const int t = blockIdx.y;
+// The nms_pre_max_size best cells of every set, in sorted order: decode_kernel :41-70 for the cell (the rows the
+// operator can return: box, score, class), and iou3d_nms_kernel.cu:294-308's remap of the box into NMS layout.
+__global__ __launch_bounds__(256) void cp_nms_boxes_kernel(CpHeads h, CpCfg c, const uint32_t* __restrict__ sidx,
+                                                           const int* __restrict__ counts, int cap,
+                                                           float* __restrict__ boxes, float* __restrict__ scores,
+                                                           int* __restrict__ labels, float* __restrict__ nms_boxes,
+                                                           BoxPre* __restrict__ pre, float4* __restrict__ xyr) {
+  const int set = blockIdx.y;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = min(counts[t], cap);
+  const int n = min(counts[set], cap);
   if (r >= n) return;
-  const uint32_t cell = sidx[(int64_t)t * hw + r];
-  const float* bx = boxes + ((int64_t)t * hw + cell) * dims;
-  float* o = nms_boxes + ((int64_t)t * cap + r) * 7;
+  const int t = set % c.num_tasks, frame = set / c.num_tasks;
+  const int i = (int)sidx[(int64_t)set * c.hw + r];
+  const int64_t bs = h.batch_stride;
+  const float* regp = h.reg[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
+  const float* heip = h.height[t] + (int64_t)frame * (bs ? bs : (int64_t)c.hw);
+  const float* dimp = h.dim[t] + (int64_t)frame * (bs ? bs : (int64_t)3 * c.hw);
+  const float* velp = h.vel[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
+  const float* rotp = h.rot[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
+  int arg;
+  const float best = cp_best_class(h, c, t, frame, i, arg);
+  const int xs = i % c.feat_w, ys = i / c.feat_w;
+  const float x = regp[i], y = regp[i + c.hw], z = heip[i];
+  float* bx = boxes + ((int64_t)set * cap + r) * c.dims;
+  bx[0] = (x + xs) * c.down_ratio * c.vx + c.pc_x;
+  bx[1] = (y + ys) * c.down_ratio * c.vy + c.pc_y;
+  bx[2] = z;
+  bx[3] = exp_rn(dimp[i]);  // :151 exp(dim)
+  bx[4] = exp_rn(dimp[i + c.hw]);
+  bx[5] = exp_rn(dimp[i + 2 * c.hw]);
+  const float ang = atan2_rn(rotp[i], rotp[i + c.hw]);
+  if (c.with_velocity) {
+    bx[6] = velp[i];
+    bx[7] = velp[i + c.hw];
+    bx[8] = ang;
+  } else {
+    bx[6] = ang;
+  }
+  scores[(int64_t)set * cap + r] = best;
+  labels[(int64_t)set * cap + r] = arg;
+  float* o = nms_boxes + ((int64_t)set * cap + r) * 7;
   o[0] = bx[0];
   o[1] = bx[1];
   o[2] = bx[2];
   o[3] = bx[4];
   o[4] = bx[3];
   o[5] = bx[5];
-  o[6] = (float)(-(double)bx[dims - 1] - 3.141592653589793 / 2);
+  o[6] = (float)(-(double)ang - 3.141592653589793 / 2);
   const float nb[7] = {o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
   const BoxPre bp = box_prepare(nb);  // what the suppression matrix needs of this box
-  pre[(int64_t)t * cap + r] = bp;
-  xyr[(int64_t)t * cap + r] = make_float4(bp.cx, bp.cy, bp.rad, 0.f);
+  pre[(int64_t)set * cap + r] = bp;
+  xyr[(int64_t)set * cap + r] = make_float4(bp.cx, bp.cy, bp.rad, 0.f);
 }
 
 // One workgroup: concatenate tasks in order (postprocess.cu:247-278).
 __global__ __launch_bounds__(256) void cp_output_kernel(
     const float* __restrict__ boxes, const float* __restrict__ scores,
-    const int* __restrict__ labels, const uint32_t* __restrict__ sidx,
+    const int* __restrict__ labels,
     const int* __restrict__ counts, const int32_t* __restrict__ keep,
     const int32_t* __restrict__ nkeep, CpHeads h, int num_tasks, int hw, int dims, int cap, int pre_max,
     int post_max, float* __restrict__ out_boxes, float* __restrict__ out_scores,
@@ -294,12 +305,11 @@ __global__ __launch_bounds__(256) void cp_output_kernel(
     // num_bboxes_for_nms = min(count, nms_pre_max_size) (postprocess.cu:212-216): none with a zero pre-NMS cap
     const int rows = pre_max > 0 ? min(nkeep[t], post_max) : 0;
     for (int r = threadIdx.x; r < rows; r += blockDim.x) {
-      const int pos = keep[(int64_t)t * cap + r];          // index into the sorted order
-      const uint32_t cell = sidx[(int64_t)t * hw + pos];   // selected_score_idx[sorted_index[keep]]
-      const float* bx = boxes + ((int64_t)t * hw + cell) * dims;
+      const int pos = keep[(int64_t)t * cap + r];  // index into the sorted order = row of the decoded candidates
+      const float* bx = boxes + ((int64_t)t * cap + pos) * dims;
       for (int k = 0; k < dims; ++k) out_boxes[(int64_t)(offset + r) * dims + k] = bx[k];
-      const float sc = scores[(int64_t)t * hw + cell];
-      const int lb = labels[(int64_t)t * hw + cell] + h.label_offset[task];
+      const float sc = scores[(int64_t)t * cap + pos];
+      const int lb = labels[(int64_t)t * cap + pos] + h.label_offset[task];
       out_scores[offset + r] = sc;
       out_labels[offset + r] = (int64_t)lb;
       if (rec && offset + r < max_per_img) {
@@ -339,9 +349,9 @@ static CpWorkspace cp_carve(void* base, int tasks, int hw, int pre_max, const Ra
   const size_t th = (size_t)tasks * hw;
   const int cap = std::max(pre_max, 1);
   const size_t cb = ((size_t)cap + 63) / 64;
-  w.boxes = c.take<float>(th * 9);
-  w.scores = c.take<float>(th);
-  w.labels = c.take<int>(th);
+  w.boxes = c.take<float>((size_t)tasks * cap * 9);  // the decoded candidates: [set][rank]
+  w.scores = c.take<float>((size_t)tasks * cap);
+  w.labels = c.take<int>((size_t)tasks * cap);
   w.counts = c.take<int>((size_t)tasks);
   w.pool.counts = c.take<int>((size_t)tasks * 2 * kNmsCtrStride);  // directly behind `counts`: one memset clears both
   w.keys_a = c.take<uint32_t>(th);
@@ -434,7 +444,7 @@ static int cp_postprocess_impl(
   hipError_t e = hipMemsetAsync(w.counts, 0, (size_t)((char*)(w.pool.counts + (size_t)sets * 2 * kNmsCtrStride) - (char*)w.counts), s);
   if (e != hipSuccess) return (int)e;
   dim3 dgrid((hw + 255) / 256, sets);
-  cp_decode_kernel<<<dgrid, 256, 0, s>>>(h, c, w.boxes, w.scores, w.labels, w.keys_a, w.counts);
+  cp_score_kernel<<<dgrid, 256, 0, s>>>(h, c, w.keys_a, w.counts);
   const uint32_t* sidx;
   if (selection < 0 || selection > 1) return PD3_EINVAL;
   if (hw <= kTopkMaxHw && hw % 2 == 0 && cap <= kTopkMaxK && selection == 0) {
@@ -450,7 +460,8 @@ static int cp_postprocess_impl(
     sidx = where ? w.vals_b : w.vals_a;
   }
   dim3 bgrid((cap + 255) / 256, sets);
-  cp_nms_boxes_kernel<<<bgrid, 256, 0, s>>>(w.boxes, sidx, w.counts, hw, c.dims, cap, w.nms_boxes, w.pre, w.pool.xyr);
+  cp_nms_boxes_kernel<<<bgrid, 256, 0, s>>>(h, c, sidx, w.counts, cap, w.boxes, w.scores, w.labels, w.nms_boxes, w.pre,
+                                            w.pool.xyr);
   nms_enqueue_mask_pooled(w.pre, w.counts, sets, cap, cb, nms_iou_threshold, w.mask, w.pool, s);
   {
     const size_t lds = nms_sweep_lds(cap);
@@ -461,7 +472,7 @@ static int cp_postprocess_impl(
     }
     nms_sweep_kernel<<<sets, 256, lds, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);
   }
-  cp_output_kernel<<<batch, 256, 0, s>>>(w.boxes, w.scores, w.labels, sidx, w.counts, w.keep, w.nkeep, h,
+  cp_output_kernel<<<batch, 256, 0, s>>>(w.boxes, w.scores, w.labels, w.counts, w.keep, w.nkeep, h,
                                      num_tasks, hw, c.dims, cap, nms_pre_max_size, nms_post_max_size, out_bboxes,
                                      out_scores, out_labels, out_count, out_records, max_per_img);
   return launch_status();

@@ -20,7 +20,7 @@ OPS = {
                       "gather_voxels", "voxel_meta", "EpiVoxelStart", "LoadNonNegative"),
     "pillar_feature_net": ("pfn_",),
     "pointpillars_scatter": ("fill_i32", "inverse_map", "canvas_write"),
-    "centerpoint_postprocess": ("cp_decode", "cp_topk", "cp_nms_boxes", "cp_output", "nms_mask", "nms_cand",
+    "centerpoint_postprocess": ("cp_decode", "cp_score", "cp_topk", "cp_nms_boxes", "cp_output", "nms_mask", "nms_cand",
                                 "nms_pairs", "nms_sweep"),
 }
 # the radix sort / scan kernels are shared: with the tiled voxelizer active they belong to the postprocess
