@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void cp_score_kernel(CpHeads h, CpCfg c, uint3
 // SELECT (10-bit LDS histograms) finds the exact cut-off key and how many cells with that key still fit; the
 // selected cells are compacted in cell order and sorted as (key, cell) pairs by a bitonic network -- the same
 // total order a stable key sort gives.  Writes sidx[set][0 .. K).
-constexpr int kTopkThreads = 256;
+constexpr int kTopkThreads = 1024;  // one workgroup per set and nothing else on its CU: the kernel is a chain of
+                                    // dependent passes, so its time is its latency -- 16 waves shorten every pass
 constexpr int kTopkMaxHw = 16384;   // keys held in LDS
 constexpr int kTopkMaxK = 1024;     // bitonic list
 
@@ -119,13 +120,14 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(const uint32_t* _
   uint32_t* ks = reinterpret_cast<uint32_t*>(topk_smem);                       // [hw]
   unsigned long long* list = reinterpret_cast<unsigned long long*>(ks + hw);   // [kTopkMaxK]
   int* hist = reinterpret_cast<int*>(list + kTopkMaxK);                        // [1024]
-  int* scr = hist + 1024;                                                      // [8]
+  int* scr = hist + 1024;                                                      // [32]: scan scratch, [30], [31] broadcast
   const int set = blockIdx.x;
   const int count = counts[set];
   const int K = min(count, cap);
   if (K <= 0) return;
   const uint32_t* kg = keys + (int64_t)set * hw;
-  for (int i = threadIdx.x; i < hw; i += kTopkThreads) ks[i] = kg[i];
+  for (int i = threadIdx.x * 4; i < hw; i += kTopkThreads * 4)  // hw % 4 == 0 (dispatch): 16-byte loads, all in flight
+    *reinterpret_cast<uint4*>(ks + i) = *reinterpret_cast<const uint4*>(kg + i);
   for (int i = threadIdx.x; i < kTopkMaxK; i += kTopkThreads) list[i] = ~0ull;
   __syncthreads();
   // ---- cut-off key kc and the number r of cells with key == kc that are taken (0: take every key < kc) -----
@@ -143,24 +145,29 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(const uint32_t* _
         if (pass == 0 || (k >> (shift + 10)) == prefix) atomicAdd(&hist[(k >> shift) & 1023u], 1);
       }
       __syncthreads();
-      // thread t owns bins 4t .. 4t+3: exclusive prefix over bins, find the bin holding rank `need`
-      const int b0 = threadIdx.x * 4;
-      const int h0 = hist[b0], h1 = hist[b0 + 1], h2 = hist[b0 + 2], h3 = hist[b0 + 3];
-      int total;
-      const int base = block_exclusive_scan<kTopkThreads>(h0 + h1 + h2 + h3, scr, total);
-      int cum = base;
-      const int hh[4] = {h0, h1, h2, h3};
+      // thread t owns bins kBpt t .. kBpt t + kBpt - 1: exclusive prefix over bins, find the bin holding rank `need`
+      constexpr int kBpt = 1024 / kTopkThreads;
+      const int b0 = threadIdx.x * kBpt;
+      int hh[kBpt], hsum = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < kBpt; ++j) {
+        hh[j] = hist[b0 + j];
+        hsum += hh[j];
+      }
+      int total;
+      const int base = block_exclusive_scan<kTopkThreads>(hsum, scr, total);
+      int cum = base;
+#pragma unroll
+      for (int j = 0; j < kBpt; ++j) {
         if (need > cum && need <= cum + hh[j]) {  // exactly one (thread, j) satisfies this
-          scr[6] = b0 + j;
-          scr[7] = need - cum;
+          scr[30] = b0 + j;
+          scr[31] = need - cum;
         }
         cum += hh[j];
       }
       __syncthreads();
-      prefix = (prefix << 10) | (uint32_t)scr[6];
-      need = scr[7];
+      prefix = (prefix << 10) | (uint32_t)scr[30];
+      need = scr[31];
       __syncthreads();
     }
     kc = prefix;
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(const uint32_t* _
 }
 
 static inline size_t cp_topk_lds(int hw) {
-  return (size_t)hw * 4 + (size_t)kTopkMaxK * 8 + 1024 * 4 + 8 * 4;
+  return (size_t)hw * 4 + (size_t)kTopkMaxK * 8 + 1024 * 4 + 32 * 4;
 }
 
 // The nms_pre_max_size best cells of every set, in sorted order: decode_kernel :41-70 for the cell (the rows the
@@ -447,7 +454,7 @@ static int cp_postprocess_impl(
   cp_score_kernel<<<dgrid, 256, 0, s>>>(h, c, w.keys_a, w.counts);
   const uint32_t* sidx;
   if (selection < 0 || selection > 1) return PD3_EINVAL;
-  if (hw <= kTopkMaxHw && hw % 2 == 0 && cap <= kTopkMaxK && selection == 0) {
+  if (hw <= kTopkMaxHw && hw % 4 == 0 && cap <= kTopkMaxK && selection == 0) {
     const size_t lds = cp_topk_lds(hw);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(cp_topk_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp_topk_lds(kTopkMaxHw));
