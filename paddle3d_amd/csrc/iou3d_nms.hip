@@ -53,7 +53,7 @@ static int run_nms(const float* boxes, int n, float thresh, int32_t* keep, int32
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
     }
-    nms_sweep_kernel<<<1, 256, lds, s>>>(mask, nullptr, n, n, cb, keep, num_to_keep);
+    nms_sweep_kernel<<<1, kNmsSweepThreads, lds, s>>>(mask, nullptr, n, n, cb, keep, num_to_keep);
   }
   return launch_status();
 }

@@ -264,10 +264,11 @@ static inline void nms_enqueue_mask_pooled(const BoxPre* pre, const int* counts,
 // The greedy sweep is inherently serial over the boxes; what can be removed is the memory latency: for
 // sets of up to kNmsLdsBoxes boxes the needed half of the bit matrix is copied into LDS by all 256 threads
 // first (one bulk round trip), then wave 0 sweeps 64 boxes per step entirely out of LDS.
+constexpr int kNmsSweepThreads = 1024;  // all of them copy the bit matrix (one bulk round trip), wave 0 then sweeps
 constexpr int kNmsLdsBoxes = 1024;
 constexpr int kNmsLdsWords = kNmsLdsBoxes / 64;
 
-static __global__ __launch_bounds__(256) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
+static __global__ __launch_bounds__(kNmsSweepThreads) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
                                                                const int* __restrict__ counts, int n_fixed,
                                                                int cap, int cb_cap,
                                                                int32_t* __restrict__ keep,

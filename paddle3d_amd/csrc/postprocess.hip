@@ -112,6 +112,8 @@ constexpr int kTopkThreads = 1024;  // one workgroup per set and nothing else on
                                     // dependent passes, so its time is its latency -- 16 waves shorten every pass
 constexpr int kTopkMaxHw = 16384;   // keys held in LDS
 constexpr int kTopkMaxK = 1024;     // bitonic list
+constexpr int kTopkCopies = 8;      // histogram replicas (lane & 7): scores crowd into a handful of exponent bins, and
+                                    // LDS atomics of one wave on one address run one lane at a time
 
 __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(const uint32_t* __restrict__ keys,
                                                                const int* __restrict__ counts, int hw,
@@ -119,8 +121,8 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(const uint32_t* _
   extern __shared__ __attribute__((aligned(16))) unsigned char topk_smem[];
   uint32_t* ks = reinterpret_cast<uint32_t*>(topk_smem);                       // [hw]
   unsigned long long* list = reinterpret_cast<unsigned long long*>(ks + hw);   // [kTopkMaxK]
-  int* hist = reinterpret_cast<int*>(list + kTopkMaxK);                        // [1024]
-  int* scr = hist + 1024;                                                      // [32]: scan scratch, [30], [31] broadcast
+  int* hist = reinterpret_cast<int*>(list + kTopkMaxK);                        // [kTopkCopies][1024]
+  int* scr = hist + kTopkCopies * 1024;                                                      // [32]: scan scratch, [30], [31] broadcast
   const int set = blockIdx.x;
   const int count = counts[set];
   const int K = min(count, cap);
@@ -138,11 +140,12 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(const uint32_t* _
     int need = K;         // rank of the cut-off inside the still-undecided set (1-based)
     for (int pass = 0; pass < 3; ++pass) {
       const int shift = 20 - 10 * pass;
-      for (int i = threadIdx.x; i < 1024; i += kTopkThreads) hist[i] = 0;
+      for (int i = threadIdx.x; i < kTopkCopies * 1024; i += kTopkThreads) hist[i] = 0;
       __syncthreads();
       for (int i = threadIdx.x; i < hw; i += kTopkThreads) {
         const uint32_t k = ks[i];
-        if (pass == 0 || (k >> (shift + 10)) == prefix) atomicAdd(&hist[(k >> shift) & 1023u], 1);
+        if (pass == 0 || (k >> (shift + 10)) == prefix)
+          atomicAdd(&hist[(threadIdx.x & (kTopkCopies - 1)) * 1024 + ((k >> shift) & 1023u)], 1);
       }
       __syncthreads();
       // thread t owns bins kBpt t .. kBpt t + kBpt - 1: exclusive prefix over bins, find the bin holding rank `need`
@@ -151,7 +154,9 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(const uint32_t* _
       int hh[kBpt], hsum = 0;
 #pragma unroll
       for (int j = 0; j < kBpt; ++j) {
-        hh[j] = hist[b0 + j];
+        hh[j] = 0;
+#pragma unroll
+        for (int c = 0; c < kTopkCopies; ++c) hh[j] += hist[c * 1024 + b0 + j];
         hsum += hh[j];
       }
       int total;
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(const uint32_t* _
 }
 
 static inline size_t cp_topk_lds(int hw) {
-  return (size_t)hw * 4 + (size_t)kTopkMaxK * 8 + 1024 * 4 + 32 * 4;
+  return (size_t)hw * 4 + (size_t)kTopkMaxK * 8 + (size_t)kTopkCopies * 1024 * 4 + 32 * 4;
 }
 
 // The nms_pre_max_size best cells of every set, in sorted order: decode_kernel :41-70 for the cell (the rows the
@@ -477,7 +482,7 @@ static int cp_postprocess_impl(
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
     }
-    nms_sweep_kernel<<<sets, 256, lds, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);
+    nms_sweep_kernel<<<sets, kNmsSweepThreads, lds, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);
   }
   cp_output_kernel<<<batch, 256, 0, s>>>(w.boxes, w.scores, w.labels, w.counts, w.keep, w.nkeep, h,
                                      num_tasks, hw, c.dims, cap, nms_pre_max_size, nms_post_max_size, out_bboxes,

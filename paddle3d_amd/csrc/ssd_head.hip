@@ -497,7 +497,7 @@ extern "C" int pd3_ssd_postprocess(const float* head_map, int64_t batch_stride, 
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  nms_sweep_kernel<<<batch, 256, lds, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);
+  nms_sweep_kernel<<<batch, kNmsSweepThreads, lds, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);
   ssd_output_kernel<<<batch, 256, 0, s>>>(w.boxes, w.scores, w.labels, sidx, w.counts, w.keep, w.nkeep, (int)a, cap,
                                           nms_pre_max_size, nms_post_max_size, out_boxes, out_scores, out_labels,
                                           out_count);
