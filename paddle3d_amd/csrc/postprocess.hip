@@ -5,14 +5,17 @@
 // The reference runs ~20 Paddle/CUDA launches and two blocking host syncs PER TASK (masked_select's
 // numel, the NMS mask copy + host sweep).  Here grid.y / grid.z indexes the task and every count stays
 // on the device:
-//   1. decode_kernel     sigmoid->max/argmax, exp(dim), box decode, range/score mask, sort key
-//   2. stable radix sort  key = 0x3F800000 - bits(score) for masked-in cells (descending score, ties in
-//                         cell order = masked_select order + stable argsort), 0x3FFFFFFF otherwise
-//   3. nms_boxes_kernel   top min(selected, nms_pre_max_size) boxes remapped (dx<->dy, -rot - pi/2)
-//   4. nms_mask_kernel + nms_sweep_kernel (nms_kernels.hpp), counts read on the device
-//   5. output_kernel      concatenates the tasks' kept rows (or the reference's fake row) in task order
+//   1. cp_score_kernel   sigmoid->max/argmax, range/score mask on the raw reg / height values, sort key (all cells)
+//   2. top-K selection    key = 0x3F800000 - bits(score) for masked-in cells (descending score, ties in
+//                         cell order = masked_select order + stable argsort), 0x3FFFFFFF otherwise; cp_topk_kernel
+//                         (radix select + ordered compaction + bitonic sort of <= 1024 pairs) or, with selection = 1
+//                         / maps beyond 16 k cells, a full stable radix sort of all keys -- identical results
+//   3. cp_nms_boxes_kernel  the top min(selected, nms_pre_max_size) cells: box decode (exp(dim), atan2), score, class,
+//                         and the box remapped for the NMS (dx<->dy, -rot - pi/2) with its per-box records
+//   4. nms_cand_kernel + nms_pairs_kernel + nms_sweep_kernel (nms_kernels.hpp), counts read on the device
+//   5. cp_output_kernel   concatenates the tasks' kept rows (or the reference's fake row) in task order
 // Work is tiny (4.6 MB read per nuScenes frame); the op is launch-latency bound, which is why the
-// launch count (15 + 5) and the absence of syncs are what matter.
+// launch count (8 for all tasks and frames of a batch) and the absence of syncs are what matter.
 #include "../../include/paddle3d_amd.h"
 #include "common.hpp"
 #include "nms_kernels.hpp"

@@ -17,7 +17,7 @@
 //                                selection = 1 a full stable radix sort of all keys -- identical results
 //   5. ssd_nms_boxes_kernel      top min(kept, nms_pre_max_size) boxes in the NMS kernel's layout
 //                                (x, y, z, l, w, h, -theta - pi/2)
-//   6. nms_mask_kernel + nms_sweep_kernel (nms_kernels.hpp)
+//   6. nms_cand_kernel + nms_pairs_kernel + nms_sweep_kernel (nms_kernels.hpp)
 //   7. ssd_output_kernel         the kept rows, object centre -> bottom centre again (both roundings kept)
 // The head maps are read where the 1x1 convolutions wrote them (NCHW, channel = anchor * width + component): the
 // reference's transpose + reshape to [B, A, width] is index arithmetic here.
