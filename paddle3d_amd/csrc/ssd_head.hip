@@ -211,10 +211,21 @@ __global__ __launch_bounds__(kSsdTopkThreads) void ssd_topk_kernel(const uint32_
       const int shift = 20 - 10 * pass;
       hist[t] = 0;
       __syncthreads();
-#pragma unroll 8
-      for (int i = t; i < n; i += kSsdTopkThreads) {
-        const uint32_t k = kg[i];
+      auto tally = [&](uint32_t k) {
         if (k != kSsdKeyOut && (pass == 0 || (k >> (shift + 10)) == prefix)) atomicAdd(&hist[(k >> shift) & 1023u], 1);
+      };
+      if ((n & 3) == 0) {  // frames start 16-byte aligned then: four keys per load, four loads in flight
+#pragma unroll 4
+        for (int i = t * 4; i < n; i += kSsdTopkThreads * 4) {
+          const uint4 kv = *reinterpret_cast<const uint4*>(kg + i);
+          tally(kv.x);
+          tally(kv.y);
+          tally(kv.z);
+          tally(kv.w);
+        }
+      } else {
+#pragma unroll 8
+        for (int i = t; i < n; i += kSsdTopkThreads) tally(kg[i]);
       }
       __syncthreads();
       const int h = hist[t];
@@ -261,16 +272,25 @@ __global__ __launch_bounds__(kSsdTopkThreads) void ssd_topk_kernel(const uint32_
     tot_less += wless[w];
   }
   const unsigned long long below = (1ull << lane) - 1ull;
-  for (int ib = i0; ib < i1; ib += kWave) {  // uniform trip count per wave: the ballots see the whole wave
-    const int i = ib + lane;
-    const uint32_t k = i < i1 ? kg[i] : kSsdKeyOut;
-    const bool isl = k < kc, ise = k == kc && kc != kSsdKeyOut;
-    const unsigned long long bl = __ballot(isl), be = __ballot(ise);
-    if (isl) list[pos_less + __popcll(bl & below)] = ((unsigned long long)k << 32) | (uint32_t)i;
-    const int slot = pos_eq + __popcll(be & below);
-    if (ise && slot < r) list[tot_less + slot] = ((unsigned long long)k << 32) | (uint32_t)i;
-    pos_less += __popcll(bl);
-    pos_eq += __popcll(be);
+  for (int ib = i0; ib < i1; ib += 4 * kWave) {  // uniform trip count per wave: the ballots see the whole wave
+    uint32_t kq[4];  // four keys per lane in flight, then their four ordered appends
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = ib + q * kWave + lane;
+      kq[q] = i < i1 ? kg[i] : kSsdKeyOut;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = ib + q * kWave + lane;
+      const uint32_t k = kq[q];
+      const bool isl = k < kc, ise = k == kc && kc != kSsdKeyOut;
+      const unsigned long long bl = __ballot(isl), be = __ballot(ise);
+      if (isl) list[pos_less + __popcll(bl & below)] = ((unsigned long long)k << 32) | (uint32_t)i;
+      const int slot = pos_eq + __popcll(be & below);
+      if (ise && slot < r) list[tot_less + slot] = ((unsigned long long)k << 32) | (uint32_t)i;
+      pos_less += __popcll(bl);
+      pos_eq += __popcll(be);
+    }
   }
   __syncthreads();
   int n2 = 64;
