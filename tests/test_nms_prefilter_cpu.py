@@ -38,3 +38,29 @@ def test_pairs_outside_the_circle_test_have_exactly_zero_overlap(seed):
         assert ov.shape == (n, n)
         assert np.all(ov[skipped] == 0.0), (kind, float(ov[skipped].max()))
         assert (ov[~skipped] > 0).any()
+
+
+def test_fixed_bubble_network_equals_the_reference_sort():
+    """box_overlap sorts up to eight vertices with a fixed eight-element bubble network over +inf-padded angles
+    (csrc/iou3d_geom.hpp); the reference bubble-sorts the first `cnt` entries (iou3d_cpu.cpp:201-210).  Same compare
+    (a[i] > a[i+1]), same order of passes: the permutation must be identical, ties and all."""
+    rng = np.random.default_rng(7)
+    for _ in range(3000):
+        cnt = int(rng.integers(1, 9))
+        ang = rng.choice(np.round(rng.uniform(-3.2, 3.2, 5), 1), cnt).astype(np.float32)  # few distinct values: ties
+        # reference: bubble sort of the first cnt entries, carrying the original index
+        ra, ri = list(ang), list(range(cnt))
+        for j in range(cnt - 1):
+            for i in range(cnt - j - 1):
+                if ra[i] > ra[i + 1]:
+                    ra[i], ra[i + 1] = ra[i + 1], ra[i]
+                    ri[i], ri[i + 1] = ri[i + 1], ri[i]
+        # kernel: eight slots, pads = +inf
+        ka = list(ang) + [np.float32(np.inf)] * (8 - cnt)
+        ki = list(range(cnt)) + [-1] * (8 - cnt)
+        for j in range(7):
+            for i in range(7 - j):
+                if ka[i] > ka[i + 1]:
+                    ka[i], ka[i + 1] = ka[i + 1], ka[i]
+                    ki[i], ki[i + 1] = ki[i + 1], ki[i]
+        assert ki[:cnt] == ri and all(k == -1 for k in ki[cnt:])
