@@ -373,14 +373,17 @@ int pd3_sparse_to_dense(const float *feats, const int32_t *coords, const int32_t
  * LoadPointCloud.__call__'s multi-sweep merge, paddle3d/transforms/reader.py:118-164.
  *   points         [sweep_offsets[num_sweeps], dim_in] fp32: key frame first, then the sweeps (device)
  *   sweep_offsets  host int64[num_sweeps + 1]; sweep 0 is the key frame (kept untouched)
- *   ref_from_curr  host double[num_sweeps][16] row-major 4x4 (NULL: no transform); time_lag host
+ *   ref_from_curr  host double[num_sweeps][16] row-major 4x4 (NULL: no transform); has_transform host
+ *                  int32[num_sweeps] (NULL: every sweep has one; 0 = this sweep's `ref_from_curr` is None,
+ *                  reader.py:150, e.g. the key frame repeated as padding at a scene start); time_lag host
  *                  float[num_sweeps] (NULL: zeros); remove_radius = sweep_remove_radius
  *   out            [<= total points, use_dim (+1 if use_time_lag)] fp32, rows in the reference's
  *                  concatenation order (given the sweep order); num_out [1] int32 (device)
  */
 size_t pd3_merge_sweeps_workspace(int64_t num_points);
 int pd3_merge_sweeps(const float *points, const int64_t *sweep_offsets, int num_sweeps, int dim_in,
-                     int use_dim, const double *ref_from_curr, const float *time_lag, int use_time_lag,
+                     int use_dim, const double *ref_from_curr, const int32_t *has_transform,
+                     const float *time_lag, int use_time_lag,
                      float remove_radius, float *out, int32_t *num_out, void *workspace,
                      size_t workspace_bytes, void *stream);
 

@@ -5,7 +5,11 @@
 //
 // One flag pass + the batched exclusive scan (scan.hpp) + its fused epilogue that writes the surviving
 // points in order: a stable compaction, so the merged cloud equals the reference's concatenation row for
-// row.  The transform is evaluated in fp64 like NumPy's float64 `dot` and rounded to fp32 once.
+// row.  The transform is evaluated in fp64 like NumPy's float64 `dot` (three unfused multiply-adds, left to
+// right: -ffp-contract=off) and rounded to fp32 once.  The BLAS dgemm NumPy calls may fuse or reorder, which moves
+// the fp64 value by an ulp in a quarter of the cases; the fp32 rounding hides that except on a double-rounding
+// boundary (~1e-9 of the values): bit-equal to the reference's own code on every golden vector
+// (tests/golden/make_reader_golden.py executes reader.py:91-170; 6 M random values on the CPU: 0 differences).
 #include "../../include/paddle3d_amd.h"
 #include "common.hpp"
 #include "scan.hpp"
@@ -89,7 +93,7 @@ extern "C" size_t pd3_merge_sweeps_workspace(int64_t num_points) {
 
 extern "C" int pd3_merge_sweeps(const float* points, const int64_t* sweep_offsets, int num_sweeps,
                                 int dim_in, int use_dim, const double* ref_from_curr,
-                                const float* time_lag, int use_time_lag, float remove_radius,
+                                const int32_t* has_transform, const float* time_lag, int use_time_lag, float remove_radius,
                                 float* out, int32_t* num_out, void* workspace, size_t workspace_bytes,
                                 void* stream) {
   if (!points || !sweep_offsets || !out || !num_out || !workspace || num_sweeps <= 0 ||
@@ -108,7 +112,9 @@ extern "C" int pd3_merge_sweeps(const float* points, const int64_t* sweep_offset
   for (int i = 0; i <= num_sweeps; ++i) t.begin[i] = sweep_offsets[i];
   for (int i = 0; i < num_sweeps; ++i) {
     t.filter[i] = i > 0;  // sweep 0 is the key frame
-    t.transform[i] = (i > 0 && ref_from_curr) ? 1 : 0;
+    // a sweep whose `ref_from_curr` is None (reader.py:150; the key frame repeated as padding at a scene start,
+    // nuscenes_pointcloud_det.py:93-100) keeps its coordinates bit for bit (an identity matrix would turn -0 into +0)
+    t.transform[i] = (i > 0 && ref_from_curr && (!has_transform || has_transform[i])) ? 1 : 0;
     t.time_lag[i] = (time_lag && i > 0) ? time_lag[i] : 0.f;
     for (int k = 0; k < 12; ++k) t.m[i][k] = ref_from_curr ? ref_from_curr[(size_t)i * 16 + k] : 0.0;
   }

@@ -188,8 +188,8 @@ def test_merge_sweeps(oracle):
     out = sw.merge_sweeps(torch.from_numpy(frames[0]).cuda(), [torch.from_numpy(f).cuda() for f in frames[1:]],
                           mats, lags).cpu().numpy()
     assert out.shape == ref.shape and out.shape[1] == 6
-    np.testing.assert_array_equal(out[:, 3:], ref[:, 3:])        # payload + time lag exact, order preserved
-    assert np.abs(out[:, :3] - ref[:, :3]).max() < 1e-5          # fp64 dot rounded once; BLAS order may differ
+    # bit for bit, 250 k points: the oracle is pinned to the reference's executed reader.py (tests/test_reader_golden.py)
+    np.testing.assert_array_equal(out.view(np.uint32), ref.view(np.uint32))
     # and the merged cloud feeds hard_voxelize unchanged
     from paddle3d_amd.ops import voxelize
     v = voxelize.hard_voxelize(torch.from_numpy(np.ascontiguousarray(out[:, :5])).cuda(), list(synth.NUSC_PILLAR),
