@@ -4,8 +4,15 @@ models/detection/centerpoint/centerpoint.py:180-201).
 
 Pure NumPy (quaternion algebra included: the reference leans on nuscenes-devkit's Box / pyquaternion, which are
 not installed here); `evaluate()` hands the JSON to nuscenes-devkit's NuScenesEval when that package and a dataset
-are present.  mAP parity itself cannot be measured offline (no data, no weights) -- what is pinned by the tests is
-the geometry of the conversion."""
+are present.  mAP parity itself cannot be measured offline (no data, no weights).  What IS pinned
+(tests/test_nuscenes_bridge.py against tests/golden/python_nuscenes.npz): the records equal the ones the reference's
+own `_parse_results_to_sample` -> `filter_fake_result` -> `second_bbox_to_nuscenes_box` ->
+`_parse_predictions_to_eval_format` -> `get_nuscenes_box_attribute` produce when executed on the same detections and
+poses (which rows survive, their order, names, attributes, sizes and scores exactly; centres / velocities to 1e-9,
+quaternions to 1e-7: the reference halves the float32 heading in whatever precision its NumPy version promotes to).
+`average_precision` / `nuscenes_style_map` below are a devkit-free restatement of the detection benchmark's matching
+(centre distance 0.5 / 1 / 2 / 4 m, greedy by descending score, AP over recall > 0.1 with precision floored at 0.1) used
+for the mAP PROXY of the bench and tests: the HIP pipeline's detections scored against the oracle pipeline's."""
 from __future__ import annotations
 
 import json
@@ -15,7 +22,7 @@ import tempfile
 import numpy as np
 
 __all__ = ["NUSC_CLASS_NAMES", "CLASS_RANGE_CVPR_2019", "DEFAULT_ATTRIBUTE", "box_attribute", "detections_to_results",
-           "results_to_json", "evaluate"]
+           "results_to_json", "evaluate", "average_precision", "nuscenes_style_map", "DIST_THRESHOLDS"]
 
 # class order of the CenterPoint nuScenes configs (tasks concatenated: centerpoint_pillars_02voxel_nuscenes_10sweep.yml)
 NUSC_CLASS_NAMES = ["car", "truck", "construction_vehicle", "bus", "trailer", "barrier", "motorcycle", "bicycle",
@@ -78,7 +85,8 @@ def detections_to_results(detections, sample_tokens, sensor_poses, ego_poses, cl
     class_range = CLASS_RANGE_CVPR_2019 if class_range is None else class_range
     res = {}
     for det, token, sp, ep in zip(detections, sample_tokens, sensor_poses, ego_poses):
-        boxes = np.asarray(det["box3d_lidar"].cpu() if hasattr(det["box3d_lidar"], "cpu") else det["box3d_lidar"], np.float64)
+        boxes32 = np.asarray(det["box3d_lidar"].cpu() if hasattr(det["box3d_lidar"], "cpu") else det["box3d_lidar"], np.float32)
+        boxes = boxes32.astype(np.float64)  # BBoxes3D is a float32 array (geometries/structure.py:35); what is read from it widens exactly
         scores = np.asarray(det["scores"].cpu() if hasattr(det["scores"], "cpu") else det["scores"], np.float64)
         labels = np.asarray(det["label_preds"].cpu() if hasattr(det["label_preds"], "cpu") else det["label_preds"])
         q_s, t_s = np.asarray(sp["rotation"], np.float64), np.asarray(sp["translation"], np.float64)
@@ -88,7 +96,8 @@ def detections_to_results(detections, sample_tokens, sensor_poses, ego_poses, cl
             if scores[i] < 0:  # filter_fake_result
                 continue
             name = class_names[int(labels[i])]
-            yaw = -boxes[i, -1] - np.pi / 2
+            # second_bbox_to_nuscenes_box rewrites the heading IN the float32 box array (nuscenes_utils.py:162)
+            yaw = float(-boxes32[i, -1] - np.float32(np.pi / 2))
             q = np.array([np.cos(yaw / 2), 0.0, 0.0, np.sin(yaw / 2)])
             center = boxes[i, :3].copy()
             vel = np.array([boxes[i, 6], boxes[i, 7], 0.0]) if boxes.shape[1] == 9 else np.zeros(3)
@@ -128,3 +137,79 @@ def evaluate(results: dict, nusc, eval_set: str, channel: str = "LIDAR_TOP", eva
         ev.main(plot_examples=0, render_curves=False)
         with open(os.path.join(tmp, "metrics_summary.json")) as f:
             return json.load(f)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# mAP proxy: the detection benchmark's matching and AP, restated without the devkit (nuscenes-devkit
+# eval/detection/algo.py `accumulate` + `calc_ap`, detection_cvpr_2019: dist_ths 0.5 / 1 / 2 / 4 m, dist_fcn
+# center_distance, min_recall 0.1, min_precision 0.1, 101 recall points).  Used to score one pipeline's detections
+# against another's on the same frames -- NOT a dataset mAP (there is no ground truth offline).
+DIST_THRESHOLDS = (0.5, 1.0, 2.0, 4.0)
+
+
+def average_precision(pred_xy, pred_score, pred_frame, gt_xy, gt_frame, dist_th, min_recall=0.1, min_precision=0.1):
+    """AP of one class at one centre-distance threshold.  pred_* / gt_*: centres [n, 2], scores [n], frame ids [n].
+    Predictions are visited by descending score (stable); each takes the closest not-yet-matched truth of its frame
+    if that is closer than `dist_th`."""
+    pred_xy, gt_xy = np.asarray(pred_xy, np.float64).reshape(-1, 2), np.asarray(gt_xy, np.float64).reshape(-1, 2)
+    pred_score, pred_frame = np.asarray(pred_score, np.float64), np.asarray(pred_frame)
+    gt_frame = np.asarray(gt_frame)
+    npos = len(gt_xy)
+    if npos == 0 or len(pred_xy) == 0:
+        return 0.0
+    by_frame = {}
+    for j, f in enumerate(gt_frame.tolist()):
+        by_frame.setdefault(f, []).append(j)
+    taken = np.zeros(npos, bool)
+    order = np.argsort(-pred_score, kind="stable")
+    tp = np.zeros(len(order))
+    for r, i in enumerate(order):
+        cand = [j for j in by_frame.get(pred_frame[i].item() if hasattr(pred_frame[i], "item") else pred_frame[i], [])
+                if not taken[j]]
+        if not cand:
+            continue
+        d = np.hypot(gt_xy[cand, 0] - pred_xy[i, 0], gt_xy[cand, 1] - pred_xy[i, 1])
+        k = int(np.argmin(d))
+        if d[k] < dist_th:
+            taken[cand[k]] = True
+            tp[r] = 1.0
+    if tp.sum() == 0:
+        return 0.0
+    ctp, cfp = np.cumsum(tp), np.cumsum(1.0 - tp)
+    prec, rec = ctp / (ctp + cfp), ctp / float(npos)
+    rec_interp = np.linspace(0, 1, 101)
+    prec = np.interp(rec_interp, rec, prec, right=0)
+    prec = prec[int(round(100 * min_recall)) + 1:] - min_precision
+    prec[prec < 0] = 0
+    return float(np.mean(prec)) / (1.0 - min_precision)
+
+
+def nuscenes_style_map(pred, truth, num_classes=10, dist_ths=DIST_THRESHOLDS):
+    """mAP of `pred` against `truth`: both lists (one entry per frame) of dict(box3d_lidar [K, >= 2], scores [K],
+    label_preds [K]) as `CenterPoint.test_forward` returns them.  Rows with score < 0 (the fake row of an empty
+    frame) are ignored.  Returns dict(mAP, per_class {label: mean AP over thresholds}, classes_scored).  Classes
+    without a truth box are left out of the mean (the devkit scores them 0 against real annotations; here there is
+    nothing to find)."""
+    def flat(dets):
+        xy, sc, lab, fr = [], [], [], []
+        for f, d in enumerate(dets):
+            b = np.asarray(d["box3d_lidar"].cpu() if hasattr(d["box3d_lidar"], "cpu") else d["box3d_lidar"], np.float64)
+            s = np.asarray(d["scores"].cpu() if hasattr(d["scores"], "cpu") else d["scores"], np.float64)
+            l = np.asarray(d["label_preds"].cpu() if hasattr(d["label_preds"], "cpu") else d["label_preds"])
+            keep = s >= 0
+            xy.append(b[keep, :2])
+            sc.append(s[keep])
+            lab.append(l[keep])
+            fr.append(np.full(int(keep.sum()), f))
+        return np.concatenate(xy), np.concatenate(sc), np.concatenate(lab), np.concatenate(fr)
+
+    pxy, ps, pl, pf = flat(pred)
+    txy, _, tl, tf = flat(truth)
+    per_class = {}
+    for c in range(num_classes):
+        if not (tl == c).any():
+            continue
+        pm, tm = pl == c, tl == c
+        per_class[c] = float(np.mean([average_precision(pxy[pm], ps[pm], pf[pm], txy[tm], tf[tm], th) for th in dist_ths]))
+    m = float(np.mean(list(per_class.values()))) if per_class else float("nan")
+    return dict(mAP=m, per_class=per_class, classes_scored=len(per_class))
