@@ -109,25 +109,36 @@ def _oracle_scene(model_cpu, max_voxels, seed):
     from paddle3d_amd import synth
 
     kind = "ref" if O.have_ref() else "port"
-    cfg = model_cpu.test_cfg
-    pts = synth.nuscenes_sweep(seed)
-    vox, co, npv, nv = O.hard_voxelize(pts, synth.NUSC_PILLAR, synth.NUSC_RANGE, P, max_voxels, kind)
-    c4 = np.concatenate([np.zeros((nv, 1), np.int32), co[:nv]], 1)
-    params = []
-    for l in model_cpu.voxel_encoder.pfn_layers:
-        params.append(dict(weight=l.linear.weight.t().detach().numpy(), gamma=l.norm.weight.detach().numpy(),
-                           beta=l.norm.bias.detach().numpy(), mean=l.norm.running_mean.numpy(),
-                           var=l.norm.running_var.numpy()))
-    feats = O.pfn_forward_torch(vox[:nv], npv[:nv], c4, params, synth.NUSC_PILLAR, synth.NUSC_RANGE)
-    canvas = O.pillar_scatter(feats, c4, 1, 512, 512)
-    with torch.no_grad():
-        preds, _ = O.center_head_torch(model_cpu.bbox_head, O.dense_forward_torch(model_cpu, torch.from_numpy(canvas)))
-    tasks = [{k: v.numpy() for k, v in p.items()} for p in preds]
-    O.centerpoint_postprocess(tasks, cfg["voxel_size"] + [8.0], cfg["point_cloud_range"] + [0.0] * 4,
-                              cfg["post_center_limit_range"], [0, 1, 3, 5, 6, 8], cfg["down_ratio"],
-                              cfg["score_threshold"], cfg["nms"]["nms_iou_threshold"],
-                              cfg["nms"]["nms_pre_max_size"], cfg["nms"]["nms_post_max_size"], True)
+    O.centerpoint_pillars_pipeline(model_cpu, [synth.nuscenes_sweep(seed)], P, max_voxels, kind, dense_batch=1)
     return kind
+
+
+def map_proxy(model, model_cpu, max_voxels, frames, dev):
+    """mAP-shaped evidence without a dataset: `frames` synthetic scenes through the oracle pipeline (CPU) and through
+    the device pipeline with the same weights; nuScenes-style AP (centre distance 0.5 / 1 / 2 / 4 m,
+    paddle3d_amd.nuscenes_bridge) of the device's detections scored against the oracle's, and the other way round."""
+    from oracle import pyoracle as O
+    from paddle3d_amd import nuscenes_bridge as nb
+    from paddle3d_amd import synth
+
+    pts = np.stack([synth.nuscenes_sweep(700 + i) for i in range(frames)])
+    t0 = time.perf_counter()
+    ref = O.centerpoint_pillars_pipeline(model_cpu, pts, P, max_voxels)
+    t_cpu = time.perf_counter() - t0
+    got = []
+    with torch.no_grad():
+        for b0 in range(0, frames, 16):
+            for d in model.test_forward(torch.from_numpy(pts[b0:b0 + 16]).to(dev)):
+                got.append({k: d[k].cpu().numpy() for k in ("box3d_lidar", "scores", "label_preds")})
+    fwd, back = nb.nuscenes_style_map(got, ref), nb.nuscenes_style_map(ref, got)
+    return dict(value=fwd["mAP"], reverse=back["mAP"], frames=frames, classes_scored=fwd["classes_scored"],
+                oracle_detections=int(sum(len(r["scores"]) for r in ref)),
+                device_detections=int(sum(int((g["scores"] >= 0).sum()) for g in got)), cpu_seconds=t_cpu,
+                note="AP of the HIP pipeline's detections against the oracle pipeline's (as if those were the "
+                     "annotations), mean over classes and the four centre-distance thresholds; random-init weights, "
+                     "so the absolute detections mean nothing -- the figure says how far the two pipelines' outputs "
+                     "are apart on the mAP scale (1.0 = identical detection sets; the north star's 0.1 mAP = 0.001 "
+                     "here); tests/test_model_gpu.py::test_map_proxy_64_frames asserts >= 0.999 over 64 frames")
 
 
 def _oracle_worker(args):
@@ -391,7 +402,7 @@ def bench_pillars(args, rank, world, dev):
         b, v, p, d = voxels.shape
         feats = model.voxel_encoder(voxels.view(b * v, p, d), npv.view(b * v), coors.view(b * v, 4))
         mark(2)
-        canvas = model.middle_encoder(feats, coors.view(b * v, 4), b)
+        canvas = model.scatter(feats, coors.view(b * v, 4), b)
         mark(3)
         x = model.dense_forward(canvas)
         preds, _ = model.bbox_head(x)
@@ -432,7 +443,7 @@ def bench_pillars(args, rank, world, dev):
                     st["feats"] = model.voxel_encoder(voxels.view(b * v, p, d), npv.view(b * v), st["c4"])
 
                 def seg_scatter():
-                    st["canvas"] = model.middle_encoder(st["feats"], st["c4"], st["b"])
+                    st["canvas"] = model.scatter(st["feats"], st["c4"], st["b"])
 
                 def seg_dense():
                     st["preds"] = model.bbox_head(model.dense_forward(st["canvas"]))[0]
@@ -507,7 +518,7 @@ def bench_pillars(args, rank, world, dev):
                                         "this interval holds the inverse-map kernels only, the canvas is never "
                                         "written; `pd3_pointpillars_scatter` alone runs at 0.49-0.51 of the HBM "
                                         "roofline (DESIGN 4.2)")
-                              if getattr(model.middle_encoder, "lazy", False)
+                              if getattr(model, "fuse_scatter", False)
                               else hbm("pointpillars_scatter", "pointpillars_scatter")),
         centerpoint_postprocess=dict(hbm("postprocess", "centerpoint_postprocess"),
                                      us_per_frame=per_op_ms["postprocess"] * 1e3 / B,
@@ -537,8 +548,8 @@ def bench_pillars(args, rank, world, dev):
                    "frames_per_gpu_per_step": B, "max_voxels": V, "parallelism": f"dp{world} (frames)",
                    "launch": launch, "host_ms_to_enqueue_one_eager_step": cpu_ms},
         "roofline": dict(rooflines["hard_voxelize"],
-                         kernel="hard_voxelize launch sequence (vt_route + vt_group + vt_assign + vt_rows_gather; --vox-path picks "
-                                "another form)"),
+                         kernel="hard_voxelize launch sequence (vw_route + vw_group + vw_assign + vw_rows: the wave form, "
+                                "voxelize_wave.hpp; --vox-path picks another form)"),
         "rooflines": rooflines,
         # `roofline` is the kernel the north star puts the HBM target on; by time the step is dominated by
         # the dense graph (rooflines["dense_backbone_fpn_head"], MFMA bound)
@@ -588,7 +599,7 @@ def bench_pillars(args, rank, world, dev):
                     voxels, coors, npv, _nv = model.voxelizer(pts)
                     b, v, p, d = voxels.shape
                     feats = model.voxel_encoder(voxels.view(b * v, p, d), npv.view(b * v), coors.view(b * v, 4))
-                    return model.middle_encoder(feats, coors.view(b * v, 4), b)
+                    return model.scatter(feats, coors.view(b * v, 4), b)
 
                 def back(canvas):
                     preds, _ = model.bbox_head(model.dense_forward(canvas))
@@ -643,6 +654,12 @@ def bench_pillars(args, rank, world, dev):
                 line["cpu_baseline"] = cpu_baseline(model_cpu, V)
             except Exception as e:  # the baseline is reported, never required
                 line["cpu_baseline"] = dict(value=None, unit="scenes/s", cores=0, kind="port", sample=f"failed: {e}")
+                model_cpu = None
+            if model_cpu is not None and args.map_frames > 0 and "extras" in line:
+                try:
+                    line["extras"]["map_proxy"] = map_proxy(model, model_cpu, V, args.map_frames, dev)
+                except Exception as e:  # noqa: BLE001 -- an extra
+                    line["extras"]["map_proxy"] = dict(value=None, note=f"failed: {type(e).__name__}: {e}")
     if world == 1 and not args.no_extras:
         del model
         torch.cuda.empty_cache()
@@ -901,8 +918,8 @@ def bench_bevfusion_lidar(args, rank, world, dev):
         "roofline": dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBPS, unit="GB/s", frac=a / HBM_PEAK_GBPS, traffic=None,
                          ms_per_launch=per_op_ms["hard_voxelize"], units_per_launch=B,
                          algorithmic_bytes_per_unit=alg_v,
-                         kernel="hard_voxelize launch sequence, tiled path (vt_route + vt_group + vt_assign + "
-                                "vt_rows_gather); the fixed-shape [V, 64, 4] output dominates the bytes"),
+                         kernel="hard_voxelize launch sequence, wave form (vw_route + vw_group + vw_assign + vw_rows); "
+                                "the fixed-shape [V, 64, 4] output dominates the bytes"),
         "rooflines": {"pointpillars_scatter": dict(bound="hbm", achieved=a_s, peak=HBM_PEAK_GBPS, unit="GB/s",
                                                    frac=a_s / HBM_PEAK_GBPS, traffic=None,
                                                    ms_per_launch=per_op_ms["pointpillars_scatter"],
@@ -938,7 +955,7 @@ def bench_pointpillars_kitti(args, rank, world, dev):
         c4 = coors.view(b * v, 4)
         feats = model.pillar_encoder(voxels.view(b * v, p, d), npv.view(b * v), c4)
         mark(2)
-        canvas = model.middle_encoder(feats, c4, b)
+        canvas = model.scatter(feats, c4, b)
         mark(3)
         x = model.neck(model.backbone(canvas))
         mark(4)
@@ -983,7 +1000,7 @@ def bench_pointpillars_kitti(args, rank, world, dev):
                                                     ms_per_launch=per_op_ms["pointpillars_scatter"], units_per_launch=B,
                                                     note="fused into the first backbone convolution: inverse-map "
                                                          "kernels only, no canvas written")
-                                               if getattr(model.middle_encoder, "lazy", False) else
+                                               if getattr(model, "fuse_scatter", False) else
                                                dict(bound="hbm", achieved=a_s, peak=HBM_PEAK_GBPS, unit="GB/s",
                                                     frac=a_s / HBM_PEAK_GBPS, traffic=None,
                                                     ms_per_launch=per_op_ms["pointpillars_scatter"],
@@ -1125,6 +1142,8 @@ def main(argv=None):
     ap.add_argument("--repeats", type=int, default=None, help="time the same K steps this many more times after the "
                     "contract block and report min / median / max (default 4 at N=1, 0 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--map-frames", type=int, default=16, help="frames of the mAP proxy in extras (device detections "
+                    "scored against the oracle pipeline's; ~1 s of CPU per frame; 0 = off)")
     ap.add_argument("--no-extras", action="store_true", help="skip the h2d-inclusive / batch-1 / ceiling measurements "
                     "and the other workloads (profiling runs: only warm-up + timed steps are launched)")
     ap.add_argument("--stub-ops", action="store_true", help="test hook: no device ops, launch / collective path only "

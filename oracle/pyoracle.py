@@ -304,6 +304,46 @@ def centerpoint_postprocess(tasks, voxel_size, pc_range, post_center_range, num_
     return res
 
 
+def centerpoint_pillars_pipeline(model_cpu, points, max_pts, max_voxels, kind=None, dense_batch=8):
+    """The CPU statement of the WHOLE CenterPoint-Pillars path for a list / array of frames [B, N, D]:
+    hard_voxelize (the reference kernel when oracle/_ref is built) -> PFN -> scatter (C port) -> SECOND + FPN +
+    CenterHead (torch CPU fp32, `dense_batch` frames at a time) -> centerpoint_postprocess (C port).
+    `model_cpu`: a paddle3d_amd.centerpoint.CenterPoint on the CPU (parameter container only).  Returns a list of
+    dict(box3d_lidar, scores, label_preds) NumPy arrays -- what `test_forward` returns on the device."""
+    import torch
+
+    kind = kind or ("ref" if have_ref() else "port")
+    cfg = model_cpu.test_cfg
+    vs3, rng6 = list(model_cpu.voxelizer.voxel_size), list(model_cpu.voxelizer.point_cloud_range)
+    nx = int(round((rng6[3] - rng6[0]) / vs3[0]))
+    ny = int(round((rng6[4] - rng6[1]) / vs3[1]))
+    params = []
+    for l in model_cpu.voxel_encoder.pfn_layers:
+        params.append(dict(weight=l.linear.weight.t().detach().numpy(), gamma=l.norm.weight.detach().numpy(),
+                           beta=l.norm.bias.detach().numpy(), mean=l.norm.running_mean.numpy(),
+                           var=l.norm.running_var.numpy()))
+    label_offsets = np.concatenate([[0], np.cumsum([t.hm[-1].out_channels for t in model_cpu.bbox_head.tasks])[:-1]])
+    out = []
+    for b0 in range(0, len(points), dense_batch):
+        canvases = []
+        for pts in points[b0:b0 + dense_batch]:
+            vox, co, npv, nv = hard_voxelize(np.ascontiguousarray(pts), vs3, rng6, max_pts, max_voxels, kind)
+            c4 = np.concatenate([np.zeros((nv, 1), np.int32), co[:nv]], 1)
+            feats = pfn_forward_torch(vox[:nv], npv[:nv], c4, params, vs3, rng6)
+            canvases.append(pillar_scatter(feats, c4, 1, ny, nx))
+        with torch.no_grad():
+            preds, _ = center_head_torch(model_cpu.bbox_head,
+                                         dense_forward_torch(model_cpu, torch.from_numpy(np.concatenate(canvases))))
+        for i in range(len(canvases)):
+            tasks = [{k: v[i:i + 1].numpy() for k, v in p.items()} for p in preds]
+            bb, sc, lab = centerpoint_postprocess(
+                tasks, cfg["voxel_size"] + [vs3[2]], cfg["point_cloud_range"] + [0.0] * 4, cfg["post_center_limit_range"],
+                [int(v) for v in label_offsets], cfg["down_ratio"], cfg["score_threshold"],
+                cfg["nms"]["nms_iou_threshold"], cfg["nms"]["nms_pre_max_size"], cfg["nms"]["nms_post_max_size"], True)
+            out.append(dict(box3d_lidar=bb, scores=sc, label_preds=lab))
+    return out
+
+
 def centerpoint_decode_ref(score, reg, height, expdim, vel, rot, score_threshold, feat_w, down_ratio,
                            voxel_size, pc_range, post_center_range, with_velocity=True):
     """The reference decode_kernel itself (oracle/_ref), for pinning the port's decode stage."""

@@ -98,6 +98,8 @@ _SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pd3_sparse_to_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pd3_selfcheck_lds_atomic_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_void_p]),
     "pd3_merge_sweeps_workspace": (C.c_size_t, [C.c_int64]),
     "pd3_merge_sweeps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

@@ -182,18 +182,41 @@ class PointPillarsScatter(nn.Module):
         self.in_channels = in_channels
         g = _grid(voxel_size, point_cloud_range)
         self.nx, self.ny = int(g[0]), int(g[1])
-        self.lazy = False  # True: return a SparseCanvas (set by the model constructors whose backbone takes one)
 
     def forward(self, voxel_features, coords, batch_size):
-        if self.lazy:  # the consumer (SecondBackbone) gathers from the pillar features itself: no canvas is written
-            return _ps.SparseCanvas(voxel_features, coords, batch_size, self.ny, self.nx)
+        """The reference's contract: the dense [B, C, ny, nx] pseudo image, always."""
         return _ps.pointpillars_scatter(voxel_features, coords, batch_size, self.ny, self.nx)
+
+    def sparse(self, voxel_features, coords, batch_size):
+        """The same scatter as a SparseCanvas (pillar features + inverse map) for a consumer that gathers from the
+        pillar features itself (SecondBackbone's first convolution): no canvas is written.  The models call this
+        when they fuse (`model.scatter`); the module's own forward keeps returning a tensor for everyone else."""
+        return _ps.SparseCanvas(voxel_features, coords, batch_size, self.ny, self.nx)
 
 
 def _param_signature(module):
     """(storage, version, device) of every parameter and buffer below `module`: changes when any of them is
-    reloaded, moved or written in place (load_state_dict on a child, param.data.copy_, an optimizer step)."""
+    reloaded, moved or written in place THROUGH THE TENSOR ITSELF (`load_state_dict` on this module or a child,
+    `.to()`, `with torch.no_grad(): p.mul_(2)`, an optimizer step).  It does NOT see a write through `p.data`
+    (`p.data.copy_(...)`, `p.data.mul_(2)`): `.data` is a detached alias with a version counter of its own, and
+    reading the contents instead would cost a device -> host round trip on every forward.  Code that writes through
+    `.data` (or through a raw pointer) calls `invalidate_derived(model)` afterwards."""
     return tuple((t.data_ptr(), t._version, str(t.device)) for t in list(module.parameters()) + list(module.buffers()))
+
+
+def invalidate_derived(module):
+    """Drop every weight derived for inference (folded BatchNorm, packed kernel layouts) below `module`; the next
+    forward rebuilds them from the current parameters.  Needed only after a write the signature cannot see
+    (`param.data.*`, see _param_signature); `load_state_dict`, `.to()`, `train()` and in-place tensor ops are
+    detected without it."""
+    for m in module.modules():
+        if hasattr(m, "_drop_cache"):
+            m._drop_cache()
+        if hasattr(m, "_folded"):
+            m._folded = None
+        if getattr(m, "_pd3_folded", None) is not None:
+            object.__setattr__(m, "_pd3_folded", None)
+    return module
 
 
 class _InferenceCache:
@@ -220,6 +243,11 @@ class _InferenceCache:
     def train(self, mode: bool = True):
         self._drop_cache()
         return super().train(mode)
+
+    def invalidate(self):
+        """Public form of _drop_cache for this module and everything below it (see invalidate_derived)."""
+        invalidate_derived(self)
+        return self
 
     def _require_eval(self):
         if self.training:
@@ -569,8 +597,20 @@ class CenterPoint(nn.Module):
         self.bbox_head = bbox_head
         self.test_cfg = test_cfg
         self.box_with_velocity = box_with_velocity
-        if isinstance(middle_encoder, PointPillarsScatter) and isinstance(backbone, SecondBackbone):
-            middle_encoder.lazy = True  # the scatter is fused into the backbone's first convolution where it can be
+        # the scatter is fused into the backbone's first convolution where it can be (a property of this model's
+        # forward, not of the scatter module: `model.middle_encoder(...)` still returns the dense pseudo image)
+        self.fuse_scatter = isinstance(middle_encoder, PointPillarsScatter) and isinstance(backbone, SecondBackbone)
+
+    def scatter(self, feats, coors, batch_size):
+        """The middle encoder as this model's forward runs it (a SparseCanvas when the scatter is fused)."""
+        if self.fuse_scatter:
+            return self.middle_encoder.sparse(feats, coors, batch_size)
+        return self.middle_encoder(feats, coors, batch_size)
+
+    def invalidate(self):
+        """Rebuild every folded / packed weight on the next forward (after a write through `param.data`)."""
+        invalidate_derived(self)
+        return self
 
     def _pack(self, points):
         if isinstance(points, torch.Tensor):
@@ -597,8 +637,9 @@ class CenterPoint(nn.Module):
             keep = coors[:, 0] >= 0
             voxels, coors, npv = voxels[keep], coors[keep].contiguous(), npv[keep]
         feats = self.voxel_encoder(voxels, npv, coors)
-        x = self.middle_encoder(feats, coors, b)
-        return x.dense() if dense and isinstance(x, _ps.SparseCanvas) else x
+        if dense:
+            return self.middle_encoder(feats, coors, b)
+        return self.scatter(feats, coors, b)
 
     def dense_forward(self, x):
         """SecondBackbone -> SecondFPN (centerpoint.py:133-137)."""

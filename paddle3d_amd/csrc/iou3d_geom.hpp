@@ -121,34 +121,28 @@ __device__ inline float box_overlap(const BoxPre& a, const BoxPre& b, float* __r
   float* va = st + 2 * kPolyCap * 64;
   int cnt = 0;
   float sx = 0.f, sy = 0.f;
+  // A 17th vertex (16 crossings + 8 contained corners are possible for degenerate / garbage boxes only) is dropped:
+  // the reference writes past `cross_points[16]` there (undefined behaviour, nothing to match); here the slot would
+  // alias the next array or another wave's polygon, so the append is bounded.
+  auto push = [&](float x, float y) {
+    if (cnt < kPolyCap) {
+      sx = sx + x;
+      sy = sy + y;
+      vx[cnt * 64] = x;
+      vy[cnt * 64] = y;
+      ++cnt;
+    }
+  };
   for (int i = 0; i < 4; ++i) {
     const Pt a0 = a.c[i], a1 = a.c[(i + 1) & 3];
     for (int j = 0; j < 4; ++j) {
       Pt hit;
-      if (seg_hit(a1, a0, b.c[(j + 1) & 3], b.c[j], hit)) {
-        sx = sx + hit.x;
-        sy = sy + hit.y;
-        vx[cnt * 64] = hit.x;
-        vy[cnt * 64] = hit.y;
-        ++cnt;
-      }
+      if (seg_hit(a1, a0, b.c[(j + 1) & 3], b.c[j], hit)) push(hit.x, hit.y);
     }
   }
   for (int k = 0; k < 4; ++k) {  // :184-195
-    if (inside(a, b.c[k])) {
-      sx = sx + b.c[k].x;
-      sy = sy + b.c[k].y;
-      vx[cnt * 64] = b.c[k].x;
-      vy[cnt * 64] = b.c[k].y;
-      ++cnt;
-    }
-    if (inside(b, a.c[k])) {
-      sx = sx + a.c[k].x;
-      sy = sy + a.c[k].y;
-      vx[cnt * 64] = a.c[k].x;
-      vy[cnt * 64] = a.c[k].y;
-      ++cnt;
-    }
+    if (inside(a, b.c[k])) push(b.c[k].x, b.c[k].y);
+    if (inside(b, a.c[k])) push(a.c[k].x, a.c[k].y);
   }
   if (cnt == 0) return 0.0f;
   sx /= cnt;  // :197-198

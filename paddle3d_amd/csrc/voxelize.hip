@@ -380,9 +380,16 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
   const int waves = plan.threads / kWave;
   const size_t lds_a = ((size_t)plan.tile + (size_t)waves * plan.groups + waves + 2) * 4;
   const unsigned tile_grid = (unsigned)(plan.tiles * batch);
+  // up to ~104 KB of dynamic LDS (1024 x 10 tile): above the 48 KB a kernel may use without asking, so the cap is
+  // raised per instantiation like every other large-LDS kernel of the library (a host-side table write per launch)
 #define PD3_VW_ROUTE(T, R)                                                                                         \
-  vw_route_kernel<T, R><<<tile_grid, T, lds_a, s>>>(points, num_points, n, dim, vg, plan.low, plan.gbits,          \
-                                                    plan.tiles, batch, max_voxels, w.recs, w.dir, w.vinfo)
+  do {                                                                                                             \
+    const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(vw_route_kernel<T, R>),                \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);             \
+    if (e_ != hipSuccess) return (int)e_;                                                                          \
+    vw_route_kernel<T, R><<<tile_grid, T, lds_a, s>>>(points, num_points, n, dim, vg, plan.low, plan.gbits,        \
+                                                      plan.tiles, batch, max_voxels, w.recs, w.dir, w.vinfo);      \
+  } while (0)
   if (plan.threads == 512 && plan.rounds == 8) PD3_VW_ROUTE(512, 8);
   else if (plan.threads == 1024 && plan.rounds == 8) PD3_VW_ROUTE(1024, 8);
   else if (plan.threads == 1024 && plan.rounds == 10) PD3_VW_ROUTE(1024, 10);

@@ -188,8 +188,9 @@ class PointPillars(nn.Module):
         self.voxelizer = voxelizer
         self.pillar_encoder = pillar_encoder
         self.middle_encoder = middle_encoder
-        if isinstance(middle_encoder, PointPillarsScatter) and isinstance(backbone, SecondBackbone):
-            middle_encoder.lazy = True  # the scatter is fused into the backbone's first convolution where it can be
+        # the scatter is fused into the backbone's first convolution where it can be (the module itself keeps
+        # returning the dense pseudo image to any other caller)
+        self.fuse_scatter = isinstance(middle_encoder, PointPillarsScatter) and isinstance(backbone, SecondBackbone)
         self.backbone = backbone
         self.neck = neck
         self.head = head
@@ -200,6 +201,12 @@ class PointPillars(nn.Module):
                                                 point_cloud_range=voxelizer.point_cloud_range,
                                                 voxel_size=voxelizer.voxel_size, anchor_configs=anchor_configs,
                                                 anchor_area_threshold=anchor_area_threshold)
+
+    def scatter(self, feats, coords, batch_size):
+        """The middle encoder as this model's forward runs it (a SparseCanvas when the scatter is fused)."""
+        if self.fuse_scatter:
+            return self.middle_encoder.sparse(feats, coords, batch_size)
+        return self.middle_encoder(feats, coords, batch_size)
 
     def _pack(self, points):
         if isinstance(points, torch.Tensor):
@@ -216,7 +223,7 @@ class PointPillars(nn.Module):
         """pointpillars.py:107-127 on voxelized input: voxels [M, P, D], coords [M, 4] int32 (batch, z, y, x; -1 on
         padding rows), num_points_per_voxel [M] int32."""
         feats = self.pillar_encoder(voxels, num_points_per_voxel, coords)
-        x = self.middle_encoder(feats, coords, batch_size)
+        x = self.scatter(feats, coords, batch_size)
         x = self.neck(self.backbone(x))
         return self.head.post_process(self.head.head_map(x), self.anchor_generator, coords, device_only=device_only)
 

@@ -285,7 +285,7 @@ def test_pointpillars_kitti_end_to_end_vs_oracle(oracle, config):
         voxels, coors, npv_d, _ = model.voxelizer(torch.from_numpy(pts[b:b + 1]).cuda())
         v = voxels.shape[1]
         f = model.pillar_encoder(voxels.view(v, p_max, 4), npv_d.view(v), coors.view(v, 4))
-        gx = model.neck(model.backbone(model.middle_encoder(f, coors.view(v, 4), 1)))
+        gx = model.neck(model.backbone(model.scatter(f, coors.view(v, 4), 1)))
         got_map = model.head.head_map(gx)[0].cpu().numpy()
         assert got_map.shape == ref_map.shape == (c_cls + c_box + apl * 2, fh, fw)
         assert np.abs(got_map - ref_map).max() < 1e-3  # the north star's bar on fp32 features
