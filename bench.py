@@ -292,8 +292,11 @@ def _events(names, steps, dev):
     return [[torch.cuda.Event(enable_timing=True) for _ in names] for _ in range(steps)]
 
 
-def _timed_loop(step, args, world, dev, names):
-    """The contract: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX
+def _timed_loop(step, args, world, dev, names, finish=None):
+    """`finish` (optional): called once after the K-th step INSIDE the timed region, before the closing synchronize +
+    barrier -- the overlapped result hand-off (dist.GatherPipeline) completes the batch still in flight there, so
+    every collective of the K steps is inside the K steps' time; its return value replaces the last output.
+    The contract: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX
     over ranks.  Returns (seconds, per-op milliseconds (median over the K steps of the HIP-event intervals), last
     output, info).  info["repeats_s"]: the same K steps timed `--repeats` more times after the contract block (the
     0.2 s region of a 20-step run moves by a few per cent from box to box; the spread is reported, `value` is always
@@ -313,6 +316,8 @@ def _timed_loop(step, args, world, dev, names):
         out = None
         for k in range(args.steps):
             out = step(events[k] if events is not None else None)
+        if finish is not None:
+            out = finish(out)
         sync()
         barrier()
         dt = time.perf_counter() - t0
@@ -325,6 +330,8 @@ def _timed_loop(step, args, world, dev, names):
     with torch.no_grad():
         for _ in range(args.warmup):
             step(None)
+        if finish is not None:
+            finish(None)
         events = _events(names, args.steps, dev)
         dt, out = block(events)
         sync()
@@ -343,6 +350,87 @@ def _timed_loop(step, args, world, dev, names):
     _LAST_LOOP.clear()
     _LAST_LOOP.update(info)
     return dt, per_op_ms, out, info
+
+
+
+def _rank_max_seconds(dt, world, dev):
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def _timed_region(fn, world, dev):
+    """barrier + synchronize, fn(), synchronize + barrier; seconds, MAX over ranks (the contract's bracket)."""
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    sync()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    fn()
+    sync()
+    if world > 1:
+        torch.distributed.barrier()
+    return _rank_max_seconds(time.perf_counter() - t0, world, dev)
+
+
+def strong_scaling(run_batch, flush, make_frames, frames, batch, rank, world, dev, passes=3):
+    """STRONG scaling beside the contract's weak-scaling line: a FIXED set of `frames` scenes (the same scenes for any
+    number of ranks), sharded round-robin by dist.shard_frames (frame i -> rank i % world), every rank walking its
+    shard in batches of `batch` with the per-batch all-gather of the result records; one pass = every frame of the set
+    once.  value = frames * passes / seconds (MAX over ranks).  Every rank must call this (collectives inside)."""
+    from paddle3d_amd import dist as pdist
+
+    if frames % world != 0:
+        return dict(value=None, note=f"skipped: {frames} frames do not split evenly over {world} ranks")
+    mine = pdist.shard_frames(frames, rank, world)
+    shard = make_frames(mine)
+    batches = [shard[i:i + batch] for i in range(0, len(mine), batch)]
+
+    def one_pass():
+        for b in batches:
+            run_batch(b)
+        if flush is not None:
+            flush()
+
+    one_pass()  # warm-up (batch shapes of the shard may differ from the weak-scaling batch)
+    dt = _timed_region(lambda: [one_pass() for _ in range(passes)], world, dev)
+    return dict(value=frames * passes / dt, unit="scenes/s", scaling="strong", frames=frames, passes=passes,
+                frames_per_rank=len(mine), batches_per_rank_per_pass=len(batches), ms_per_pass=dt / passes * 1e3,
+                note="a fixed frame set sharded by dist.shard_frames over the ranks (total work constant as N grows), "
+                     "inputs resident in HBM, one all-gather of the result records per batch; the >= 6x target at 8 "
+                     "GPUs is read from the weak-scaling `value` of the driver's N = 1, 2, 4, 8 lines (the "
+                     "contract), this figure shows what the same node does on a fixed job")
+
+
+def h2d_inclusive(run_batch, flush, host_batch, stage, steps, world, dev):
+    """The same steps with the batch copied from PINNED host memory inside every step, not overlapped with compute,
+    on every rank at once (N ranks share the host's PCIe root complexes and memory channels): scenes/s over all
+    ranks, MAX over ranks."""
+    def step():
+        stage.copy_(host_batch, non_blocking=True)
+        run_batch(stage)
+
+    for _ in range(2):
+        step()
+    if flush is not None:
+        flush()
+
+    def region():
+        for _ in range(steps):
+            step()
+        if flush is not None:
+            flush()
+
+    dt = _timed_region(region, world, dev)
+    b = host_batch.shape[0]
+    return dict(value=world * b * steps / dt, unit="scenes/s",
+                note=f"{host_batch[0].numel() * 4 / 1e6:.1f} MB per scene over PCIe from pinned memory inside every "
+                     f"step on each of the {world} rank(s), not overlapped with compute; MAX over ranks")
 
 
 _LAST_LOOP = {}  # what the last _timed_loop saw (contract-block seconds, repeated blocks, ranks): main() adds it to the line
@@ -390,6 +478,18 @@ def bench_pillars(args, rank, world, dev):
     cfg = model.test_cfg
     max_per_img = cfg["max_per_img"]
     names = ["start", "hard_voxelize", "pillar_feature_net", "pointpillars_scatter", "dense", "postprocess", "gather"]
+    # the result hand-off: batch k's all-gather travels on RCCL's stream while batch k + 1 is computed (--gather sync:
+    # the collective inside the step, on the compute stream's critical path)
+    pipe = pdist.GatherPipeline() if args.gather == "overlap" else None
+
+    def hand_off(rec, cnt):
+        if pipe is None:
+            return pdist.gather_detections(rec, cnt)
+        prev = pipe.submit(rec, cnt)
+        return prev if prev is not None else (rec, cnt)
+
+    def finish(out):
+        return pipe.flush() if pipe is not None else out
 
     def run(points, events):
         def mark(i):
@@ -410,7 +510,7 @@ def bench_pillars(args, rank, world, dev):
         _bx, _sc, _lb, cnt, rec = model.bbox_head.predict_by_custom_op(preds, cfg, device_only=True,
                                                                       records=max_per_img)
         mark(5)
-        all_rec, all_cnt = pdist.gather_detections(rec, cnt)  # the record comes out of the operator itself
+        all_rec, all_cnt = hand_off(rec, cnt)  # the record comes out of the operator itself
         mark(6)
         return all_rec, all_cnt
 
@@ -470,7 +570,7 @@ def bench_pillars(args, rank, world, dev):
                         if events is not None:
                             events[i + 1].record()
                     _bx, _sc, _lb, cnt, rec = st["post"]
-                    res = pdist.gather_detections(rec, cnt)
+                    res = hand_off(rec, cnt)
                     if events is not None:
                         events[6].record()
                     return res
@@ -485,7 +585,26 @@ def bench_pillars(args, rank, world, dev):
                 torch.cuda.synchronize()
                 print(f"bench: HIP-graph capture failed ({type(e).__name__}: {e}); running the eager step", file=sys.stderr)
                 step, launch = (lambda ev: run(pts, ev)), "eager (graph capture failed)"
-    dt, per_op_ms, out, info = _timed_loop(step, args, world, dev, names)
+    dt, per_op_ms, out, info = _timed_loop(step, args, world, dev, names, finish=finish)
+    multi = {}
+    if args.strong_frames > 0 and not args.no_extras:
+        # every rank takes part (collectives inside); the line is rank 0's
+        loop = dict(_LAST_LOOP)
+        with torch.no_grad():
+            from paddle3d_amd import synth
+
+            def shard(ids):
+                return torch.from_numpy(np.stack([synth.nuscenes_sweep(1000 + i) for i in ids])).to(dev)
+
+            flush = (lambda: pipe.flush()) if pipe is not None else None
+            multi["strong_scaling"] = strong_scaling(lambda b: run(b, None), flush, shard, args.strong_frames, B, rank,
+                                                     world, dev)
+            if world > 1:
+                host = make_batch(B, 100 + B * rank, pin=True)
+                multi["h2d_inclusive"] = h2d_inclusive(lambda b: run(b, None), flush, host, torch.empty_like(pts),
+                                                       args.steps, world, dev)
+        _LAST_LOOP.clear()
+        _LAST_LOOP.update(loop)
     if rank != 0:
         return None
     alg = algorithmic_bytes(V)
@@ -546,7 +665,9 @@ def bench_pillars(args, rank, world, dev):
                                "weights, full graph voxelize->PFN->scatter->SECOND+FPN->CenterHead->postprocess"
                                + ("->RCCL all-gather" if world > 1 else ""),
                    "frames_per_gpu_per_step": B, "max_voxels": V, "parallelism": f"dp{world} (frames)",
-                   "launch": launch, "host_ms_to_enqueue_one_eager_step": cpu_ms},
+                   "launch": launch, "host_ms_to_enqueue_one_eager_step": cpu_ms,
+                   "result_hand_off": ("all-gather of batch k overlapped with batch k + 1 (dist.GatherPipeline)"
+                                       if pipe is not None else "all-gather inside the step")},
         "roofline": dict(rooflines["hard_voxelize"],
                          kernel="hard_voxelize launch sequence (vw_route + vw_group + vw_assign + vw_rows: the wave form, "
                                 "voxelize_wave.hpp; --vox-path picks another form)"),
@@ -557,8 +678,10 @@ def bench_pillars(args, rank, world, dev):
         "per_op_ms": per_op_ms,
         "detections_first_frame": int(out[1][0].item()),
     }
+    if multi:
+        line["extras"] = dict(multi)
     if world == 1 and not args.no_extras:
-        extras = {}
+        extras = line.setdefault("extras", {})
         with torch.no_grad():
             # (a) the same steps with the batch copied from pinned host memory inside every step (not overlapped)
             host = make_batch(B, 100, pin=True)
@@ -645,7 +768,6 @@ def bench_pillars(args, rank, world, dev):
                 torch.cuda.synchronize()
                 extras["pipelined_two_streams"] = dict(value=None, note=f"failed: {type(e).__name__}: {e}")
         extras["measured_ceilings"] = measured_ceilings(dev)
-        line["extras"] = extras
     if world == 1:
         if not args.no_cpu_baseline:
             try:
@@ -1078,21 +1200,49 @@ def bench_stub(args, rank, world, dev):
     lb = torch.randint(0, 10, (B, 498), generator=g)
     cnt = torch.randint(1, 498, (B,), generator=g, dtype=torch.int32)
     names = ["start", "ops_stub", "gather"]
+    pipe = pdist.GatherPipeline() if args.gather == "overlap" else None
 
-    def run(events):
+    def hand_off(rec, c):
+        if pipe is None:
+            return pdist.gather_detections(rec, c)
+        prev = pipe.submit(rec, c)
+        return prev if prev is not None else (rec, c)
+
+    def run_batch(frames, events=None):
+        """`frames`: a [b, ...] tensor standing for a batch of scenes (only its length is used)."""
+        b = frames.shape[0]
         if events is not None:
             events[0].record()
         time.sleep(0.002)  # stands for the device work of a step
         if events is not None:
             events[1].record()
-        rec = pdist.pack_records(bx, sc, lb, cnt, max_per_img)
-        out = pdist.gather_detections(rec, cnt)
+        rec = pdist.pack_records(bx[:b], sc[:b], lb[:b], cnt[:b], max_per_img)
+        out = hand_off(rec, cnt[:b])
         if events is not None:
             events[2].record()
         return out
 
-    dt, per_op_ms, out, _info = _timed_loop(run, args, world, dev, names)
+    fake = torch.zeros(B, 4)
+    finish = (lambda out: pipe.flush()) if pipe is not None else None
+    dt, per_op_ms, out, _info = _timed_loop(lambda ev: run_batch(fake, ev), args, world, dev, names, finish=finish)
     assert out[0].shape[0] == world * B and out[1].shape[0] == world * B
+    # what arrived is every rank's own record, in rank order (rank r's generator seed is 1234 + r)
+    for r in range(world):
+        gr = torch.Generator().manual_seed(1234 + r)
+        want = pdist.pack_records(torch.randn(B, 498, 9, generator=gr), torch.rand(B, 498, generator=gr),
+                                  torch.randint(0, 10, (B, 498), generator=gr),
+                                  torch.randint(1, 498, (B,), generator=gr, dtype=torch.int32), max_per_img)
+        assert torch.equal(out[0][r * B:(r + 1) * B], want), f"rank {r}'s records did not arrive intact"
+    multi = {}
+    if args.strong_frames > 0:
+        loop = dict(_LAST_LOOP)
+        flush = (lambda: pipe.flush()) if pipe is not None else None
+        multi["strong_scaling"] = strong_scaling(lambda b: run_batch(b), flush, lambda ids: torch.zeros(len(ids), 4),
+                                                 args.strong_frames, B, rank, world, dev, passes=2)
+        multi["h2d_inclusive"] = h2d_inclusive(lambda b: run_batch(b), flush, torch.zeros(B, 4), torch.zeros(B, 4),
+                                               args.steps, world, dev)
+        _LAST_LOOP.clear()
+        _LAST_LOOP.update(loop)
     if rank != 0:
         return None
     return {"metric": "scenes/sec CenterPoint-Pillars nuScenes 300k-pt sweeps", "stub": True,
@@ -1101,7 +1251,8 @@ def bench_stub(args, rank, world, dev):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "STUB: no device ops; launch / collective path only", "frames_per_gpu_per_step": B,
                        "parallelism": f"dp{world} (frames)"},
-            "per_op_ms": per_op_ms, "frames_gathered": int(out[1].shape[0])}
+            "per_op_ms": per_op_ms, "frames_gathered": int(out[1].shape[0]), "extras": multi,
+            "result_hand_off": "overlap" if pipe is not None else "sync"}
 
 
 def _self_launch(args, argv):
@@ -1141,6 +1292,12 @@ def main(argv=None):
                     "instead of launching every kernel from the host (centerpoint_pillars; same kernels and buffers)")
     ap.add_argument("--repeats", type=int, default=None, help="time the same K steps this many more times after the "
                     "contract block and report min / median / max (default 4 at N=1, 0 otherwise)")
+    ap.add_argument("--gather", choices=["overlap", "sync"], default="overlap", help="result hand-off: the all-gather "
+                    "of batch k overlapped with batch k + 1 (default) or inside the step")
+    ap.add_argument("--strong-frames", type=int, default=128, help="frames of the fixed set of the strong-scaling extra "
+                    "(sharded over the ranks by dist.shard_frames; 0 = off)")
+    ap.add_argument("--no-affinity", action="store_true", help="do not pin the ranks of an N > 1 run to the cores next "
+                    "to their GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--map-frames", type=int, default=16, help="frames of the mAP proxy in extras (device detections "
                     "scored against the oracle pipeline's; ~1 s of CPU per frame; 0 = off)")
@@ -1166,6 +1323,9 @@ def main(argv=None):
             torch.distributed.destroy_process_group()
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing "
                          "to print a line whose n_gpus would not be what was asked for")
+    affinity = None
+    if world > 1 and not args.no_affinity:
+        affinity = pdist.set_cpu_affinity(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if args.stub_ops:
         dev = torch.device("cpu")
         line = bench_stub(args, rank, world, dev)
@@ -1182,6 +1342,9 @@ def main(argv=None):
                   bevfusion_lidar=bench_bevfusion_lidar, pointpillars_kitti=bench_pointpillars_kitti)[args.workload]
         line = fn(args, rank, world, dev)
     if rank == 0:
+        if world > 1:
+            line.setdefault("config", {})["cpu_affinity_rank0"] = (
+                f"{len(affinity)} cpus {affinity[0]}-{affinity[-1]}" if affinity else "not pinned")
         print(json.dumps(_dist_fields(line, args, world)))
     if world > 1:
         torch.distributed.destroy_process_group()

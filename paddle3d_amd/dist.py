@@ -7,7 +7,12 @@ the north star asks for: ONE all-gather per batch of frames of a fixed-shape rec
     float32 [frames, max_per_img, 11] = 9 box values (7 without velocity, zero padded), score, label
 plus int32 [frames] row counts.  At ~22 KB per frame the collective is latency bound, so it is issued
 once per batch, never per frame or per task.
-`backend="nccl"` is RCCL on ROCm; tests run the same code over gloo on CPU with world_size 2.
+`backend="nccl"` is RCCL on ROCm; tests run the same code over gloo on CPU with world_size 2 and 8.
+
+`GatherPipeline` issues that all-gather asynchronously (RCCL runs it on its own stream): batch k's records travel
+while batch k + 1 is computed, the gathered result of batch k is handed out when batch k + 1 is submitted (or by
+`flush()`).  `set_cpu_affinity` pins a rank's host threads to the cores next to its GPU (eight ranks of one node
+otherwise migrate across both sockets while they enqueue ~60 launches per step).
 """
 from __future__ import annotations
 
@@ -80,3 +85,110 @@ def unpack_records(records: torch.Tensor, counts: torch.Tensor, with_velocity: b
     for rec, k in zip(records.cpu(), counts.cpu().tolist()):
         out.append(dict(box3d_lidar=rec[:k, :dims], scores=rec[:k, 9], label_preds=rec[:k, 10].to(torch.int64)))
     return out
+
+
+class GatherPipeline:
+    """The per-batch result hand-off, one batch deep: `submit(records, counts)` starts the all-gather of THIS batch
+    without waiting for it (async_op: RCCL's own stream, ordered after the producing kernels of the current stream)
+    and returns the gathered (records, counts) of the PREVIOUS batch (None the first time); `flush()` waits for the
+    batch in flight and returns it.  With one rank it degenerates to handing the tensors through one batch late, so
+    the calling code is the same for any world size.  The input tensors stay referenced until their collective has
+    completed."""
+
+    def __init__(self):
+        self._pending = None
+
+    @staticmethod
+    def _start(records, counts):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return (None, None, records, counts, records, counts)
+        world = dist.get_world_size()
+        records, counts = records.contiguous(), counts.contiguous()
+        out_r = torch.empty((world * records.shape[0],) + tuple(records.shape[1:]), dtype=records.dtype,
+                            device=records.device)
+        out_c = torch.empty((world * counts.shape[0],), dtype=counts.dtype, device=counts.device)
+        w_r = dist.all_gather_into_tensor(out_r, records, async_op=True)
+        w_c = dist.all_gather_into_tensor(out_c, counts, async_op=True)
+        return (w_r, w_c, out_r, out_c, records, counts)
+
+    @staticmethod
+    def _finish(p):
+        if p is None:
+            return None
+        w_r, w_c, out_r, out_c, _r, _c = p
+        if w_r is not None:
+            w_r.wait()  # makes the CURRENT stream wait for the collective (no host block on RCCL)
+            w_c.wait()
+        return out_r, out_c
+
+    def submit(self, records: torch.Tensor, counts: torch.Tensor):
+        prev = self._finish(self._pending)
+        self._pending = self._start(records, counts)
+        return prev
+
+    def flush(self):
+        prev, self._pending = self._finish(self._pending), None
+        return prev
+
+
+def _cpulist(text: str):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_node(local_rank: int):
+    """NUMA node of the GPU a rank drives (sysfs, by PCI address), or None when it cannot be told."""
+    try:
+        prop = torch.cuda.get_device_properties(local_rank)
+        addr = f"{getattr(prop, 'pci_domain_id', 0):04x}:{prop.pci_bus_id:02x}:{prop.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{addr}/numa_node") as f:
+            node = int(f.read().strip())
+        return node if node >= 0 else None
+    except Exception:  # noqa: BLE001 -- no GPU, an older torch, a container without sysfs
+        return None
+
+
+def plan_cpu_affinity(local_rank: int, local_world: int, allowed=None, numa_of_rank=None, node_cpus=None):
+    """CPUs for one of `local_world` ranks of a node: the cores of its GPU's NUMA node (shared evenly among the ranks
+    whose GPUs sit on that node) when the topology is known, else a contiguous 1 / local_world slice of the allowed
+    set.  Pure function of its arguments (the test feeds it a made-up topology)."""
+    allowed = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
+    if local_world <= 1 or not allowed:
+        return allowed
+    if numa_of_rank is not None and node_cpus is not None and numa_of_rank[local_rank] is not None:
+        node = numa_of_rank[local_rank]
+        mates = [r for r in range(local_world) if numa_of_rank[r] == node]
+        cpus = [c for c in node_cpus.get(node, []) if c in set(allowed)]
+        if len(cpus) >= len(mates):
+            k = mates.index(local_rank)
+            per = len(cpus) // len(mates)
+            return cpus[k * per:(k + 1) * per]
+    per = max(1, len(allowed) // local_world)
+    lo = min(local_rank * per, len(allowed) - per)
+    return allowed[lo:lo + per]
+
+
+def set_cpu_affinity(local_rank: int, local_world: int):
+    """Pin this process (and the threads it starts later) per plan_cpu_affinity; returns the CPU list it chose, or
+    None when the platform has no sched_setaffinity / the call is refused.  torch's intra-op thread count follows."""
+    try:
+        numa = [gpu_numa_node(r) for r in range(local_world)] if torch.cuda.is_available() else None
+        node_cpus = None
+        if numa and any(n is not None for n in numa):
+            node_cpus = {}
+            for n in set(x for x in numa if x is not None):
+                with open(f"/sys/devices/system/node/node{n}/cpulist") as f:
+                    node_cpus[n] = _cpulist(f.read())
+        cpus = plan_cpu_affinity(local_rank, local_world, None, numa, node_cpus)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(cpus))))
+        return cpus
+    except Exception:  # noqa: BLE001 -- affinity is an optimisation, never a requirement
+        return None

@@ -31,6 +31,34 @@ def test_self_launch_two_ranks_over_gloo():
     assert abs(line["value"] - 2 * 2 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
 
 
+def test_eight_ranks_over_gloo_with_extras():
+    """What the driver's 8-GPU run exercises, minus the device: eight ranks, CPU affinity per local rank, the
+    overlapped all-gather (every rank's records arrive intact and in rank order -- asserted inside the stub), the
+    strong-scaling pass over a fixed 32-frame set sharded by dist.shard_frames, the per-rank H2D-inclusive figure."""
+    r = _run(["--gpus", "8", "--stub-ops", "--steps", "3", "--warmup", "1", "--batch", "2", "--strong-frames", "32"],
+             timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["frames_gathered"] == 16
+    assert line["result_hand_off"] == "overlap" and line["scaling"] == "weak"
+    ss = line["extras"]["strong_scaling"]
+    assert ss["scaling"] == "strong" and ss["frames"] == 32 and ss["frames_per_rank"] == 4
+    assert ss["batches_per_rank_per_pass"] == 2 and ss["value"] > 0
+    assert line["extras"]["h2d_inclusive"]["value"] > 0
+    assert "cpu_affinity_rank0" in line["config"]
+
+
+def test_sync_gather_mode_still_works():
+    r = _run(["--gpus", "2", "--stub-ops", "--steps", "2", "--warmup", "1", "--batch", "2", "--gather", "sync",
+              "--strong-frames", "0", "--no-affinity"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["result_hand_off"] == "sync" and line["frames_gathered"] == 4 and line["extras"] == {}
+    assert line["config"]["cpu_affinity_rank0"] == "not pinned"
+
+
 def test_single_rank_line_has_launch_fields():
     r = _run(["--gpus", "1", "--stub-ops", "--steps", "2", "--warmup", "0", "--batch", "2", "--repeats", "2"])
     assert r.returncode == 0, r.stderr[-2000:]

@@ -94,3 +94,39 @@ def test_single_process_is_passthrough():
     cnt = torch.zeros(2, dtype=torch.int32)
     a, b = pdist.gather_detections(rec, cnt)
     assert a is rec and b is cnt
+
+
+def test_plan_cpu_affinity():
+    """Ranks get disjoint CPU sets: the cores of their GPU's NUMA node when the topology is known, else contiguous
+    slices; more ranks than cores on a node falls back to the slices."""
+    from paddle3d_amd import dist as pdist
+
+    flat = [pdist.plan_cpu_affinity(r, 8, range(128)) for r in range(8)]
+    assert all(len(c) == 16 for c in flat) and sorted(sum(flat, [])) == list(range(128))
+    numa = [0, 0, 0, 0, 1, 1, 1, 1]
+    nodes = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    by_node = [pdist.plan_cpu_affinity(r, 8, range(128), numa, nodes) for r in range(8)]
+    assert sorted(sum(by_node, [])) == list(range(128))
+    assert all(set(by_node[r]) <= set(nodes[numa[r]]) for r in range(8))
+    # interleaved GPU -> node map (how some boards enumerate): still disjoint, still on the right node
+    numa2 = [0, 1, 0, 1, 0, 1, 0, 1]
+    by2 = [pdist.plan_cpu_affinity(r, 8, range(128), numa2, nodes) for r in range(8)]
+    assert len(set(sum(by2, []))) == 128 and all(set(by2[r]) <= set(nodes[numa2[r]]) for r in range(8))
+    # a restricted cgroup (8 cpus allowed, all on node 0, 8 ranks): slices of the allowed set, one cpu each
+    tiny = [pdist.plan_cpu_affinity(r, 8, range(8), numa, nodes) for r in range(8)]
+    assert all(len(c) >= 1 for c in tiny)
+    assert pdist.plan_cpu_affinity(0, 1, range(4)) == [0, 1, 2, 3]
+    assert pdist._cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
+
+
+def test_gather_pipeline_single_rank_is_one_batch_late():
+    from paddle3d_amd import dist as pdist
+
+    pipe = pdist.GatherPipeline()
+    a, b = (torch.ones(2, 3, 11), torch.tensor([1, 2], dtype=torch.int32)), (torch.zeros(2, 3, 11), torch.tensor([0, 3], dtype=torch.int32))
+    assert pipe.submit(*a) is None
+    got = pipe.submit(*b)
+    assert torch.equal(got[0], a[0]) and torch.equal(got[1], a[1])
+    got = pipe.flush()
+    assert torch.equal(got[0], b[0]) and torch.equal(got[1], b[1])
+    assert pipe.flush() is None
