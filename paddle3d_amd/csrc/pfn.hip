@@ -520,58 +520,74 @@ __device__ __forceinline__ float pk_max(float x, float y) {
   return r;
 }
 
-template <int D, int CD, int NV>
-__global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
+// C1 = width of the first layer (32: PillarFeatureNet of the pillar models; 64: HardVFE of the BEVFusion LiDAR stream,
+// voxel_encoder.py:142-283 -- the same two-layer algebra with Linear(10, 64), Linear([64 | 64], 64) and up to 64 points
+// per pillar), PC = pillars per chunk (8; 4 for HardVFE, whose pillars are 256 floats each: two workgroups per CU).
+template <int D, int CD, int NV, int C1 = 32, int PC = kPkPillars>
+__global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_packed_kernel(PfnArgs a) {
   constexpr int IN = D + 3 + CD;
   static_assert(IN <= 12, "layer-1 K is padded to 12");
-  constexpr int PC = kPkPillars, YS = 34, AS = 68;
+  static_assert((C1 == 32 || C1 == 64) && (PC == 8 || PC == 4), "shapes the walk and the finishing step are written for");
+  constexpr int CB1 = C1 / 16;          // 16-column blocks of layer 1
+  constexpr int KS2 = C1 / 4;           // K steps of layer 2 (both halves of the concat)
+  constexpr int LPP = 64 / PC;          // lanes per pillar in the cluster-mean step
+  constexpr int REP = 16 / PC;          // copies of the chunk's pillars among the 16 rows of the `base` block
+  constexpr int CBF = 4 / REP;          // column blocks a lane group finishes
+  // row strides of the two LDS tiles: conflict-free for the A-operand reads (lane = (row, k group)) and the stores
+  constexpr int YS = C1 == 32 ? 34 : 68, AS = 68;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = lane_id(), wave = wave_id();
   const int r16 = lane & 15, g = lane >> 4;
   const int pd = a.p * D;  // PC * pd <= NV * 64 (dispatch)
   const int rcap = (PC * a.p + 15) & ~15;
-  const bool park_in_ln = pd >= 96;  // a pillar's 32 + 64 maxima fit the slot of its raw points
-  const int wave_floats = NV * 64 + 16 * YS + 16 * AS + PC * 8 + rcap + 16 + (park_in_ln ? 0 : PC * 96);
+  const bool park_in_ln = pd >= C1 + 64;  // a pillar's C1 + 64 maxima fit the slot of its raw points
+  const int wave_floats = NV * 64 + 16 * YS + 16 * AS + PC * 8 + rcap + 16 + (park_in_ln ? 0 : PC * (C1 + 64));
   float* ln = smem + wave * wave_floats;            // the chunk's raw pillars, [pillar][k][D]
   float* y1T = ln + NV * 64;                        // [16 rows][YS]: layer-1 output of the current block
   float* accT = y1T + 16 * YS;                      // [16 rows][AS]: y1 W2[0:32] (sign-folded) of the block
   float* sub = accT + 16 * AS;                      // [PC][8]: cluster mean xyz, pillar centre xyz, 0, count
   int* rinfo = reinterpret_cast<int*>(sub + PC * 8);  // [rcap]: pillar | k << 4 | last row << 13
   int* ends = rinfo + rcap;                         // [PC] inclusive row prefix, [PC] stored points
-  float* park = park_in_ln ? ln : reinterpret_cast<float*>(ends + 16);  // [PC][pst]: max y1 (32), max t (64)
-  const int pst = park_in_ln ? pd : 96;
-  float* w2bs = smem + 4 * wave_floats;             // [32][64]: W2[32:64], shared by the four waves
+  float* park = park_in_ln ? ln : reinterpret_cast<float*>(ends + 16);  // [PC][pst]: max y1 (C1), max t (64)
+  const int pst = park_in_ln ? pd : C1 + 64;
+  float* w2bs = smem + 4 * wave_floats;             // [C1][64]: W2[C1:2 C1], shared by the four waves
   // ---- weights and folded BatchNorm in registers ------------------------------------------------
-  float w1r[3][2], w2a[8][4], sc1[2], sh1[2], sc2m[2], sh2m[2];
+  float w1r[3][CB1], w2a[KS2][4], sc1[CB1], sh1[CB1], sc2m[CBF], sh2m[CBF];
 #pragma unroll
   for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < CB1; ++cb) {
       const int k = ks * 4 + g;
-      w1r[ks][cb] = k < IN ? a.w1[k * 32 + cb * 16 + r16] : 0.f;
+      w1r[ks][cb] = k < IN ? a.w1[k * C1 + cb * 16 + r16] : 0.f;
     }
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
     const float sg = a.scale2[cb * 16 + r16] < 0.f ? -1.f : 1.f;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) w2a[ks][cb] = a.w2[(ks * 4 + g) * 64 + cb * 16 + r16] * sg;
+    for (int ks = 0; ks < KS2; ++ks) w2a[ks][cb] = a.w2[(ks * 4 + g) * 64 + cb * 16 + r16] * sg;
   }
-  for (int i = threadIdx.x; i < 32 * 64; i += 256) w2bs[i] = a.w2[32 * 64 + i];
+  for (int i = threadIdx.x; i < C1 * 64; i += 256) w2bs[i] = a.w2[C1 * 64 + i];
   __syncthreads();
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
+  for (int cb = 0; cb < CB1; ++cb) {
     sc1[cb] = a.scale1[cb * 16 + r16];
     sh1[cb] = a.shift1[cb * 16 + r16];
-    // the finishing step: lanes of row groups 0, 1 take column blocks 0, 1, those of groups 2, 3 blocks 2, 3
-    sc2m[cb] = a.scale2[((g >> 1) * 2 + cb) * 16 + r16];
-    sh2m[cb] = a.shift2[((g >> 1) * 2 + cb) * 16 + r16];
   }
-  // the padded row (lane = channel): y1 = relu(bn1(0)), t = y1 W2[0:32] with the column's sign folded in
-  const float y1pad = fmaxf(a.shift1[lane & 31], 0.f);
+  // the finishing step: the 16 rows of the `base` block hold the chunk's PC pillars REP times; the lanes of copy
+  // `fin` (PC = 8: row groups 0, 1 -> copy 0, groups 2, 3 -> copy 1; PC = 4: group g -> copy g) take column blocks
+  // fin * CBF .. fin * CBF + CBF - 1
+  const int fin = (4 * g) / PC;
+#pragma unroll
+  for (int cb = 0; cb < CBF; ++cb) {
+    sc2m[cb] = a.scale2[(fin * CBF + cb) * 16 + r16];
+    sh2m[cb] = a.shift2[(fin * CBF + cb) * 16 + r16];
+  }
+  // the padded row (lane = channel): y1 = relu(bn1(0)), t = y1 W2[0:C1] with the column's sign folded in
+  const float y1pad = fmaxf(a.shift1[lane & (C1 - 1)], 0.f);
   float tpad = 0.f;
   {
     const float sg = a.scale2[lane] < 0.f ? -1.f : 1.f;
-    for (int c = 0; c < 32; ++c) tpad = fmaf(fmaxf(a.shift1[c], 0.f), a.w2[c * 64 + lane] * sg, tpad);
+    for (int c = 0; c < C1; ++c) tpad = fmaf(fmaxf(a.shift1[c], 0.f), a.w2[c * 64 + lane] * sg, tpad);
   }
   // this lane's A-operand features: k-step ks carries decorated feature i = 4 ks + g of the row lane & 15
   int fsrc[3], fsub[3];  // source coordinate; slot of `sub` that is subtracted (6 = the zero slot)
@@ -640,23 +656,23 @@ __global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
       a.out[(p0 + q) * 64 + lane] = 0.f;
     }
     wave_lds_order();
-    // cluster means (pillar_encoder.py:166-176; the reference divides by num_points without epsilon): eight lanes
-    // per pillar sum every eighth stored point, a three-step butterfly adds the partial sums
+    // cluster means (pillar_encoder.py:166-176; the reference divides by num_points without epsilon): LPP lanes
+    // per pillar sum every LPP-th stored point, a butterfly adds the partial sums
     {
-      const int q = lane >> 3, j = lane & 7;
+      const int q = lane / LPP, j = lane % LPP;
       const int npl = ends[PC + q];
       const float* src = ln + q * pd;
       float sx = 0.f, sy = 0.f, sz = 0.f;
-      for (int k = j; k < npl; k += 8) {
+      for (int k = j; k < npl; k += LPP) {
         sx += src[k * D + 0];
         sy += src[k * D + 1];
         sz += src[k * D + 2];
       }
 #pragma unroll
-      for (int dlt = 1; dlt < 8; dlt <<= 1) {
-        sx += __shfl_xor(sx, dlt, 8);
-        sy += __shfl_xor(sy, dlt, 8);
-        sz += __shfl_xor(sz, dlt, 8);
+      for (int dlt = 1; dlt < LPP; dlt <<= 1) {
+        sx += __shfl_xor(sx, dlt, LPP);
+        sy += __shfl_xor(sy, dlt, LPP);
+        sz += __shfl_xor(sz, dlt, LPP);
       }
       if (j < 3 && npl > 0) sub[q * 8 + j] = (j == 0 ? sx : (j == 1 ? sy : sz)) / sub[q * 8 + 7];
     }
@@ -685,9 +701,9 @@ __global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
       const unsigned endmask = (unsigned)(__ballot((info >> 13) & 1) & 0xffffull);
       const int q = info & 15, k = (info >> 4) & 255;
       // ---- layer 1 on the matrix cores; Y1 = relu(bn1(X W1)) -> y1T --------------------------------
-      pfn_f32x4 acc1[2];
+      pfn_f32x4 acc1[CB1];
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) acc1[cb] = (pfn_f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int cb = 0; cb < CB1; ++cb) acc1[cb] = (pfn_f32x4){0.f, 0.f, 0.f, 0.f};
       // rows past the chunk's last one (info = 0) read pillar 0's slot: whatever they hold stays in their own rows of
       // the products (MFMA rows are independent) and no walk reads those rows, so the loads need no predicate
       float av[3];
@@ -697,11 +713,11 @@ __global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
       for (int ks = 0; ks < 3; ++ks) {
         const float v = fzero[ks] ? 0.f : av[ks];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < CB1; ++cb)
           acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, w1r[ks][cb], acc1[cb], 0, 0, 0);
       }
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+      for (int cb = 0; cb < CB1; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           y1T[(4 * g + r) * YS + cb * 16 + r16] = fmaxf(fmaf(acc1[cb][r], sc1[cb], sh1[cb]), 0.f);
@@ -711,7 +727,7 @@ __global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) acc2[cb] = (pfn_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
+      for (int ks = 0; ks < KS2; ++ks) {
         const float av = y1T[r16 * YS + ks * 4 + g];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
@@ -727,15 +743,15 @@ __global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         tv[r] = accT[r * AS + lane];
-        yv[r] = y1T[r * YS + (lane & 31)];
+        yv[r] = y1T[r * YS + (lane & (C1 - 1))];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         m2 = pk_max(m2, tv[r]);
         m1 = pk_max(m1, yv[r]);
         if ((endmask >> r) & 1u) {
-          if (lane < 32) park[cur * pst + lane] = m1;
-          park[cur * pst + 32 + lane] = m2;
+          if (lane < C1) park[cur * pst + lane] = m1;
+          park[cur * pst + C1 + lane] = m2;
           live &= live - 1;
           cur = live ? __builtin_ctz(live) : 0;
           m1 = (notfull >> cur) & 1u ? y1pad : -INFINITY;
@@ -745,30 +761,31 @@ __global__ __launch_bounds__(256, 3) void pfn_packed_kernel(PfnArgs a) {
       wave_lds_order();  // the next block overwrites the tiles
     }
     if (live0 == 0u) continue;
-    // ---- base = max_rows(Y1) W2[32:64] (the row-independent half of the concat, PFNLayer :100-104) for the
-    // chunk's pillars as one more MFMA block: row = pillar (rows 8..15 repeat 0..7), then bn2 + ReLU once per
-    // pillar and channel: rows 0..7 (lane groups 0, 1) finish column blocks 0, 1, their repeats blocks 2, 3
+    // ---- base = max_rows(Y1) W2[C1:2 C1] (the row-independent half of the concat, PFNLayer :100-104, VFELayer
+    // :128-138) for the chunk's pillars as one more MFMA block: row = pillar (rows PC..15 repeat 0..PC-1), then bn2 +
+    // ReLU once per pillar and channel: copy `fin` of the pillars finishes column blocks fin * CBF ..
     {
       pfn_f32x4 accb[4];
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) accb[cb] = (pfn_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const float av = park[(r16 & 7) * pst + ks * 4 + g];
+      for (int ks = 0; ks < KS2; ++ks) {
+        const float av = park[(r16 & (PC - 1)) * pst + ks * 4 + g];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
           accb[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2bs[(ks * 4 + g) * 64 + cb * 16 + r16], accb[cb], 0, 0, 0);
       }
-      const int half = g >> 1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int q = (4 * g + r) & 7;
+        const int q = (4 * g + r) & (PC - 1);
         if ((live0 >> q) & 1u) {
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            const int c = (half * 2 + cb) * 16 + r16;
-            const float bs = half ? accb[2 + cb][r] : accb[cb][r];
-            const float t = park[q * pst + 32 + c];
+          for (int cb = 0; cb < CBF; ++cb) {
+            const int c = (fin * CBF + cb) * 16 + r16;
+            float bs;  // accb[fin * CBF + cb][r]: `fin` differs between lanes, so it is a select, not an index
+            if (REP == 2) bs = fin ? accb[2 + cb][r] : accb[cb][r];
+            else bs = fin == 0 ? accb[0][r] : (fin == 1 ? accb[1][r] : (fin == 2 ? accb[2][r] : accb[3][r]));
+            const float t = park[q * pst + C1 + c];
             const float x = (sc2m[cb] < 0.f ? -t : t) + bs;
             a.out[(p0 + q) * 64 + c] = fmaxf(fmaf(x, sc2m[cb], sh2m[cb]), 0.f);
           }
@@ -860,7 +877,26 @@ static int pfn_dispatch(const float* voxels, const int32_t* num_points, const in
   // packed form (path 0 picks it where it applies; path 1 = the per-pillar forms below; path 2 = this or nothing)
   const bool packed_ok = w2 && c1 == 32 && c2 == 64 && max_points <= 32 && (num_point_dim == 4 || num_point_dim == 5) &&
                          a.in_dim <= 12 && kPkPillars * max_points * num_point_dim <= 20 * 64;
-  if (path == 2 && !packed_ok) return PD3_EUNSUPPORTED;
+  // the same form for HardVFE's widths (Linear(10, 64), Linear([64 | 64], 64), up to 64 points of 4 floats): four
+  // pillars per chunk
+  const bool packed64_ok = w2 && c1 == 64 && c2 == 64 && max_points <= 64 && num_point_dim == 4 &&
+                           voxel_center_dims == 3 && a.in_dim <= 12 && 4 * max_points * num_point_dim <= 16 * 64;
+  if (path == 2 && !packed_ok && !packed64_ok) return PD3_EUNSUPPORTED;
+  if (packed64_ok && path != 1) {
+    constexpr int kPc = 4, kNv = 16, kC1 = 64;
+    const int64_t nchunks = ceil_div(num_pillars, (int64_t)kPc);
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(nchunks, 4), 256 * 2);
+    const int rcap = (kPc * max_points + 15) & ~15;
+    const size_t lds = ((size_t)4 * (kNv * 64 + 16 * 68 + 16 * 68 + kPc * 8 + rcap + 16 +
+                                     (max_points * num_point_dim >= kC1 + 64 ? 0 : kPc * (kC1 + 64))) + kC1 * 64) * sizeof(float);
+    if (lds > 48 * 1024) {
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(pfn_packed_kernel<4, 3, kNv, kC1, kPc>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e_ != hipSuccess) return (int)e_;
+    }
+    pfn_packed_kernel<4, 3, kNv, kC1, kPc><<<blocks, 256, lds, s>>>(a);
+    return launch_status();
+  }
   if (packed_ok && path != 1) {
     const int64_t nchunks = ceil_div(num_pillars, (int64_t)kPkPillars);
     const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(nchunks, 4), 256 * 3);

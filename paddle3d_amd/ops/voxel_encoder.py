@@ -51,12 +51,13 @@ def pillar_feature_net(voxels, num_points, coors, vx, vy, x_offset, y_offset, w1
     return out
 
 
-def hard_vfe(voxels, num_points, coors, voxel_size, point_cloud_range, w1, scale1, shift1, w2, scale2, shift2):
-    """HardVFE.forward (eval, with_cluster_center + with_voxel_center, two VFE layers)."""
+def hard_vfe(voxels, num_points, coors, voxel_size, point_cloud_range, w1, scale1, shift1, w2, scale2, shift2, path=0):
+    """HardVFE.forward (eval, with_cluster_center + with_voxel_center, two VFE layers).  path as in
+    pillar_feature_net (0 = the library's choice: the packed form for the 64 / 64 net of the BEVFusion config)."""
     vx, vy, vz = (float(v) for v in voxel_size)
     return pillar_feature_net(voxels, num_points, coors, vx, vy, vx / 2 + point_cloud_range[0],
                               vy / 2 + point_cloud_range[1], w1, scale1, shift1, w2, scale2, shift2, vz=vz,
-                              z_offset=vz / 2 + point_cloud_range[2], voxel_center_dims=3)
+                              z_offset=vz / 2 + point_cloud_range[2], voxel_center_dims=3, path=path)
 
 
 def voxel_mean(voxels, num_points):

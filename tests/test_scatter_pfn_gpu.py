@@ -140,8 +140,10 @@ def test_voxel_mean(oracle):
     assert np.abs(out - ref).max() < 1e-4
 
 
-def test_hard_vfe(oracle):
-    """BEVFusion LiDAR-stream encoder (C5: 0.25 m pillars, P=64, D=4) vs the torch-CPU restatement."""
+@pytest.mark.parametrize("path", [0, 1, 2])
+def test_hard_vfe(oracle, path):
+    """BEVFusion LiDAR-stream encoder (C5: 0.25 m pillars, P=64, D=4) vs the torch-CPU restatement; per-pillar
+    form (path 1) and packed form (path 2 = what path 0 picks since round 4)."""
     from paddle3d_amd.ops import voxel_encoder as ve
 
     rng = np.random.default_rng(4)
@@ -163,9 +165,51 @@ def test_hard_vfe(oracle):
     for p in params:
         s, sh = ve.fold_batchnorm(t(p["gamma"]), t(p["beta"]), t(p["mean"]), t(p["var"]), 1e-3)
         args += [t(p["weight"]), s, sh]
-    out = ve.hard_vfe(t(vox), t(npv), t(c4), vs, pr, *args).cpu().numpy()
+    out = ve.hard_vfe(t(vox), t(npv), t(c4), vs, pr, *args, path=path).cpu().numpy()
     assert out.shape == ref.shape == (nv, 64)
     assert np.abs(out - ref).max() < 1e-3, np.abs(out - ref).max()
+
+
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("p,m", [(64, 1003), (32, 517), (40, 64), (64, 3), (16, 203)])
+def test_hard_vfe_fill_levels(oracle, path, p, m):
+    """Random HardVFE pillars with every fill level 0..P (empty, one point, partial, full: up to four 16-row blocks
+    per pillar), chunks made of full pillars only, an empty chunk, pillar counts that are not a multiple of the packed
+    form's chunk of 4, BatchNorm scales of both signs and zero."""
+    from paddle3d_amd.ops import voxel_encoder as ve
+
+    rng = np.random.default_rng(p * 7 + m)
+    vs, pr = (0.25, 0.25, 8.0), (-50.0, -50.0, -5.0, 50.0, 50.0, 3.0)
+    npv = rng.integers(0, p + 1, m).astype(np.int32)
+    npv[:3] = [0, p, 1]
+    if m > 100:
+        npv[40:56] = p      # chunks of full pillars
+        npv[80:92] = 0      # chunks without any row
+        npv[100:108] = 1
+        npv[200:260] = rng.integers(1, 4, 60)   # the common case: a few points per pillar
+    vox = rng.uniform(-3, 3, (m, p, 4)).astype(np.float32)
+    vox *= (np.arange(p)[None, :, None] < npv[:, None, None])
+    c4 = np.concatenate([np.zeros((m, 1), np.int32), np.zeros((m, 1), np.int32),
+                         rng.integers(0, 400, (m, 2)).astype(np.int32)], 1)
+
+    def layer(i, o):
+        g = rng.uniform(-1.5, 1.5, o).astype(np.float32)
+        g[:3] = 0.0
+        return dict(weight=(rng.uniform(-1, 1, (i, o)) / np.sqrt(i)).astype(np.float32), gamma=g,
+                    beta=rng.normal(0, 0.2, o).astype(np.float32), mean=rng.normal(0, 0.2, o).astype(np.float32),
+                    var=rng.uniform(0.5, 1.5, o).astype(np.float32))
+
+    params = [layer(10, 64), layer(128, 64)]
+    keep = npv > 0
+    ref = oracle.hard_vfe_forward_torch(vox[keep], npv[keep], c4[keep], params, vs, pr)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    args = []
+    for q in params:
+        s, sh = ve.fold_batchnorm(t(q["gamma"]), t(q["beta"]), t(q["mean"]), t(q["var"]), 1e-3)
+        args += [t(q["weight"]), s, sh]
+    out = ve.hard_vfe(t(vox), t(npv), t(c4), vs, pr, *args, path=path).cpu().numpy()
+    assert np.all(out[~keep] == 0)
+    assert np.abs(out[keep] - ref).max() < 1e-3, np.abs(out[keep] - ref).max()
 
 
 def test_merge_sweeps(oracle):
