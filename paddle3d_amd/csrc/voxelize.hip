@@ -21,6 +21,8 @@
 // scratch (a few MB per frame) lives in L2 / Infinity Cache.
 #include "../../include/paddle3d_amd.h"
 #include "common.hpp"
+
+#include <mutex>
 #include "radix_sort.hpp"
 #include "scan.hpp"
 #include "voxelize_wave.hpp"
@@ -369,9 +371,12 @@ static bool wave_applicable(const VoxGrid& g, int64_t n, int dim, int max_pts, i
   return plan.ok && (int64_t)max_voxels * rowq < ((int64_t)1 << 24) - 4096;
 }
 
+// variant bit 0: heavy waves of the group kernel raise their issue priority; bit 1 (run_wave_split): two half batches
+// on two streams
 static int run_wave(const float* points, const int32_t* num_points, int batch, int64_t n, int dim, const VoxGrid& g,
                     int max_pts, int max_voxels, const VwPlan& plan, float* voxels, int32_t* coords,
-                    int32_t* num_pts, int32_t* num_voxels, int32_t* coors4, void* workspace, hipStream_t s) {
+                    int32_t* num_pts, int32_t* num_voxels, int32_t* coors4, void* workspace, hipStream_t s,
+                    int variant = 0, int frame0 = 0) {
   VwWorkspace w = vw_carve(workspace, batch, n, max_voxels, plan);
   VtGrid vg{g.min_x, g.min_y, g.min_z, g.size_x, g.size_y, g.size_z,
             (float)(1.0 / (double)g.size_x), (float)(1.0 / (double)g.size_y), (float)(1.0 / (double)g.size_z),
@@ -399,11 +404,12 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
 #undef PD3_VW_ROUTE
   const int tp = vw_pow2_above(plan.tiles);
   vw_group_kernel<<<(unsigned)(plan.groups * batch), kWave, vw_group_lds(plan.cpg, plan.tiles), s>>>(
-      w.recs, w.dir, plan.low, plan.gbits, plan.tiles, plan.tile, tp, batch, max_pts, w.clist, w.cap, w.flist, w.fcnt);
+      w.recs, w.dir, plan.low, plan.gbits, plan.tiles, plan.tile, tp, batch, max_pts, w.clist, w.cap, w.flist, w.fcnt,
+      (variant & 1) ? (uint32_t)std::max<int64_t>(n / plan.groups, 1) : 0u);
   const size_t lds_c = (size_t)2 * (((size_t)plan.tile + 31) / 32) * 4 + (size_t)kVwAssignCap * 8;
   vw_assign_kernel<<<(unsigned)(plan.tiles * batch), kVwAssignThreads, lds_c, s>>>(
       w.flist, w.fcnt, plan.low, plan.gbits, plan.tiles, plan.tile, tp, batch, max_voxels, vg, w.vinfo, w.totals, coords,
-      num_pts, coors4);
+      num_pts, coors4, frame0);
   const int64_t row = (int64_t)max_pts * dim;
   const bool vec4 = (row % 4 == 0) && (reinterpret_cast<uintptr_t>(voxels) % 16 == 0);
   const int rowq = (int)(vec4 ? row / 4 : row);
@@ -430,6 +436,52 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
         points, n, w.clist, w.cap, w.vinfo, w.totals, batch, units, max_voxels, rowq, step_v, step_j, dim, voxels,
         coords, num_pts, num_voxels, coors4);
   return launch_status();
+}
+
+// Two half batches on two streams (measurement form, path 12 / 13): the four kernels of a half are a chain of
+// differently bound launches (route: instruction + read stream, group / assign: latency, rows: write stream) with an
+// idle tail at every boundary; two independent chains let the hardware run one half's latency-bound kernels beside
+// the other half's streaming ones.  Fork / join by events on the caller's stream, so the op stays one unit of work
+// on that stream (and stays capturable).  Same bytes out: every frame is processed by the same kernels.
+static int run_wave_split(const float* points, const int32_t* num_points, int batch, int64_t n, int dim,
+                          const VoxGrid& g, int max_pts, int max_voxels, const VwPlan& plan, float* voxels,
+                          int32_t* coords, int32_t* num_pts, int32_t* num_voxels, int32_t* coors4, void* workspace,
+                          hipStream_t s, int variant) {
+  constexpr int kMaxDev = 16;
+  static hipStream_t side[kMaxDev] = {};
+  static hipEvent_t fork_ev[kMaxDev] = {}, join_ev[kMaxDev] = {};
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev || batch < 2)
+    return run_wave(points, num_points, batch, n, dim, g, max_pts, max_voxels, plan, voxels, coords, num_pts,
+                    num_voxels, coors4, workspace, s, variant);
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!side[dev]) {
+      if (hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&fork_ev[dev], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&join_ev[dev], hipEventDisableTiming) != hipSuccess)
+        return PD3_EINVAL;
+    }
+  }
+  const int b0 = batch / 2, b1 = batch - b0;
+  const size_t half_bytes = align_up(vw_carve(nullptr, b0, n, max_voxels, plan).bytes, 256);
+  const int64_t vrow = (int64_t)max_voxels * max_pts * dim;
+  hipError_t e = hipEventRecord(fork_ev[dev], s);
+  if (e == hipSuccess) e = hipStreamWaitEvent(side[dev], fork_ev[dev], 0);
+  if (e != hipSuccess) return (int)e;
+  int rc = run_wave(points, num_points, b0, n, dim, g, max_pts, max_voxels, plan, voxels, coords, num_pts, num_voxels,
+                    coors4, workspace, s, variant);
+  if (rc != 0) return rc;
+  rc = run_wave(points + (int64_t)b0 * n * dim, num_points ? num_points + b0 : nullptr, b1, n, dim, g, max_pts,
+                max_voxels, plan, voxels + (int64_t)b0 * vrow, coords + (int64_t)b0 * max_voxels * 3,
+                num_pts + (int64_t)b0 * max_voxels, num_voxels + b0,
+                coors4 ? coors4 + (int64_t)b0 * max_voxels * 4 : nullptr, static_cast<char*>(workspace) + half_bytes,
+                side[dev], variant, b0);
+  if (rc != 0) return rc;
+  e = hipEventRecord(join_ev[dev], side[dev]);
+  if (e == hipSuccess) e = hipStreamWaitEvent(s, join_ev[dev], 0);
+  return e == hipSuccess ? 0 : (int)e;
 }
 
 // generic path: stable radix sort of (cell, index), segment heads, flag scan in point order, voxel-parallel gather
@@ -482,8 +534,12 @@ extern "C" size_t pd3_hard_voxelize_workspace(int batch, int64_t max_points, int
                                      g.ncells, vp).bytes);
   for (int shape = -1; shape < kVwShapes; ++shape) {
     VwPlan wp;
-    if (wave_applicable(g, max_points, num_point_dim, max_num_points_in_voxel, max_voxels, batch, shape, wp))
+    if (wave_applicable(g, max_points, num_point_dim, max_num_points_in_voxel, max_voxels, batch, shape, wp)) {
       bytes = std::max(bytes, vw_carve(nullptr, batch, max_points, max_voxels, wp).bytes);
+      if (batch >= 2)  // the two-stream form carves one region per half batch
+        bytes = std::max(bytes, align_up(vw_carve(nullptr, batch / 2, max_points, max_voxels, wp).bytes, 256) +
+                                    vw_carve(nullptr, batch - batch / 2, max_points, max_voxels, wp).bytes);
+    }
   }
   return bytes;
 }
@@ -501,13 +557,26 @@ extern "C" int pd3_hard_voxelize_path(const float* points, const int32_t* num_po
   if (batch <= 0 || max_points <= 0 || max_points >= ((int64_t)1 << 31) || num_point_dim < 3 ||
       max_num_points_in_voxel <= 0 || max_voxels <= 0)
     return PD3_EINVAL;
-  if (!make_grid(voxel_size, point_cloud_range, g) || path < 0 || path > 5 + kVwShapes) return PD3_EINVAL;
+  // paths: 0 the library's choice; 1 sort; 2 / 3 tiled forms; 5 wave form; 6 .. 5 + kVwShapes wave form with a forced
+  // route-tile shape; 11 wave form + wave priorities; 12 wave form as two half batches on two streams; 13 both
+  if (!make_grid(voxel_size, point_cloud_range, g) || path < 0 || path > 13) return PD3_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t n = max_points;
   if (workspace_bytes < pd3_hard_voxelize_workspace(batch, max_points, num_point_dim, voxel_size,
                                                     point_cloud_range, max_num_points_in_voxel,
                                                     max_voxels))
     return PD3_EWORKSPACE;
+  if (path >= 11) {  // measurement variants of the wave form
+    VwPlan wp;
+    if (!wave_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, batch, -1, wp))
+      return PD3_EUNSUPPORTED;
+    const int variant = path == 11 ? 1 : (path == 12 ? 2 : 3);
+    if (variant & 2)
+      return run_wave_split(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel, max_voxels, wp,
+                            voxels, coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s, variant);
+    return run_wave(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel, max_voxels, wp, voxels,
+                    coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s, variant);
+  }
   if (path >= 5) {  // wave form: 5 = shape chosen from the sizes, 6 .. = route-kernel shape forced (measurement)
     VwPlan wp;
     if (!wave_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, batch, path - 6, wp))

@@ -202,7 +202,7 @@ __device__ __forceinline__ uint32_t vw_tile_of(const uint32_t* pre, int tp, uint
 __global__ __launch_bounds__(kWave) void vw_group_kernel(
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ dir, int low, int gbits, int tiles, int tile_len,
     int tp, int batch, int max_pts, uint32_t* __restrict__ clist, int64_t cap, uint2* __restrict__ flist,
-    uint32_t* __restrict__ fcnt) {
+    uint32_t* __restrict__ fcnt, uint32_t prio_unit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
   const int cpg = 1 << low, groups = 1 << gbits;
   uint32_t* A = reinterpret_cast<uint32_t*>(vt_smem);  // [cpg] (kept << 24) | place of the cell in the region
@@ -244,6 +244,14 @@ __global__ __launch_bounds__(kWave) void vw_group_kernel(
   if (total == 0u) {
     for (int t = lane; t < tiles; t += kWave) fcol[(int64_t)t * groups] = 0u;
     return;
+  }
+  // The kernel lasts as long as its heaviest wave (1.5x the mean records) and all waves are resident at once, four
+  // per SIMD: a wave that knows it is heavy asks the issue arbiter for more than its share while its lighter
+  // neighbours are still running (prio_unit = mean records per group; 0 = off, the round-3 behaviour).
+  if (prio_unit) {
+    if (total > prio_unit + (prio_unit >> 1)) __builtin_amdgcn_s_setprio(3);
+    else if (total > prio_unit) __builtin_amdgcn_s_setprio(2);
+    else if (total > (prio_unit >> 1)) __builtin_amdgcn_s_setprio(1);
   }
 
   const uint32_t* rf = recs + (int64_t)frame * tiles * tile_len;
@@ -431,7 +439,7 @@ constexpr int kVwAssignCap = 4096;  // records staged in voxel order (a tile tha
 __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
     const uint2* __restrict__ flist, const uint32_t* __restrict__ fcnt, int low, int gbits, int tiles, int tile_len,
     int tp, int batch, int max_voxels, VtGrid g, uint2* __restrict__ vinfo, int* __restrict__ totals,
-    int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ coors4) {
+    int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ coors4, int frame0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
   const int groups = 1 << gbits, cpg = 1 << low;
   const int words = (tile_len + 31) >> 5;
@@ -535,7 +543,8 @@ __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
     const VtInt3 c3{(int)cz, cy, cx};
     __builtin_memcpy(coords + row * 3, &c3, sizeof(c3));
     num_pts[row] = (int)kept;
-    if (coors4) *reinterpret_cast<int4*>(coors4 + row * 4) = make_int4(frame, (int)cz, cy, cx);
+    // frame0: batch index of this launch's first frame (a half batch of the two-stream form starts at batch / 2)
+    if (coors4) *reinterpret_cast<int4*>(coors4 + row * 4) = make_int4(frame0 + frame, (int)cz, cy, cx);
   };
   // pass B: records to their rank
   auto place = [&](int gi, uint2 e) {

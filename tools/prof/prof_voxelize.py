@@ -16,10 +16,13 @@ v = int(sys.argv[2]) if len(sys.argv) > 2 else 30000
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 paths = [int(p) for p in sys.argv[4].split(",")] if len(sys.argv) > 4 else [2, 3]
 shuffle = len(sys.argv) > 5 and sys.argv[5] == "shuffle"
+c4 = len(sys.argv) > 5 and sys.argv[5] == "c4"   # config 4: 0.075 m voxels on 1440 x 1440 x 40, P = 10 (pass max_voxels 160000)
 pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(100 + i, shuffle=shuffle) for i in range(batch)])).cuda()
-args = (list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), 20, v)
+P = 10 if c4 else 20
+args = ((list(synth.NUSC_VOXEL), list(synth.NUSC_VOXEL_RANGE), P, v) if c4 else
+        (list(synth.NUSC_PILLAR), list(synth.NUSC_RANGE), P, v))
 ref = voxelize.hard_voxelize_batch(pts, *args, with_batch_coors=True, path=1)
-alg = (4 * 300000 * 5 + 4 * v * 20 * 5 + 16 * v + 4) * batch
+alg = (4 * 300000 * 5 + 4 * v * P * 5 + 16 * v + 4) * batch
 for path in paths:
     for _ in range(3):
         out = voxelize.hard_voxelize_batch(pts, *args, with_batch_coors=True, path=path)
