@@ -523,7 +523,12 @@ __device__ __forceinline__ float pk_max(float x, float y) {
 // C1 = width of the first layer (32: PillarFeatureNet of the pillar models; 64: HardVFE of the BEVFusion LiDAR stream,
 // voxel_encoder.py:142-283 -- the same two-layer algebra with Linear(10, 64), Linear([64 | 64], 64) and up to 64 points
 // per pillar), PC = pillars per chunk (8; 4 for HardVFE, whose pillars are 256 floats each: two workgroups per CU).
-template <int D, int CD, int NV, int C1 = 32, int PC = kPkPillars>
+// W2G: W2[C1:2 C1] (the B operand of the `base` block, 16 KB for C1 = 64) is read from global memory / L1 instead of
+// being staged in LDS, which is what lets eight-pillar chunks of 8 KB of raw floats keep two workgroups on a CU.
+// (Tried with it and dropped: not loading the 64-float pieces behind a pillar's last stored point -- 22 of a HardVFE
+// pillar's 256 floats are stored on average -- with num_points travelling two chunks ahead; every form of the
+// conditional loads made the register allocator spill 32-219 registers at the 256 this kernel may use.)
+template <int D, int CD, int NV, int C1 = 32, int PC = kPkPillars, bool W2G = false>
 __global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_packed_kernel(PfnArgs a) {
   constexpr int IN = D + 3 + CD;
   static_assert(IN <= 12, "layer-1 K is padded to 12");
@@ -541,9 +546,10 @@ __global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_packed_kernel(PfnAr
   const int pd = a.p * D;  // PC * pd <= NV * 64 (dispatch)
   const int rcap = (PC * a.p + 15) & ~15;
   const bool park_in_ln = pd >= C1 + 64;  // a pillar's C1 + 64 maxima fit the slot of its raw points
-  const int wave_floats = NV * 64 + 16 * YS + 16 * AS + PC * 8 + rcap + 16 + (park_in_ln ? 0 : PC * (C1 + 64));
+  const int ln_floats = NV * 64;
+  const int wave_floats = ln_floats + 16 * YS + 16 * AS + PC * 8 + rcap + 16 + (park_in_ln ? 0 : PC * (C1 + 64));
   float* ln = smem + wave * wave_floats;            // the chunk's raw pillars, [pillar][k][D]
-  float* y1T = ln + NV * 64;                        // [16 rows][YS]: layer-1 output of the current block
+  float* y1T = ln + ln_floats;                      // [16 rows][YS]: layer-1 output of the current block
   float* accT = y1T + 16 * YS;                      // [16 rows][AS]: y1 W2[0:32] (sign-folded) of the block
   float* sub = accT + 16 * AS;                      // [PC][8]: cluster mean xyz, pillar centre xyz, 0, count
   int* rinfo = reinterpret_cast<int*>(sub + PC * 8);  // [rcap]: pillar | k << 4 | last row << 13
@@ -566,8 +572,11 @@ __global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_packed_kernel(PfnAr
 #pragma unroll
     for (int ks = 0; ks < KS2; ++ks) w2a[ks][cb] = a.w2[(ks * 4 + g) * 64 + cb * 16 + r16] * sg;
   }
-  for (int i = threadIdx.x; i < C1 * 64; i += 256) w2bs[i] = a.w2[C1 * 64 + i];
-  __syncthreads();
+  if (!W2G) {
+    for (int i = threadIdx.x; i < C1 * 64; i += 256) w2bs[i] = a.w2[C1 * 64 + i];
+    __syncthreads();
+  }
+  const float* w2b = W2G ? a.w2 + C1 * 64 : w2bs;
 #pragma unroll
   for (int cb = 0; cb < CB1; ++cb) {
     sc1[cb] = a.scale1[cb * 16 + r16];
@@ -768,12 +777,30 @@ __global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_packed_kernel(PfnAr
       pfn_f32x4 accb[4];
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) accb[cb] = (pfn_f32x4){0.f, 0.f, 0.f, 0.f};
+      // four K steps at a time; with W2G the sixteen B values of a group are global loads, and the loop stays rolled:
+      // all KS2 * 4 of them in flight at once would not fit the register file
+      auto base_group = [&](int ks0) {
+        float av[4], bw[4][4];
 #pragma unroll
-      for (int ks = 0; ks < KS2; ++ks) {
-        const float av = park[(r16 & (PC - 1)) * pst + ks * 4 + g];
+        for (int i = 0; i < 4; ++i) {
+          av[i] = park[(r16 & (PC - 1)) * pst + (ks0 + i) * 4 + g];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-          accb[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w2bs[(ks * 4 + g) * 64 + cb * 16 + r16], accb[cb], 0, 0, 0);
+          for (int cb = 0; cb < 4; ++cb) bw[i][cb] = w2b[((ks0 + i) * 4 + g) * 64 + cb * 16 + r16];
+        }
+        if (W2G) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb)
+            accb[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bw[i][cb], accb[cb], 0, 0, 0);
+        if (W2G) __builtin_amdgcn_sched_barrier(0);
+      };
+      if (W2G) {
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < KS2; ks0 += 4) base_group(ks0);
+      } else {
+#pragma unroll
+        for (int ks0 = 0; ks0 < KS2; ks0 += 4) base_group(ks0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -880,21 +907,23 @@ static int pfn_dispatch(const float* voxels, const int32_t* num_points, const in
   // the same form for HardVFE's widths (Linear(10, 64), Linear([64 | 64], 64), up to 64 points of 4 floats): four
   // pillars per chunk
   const bool packed64_ok = w2 && c1 == 64 && c2 == 64 && max_points <= 64 && num_point_dim == 4 &&
-                           voxel_center_dims == 3 && a.in_dim <= 12 && 4 * max_points * num_point_dim <= 16 * 64;
+                           voxel_center_dims == 3 && a.in_dim <= 12 && 8 * max_points * num_point_dim <= 32 * 64;
   if (path == 2 && !packed_ok && !packed64_ok) return PD3_EUNSUPPORTED;
   if (packed64_ok && path != 1) {
-    constexpr int kPc = 4, kNv = 16, kC1 = 64;
+    // eight pillars per chunk (8 KB of raw floats per wave), W2[64:128] from L1 instead of LDS: 75 KB per workgroup,
+    // two workgroups per CU
+    constexpr int kPc = 8, kNv = 32, kC1 = 64;
     const int64_t nchunks = ceil_div(num_pillars, (int64_t)kPc);
     const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(nchunks, 4), 256 * 2);
     const int rcap = (kPc * max_points + 15) & ~15;
     const size_t lds = ((size_t)4 * (kNv * 64 + 16 * 68 + 16 * 68 + kPc * 8 + rcap + 16 +
-                                     (max_points * num_point_dim >= kC1 + 64 ? 0 : kPc * (kC1 + 64))) + kC1 * 64) * sizeof(float);
+                                     (max_points * num_point_dim >= kC1 + 64 ? 0 : kPc * (kC1 + 64)))) * sizeof(float);
     if (lds > 48 * 1024) {
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(pfn_packed_kernel<4, 3, kNv, kC1, kPc>),
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(pfn_packed_kernel<4, 3, kNv, kC1, kPc, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e_ != hipSuccess) return (int)e_;
     }
-    pfn_packed_kernel<4, 3, kNv, kC1, kPc><<<blocks, 256, lds, s>>>(a);
+    pfn_packed_kernel<4, 3, kNv, kC1, kPc, true><<<blocks, 256, lds, s>>>(a);
     return launch_status();
   }
   if (packed_ok && path != 1) {

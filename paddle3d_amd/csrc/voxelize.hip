@@ -23,6 +23,7 @@
 #include "common.hpp"
 
 #include <mutex>
+#include <type_traits>
 #include "radix_sort.hpp"
 #include "scan.hpp"
 #include "voxelize_wave.hpp"
@@ -156,15 +157,16 @@ __global__ __launch_bounds__(256) void voxel_meta_kernel(
     const uint32_t* __restrict__ skey, const int* __restrict__ vox_start,
     const int* __restrict__ totals, int64_t n, int max_pts, int max_voxels, VoxGrid g,
     int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ num_voxels,
-    int32_t* __restrict__ coors4) {
+    int32_t* __restrict__ coors4, uint2* __restrict__ vinfo) {
   const int frame = blockIdx.y;
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   const int nv = min(totals[frame], max_voxels);
   if (v == 0) num_voxels[frame] = nv;
   if (v >= max_voxels) return;
   int cz = 0, cy = 0, cx = 0, cnt = 0;
+  int64_t s = 0;
   if (v < nv) {
-    const int64_t s = vox_start[(int64_t)frame * max_voxels + v];
+    s = vox_start[(int64_t)frame * max_voxels + v];
     const uint32_t* keyp = skey + (int64_t)frame * n;
     const uint32_t key = keyp[s];
     cx = (int)(key % (uint32_t)g.gx);
@@ -180,6 +182,9 @@ __global__ __launch_bounds__(256) void voxel_meta_kernel(
   co[1] = cy;
   co[2] = cx;
   num_pts[(int64_t)frame * max_voxels + v] = cnt;
+  // (place of the voxel's points in the sorted index list, points kept): what the slot-per-lane row writer of the
+  // wave form (vw_rows_kernel) reads -- the sorted index list is its `clist`
+  if (vinfo) vinfo[(int64_t)frame * max_voxels + v] = make_uint2((uint32_t)s, (uint32_t)cnt);
   if (coors4) {
     int32_t* c4 = coors4 + ((int64_t)frame * max_voxels + v) * 4;
     c4[0] = v < nv ? frame : -1;
@@ -210,6 +215,7 @@ static bool make_grid(const float* voxel_size, const float* range, VoxGrid& g) {
 struct VoxWorkspace {
   uint32_t *keys_a, *vals_a, *keys_b, *vals_b;
   int *mark, *vox_start, *hist, *partial, *totals;
+  uint2* vinfo;
   size_t bytes;
 };
 
@@ -228,6 +234,7 @@ static VoxWorkspace carve(void* base, int batch, int64_t n, int max_voxels, cons
       (size_t)std::max(scan_num_tiles((int64_t)radix_hist_ints(plan)), scan_num_tiles(n));
   w.partial = c.take<int>((size_t)batch * scan_tiles);
   w.totals = c.take<int>((size_t)batch);
+  w.vinfo = c.take<uint2>((size_t)batch * max_voxels);
   w.bytes = c.off;
   return w;
 }
@@ -504,14 +511,36 @@ static int run_sort_path(const T* points, const int32_t* num_points, int batch, 
   EpiVoxelStart epi{w.mark, w.vox_start, n, max_voxels};
   enqueue_exclusive_scan(w.mark, n, n, batch, w.partial, w.totals, (int*)nullptr, LoadNonNegative{},
                          epi, s);
-  const int64_t per_frame = (int64_t)max_voxels * max_num_points_in_voxel * num_point_dim;
+  dim3 mgrid((unsigned)ceil_div(max_voxels, 256), batch);
+  // fp32 points of 4 / 5 floats: the fixed-shape rows are written by the wave form's slot-per-lane row writer (one
+  // index load, the point's 16 + 4 bytes, the same two streaming stores; a wave writes 64 * D * 4 contiguous bytes),
+  // with the sorted index list as its `clist`.  The float-per-thread gather it replaces here spent 205 us per 8
+  // frames of config 4 (1.25 TB/s) on three divisions and three dependent loads per output float.
+  const int64_t slots = (int64_t)max_voxels * max_num_points_in_voxel;
+  if constexpr (std::is_same<T, float>::value) {
+    if ((num_point_dim == 4 || num_point_dim == 5) && slots < ((int64_t)1 << 24) - 4096) {
+      voxel_meta_kernel<<<mgrid, 256, 0, s>>>(skey, w.vox_start, w.totals, n, max_num_points_in_voxel, max_voxels, g,
+                                              coords, num_points_per_voxel, num_voxels, coors_batched, w.vinfo);
+      const int sunits = (int)ceil_div(slots, kVwRowsThreads);
+      if (num_point_dim == 4)
+        vw_rows_kernel<4><<<(unsigned)(sunits * batch), kVwRowsThreads, 0, s>>>(
+            points, n, sidx, n, w.vinfo, w.totals, batch, sunits, max_voxels, max_num_points_in_voxel, voxels, coords,
+            num_points_per_voxel, num_voxels, coors_batched);
+      else
+        vw_rows_kernel<5><<<(unsigned)(sunits * batch), kVwRowsThreads, 0, s>>>(
+            points, n, sidx, n, w.vinfo, w.totals, batch, sunits, max_voxels, max_num_points_in_voxel, voxels, coords,
+            num_points_per_voxel, num_voxels, coors_batched);
+      return launch_status();
+    }
+  }
+  const int64_t per_frame = slots * num_point_dim;
   dim3 ggrid((unsigned)ceil_div(per_frame, 256), batch);
   gather_voxels_kernel<T><<<ggrid, 256, 0, s>>>(points, skey, sidx, w.vox_start, w.totals, n,
                                                 num_point_dim, max_num_points_in_voxel, max_voxels,
                                                 voxels);
-  dim3 mgrid((unsigned)ceil_div(max_voxels, 256), batch);
   voxel_meta_kernel<<<mgrid, 256, 0, s>>>(skey, w.vox_start, w.totals, n, max_num_points_in_voxel,
-                                          max_voxels, g, coords, num_points_per_voxel, num_voxels, coors_batched);
+                                          max_voxels, g, coords, num_points_per_voxel, num_voxels, coors_batched,
+                                          nullptr);
   return launch_status();
 }
 

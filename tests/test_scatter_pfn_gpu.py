@@ -186,7 +186,7 @@ def test_hard_vfe_fill_levels(oracle, path, p, m):
         npv[40:56] = p      # chunks of full pillars
         npv[80:92] = 0      # chunks without any row
         npv[100:108] = 1
-        npv[200:260] = rng.integers(1, 4, 60)   # the common case: a few points per pillar
+        npv[200:260] = rng.integers(1, 4, len(npv[200:260]))   # the common case: a few points per pillar
     vox = rng.uniform(-3, 3, (m, p, 4)).astype(np.float32)
     vox *= (np.arange(p)[None, :, None] < npv[:, None, None])
     c4 = np.concatenate([np.zeros((m, 1), np.int32), np.zeros((m, 1), np.int32),
