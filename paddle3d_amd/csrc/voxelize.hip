@@ -26,7 +26,7 @@
 #include <type_traits>
 #include "radix_sort.hpp"
 #include "scan.hpp"
-#include "voxelize_wave.hpp"
+#include "voxelize_wave3d.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -349,11 +349,14 @@ struct VwWorkspace {
   uint32_t *recs, *dir, *clist, *fcnt;
   uint2 *vinfo, *flist;
   int* totals;
+  uint32_t *gregion, *aux;  // 3-D form only
   int64_t cap;
   size_t bytes;
 };
 
-static VwWorkspace vw_carve(void* base, int batch, int64_t n, int max_voxels, const VwPlan& p) {
+// three_d (voxelize_wave3d.hpp): first-point lists sized by the points ([frame][N], in the groups' regions) instead
+// of [group][cells per group], + the region starts and the per-record word of the multi-pass groups
+static VwWorkspace vw_carve(void* base, int batch, int64_t n, int max_voxels, const VwPlan& p, bool three_d = false) {
   Carver c(base);
   VwWorkspace w;
   w.cap = n;
@@ -362,10 +365,19 @@ static VwWorkspace vw_carve(void* base, int batch, int64_t n, int max_voxels, co
   w.clist = c.take<uint32_t>((size_t)batch * w.cap + 4);
   w.vinfo = c.take<uint2>((size_t)batch * max_voxels);
   w.totals = c.take<int>((size_t)batch);
-  w.flist = c.take<uint2>((size_t)batch * p.groups * p.cpg);
+  w.flist = c.take<uint2>(three_d ? (size_t)batch * w.cap + 4 : (size_t)batch * p.groups * p.cpg);
   w.fcnt = c.take<uint32_t>((size_t)batch * vw_pow2_above(p.tiles) * p.groups);
+  w.gregion = three_d ? c.take<uint32_t>((size_t)batch * p.groups) : nullptr;
+  w.aux = three_d ? c.take<uint32_t>((size_t)batch * w.cap + 4) : nullptr;
   w.bytes = c.off;
   return w;
+}
+
+static bool wave3d_applicable(const VoxGrid& g, int64_t n, int dim, int max_pts, int max_voxels, int batch, int shape,
+                              VwPlan& plan) {
+  plan = v3_plan(g.ncells, n, max_pts, batch, shape);
+  // (the slot-per-lane row writer: D = 4 / 5, voxel * slot below 2^24)
+  return plan.ok && (dim == 4 || dim == 5) && (int64_t)max_voxels * max_pts < ((int64_t)1 << 24) - 4096;
 }
 
 constexpr int kVwShapes = 5;
@@ -383,8 +395,8 @@ static bool wave_applicable(const VoxGrid& g, int64_t n, int dim, int max_pts, i
 static int run_wave(const float* points, const int32_t* num_points, int batch, int64_t n, int dim, const VoxGrid& g,
                     int max_pts, int max_voxels, const VwPlan& plan, float* voxels, int32_t* coords,
                     int32_t* num_pts, int32_t* num_voxels, int32_t* coors4, void* workspace, hipStream_t s,
-                    int variant = 0, int frame0 = 0) {
-  VwWorkspace w = vw_carve(workspace, batch, n, max_voxels, plan);
+                    int variant = 0, int frame0 = 0, bool three_d = false) {
+  VwWorkspace w = vw_carve(workspace, batch, n, max_voxels, plan, three_d);
   VtGrid vg{g.min_x, g.min_y, g.min_z, g.size_x, g.size_y, g.size_z,
             (float)(1.0 / (double)g.size_x), (float)(1.0 / (double)g.size_y), (float)(1.0 / (double)g.size_z),
             g.gx, g.gy, g.gz, g.ncells};
@@ -400,7 +412,8 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);             \
     if (e_ != hipSuccess) return (int)e_;                                                                          \
     vw_route_kernel<T, R><<<tile_grid, T, lds_a, s>>>(points, num_points, n, dim, vg, plan.low, plan.gbits,        \
-                                                      plan.tiles, batch, max_voxels, w.recs, w.dir, w.vinfo);      \
+                                                      plan.tiles, batch, max_voxels, w.recs, w.dir, w.vinfo,       \
+                                                      three_d ? 1 : 0);                                            \
   } while (0)
   if (plan.threads == 512 && plan.rounds == 8) PD3_VW_ROUTE(512, 8);
   else if (plan.threads == 1024 && plan.rounds == 8) PD3_VW_ROUTE(1024, 8);
@@ -410,13 +423,18 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
   else return PD3_EINVAL;
 #undef PD3_VW_ROUTE
   const int tp = vw_pow2_above(plan.tiles);
-  vw_group_kernel<<<(unsigned)(plan.groups * batch), kWave, vw_group_lds(plan.cpg, plan.tiles), s>>>(
-      w.recs, w.dir, plan.low, plan.gbits, plan.tiles, plan.tile, tp, batch, max_pts, w.clist, w.cap, w.flist, w.fcnt,
-      (variant & 1) ? (uint32_t)std::max<int64_t>(n / plan.groups, 1) : 0u);
+  if (three_d)
+    v3_group_kernel<<<(unsigned)(plan.groups * batch), kWave, v3_group_lds(plan.tiles), s>>>(
+        w.recs, w.dir, plan.gbits, plan.tiles, plan.tile, tp, batch, max_pts, w.clist, w.cap, w.flist, w.fcnt,
+        w.gregion, w.aux);
+  else
+    vw_group_kernel<<<(unsigned)(plan.groups * batch), kWave, vw_group_lds(plan.cpg, plan.tiles), s>>>(
+        w.recs, w.dir, plan.low, plan.gbits, plan.tiles, plan.tile, tp, batch, max_pts, w.clist, w.cap, w.flist,
+        w.fcnt, (variant & 1) ? (uint32_t)std::max<int64_t>(n / plan.groups, 1) : 0u);
   const size_t lds_c = (size_t)2 * (((size_t)plan.tile + 31) / 32) * 4 + (size_t)kVwAssignCap * 8;
   vw_assign_kernel<<<(unsigned)(plan.tiles * batch), kVwAssignThreads, lds_c, s>>>(
       w.flist, w.fcnt, plan.low, plan.gbits, plan.tiles, plan.tile, tp, batch, max_voxels, vg, w.vinfo, w.totals, coords,
-      num_pts, coors4, frame0);
+      num_pts, coors4, frame0, three_d ? w.gregion : nullptr, w.cap);
   const int64_t row = (int64_t)max_pts * dim;
   const bool vec4 = (row % 4 == 0) && (reinterpret_cast<uintptr_t>(voxels) % 16 == 0);
   const int rowq = (int)(vec4 ? row / 4 : row);
@@ -570,6 +588,11 @@ extern "C" size_t pd3_hard_voxelize_workspace(int batch, int64_t max_points, int
                                     vw_carve(nullptr, batch - batch / 2, max_points, max_voxels, wp).bytes);
     }
   }
+  for (int shape = -1; shape < 3; ++shape) {
+    VwPlan wp;
+    if (wave3d_applicable(g, max_points, num_point_dim, max_num_points_in_voxel, max_voxels, batch, shape, wp))
+      bytes = std::max(bytes, vw_carve(nullptr, batch, max_points, max_voxels, wp, true).bytes);
+  }
   return bytes;
 }
 
@@ -587,14 +610,22 @@ extern "C" int pd3_hard_voxelize_path(const float* points, const int32_t* num_po
       max_num_points_in_voxel <= 0 || max_voxels <= 0)
     return PD3_EINVAL;
   // paths: 0 the library's choice; 1 sort; 2 / 3 tiled forms; 5 wave form; 6 .. 5 + kVwShapes wave form with a forced
-  // route-tile shape; 11 wave form + wave priorities; 12 wave form as two half batches on two streams; 13 both
-  if (!make_grid(voxel_size, point_cloud_range, g) || path < 0 || path > 13) return PD3_EINVAL;
+  // route-tile shape; 11 wave form + wave priorities; 12 wave form as two half batches on two streams; 13 both;
+  // 14 the wave form for 3-D grids (voxelize_wave3d.hpp; 15 / 16: its route tile forced to 8192 / 10240 points)
+  if (!make_grid(voxel_size, point_cloud_range, g) || path < 0 || path > 16) return PD3_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t n = max_points;
   if (workspace_bytes < pd3_hard_voxelize_workspace(batch, max_points, num_point_dim, voxel_size,
                                                     point_cloud_range, max_num_points_in_voxel,
                                                     max_voxels))
     return PD3_EWORKSPACE;
+  if (path >= 14) {
+    VwPlan wp;
+    if (!wave3d_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, batch, path == 14 ? -1 : path - 14, wp))
+      return PD3_EUNSUPPORTED;
+    return run_wave(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel, max_voxels, wp, voxels,
+                    coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s, 0, 0, true);
+  }
   if (path >= 11) {  // measurement variants of the wave form
     VwPlan wp;
     if (!wave_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, batch, -1, wp))
@@ -613,11 +644,14 @@ extern "C" int pd3_hard_voxelize_path(const float* points, const int32_t* num_po
     return run_wave(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel, max_voxels, wp, voxels,
                     coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s);
   }
-  if (path == 0) {  // the library's choice: wave form, else the tiled gather form, else the sort path
+  if (path == 0) {  // the library's choice: wave form (2-D, else 3-D), else the tiled gather form, else the sort path
     VwPlan wp;
     if (wave_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, batch, -1, wp))
       return run_wave(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel, max_voxels, wp, voxels,
                       coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s);
+    if (wave3d_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, batch, -1, wp))
+      return run_wave(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel, max_voxels, wp, voxels,
+                      coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s, 0, 0, true);
   }
   {
     VtPlan vp;

@@ -80,7 +80,9 @@ template <int THREADS, int R>
 __global__ __launch_bounds__(THREADS, 8) void vw_route_kernel(
     const float* __restrict__ points, const int32_t* __restrict__ num_points, int64_t n, int dim, VtGrid g, int low,
     int gbits, int tiles, int batch, int max_voxels, uint32_t* __restrict__ recs, uint32_t* __restrict__ dir,
-    uint2* __restrict__ vinfo) {
+    uint2* __restrict__ vinfo, int in_tile_index) {
+  // in_tile_index (the 3-D form, voxelize_wave3d.hpp): the record carries the point's index INSIDE its tile (< 2^14)
+  // above `low` = 18 cell bits; the tile is what the group kernel's directory search finds anyway
   constexpr int kTile = THREADS * R;
   constexpr int kWaves = THREADS / kWave;
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
@@ -159,7 +161,8 @@ __global__ __launch_bounds__(THREADS, 8) void vw_route_kernel(
   for (int r = 0; r < R; ++r) {
     const uint32_t k = key[r];
     const int64_t i = wave_base + r * kWave + lane;
-    if (k != 0xFFFFFFFFu) stage[cnt[k >> low] + ord[r]] = ((uint32_t)i << low) | (k & low_mask);
+    const uint32_t iw = in_tile_index ? (uint32_t)(wave * (R * kWave) + r * kWave + lane) : (uint32_t)i;
+    if (k != 0xFFFFFFFFu) stage[cnt[k >> low] + ord[r]] = (iw << low) | (k & low_mask);
   }
   __syncthreads();
   // phase 4: the slice leaves as one coalesced run
@@ -439,9 +442,14 @@ constexpr int kVwAssignCap = 4096;  // records staged in voxel order (a tile tha
 __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
     const uint2* __restrict__ flist, const uint32_t* __restrict__ fcnt, int low, int gbits, int tiles, int tile_len,
     int tp, int batch, int max_voxels, VtGrid g, uint2* __restrict__ vinfo, int* __restrict__ totals,
-    int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ coors4, int frame0) {
+    int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ coors4, int frame0,
+    const uint32_t* __restrict__ gregion, int64_t cap) {
+  // gregion != nullptr (the 3-D form): a group's list of first points lies at flist[frame * cap + gregion[frame][group]]
+  // (sized by the group's records) instead of at a fixed [groups][cells per group] place, and cell keys may exceed
+  // 2^24 (exact integer division instead of the float estimate)
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
   const int groups = 1 << gbits, cpg = 1 << low;
+
   const int words = (tile_len + 31) >> 5;
   uint32_t* bits = reinterpret_cast<uint32_t*>(vt_smem);     // [words]
   uint32_t* wpre = bits + words;                             // [words] first points of the tile before word w
@@ -451,6 +459,10 @@ __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
   int frame, tile;
   vt_unit(blockIdx.x, (uint32_t)tiles, (uint32_t)batch, frame, tile);
   const uint32_t* fc = fcnt + (int64_t)frame * tp * groups;
+  auto list_of = [&](int gi) -> const uint2* {
+    return gregion ? flist + (int64_t)frame * cap + gregion[(int64_t)frame * groups + gi]
+                   : flist + ((int64_t)frame * groups + gi) * cpg;
+  };
   for (int w = threadIdx.x; w < words; w += kVwAssignThreads) bits[w] = 0u;
   __syncthreads();
   // per group (thread g, g + 512 with 1024 groups; with fewer groups than threads several threads share one):
@@ -492,7 +504,7 @@ __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
   for (int q = 0; q < kGpt; ++q) {
     const int gi = group_of(q);
     const uint32_t c = gi < groups ? gcnt[q] : 0u;
-    const uint2* fl = flist + ((int64_t)frame * groups + min(gi, groups - 1)) * cpg + goff[q];
+    const uint2* fl = list_of(min(gi, groups - 1)) + goff[q];
 #pragma unroll
     for (int k = 0; k < kHold; ++k) held[q][k] = c ? fl[min((uint32_t)k, c - 1u)] : make_uint2(0u, 0u);
 #pragma unroll
@@ -536,9 +548,9 @@ __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
     const int64_t row = (int64_t)frame * max_voxels + vid;
     const uint32_t kept = word >> 24;
     vinfo[row] = make_uint2(word & 0xFFFFFFu, kept);
-    const uint32_t t = vt_div(key, (uint32_t)g.gx, inv_gx);
+    const uint32_t t = gregion ? key / (uint32_t)g.gx : vt_div(key, (uint32_t)g.gx, inv_gx);
     const int cx = (int)(key - t * (uint32_t)g.gx);
-    const uint32_t cz = vt_div(t, (uint32_t)g.gy, inv_gy);
+    const uint32_t cz = gregion ? t / (uint32_t)g.gy : vt_div(t, (uint32_t)g.gy, inv_gy);
     const int cy = (int)(t - cz * (uint32_t)g.gy);
     const VtInt3 c3{(int)cz, cy, cx};
     __builtin_memcpy(coords + row * 3, &c3, sizeof(c3));
@@ -562,7 +574,7 @@ __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
 #pragma unroll
     for (int k = 0; k < kHold; ++k)
       if ((uint32_t)k < c) place(gi, held[q][k]);
-    const uint2* fl = flist + ((int64_t)frame * groups + gi) * cpg + goff[q];
+    const uint2* fl = list_of(gi) + goff[q];
     for (uint32_t k0 = kHold; k0 < c; k0 += 8) {
       uint2 e[8];
 #pragma unroll

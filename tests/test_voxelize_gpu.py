@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 PATH = 0  # pd3_hard_voxelize_path selector of the running parametrisation (0 automatic, 1 generic sort path, ...)
 
 
-@pytest.fixture(params=["auto", "sort", "tiled", "gather", "wave", "wave_s1", "wave_s2", "wave_prio_split"], autouse=True)
+@pytest.fixture(params=["auto", "sort", "tiled", "gather", "wave", "wave_s1", "wave_s2", "wave_prio_split", "wave3d"], autouse=True)
 def vox_path(request):
     """Every test runs on the automatic path choice, with the generic sort path forced, and with each form of the
     tiled path forced (2 = payload copied into a compact array, 3 = rows gathered through an index list, 5 = the
@@ -22,7 +22,7 @@ def vox_path(request):
     # 13 = the wave form with both round-4 measurement variants on: heavy waves of the group kernel at raised issue
     # priority, the batch as two half batches on two streams (the batch index of coors_batched continues across them)
     PATH = {"auto": 0, "sort": 1, "tiled": 2, "gather": 3, "wave": 5, "wave_s1": 7, "wave_s2": 8,
-            "wave_prio_split": 13}[request.param]
+            "wave_prio_split": 13, "wave3d": 14}[request.param]  # 14: the wave form for 3-D grids (hash tables per group)
     yield request.param
     PATH = 0
 
@@ -243,3 +243,30 @@ def test_float64_points(oracle, name):
     cpu_out = voxelize.hard_voxelize(torch.from_numpy(pts), list(vs), list(pr), p, v, path=PATH)  # CPU in -> CPU out
     assert not cpu_out[0].is_cuda and torch.equal(cpu_out[0], vox.cpu())
 
+
+
+def test_wave3d_heavy_group(oracle):
+    """The multi-pass branch of the 3-D wave form (voxelize_wave3d.hpp): a 512 x 512 x 16 grid (2^22 cells, 4096
+    possible cells per group) with two groups far over the 768 cells a hash pass takes -- one with 2500 occupied cells
+    of 1 .. 14 points (three passes of eight fit), one with 1530 single-point cells (765 per pass expected, so a pass
+    overflows and the pass count doubles from the start) -- inside 20 000 background points, shuffled.  Bit-exact
+    against the oracle like every other input; paths that do not take the grid skip."""
+    rng = np.random.default_rng(77)
+    gx, gy, gz, vs = 512, 512, 16, 0.25
+    pr = (-64.0, -64.0, -2.0, 64.0, 64.0, 2.0)
+    keys = []
+    for g0, ncell, reps in ((5, 2500, (1, 15)), (9, 1530, (1, 2))):
+        L = rng.choice(4096, ncell, replace=False).astype(np.int64)
+        lo = (g0 - 37 * L) & 1023
+        k = L * 1024 + lo
+        keys.append(np.repeat(k, rng.integers(reps[0], reps[1], ncell)))
+    keys = np.concatenate(keys)
+    cx, cy, cz = keys % gx, (keys // gx) % gy, keys // (gx * gy)
+    jit = rng.uniform(0.2, 0.8, (len(keys), 3))
+    heavy = np.stack([pr[0] + (cx + jit[:, 0]) * vs, pr[1] + (cy + jit[:, 1]) * vs, pr[2] + (cz + jit[:, 2]) * vs], 1)
+    bg = np.stack([rng.uniform(-70, 70, 20000), rng.uniform(-70, 70, 20000), rng.uniform(-2.5, 2.5, 20000)], 1)
+    pts = np.concatenate([heavy, bg]).astype(np.float32)
+    pts = np.concatenate([pts, rng.uniform(0, 1, (len(pts), 2)).astype(np.float32)], 1)
+    rng.shuffle(pts, axis=0)
+    nv = _check(oracle, np.ascontiguousarray(pts), (vs, vs, vs), pr, 10, 30000)
+    assert nv > 10000
