@@ -646,9 +646,11 @@ extern "C" int pd3_hard_voxelize_path(const float* points, const int32_t* num_po
   }
   if (path == 0) {  // the library's choice: wave form (2-D, else 3-D), else the tiled gather form, else the sort path
     VwPlan wp;
+    // (heavy group waves at raised issue priority: 112.8-116.2 against 113.1-122.1 us per 16 frames in four A/B pairs
+    //  on two boxes, profiles/r04_vox_paths.txt; path 5 is the same without it)
     if (wave_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, batch, -1, wp))
       return run_wave(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel, max_voxels, wp, voxels,
-                      coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s);
+                      coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s, 1);
     if (wave3d_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, batch, -1, wp))
       return run_wave(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel, max_voxels, wp, voxels,
                       coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s, 0, 0, true);

@@ -32,6 +32,7 @@ constexpr int kV3Gbits = 10;        // 1024 groups per frame
 constexpr int kV3Low = 18;          // cell-in-group bits of a record; 14 bits of in-tile index above them
 constexpr int kV3Slots = 1024;      // hash slots per wave: keys, places, counters = 12 KB
 constexpr int kV3Load = 768;        // distinct cells a pass may hold
+constexpr int kV3RegSteps = 12;     // groups of up to 768 records keep (tile, record, hash slot) in registers
 constexpr uint32_t kV3Empty = 0xFFFFFFFFu;
 constexpr uint32_t kV3CellMask = (1u << kV3Low) - 1u;
 
@@ -49,7 +50,9 @@ static inline VwPlan v3_plan(uint32_t ncells, int64_t n, int max_pts, int batch,
   if (pick < 0 || pick >= 3) {
     pick = 0;
     for (int k = 1; k < 3; ++k)
-      if (ceil_div(n, (int64_t)shapes[k].threads * shapes[k].rounds) * batch >= 384) pick = k;
+      // (measured on 8 frames of config 4: 10240-point tiles 141.8 us, 4096-point tiles 148.5 us -- the group and assign
+      //  kernels walk a directory column per group, so fewer, longer tiles win as long as the route kernel covers the chip)
+      if (ceil_div(n, (int64_t)shapes[k].threads * shapes[k].rounds) * batch >= 192) pick = k;
   }
   p.threads = shapes[pick].threads;
   p.rounds = shapes[pick].rounds;
@@ -135,85 +138,143 @@ __global__ __launch_bounds__(kWave) void v3_group_kernel(
     nfirst += (uint32_t)__popcll(m);
   };
 
+  // claim / find the slot of `cell` (linear probing); a claim that takes a free slot counts in `ndist`
+  auto insert = [&](uint32_t cell, bool act, uint32_t& ndist) -> uint32_t {
+    uint32_t h = slot_of(cell);
+    bool pend = act;
+    while (__ballot(pend)) {
+      uint32_t old = cell;
+      if (pend) old = atomicCAS(&K[h], kV3Empty, cell);
+      ndist += (uint32_t)__popcll(__ballot(pend && old == kV3Empty));
+      if (pend && (old == kV3Empty || old == cell)) pend = false;
+      if (pend) h = (h + 1u) & (uint32_t)(kV3Slots - 1);
+    }
+    return h;
+  };
+  // slots -> places in the group's region, behind the earlier passes' (any order will do: the list is scratch)
+  auto place_cells = [&](uint32_t& kept_base) {
+    uint32_t cnt[kV3Slots / kWave];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < kV3Slots / kWave; ++j) {
+      cnt[j] = min(B[lane + j * kWave], P);
+      sum += cnt[j];
+    }
+    const uint32_t inc = (uint32_t)wave_inclusive_scan((int)sum);
+    uint32_t at = kept_base + inc - sum;
+#pragma unroll
+    for (int j = 0; j < kV3Slots / kWave; ++j) {
+      A[lane + j * kWave] = (cnt[j] << 24) | at;
+      B[lane + j * kWave] = 0u;
+      at += cnt[j];
+    }
+    kept_base += (uint32_t)__shfl((int)inc, kWave - 1, kWave);
+  };
+  // a record whose cell sits in slot h: its slot in the cell (returning add: ONE instruction per step, lane order =
+  // stream order), its entry of the index list; returns the word its first-point record carries, kV3Empty if it is
+  // not a first point
+  auto emit = [&](uint32_t t, uint32_t w, uint32_t h, bool act) -> uint32_t {
+    const uint32_t slot = atomicAdd(&B[act ? h : (uint32_t)lane], act ? 1u : 0u);  // idle lanes: + 0 on a word of their own
+    const uint32_t info = A[h];
+    const uint32_t place = info & 0xFFFFFFu;
+    if (act && slot < P) cl[place + slot] = t * (uint32_t)tile_len + (w >> kV3Low);
+    return act && slot == 0u ? (region + place) | (info & 0xFF000000u) : kV3Empty;
+  };
+
   int kbits = 0;
   while ((total >> kbits) > (uint32_t)kV3Load) ++kbits;
-  for (;;) {
-    bool overflow = false;
-    uint32_t kept_base = 0;
-    const int npass = 1 << kbits;
-    for (int p = 0; p < npass && !overflow; ++p) {
-      for (int c = lane; c < kV3Slots; c += kWave) {
-        K[c] = kV3Empty;
-        B[c] = 0u;
-      }
-      vt_wave_sync();
-      // sweep 1: the pass's cells claim slots; records per cell
-      uint32_t ndist = 0;  // wave-uniform
-      for (int s = 0; s < nsteps && !overflow; ++s) {
-        uint32_t t, w;
-        const bool valid = load(s, t, w);
-        const uint32_t cell = w & kV3CellMask;
-        const bool act = valid && pass_of(cell, kbits) == (uint32_t)p;
-        uint32_t h = slot_of(cell);
-        bool pend = act;
-        while (__ballot(pend)) {
-          uint32_t old = cell;
-          if (pend) old = atomicCAS(&K[h], kV3Empty, cell);
-          ndist += (uint32_t)__popcll(__ballot(pend && old == kV3Empty));
-          if (pend && (old == kV3Empty || old == cell)) pend = false;
-          if (pend) h = (h + 1u) & (uint32_t)(kV3Slots - 1);
-        }
-        if (act) atomicAdd(&B[h], 1u);
-        overflow = ndist > (uint32_t)kV3Load;  // (<= 768 + 64 slots are taken at this point: probing always ends)
-      }
-      if (overflow) break;
-      vt_wave_sync();
-      // slots -> places in the group's region, behind the earlier passes' (any order will do: the list is scratch)
-      {
-        uint32_t cnt[kV3Slots / kWave];
-        uint32_t sum = 0;
-#pragma unroll
-        for (int j = 0; j < kV3Slots / kWave; ++j) {
-          cnt[j] = min(B[lane + j * kWave], P);
-          sum += cnt[j];
-        }
-        const uint32_t inc = (uint32_t)wave_inclusive_scan((int)sum);
-        uint32_t at = kept_base + inc - sum;
-#pragma unroll
-        for (int j = 0; j < kV3Slots / kWave; ++j) {
-          A[lane + j * kWave] = (cnt[j] << 24) | at;
-          B[lane + j * kWave] = 0u;
-          at += cnt[j];
-        }
-        kept_base += (uint32_t)__shfl((int)inc, kWave - 1, kWave);
-      }
-      vt_wave_sync();
-      // sweep 2: slots (returning adds, one instruction per step: lane order = stream order), the index list, and
-      // the first points -- straight into the list when this is the only pass, else parked per record
-      for (int s = 0; s < nsteps; ++s) {
-        uint32_t t, w;
-        const bool valid = load(s, t, w);
-        const uint32_t cell = w & kV3CellMask;
-        const bool act = valid && pass_of(cell, kbits) == (uint32_t)p;
-        uint32_t h = slot_of(cell);
-        bool pend = act;
-        while (__ballot(pend)) {  // the cell is in the table
-          const uint32_t k = K[h];
-          if (pend && k == cell) pend = false;
-          if (pend) h = (h + 1u) & (uint32_t)(kV3Slots - 1);
-        }
-        const uint32_t slot = atomicAdd(&B[act ? h : (uint32_t)lane], act ? 1u : 0u);  // idle lanes: + 0 on a word of their own
-        const uint32_t info = A[h];
-        const uint32_t place = info & 0xFFFFFFu;
-        if (act && slot < P) cl[place + slot] = t * (uint32_t)tile_len + (w >> kV3Low);
-        const uint32_t word = (region + place) | (info & 0xFF000000u);
-        if (kbits == 0) announce(act && slot == 0u, t, w, word);
-        else if (act) ax[(uint32_t)s * kWave + (uint32_t)lane] = slot == 0u ? word : kV3Empty;
-      }
-      vt_wave_sync();
+  if (kbits == 0 && nsteps <= kV3RegSteps) {
+    // the usual case (config 4: 266 +- 40 records per group): one pass, tiles / records / hash slots of all steps stay
+    // in registers between the sweeps; all directory searches advance level by level together, then all loads
+    for (int c = lane; c < kV3Slots; c += kWave) {
+      K[c] = kV3Empty;
+      B[c] = 0u;
     }
-    if (!overflow) break;
-    ++kbits;  // some pass held more than 768 cells: twice as many passes, from the start (every write is repeated)
+    uint32_t tt[kV3RegSteps], ww[kV3RegSteps], hh[kV3RegSteps];
+#pragma unroll
+    for (int k = 0; k < kV3RegSteps; ++k) tt[k] = 0u;
+    for (int st = tp >> 1; st > 0; st >>= 1) {
+#pragma unroll
+      for (int k = 0; k < kV3RegSteps; ++k)
+        if (k < nsteps) {
+          const uint32_t r = (uint32_t)k * kWave + (uint32_t)lane;
+          if (pre[tt[k] + (uint32_t)st] <= (r < total ? r : 0u)) tt[k] += (uint32_t)st;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kV3RegSteps; ++k) {
+      ww[k] = 0u;
+      if (k < nsteps) {
+        const uint32_t r = (uint32_t)k * kWave + (uint32_t)lane, rr = r < total ? r : 0u;
+        ww[k] = rf[tsrc[tt[k]] + (rr - pre[tt[k]])];
+      }
+    }
+    vt_wave_sync();
+    uint32_t ndist = 0;
+#pragma unroll
+    for (int k = 0; k < kV3RegSteps; ++k) {
+      hh[k] = 0u;
+      if (k < nsteps) {
+        const bool act = (uint32_t)k * kWave + (uint32_t)lane < total;
+        hh[k] = insert(ww[k] & kV3CellMask, act, ndist);
+        if (act) atomicAdd(&B[hh[k]], 1u);
+      }
+    }
+    vt_wave_sync();
+    uint32_t kept_base = 0;
+    place_cells(kept_base);
+    vt_wave_sync();
+#pragma unroll
+    for (int k = 0; k < kV3RegSteps; ++k)
+      if (k < nsteps) {
+        const bool act = (uint32_t)k * kWave + (uint32_t)lane < total;
+        const uint32_t word = emit(tt[k], ww[k], hh[k], act);
+        announce(word != kV3Empty, tt[k], ww[k], word);
+      }
+  } else {
+    for (;;) {
+      bool overflow = false;
+      uint32_t kept_base = 0;
+      const int npass = 1 << kbits;
+      for (int p = 0; p < npass && !overflow; ++p) {
+        for (int c = lane; c < kV3Slots; c += kWave) {
+          K[c] = kV3Empty;
+          B[c] = 0u;
+        }
+        vt_wave_sync();
+        // sweep 1: the pass's cells claim slots; records per cell
+        uint32_t ndist = 0;  // wave-uniform
+        for (int s = 0; s < nsteps && !overflow; ++s) {
+          uint32_t t, w;
+          const bool valid = load(s, t, w);
+          const uint32_t cell = w & kV3CellMask;
+          const bool act = valid && pass_of(cell, kbits) == (uint32_t)p;
+          const uint32_t h = insert(cell, act, ndist);
+          if (act) atomicAdd(&B[h], 1u);
+          overflow = ndist > (uint32_t)kV3Load;  // (<= 768 + 64 slots are taken at this point: probing always ends)
+        }
+        if (overflow) break;
+        vt_wave_sync();
+        place_cells(kept_base);
+        vt_wave_sync();
+        // sweep 2: slots, the index list, and the first points -- straight into the list when this is the only pass,
+        // else parked per record
+        for (int s = 0; s < nsteps; ++s) {
+          uint32_t t, w;
+          const bool valid = load(s, t, w);
+          const uint32_t cell = w & kV3CellMask;
+          const bool act = valid && pass_of(cell, kbits) == (uint32_t)p;
+          uint32_t nd = 0;
+          const uint32_t h = insert(cell, act, nd);  // finds the slot claimed in sweep 1 (nothing is free on its way)
+          const uint32_t word = emit(t, w, h, act);
+          if (kbits == 0) announce(word != kV3Empty, t, w, word);
+          else if (act) ax[(uint32_t)s * kWave + (uint32_t)lane] = word;
+        }
+        vt_wave_sync();
+      }
+      if (!overflow) break;
+      ++kbits;  // some pass held more than 768 cells: twice as many passes, from the start (every write is repeated)
+    }
   }
   if (kbits > 0) {  // the parked first points, in stream order
     for (int s = 0; s < nsteps; ++s) {

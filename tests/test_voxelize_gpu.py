@@ -270,3 +270,27 @@ def test_wave3d_heavy_group(oracle):
     rng.shuffle(pts, axis=0)
     nv = _check(oracle, np.ascontiguousarray(pts), (vs, vs, vs), pr, 10, 30000)
     assert nv > 10000
+
+
+def test_wave3d_batch_ragged_coors(oracle):
+    """The 3-D wave form on a ragged batch of three frames of the 0.075 m grid (1440 x 1440 x 40) with the batched
+    coors output: every frame equals the oracle's run on its own points, padding rows carry batch -1."""
+    from paddle3d_amd.ops import voxelize
+
+    frames = [synth.nuscenes_sweep(30 + i, n_points=60000) for i in range(3)]
+    lens = [60000, 41234, 1]
+    pts = torch.from_numpy(np.stack(frames)).cuda()
+    num = torch.tensor(lens, dtype=torch.int32).cuda()
+    out = _unsupported_ok(voxelize.hard_voxelize_batch, pts, list(synth.NUSC_VOXEL), list(synth.NUSC_VOXEL_RANGE), 10,
+                          40000, num_points=num, with_batch_coors=True, path=PATH)
+    vox, co, npv, nv, c4 = out
+    torch.cuda.synchronize()
+    c4 = c4.cpu().numpy().reshape(3, 40000, 4)
+    for b in range(3):
+        rv, rc, rn, rnv = oracle.hard_voxelize(frames[b][: lens[b]], synth.NUSC_VOXEL, synth.NUSC_VOXEL_RANGE, 10, 40000)
+        assert int(nv[b]) == rnv
+        np.testing.assert_array_equal(co[b].cpu().numpy(), rc)
+        np.testing.assert_array_equal(npv[b].cpu().numpy(), rn)
+        np.testing.assert_array_equal(vox[b].cpu().numpy().view(np.uint32), rv.view(np.uint32))
+        assert (c4[b, :rnv, 0] == b).all() and (c4[b, rnv:, 0] == -1).all()
+        np.testing.assert_array_equal(c4[b, :rnv, 1:], rc[:rnv])
