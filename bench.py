@@ -490,6 +490,8 @@ def bench_pillars(args, rank, world, dev):
     V, B = args.max_voxels, args.batch
     model = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(V, V)).to(dev).eval()
     model.voxelizer.path = args.vox_path
+    amp = args.workload == "centerpoint_pillars_amp"
+    model.set_amp(amp)
     pts = make_batch(B, 100 + B * rank, dev)
     cfg = model.test_cfg
     max_per_img = cfg["max_per_img"]
@@ -672,10 +674,12 @@ def bench_pillars(args, rank, world, dev):
                                      "FPN levels run direct GEMMs, all fp32; direct_form_tflops = 127.2 GFLOP/scene "
                                      "/ time (may exceed the peak: fewer multiplies are issued than counted)"))
     line = {
-        "metric": "scenes/sec CenterPoint-Pillars nuScenes 300k-pt sweeps",
+        "metric": ("scenes/sec CenterPoint-Pillars nuScenes 300k-pt sweeps" +
+                   (" (AMP O2: fp16 matrix cores in the stride-1 convolutions)" if amp else "")),
         "value": world * B * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16 x f16 -> f32 (dense 3x3 stride 1), f32 elsewhere" if amp else "f32",
+        "data": "synthetic",
         "config": {"workload": "CenterPoint-Pillars nuScenes 10-sweep: 300000 pts x 5 per scene, 0.2 m pillars "
                                f"(512x512), P=20, max_voxels={V}, batch {B} distinct scenes/GPU/step, random-init "
                                "weights, full graph voxelize->PFN->scatter->SECOND+FPN->CenterHead->postprocess"
@@ -694,6 +698,31 @@ def bench_pillars(args, rank, world, dev):
         "per_op_ms": per_op_ms,
         "detections_first_frame": int(out[1][0].item()),
     }
+    if amp:
+        # what the mixed-precision graph costs in accuracy on this batch: head maps against the fp32 graph's, and the
+        # detections of the two graphs scored against each other on the mAP scale (the fp32 graph as the annotations)
+        from paddle3d_amd import nuscenes_bridge as nb
+
+        with torch.no_grad():
+            def maps_and_dets(flag):
+                model.set_amp(flag)
+                canvas = model.extract_pillars(pts, dense=False)
+                preds, _ = model.bbox_head(model.dense_forward(canvas))
+                dets = model.bbox_head.predict_by_custom_op(preds, cfg)
+                return preds, [{k: d[k].cpu().numpy() for k in ("box3d_lidar", "scores", "label_preds")} for d in dets]
+
+            p16, d16 = maps_and_dets(True)
+            p32, d32 = maps_and_dets(False)
+            model.set_amp(True)
+            err = max(float((a[k].float() - b[k].float()).abs().max()) for a, b in zip(p16, p32) for k in a)
+            mag = max(float(b[k].float().abs().max()) for b in p32 for k in b)
+        line["amp_error"] = dict(head_maps_max_abs=err, head_maps_max_magnitude=mag,
+                                 map_proxy_vs_fp32=nb.nuscenes_style_map(d16, d32)["mAP"],
+                                 note="fp16 activations and weights, fp32 accumulation; random-init weights")
+        for k in ("dense_backbone_fpn_head",):
+            rooflines[k]["note"] = ("AMP: the stride-1 3x3 layers run direct-form on the fp16 matrix cores (peak 2.5 "
+                                    "PFLOP/s); achieved / frac here are still priced against the fp32 peak with the "
+                                    "fp32 graph's executed-flop count and are not a utilisation figure for this mode")
     if multi:
         line["extras"] = dict(multi)
     if world == 1 and not args.no_extras:
@@ -897,7 +926,8 @@ def other_workloads(args, rank, world, dev):
     import copy
 
     out = {}
-    todo = [("pointpillars_kitti", bench_pointpillars_kitti, 16), ("centerpoint_voxel", bench_voxel, 8),
+    todo = [("centerpoint_pillars_amp", bench_pillars, 16),
+            ("pointpillars_kitti", bench_pointpillars_kitti, 16), ("centerpoint_voxel", bench_voxel, 8),
             ("bevfusion_lidar", bench_bevfusion_lidar, 16), ("bev_pool_v2", bench_bev_pool, 1)]
     for name, fn, batch in todo:
         a = copy.copy(args)
@@ -915,6 +945,9 @@ def other_workloads(args, rank, world, dev):
                              rooflines={k: dict(bound=v["bound"], frac=v.get("frac")) for k, v in
                                         line.get("rooflines", {}).items()},
                              per_op_ms=line["per_op_ms"])
+            for extra in ("amp_error", "dtype"):
+                if extra in line:
+                    out[name][extra] = line[extra]
         except Exception as e:  # noqa: BLE001 -- reported extras, never required for the headline
             out[name] = dict(error=f"{type(e).__name__}: {e}")
         torch.cuda.synchronize()
@@ -1300,8 +1333,8 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 16; 8 for centerpoint_voxel; 32 gives the headline workload +2 %% scenes/s)")
     ap.add_argument("--max-voxels", type=int, default=30000)
     ap.add_argument("--workload", default="centerpoint_pillars",
-                    choices=["centerpoint_pillars", "centerpoint_voxel", "bev_pool_v2", "bevfusion_lidar",
-                             "pointpillars_kitti"])
+                    choices=["centerpoint_pillars", "centerpoint_pillars_amp", "centerpoint_voxel", "bev_pool_v2",
+                             "bevfusion_lidar", "pointpillars_kitti"])
     ap.add_argument("--vox-path", type=int, default=0, help="pd3_hard_voxelize_path selector (0 = library default, "
                     "1 generic sort, 2 tiled with a compact payload array, 3 tiled with gathered rows, 5 wave form)")
     ap.add_argument("--graph", action="store_true", help="replay the step as five captured HIP graphs (one per op) "
@@ -1354,7 +1387,8 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
         torch.manual_seed(0)
-        fn = dict(centerpoint_pillars=bench_pillars, centerpoint_voxel=bench_voxel, bev_pool_v2=bench_bev_pool,
+        fn = dict(centerpoint_pillars=bench_pillars, centerpoint_pillars_amp=bench_pillars,
+                  centerpoint_voxel=bench_voxel, bev_pool_v2=bench_bev_pool,
                   bevfusion_lidar=bench_bevfusion_lidar, pointpillars_kitti=bench_pointpillars_kitti)[args.workload]
         line = fn(args, rank, world, dev)
     if rank == 0:

@@ -434,6 +434,26 @@ int pd3_conv3x3_winograd43_bias_relu(const float *x, const float *u_packed, cons
                                      int channels_per_tile, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * conv3x3_f16_bias_relu -- the stride-1 3x3 / pad 1 convolutions of SecondBackbone and CenterHead in MIXED PRECISION:
+ * fp16 activations and weights on the fp16 matrix cores, fp32 accumulation, bias + ReLU fused.  The reference's AMP
+ * configuration of the model (configs/centerpoint/centerpoint_pillars_02voxel_nuscenes_10sweep_ampO2_ultra.yml:5-9,
+ * `amp_cfg: level O2`, cuDNN fp16 convolutions there); an option of the host classes (`model.set_amp(True)`), never the
+ * fp32 default.
+ *   x            [batch, h, w, cin] fp16 NHWC (16-byte aligned; pd3_f32_nchw_to_f16_nhwc makes it from an fp32 map)
+ *   w_packed_f16 [cout / T][cin / 16][9 taps][T][16] fp16, T = channels_per_tile (paddle3d_amd/ops/conv.py:
+ *                pack_conv3x3_f16_weight), bias [cout] fp32 or NULL
+ *   out          out_mode 0: [batch, h, w, cout] fp16 NHWC (the next fp16 layer's input);
+ *                out_mode 1: [batch, cout, h, w] fp32 NCHW (what the fp32 kernels of the graph read)
+ *   channels_per_tile 128 (workgroup = 128 channels x 16 rows x 32 columns) or 64 (64 channels x 32 rows x 32 columns)
+ *   requires cin % 16 == 0, cout % T == 0, w % 32 == 0, h % (16 | 32) == 0; else PD3_EUNSUPPORTED (the caller runs fp32)
+ */
+int pd3_conv3x3_f16_bias_relu(const void *x_f16_nhwc, const void *w_packed_f16, const float *bias, int batch, int cin,
+                              int cout, int h, int w, int relu, void *out, int out_mode, int channels_per_tile,
+                              void *stream);
+/* x [batch, channels, h, w] fp32 NCHW -> out [batch, h, w, channels] fp16 NHWC (round to nearest even) */
+int pd3_f32_nchw_to_f16_nhwc(const float *x, int batch, int channels, int h, int w, void *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * grouped_conv3x3_small -- grouped 3x3 / stride 1 / pad 1 convolution with 1..4 output channels per group and
  * bias, no activation: the final convolutions of all SeparateHead branches (center_head.py:99-118) as one
  * launch over the concatenated first-stage maps.

@@ -297,6 +297,20 @@ class _Conv3x3:
         raise Paddle3DAmdError(f"conv3x3: unsupported configuration (cin {self.cin}, cout {self.cout}, stride "
                                f"{self.stride}, input {h}x{wv}) (status -3)")
 
+    def f16_ok(self, h, w):
+        return self.stride == 1 and _conv.f16_supported(self.cin, self.cout, int(h), int(w))
+
+    def f16(self, x_h, out_f32_nchw=False, out=None, tiles=None):
+        """The same layer in mixed precision (AMP): x_h [n, h, w, cin] fp16 NHWC -> fp16 NHWC, or fp32 NCHW for the
+        fp32 kernels behind a chain.  tiles = (first, last) channel tile of the packed weight (the head's slices)."""
+        if "f16" not in self.packed:
+            self.packed["f16"] = _conv.pack_conv3x3_f16_weight(self.w)
+        wp, b, cout = self.packed["f16"], self.b, self.cout
+        if tiles is not None:
+            t = int(wp.shape[3])
+            wp, b, cout = wp[tiles[0]:tiles[1]], self.b[tiles[0] * t:tiles[1] * t], (tiles[1] - tiles[0]) * t
+        return _conv.conv3x3_f16_bias_relu(x_h, wp, b, cout, relu=True, out_f32_nchw=out_f32_nchw, out=out)
+
 
 def _valid_w(t) -> int:
     """Real width of a feature map (its rows may be zero-padded to a multiple of 4)."""
@@ -332,6 +346,7 @@ class SecondBackbone(_InferenceCache, nn.Module):
                 block += _conv_bn_relu(out_channels[i], out_channels[i], 3, padding=1)
             blocks.append(nn.Sequential(*block))
         self.blocks = nn.ModuleList(blocks)
+        self.amp = False  # True: the stride-1 layers run on the fp16 matrix cores (the reference's amp_cfg O2 configs)
 
     def _plan(self):
         if not self._cache_valid():
@@ -362,11 +377,27 @@ class SecondBackbone(_InferenceCache, nn.Module):
                                    "multiple of 4) (status -3)")
         outs, wv = [], (0 if first is not None else int(x.shape[3]))
         for bi, layers in enumerate(plan):
-            for li, conv in enumerate(layers):
+            li = 0
+            while li < len(layers):
+                conv = layers[li]
                 if first is not None and bi == 0 and li == 0:
                     x, wv = first
-                else:
-                    x, wv = conv(x, wv)
+                    li += 1
+                    continue
+                # mixed precision (set_amp): a run of stride-1 layers the fp16 kernel takes travels as fp16 NHWC --
+                # one conversion in front, the last layer of the run writes fp32 NCHW for the kernels behind it
+                run = li
+                while (self.amp and run < len(layers) and wv == x.shape[3]
+                       and layers[run].f16_ok(x.shape[2], x.shape[3])):
+                    run += 1
+                if run > li:
+                    xh = _conv.to_f16_nhwc(x)
+                    for k in range(li, run):
+                        xh = layers[k].f16(xh, out_f32_nchw=(k == run - 1))
+                    x, li = xh, run
+                    continue
+                x, wv = conv(x, wv)
+                li += 1
             outs.append(_tag_valid_w(x, wv))
         return tuple(outs)
 
@@ -473,6 +504,7 @@ class CenterHead(_InferenceCache, nn.Module):
         # branches per slice of the head (0 = automatic: see forward)
         self.head_chunk = 0
         self.head_chunk_bytes = 1 << 30
+        self.amp = False  # True: shared + first-stage convolutions on the fp16 matrix cores (CenterPoint.set_amp)
         self.tasks = nn.ModuleList()
         for ncls in self.num_classes:
             heads = dict(common_heads)
@@ -515,8 +547,16 @@ class CenterHead(_InferenceCache, nn.Module):
         if x.shape[3] % 4:
             raise Paddle3DAmdError(f"CenterHead: unsupported configuration (map width {x.shape[3]} is not a multiple "
                                    "of 4) (status -3)")
-        x, _ = f["shared"](x)
-        n, _, h, w = (int(v) for v in x.shape)
+        amp = (self.amp and f["shared"].f16_ok(x.shape[2], x.shape[3])
+               and f["first"].f16_ok(x.shape[2], x.shape[3]) and f["hc"] == 64)
+        if amp:
+            # mixed precision: shared convolution and the 36 first-stage convolutions on the fp16 matrix cores (fp16
+            # NHWC between them); the first stage writes fp32 NCHW for the grouped final convolutions, which stay fp32
+            x = f["shared"].f16(_conv.to_f16_nhwc(x))
+            n, h, w, _ = (int(v) for v in x.shape)
+        else:
+            x, _ = f["shared"](x)
+            n, _, h, w = (int(v) for v in x.shape)
         if not _conv.grouped_small_supported(f["hc"], f["cmax"], h, w):
             raise Paddle3DAmdError(f"grouped_conv3x3_small: unsupported configuration ({f['hc']} -> {f['cmax']} "
                                    f"channels per group, map {(h, w)}) (status -3)")
@@ -528,6 +568,21 @@ class CenterHead(_InferenceCache, nn.Module):
         # lose more than the cache gives, so a map above head_chunk_bytes is cut in two and no further.
         full = n * f["hc"] * h * w * 4 * groups
         k = self.head_chunk if self.head_chunk else ((groups + 1) // 2 if full > self.head_chunk_bytes else groups)
+        if amp:
+            k = k + (k & 1) if k < groups else groups  # slices of whole 128-channel tiles (two branches each)
+            z = torch.empty((n, groups * f["cmax"], h, w), dtype=torch.float32, device=x.device)
+            buf = torch.empty((n * min(k, groups) * 64 * h * w,), dtype=torch.float32, device=x.device)
+            per = _conv.f16_tile(first.cout) // 64
+            for c0 in range(0, groups, k):
+                c1 = min(c0 + k, groups)
+                y = buf[: n * (c1 - c0) * 64 * h * w].view(n, (c1 - c0) * 64, h, w)
+                first.f16(x, out_f32_nchw=True, out=y, tiles=(c0 // per, c1 // per))
+                _conv.grouped_conv3x3_small(y, f["pf"][c0:c1], f["bf"][c0 * f["cmax"]:c1 * f["cmax"]], c1 - c0, out=z,
+                                            out_groups=groups, out_group0=c0)
+            rets = [dict() for _ in self.tasks]
+            for g, (t, head) in enumerate(f["plan"]):
+                rets[t][head] = z[:, g * f["cmax"]:g * f["cmax"] + f["ncls"][g]]
+            return rets, x
         chunked = (k < groups and f["hc"] == 64 and first.stride == 1 and _conv.winograd43_supported(first.cin, first.cout, h, w)
                    and w % 4 == 0)
         if chunked:
@@ -610,6 +665,18 @@ class CenterPoint(nn.Module):
     def invalidate(self):
         """Rebuild every folded / packed weight on the next forward (after a write through `param.data`)."""
         invalidate_derived(self)
+        return self
+
+    def set_amp(self, enabled: bool = True):
+        """Mixed precision for the dense graph, the reference's `amp_cfg: level O2` configurations
+        (configs/centerpoint/centerpoint_pillars_02voxel_nuscenes_10sweep_ampO2_ultra.yml:5-9): the stride-1 3x3
+        convolutions of the backbone and the head (98 % of the graph's multiplies) run on the fp16 matrix cores with fp32
+        accumulation (csrc/conv_f16.hip), fp16 NHWC activations between them; the stride-2 convolutions, the FPN, the
+        final head convolutions, the front half and the post-processing stay fp32.  Off by default; layers the fp16
+        kernel does not take (maps that are not a multiple of 32 wide) stay fp32."""
+        for m in (self.backbone, self.bbox_head):
+            if hasattr(m, "amp"):
+                m.amp = bool(enabled)
         return self
 
     def _pack(self, points):

@@ -11,7 +11,8 @@ from ._common import check, lib, ptr, require_gpu, stream_ptr
 __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pitch4", "pack_grouped_weight", "grouped_conv3x3_small",
            "grouped_small_supported", "winograd_supported", "pack_winograd_weight", "conv3x3_winograd_bias_relu",
            "patch_mode", "patch_supported", "pack_patch_weight", "patch_conv_bias_relu",
-           "winograd43_supported", "winograd43_tile", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu"]
+           "winograd43_supported", "winograd43_tile", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu",
+           "f16_supported", "f16_tile", "pack_conv3x3_f16_weight", "conv3x3_f16_bias_relu", "to_f16_nhwc"]
 
 
 def pitch4(w: int) -> int:
@@ -212,4 +213,50 @@ def grouped_conv3x3_small(x: torch.Tensor, w_grouped: torch.Tensor, bias, groups
     check(lib().pd3_grouped_conv3x3_small_slice(ptr(xx), ptr(w_grouped), ptr(bias), n, groups, cg, co, h, w, ptr(out),
                                                 total, int(out_group0), stream_ptr(xx.device)),
           "grouped_conv3x3_small")
+    return out
+
+
+# ---- mixed precision (AMP): the stride-1 3x3 layers on the fp16 matrix cores (csrc/conv_f16.hip) -----------------------
+def f16_tile(cout: int) -> int:
+    """Output channels per workgroup of pd3_conv3x3_f16_bias_relu: 128 where the layer allows, else 64."""
+    return 128 if cout % 128 == 0 else 64
+
+
+def f16_supported(cin: int, cout: int, h: int, w: int) -> bool:
+    t = f16_tile(cout)
+    return cin % 16 == 0 and cout % t == 0 and w % 32 == 0 and h % (16 if t == 128 else 32) == 0
+
+
+def pack_conv3x3_f16_weight(weight: torch.Tensor, tile: int | None = None) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] fp32 -> fp16 [Cout/T][Cin/16][9 taps (dy*3+dx)][T co][16 ci]: a 16-channel chunk of a
+    workgroup's weights is one contiguous piece, a lane's A operand (8 consecutive ci of one co) 16 aligned bytes."""
+    cout, cin = weight.shape[:2]
+    t = f16_tile(cout) if tile is None else tile
+    assert weight.shape[2:] == (3, 3) and cout % t == 0 and cin % 16 == 0 and t in (64, 128)
+    w = weight.to(torch.float16).reshape(cout // t, t, cin // 16, 16, 9).permute(0, 2, 4, 1, 3)
+    return w.contiguous()
+
+
+def to_f16_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """[n, c, h, w] fp32 NCHW -> [n, h, w, c] fp16 NHWC on the device (pd3_f32_nchw_to_f16_nhwc)."""
+    xx = require_gpu(x, "f32_nchw_to_f16_nhwc")
+    n, c, h, w = xx.shape
+    out = torch.empty((n, h, w, c), dtype=torch.float16, device=xx.device)
+    check(lib().pd3_f32_nchw_to_f16_nhwc(ptr(xx), n, c, h, w, ptr(out), stream_ptr(xx.device)), "f32_nchw_to_f16_nhwc")
+    return out
+
+
+def conv3x3_f16_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, relu: bool = True,
+                          out_f32_nchw: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
+    """x [n, h, w, cin] fp16 NHWC -> [n, h, w, cout] fp16 NHWC, or (out_f32_nchw) [n, cout, h, w] fp32 NCHW."""
+    if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous():
+        raise RuntimeError("conv3x3_f16_bias_relu: x must be a contiguous fp16 NHWC tensor on the GPU")
+    n, h, w, cin = x.shape
+    tile = int(w_packed.shape[3])
+    if out is None:
+        out = (torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device) if out_f32_nchw
+               else torch.empty((n, h, w, cout), dtype=torch.float16, device=x.device))
+    check(lib().pd3_conv3x3_f16_bias_relu(ptr(x), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
+                                          ptr(out), 1 if out_f32_nchw else 0, tile, stream_ptr(x.device)),
+          "conv3x3_f16_bias_relu")
     return out

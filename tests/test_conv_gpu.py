@@ -281,3 +281,47 @@ def test_scatter_fused_into_stride2_conv(ny, nx, batch):
     assert got.shape == want.shape
     assert torch.equal(got, want)
     assert torch.equal(ps.SparseCanvas(feats, coords, batch, ny, nx).dense(), canvas)
+
+
+# ---- mixed precision: the fp16 matrix-core form of the stride-1 layers (csrc/conv_f16.hip) -----------------------------
+@pytest.mark.parametrize("out_f32", [False, True])
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 32, 64), (32, 64, 64, 32), (128, 256, 16, 32), (16, 64, 32, 96),
+                                          (48, 384, 48, 32)])
+def test_conv3x3_f16_matches_fp32_math_on_fp16_operands(cin, cout, h, w, out_f32):
+    """v_mfma_f32_32x32x16_f16 accumulates in fp32, so on operands that are already fp16 values the kernel must agree
+    with an fp32 convolution of the same values to accumulation-order noise -- which pins the whole layout (A / B
+    fragment order, tap order, channel tiles of 128 and 64, NHWC and NCHW epilogues, image borders) on asymmetric data."""
+    import torch.nn.functional as F
+
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator(device="cuda").manual_seed(cin * 1000 + cout + h)
+    x = torch.randn(2, cin, h, w, device="cuda", generator=g)
+    wt = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, device="cuda", generator=g)
+    xh = conv.to_f16_nhwc(x)
+    assert torch.equal(xh, x.half().permute(0, 2, 3, 1).contiguous())  # round to nearest even, NHWC
+    assert conv.f16_supported(cin, cout, h, w)
+    ref = F.relu(F.conv2d(x.half().float().cpu(), wt.half().float().cpu(), b.cpu(), padding=1)).cuda()  # torch CPU fp32
+    got = conv.conv3x3_f16_bias_relu(xh, conv.pack_conv3x3_f16_weight(wt), b, cout, relu=True, out_f32_nchw=out_f32)
+    if out_f32:
+        assert got.shape == ref.shape and got.dtype == torch.float32
+        assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+    else:
+        assert got.shape == (2, h, w, cout) and got.dtype == torch.float16
+        err = (got.float().permute(0, 3, 1, 2) - ref).abs().max().item()
+        assert err < 2e-3 * max(1.0, ref.abs().max().item())  # + the fp16 rounding of the stored result
+    # no ReLU, no bias
+    got2 = conv.conv3x3_f16_bias_relu(xh, conv.pack_conv3x3_f16_weight(wt), None, cout, relu=False, out_f32_nchw=True)
+    ref2 = F.conv2d(x.half().float().cpu(), wt.half().float().cpu(), None, padding=1).cuda()
+    assert (got2 - ref2).abs().max().item() < 2e-4 * max(1.0, ref2.abs().max().item())
+
+
+def test_conv3x3_f16_refuses_shapes_it_does_not_take():
+    from paddle3d_amd._lib import Paddle3DAmdError
+    from paddle3d_amd.ops import conv
+
+    assert not conv.f16_supported(64, 64, 180, 180) and not conv.f16_supported(8, 64, 32, 32)
+    x = torch.zeros(1, 20, 32, 64, dtype=torch.float16, device="cuda")  # w % 32 != 0 as NHWC [1, 20, 32, 64]: h = 20
+    with pytest.raises(Paddle3DAmdError, match="status -3"):
+        conv.conv3x3_f16_bias_relu(x, torch.zeros(1, 4, 9, 64, 16, dtype=torch.float16, device="cuda"), None, 64)

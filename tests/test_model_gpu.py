@@ -449,3 +449,40 @@ def test_map_proxy_64_frames(oracle):
     # and the other way round (the oracle's detections scored against the device's): symmetric evidence
     back = nb.nuscenes_style_map(ref, dev)
     assert back["mAP"] >= 0.999, back
+
+
+def test_amp_graph_close_to_fp32():
+    """set_amp(True): the stride-1 3x3 layers of backbone and head on the fp16 matrix cores (the reference's amp_cfg O2
+    configuration) -- head maps stay within fp16's resolution of the fp32 graph's, and the detections of the two
+    graphs (spread heat maps, see test_map_proxy_64_frames) agree on the mAP scale."""
+    from paddle3d_amd import centerpoint as cpm
+    from paddle3d_amd import nuscenes_bridge as nb
+
+    torch.manual_seed(12)
+    model = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(30000, 30000)).cuda().eval()
+    _randomise_bn(model)
+    with torch.no_grad():
+        for task in model.bbox_head.tasks:
+            task.hm[-1].weight.mul_(30.0)
+            task.hm[-1].bias.fill_(-3.0)
+    pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(400 + i) for i in range(4)])).cuda()
+
+    def run(flag):
+        model.set_amp(flag)
+        with torch.no_grad():
+            canvas = model.extract_pillars(pts, dense=False)
+            feats = model.dense_forward(canvas)
+            preds, _ = model.bbox_head(feats)
+            dets = model.bbox_head.predict_by_custom_op(preds, model.test_cfg)
+        return feats, preds, [{k: d[k].cpu().numpy() for k in ("box3d_lidar", "scores", "label_preds")} for d in dets]
+
+    f32, p32, d32 = run(False)
+    f16, p16, d16 = run(True)
+    model.set_amp(False)
+    rel_f = ((f16 - f32).abs().max() / f32.abs().max()).item()
+    rel_p = max(((a[k] - b[k]).abs().max() / b[k].abs().max().clamp(min=1e-3)).item() for a, b in zip(p16, p32) for k in a)
+    m = nb.nuscenes_style_map(d16, d32)["mAP"]
+    print(f"AMP vs fp32: FPN features {rel_f:.2e} of max, head maps {rel_p:.2e} of max, mAP proxy {m:.4f}")
+    assert f16.dtype == torch.float32 and f16.shape == f32.shape
+    assert 0 < rel_f < 2e-2 and rel_p < 5e-2
+    assert m > 0.97
