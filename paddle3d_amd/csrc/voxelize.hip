@@ -442,7 +442,7 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
   const int step_v = kVtRowsThreads / rowq, step_j = kVtRowsThreads % rowq;
   if (dim == 4 || dim == 5) {
     const int64_t slots = (int64_t)max_voxels * max_pts;
-    const int sunits = (int)ceil_div(slots, kVwRowsThreads);
+    const int sunits = (int)ceil_div(slots, kVwRowsThreads * kVwRowsIlp);
 #define PD3_VW_ROWS(D)                                                                                            \
   vw_rows_kernel<D><<<(unsigned)(sunits * batch), kVwRowsThreads, 0, s>>>(                                   \
       points, n, w.clist, w.cap, w.vinfo, w.totals, batch, sunits, max_voxels, max_pts, voxels, coords, num_pts,   \
@@ -539,7 +539,7 @@ static int run_sort_path(const T* points, const int32_t* num_points, int batch, 
     if ((num_point_dim == 4 || num_point_dim == 5) && slots < ((int64_t)1 << 24) - 4096) {
       voxel_meta_kernel<<<mgrid, 256, 0, s>>>(skey, w.vox_start, w.totals, n, max_num_points_in_voxel, max_voxels, g,
                                               coords, num_points_per_voxel, num_voxels, coors_batched, w.vinfo);
-      const int sunits = (int)ceil_div(slots, kVwRowsThreads);
+      const int sunits = (int)ceil_div(slots, kVwRowsThreads * kVwRowsIlp);
       if (num_point_dim == 4)
         vw_rows_kernel<4><<<(unsigned)(sunits * batch), kVwRowsThreads, 0, s>>>(
             points, n, sidx, n, w.vinfo, w.totals, batch, sunits, max_voxels, max_num_points_in_voxel, voxels, coords,

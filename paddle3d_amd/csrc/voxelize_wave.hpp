@@ -604,8 +604,13 @@ __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
 // while the ranking kernels run and storing only the slots that hold a point (the row writer alone 47 -> 39 us, but
 // the fill slows the kernels it runs beside by more than that: 125 -> 136 us).
 constexpr int kVwRowsThreads = 256;
+constexpr int kVwRowsIlp = 4;  // (voxel, slot) pairs per lane: four independent vinfo -> index -> point -> store chains
 
-template <int D>
+// A lane's chain is three dependent global round trips (vinfo, index list, point) in front of its stores; with one
+// pair per lane the kernel's time was (waves / waves in flight) x that latency -- 150 k waves, 8 k in flight, ~3 us:
+// 47-51 us for a 192 MB tensor that a bare fill writes in 27.  ILP pairs per lane (a workgroup covers ILP * 256
+// consecutive slots, element u of lane i is slot i + 256 u: a wave's stores stay contiguous 64 * D * 4-byte runs).
+template <int D, int ILP = kVwRowsIlp>
 __global__ __launch_bounds__(kVwRowsThreads) void vw_rows_kernel(
     const float* __restrict__ points, int64_t n, const uint32_t* __restrict__ clist, int64_t cap,
     const uint2* __restrict__ vinfo, const int* __restrict__ totals, int batch, int units, int max_voxels, int max_pts,
@@ -614,35 +619,56 @@ __global__ __launch_bounds__(kVwRowsThreads) void vw_rows_kernel(
   int frame, unit;
   vt_unit(blockIdx.x, (uint32_t)units, (uint32_t)batch, frame, unit);
   const uint32_t total_q = (uint32_t)max_voxels * (uint32_t)max_pts;
-  const uint32_t q = (uint32_t)unit * kVwRowsThreads + threadIdx.x;
-  if (q >= total_q) return;
-  const uint32_t v = vt_div(q, (uint32_t)max_pts, 1.0f / (float)max_pts);
-  const uint32_t slot = q - v * (uint32_t)max_pts;
-  const uint2 info = vinfo[(int64_t)frame * max_voxels + v];
-  const bool live = slot < info.y;
-  if (slot == 0u) {
-    const int nv = min(totals[frame], max_voxels);
-    if (v == 0u) num_voxels[frame] = nv;
-    if ((int)v >= nv) {  // padding rows of coords / count / coors4 (batch = -1)
-      const int64_t row = (int64_t)frame * max_voxels + v;
-      const VtInt3 z3{0, 0, 0};
-      __builtin_memcpy(coords + row * 3, &z3, sizeof(z3));
-      num_pts[row] = 0;
-      if (coors4) *reinterpret_cast<int4*>(coors4 + row * 4) = make_int4(-1, 0, 0, 0);
+  const uint32_t q0 = (uint32_t)unit * (kVwRowsThreads * ILP) + threadIdx.x;
+  const float inv_p = 1.0f / (float)max_pts;
+  uint32_t q[ILP], slot[ILP];
+  uint2 info[ILP];
+  bool in[ILP], live[ILP];
+#pragma unroll
+  for (int u = 0; u < ILP; ++u) {
+    q[u] = q0 + (uint32_t)u * kVwRowsThreads;
+    in[u] = q[u] < total_q;
+    const uint32_t qq = in[u] ? q[u] : 0u;
+    const uint32_t v = vt_div(qq, (uint32_t)max_pts, inv_p);
+    slot[u] = qq - v * (uint32_t)max_pts;
+    info[u] = vinfo[(int64_t)frame * max_voxels + v];
+    if (in[u] && slot[u] == 0u) {
+      const int nv = min(totals[frame], max_voxels);
+      if (v == 0u) num_voxels[frame] = nv;
+      if ((int)v >= nv) {  // padding rows of coords / count / coors4 (batch = -1)
+        const int64_t row = (int64_t)frame * max_voxels + v;
+        const VtInt3 z3{0, 0, 0};
+        __builtin_memcpy(coords + row * 3, &z3, sizeof(z3));
+        num_pts[row] = 0;
+        if (coors4) *reinterpret_cast<int4*>(coors4 + row * 4) = make_int4(-1, 0, 0, 0);
+      }
     }
   }
-  const uint32_t idx = live ? clist[(int64_t)frame * cap + info.x + slot] : 0u;
-  const float* src = points + ((int64_t)frame * n + idx) * D;
-  vt_f32x4u a = *reinterpret_cast<const vt_f32x4u*>(src);
-  float e = 0.f;
-  if (D == 5) e = src[4];
-  if (!live) {
-    a = vt_f32x4u{0.f, 0.f, 0.f, 0.f};
-    e = 0.f;
+  uint32_t idx[ILP];
+#pragma unroll
+  for (int u = 0; u < ILP; ++u) {
+    live[u] = in[u] && slot[u] < info[u].y;
+    idx[u] = live[u] ? clist[(int64_t)frame * cap + info[u].x + slot[u]] : 0u;
   }
-  float* dst = voxels + ((int64_t)frame * total_q + q) * D;
-  __builtin_nontemporal_store(a, reinterpret_cast<vt_f32x4u*>(dst));
-  if (D == 5) __builtin_nontemporal_store(e, dst + 4);
+  vt_f32x4u a[ILP];
+  float e[ILP];
+#pragma unroll
+  for (int u = 0; u < ILP; ++u) {
+    const float* src = points + ((int64_t)frame * n + idx[u]) * D;
+    a[u] = *reinterpret_cast<const vt_f32x4u*>(src);
+    e[u] = D == 5 ? src[4] : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < ILP; ++u) {
+    if (!in[u]) continue;
+    if (!live[u]) {
+      a[u] = vt_f32x4u{0.f, 0.f, 0.f, 0.f};
+      e[u] = 0.f;
+    }
+    float* dst = voxels + ((int64_t)frame * total_q + q[u]) * D;
+    __builtin_nontemporal_store(a[u], reinterpret_cast<vt_f32x4u*>(dst));
+    if (D == 5) __builtin_nontemporal_store(e[u], dst + 4);
+  }
 }
 
 }  // namespace pd3
