@@ -346,8 +346,8 @@ static int run_tiled(const float* points, const int32_t* num_points, int batch, 
 // wave form of the tiled path (voxelize_wave.hpp)
 // ---------------------------------------------------------------------------------------------------
 struct VwWorkspace {
-  uint32_t *recs, *dir, *clist, *fcnt;
-  uint2 *vinfo, *flist;
+  uint32_t *recs, *dir, *clist;
+  uint2 *vinfo, *flist, *fcnt;
   int* totals;
   uint32_t *gregion, *aux;  // 3-D form only
   int64_t cap;
@@ -366,7 +366,7 @@ static VwWorkspace vw_carve(void* base, int batch, int64_t n, int max_voxels, co
   w.vinfo = c.take<uint2>((size_t)batch * max_voxels);
   w.totals = c.take<int>((size_t)batch);
   w.flist = c.take<uint2>(three_d ? (size_t)batch * w.cap + 4 : (size_t)batch * p.groups * p.cpg);
-  w.fcnt = c.take<uint32_t>((size_t)batch * vw_pow2_above(p.tiles) * p.groups);
+  w.fcnt = c.take<uint2>((size_t)batch * vw_pow2_above(p.tiles) * p.groups);
   w.gregion = three_d ? c.take<uint32_t>((size_t)batch * p.groups) : nullptr;
   w.aux = three_d ? c.take<uint32_t>((size_t)batch * w.cap + 4) : nullptr;
   w.bytes = c.off;

@@ -205,7 +205,7 @@ __device__ __forceinline__ uint32_t vw_tile_of(const uint32_t* pre, int tp, uint
 __global__ __launch_bounds__(kWave) void vw_group_kernel(
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ dir, int low, int gbits, int tiles, int tile_len,
     int tp, int batch, int max_pts, uint32_t* __restrict__ clist, int64_t cap, uint2* __restrict__ flist,
-    uint32_t* __restrict__ fcnt, uint32_t prio_unit) {
+    uint2* __restrict__ fcnt, uint32_t prio_unit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
   const int cpg = 1 << low, groups = 1 << gbits;
   uint32_t* A = reinterpret_cast<uint32_t*>(vt_smem);  // [cpg] (kept << 24) | place of the cell in the region
@@ -216,7 +216,8 @@ __global__ __launch_bounds__(kWave) void vw_group_kernel(
   int frame, grp;
   vt_unit(blockIdx.x, (uint32_t)groups, (uint32_t)batch, frame, grp);
   const int lane = threadIdx.x;
-  uint32_t* fcol = fcnt + (int64_t)frame * tp * groups + grp;  // this group's column of [tp][groups]
+  // this group's column of [tp][groups]: (first points of the group in tile t, those in the tiles before it)
+  uint2* fcol = fcnt + (int64_t)frame * tp * groups + grp;
 
   // directory column -> prefix of the run lengths; the group's region of the index list is sized by its record
   // count and starts at the sum of its offsets inside the tiles' slices (no global counter)
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kWave) void vw_group_kernel(
   }
   vt_wave_sync();
   if (total == 0u) {
-    for (int t = lane; t < tiles; t += kWave) fcol[(int64_t)t * groups] = 0u;
+    for (int t = lane; t < tiles; t += kWave) fcol[(int64_t)t * groups] = make_uint2(0u, 0u);
     return;
   }
   // The kernel lasts as long as its heaviest wave (1.5x the mean records) and all waves are resident at once, four
@@ -427,7 +428,17 @@ __global__ __launch_bounds__(kWave) void vw_group_kernel(
     }
   }
   vt_wave_sync();
-  for (int t = lane; t < tiles; t += kWave) fcol[(int64_t)t * groups] = cntT[t];
+  {  // per tile: the group's first points and their exclusive prefix over the tiles (the assign kernel's offset of
+     // the tile's piece in the group's list: it used to sum the column itself, up to 74 loads per thread)
+    uint32_t before = 0;
+    for (int t0 = 0; t0 < tiles; t0 += kWave) {
+      const int t = t0 + lane;
+      const uint32_t c = t < tiles ? cntT[t] : 0u;
+      const uint32_t inc = (uint32_t)wave_inclusive_scan((int)c);
+      if (t < tiles) fcol[(int64_t)t * groups] = make_uint2(c, before + inc - c);
+      before += (uint32_t)__shfl((int)inc, kWave - 1, kWave);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ C
@@ -440,7 +451,7 @@ constexpr int kVwAssignThreads = 512;  // with 256 groups two threads share a gr
 constexpr int kVwAssignCap = 4096;  // records staged in voxel order (a tile that opens more voxels stores the rest directly)
 
 __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
-    const uint2* __restrict__ flist, const uint32_t* __restrict__ fcnt, int low, int gbits, int tiles, int tile_len,
+    const uint2* __restrict__ flist, const uint2* __restrict__ fcnt, int low, int gbits, int tiles, int tile_len,
     int tp, int batch, int max_voxels, VtGrid g, uint2* __restrict__ vinfo, int* __restrict__ totals,
     int32_t* __restrict__ coords, int32_t* __restrict__ num_pts, int32_t* __restrict__ coors4, int frame0,
     const uint32_t* __restrict__ gregion, int64_t cap) {
@@ -458,7 +469,7 @@ __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
   __shared__ int s_before[kVwAssignThreads / kWave];
   int frame, tile;
   vt_unit(blockIdx.x, (uint32_t)tiles, (uint32_t)batch, frame, tile);
-  const uint32_t* fc = fcnt + (int64_t)frame * tp * groups;
+  const uint2* fc = fcnt + (int64_t)frame * tp * groups;
   auto list_of = [&](int gi) -> const uint2* {
     return gregion ? flist + (int64_t)frame * cap + gregion[(int64_t)frame * groups + gi]
                    : flist + ((int64_t)frame * groups + gi) * cpg;
@@ -466,8 +477,8 @@ __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
   for (int w = threadIdx.x; w < words; w += kVwAssignThreads) bits[w] = 0u;
   __syncthreads();
   // per group (thread g, g + 512 with 1024 groups; with fewer groups than threads several threads share one):
-  // offset of the tile's piece in the group's list = its counts of the earlier tiles; loads eight tiles at a time,
-  // all in flight (one at a time was a chain of up to 29 round trips)
+  // offset of the tile's piece in the group's list = its counts of the earlier tiles, which the group's wave left
+  // next to the tile's own count (round 4; the threads used to sum the column themselves)
   constexpr int kGpt = (1 << kVtMaxGbits) / kVwAssignThreads;  // groups per thread, at most
   uint32_t goff[kGpt], gcnt[kGpt];
   int before = 0;
@@ -480,15 +491,8 @@ __global__ __launch_bounds__(kVwAssignThreads) void vw_assign_kernel(
     goff[q] = 0u;
     gcnt[q] = 0u;
     if (gi < groups && (tpg == 1 || q == 0)) {
-      uint32_t off = 0;
-      for (int t0 = 0; t0 < tile; t0 += 8) {
-        uint32_t v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = fc[(int64_t)min(t0 + k, tile) * groups + gi];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) off += t0 + k < tile ? v[k] : 0u;
-      }
-      const uint32_t c = fc[(int64_t)tile * groups + gi];
+      const uint2 ent = fc[(int64_t)tile * groups + gi];  // (count in this tile, count in the tiles before it)
+      const uint32_t off = ent.y, c = ent.x;
       if (sub == 0) before += (int)off;
       const uint32_t lo = c * (uint32_t)sub / (uint32_t)tpg, hi = c * (uint32_t)(sub + 1) / (uint32_t)tpg;
       goff[q] = off + lo;

@@ -68,7 +68,7 @@ static inline size_t v3_group_lds(int tiles) { return ((size_t)3 * kV3Slots + (s
 __global__ __launch_bounds__(kWave) void v3_group_kernel(
     const uint32_t* __restrict__ recs, const uint32_t* __restrict__ dir, int gbits, int tiles, int tile_len, int tp,
     int batch, int max_pts, uint32_t* __restrict__ clist, int64_t cap, uint2* __restrict__ flist,
-    uint32_t* __restrict__ fcnt, uint32_t* __restrict__ gregion, uint32_t* __restrict__ aux) {
+    uint2* __restrict__ fcnt, uint32_t* __restrict__ gregion, uint32_t* __restrict__ aux) {
   extern __shared__ __attribute__((aligned(16))) unsigned char vt_smem[];
   const int groups = 1 << gbits;
   uint32_t* K = reinterpret_cast<uint32_t*>(vt_smem);  // [slots] cell of the slot, kV3Empty: free
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(kWave) void v3_group_kernel(
   int frame, grp;
   vt_unit(blockIdx.x, (uint32_t)groups, (uint32_t)batch, frame, grp);
   const int lane = threadIdx.x;
-  uint32_t* fcol = fcnt + (int64_t)frame * tp * groups + grp;  // this group's column of [tp][groups]
+  // this group's column of [tp][groups]: (first points of the group in tile t, those in the tiles before it)
+  uint2* fcol = fcnt + (int64_t)frame * tp * groups + grp;
 
   // directory column -> prefix of the run lengths (as vw_group_kernel): the group's region of the index list / of the
   // first-point list is sized by its record count and starts at the sum of its offsets inside the tiles' slices
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(kWave) void v3_group_kernel(
   if (lane == 0) gregion[(int64_t)frame * groups + grp] = region;
   vt_wave_sync();
   if (total == 0u) {
-    for (int t = lane; t < tiles; t += kWave) fcol[(int64_t)t * groups] = 0u;
+    for (int t = lane; t < tiles; t += kWave) fcol[(int64_t)t * groups] = make_uint2(0u, 0u);
     return;
   }
   const uint32_t* rf = recs + (int64_t)frame * tiles * tile_len;
@@ -285,7 +286,17 @@ __global__ __launch_bounds__(kWave) void v3_group_kernel(
     }
   }
   vt_wave_sync();
-  for (int t = lane; t < tiles; t += kWave) fcol[(int64_t)t * groups] = cntT[t];
+  {  // per tile: the group's first points and their exclusive prefix over the tiles (the assign kernel's offset of
+     // the tile's piece in the group's list: it used to sum the column itself, up to 74 loads per thread)
+    uint32_t before = 0;
+    for (int t0 = 0; t0 < tiles; t0 += kWave) {
+      const int t = t0 + lane;
+      const uint32_t c = t < tiles ? cntT[t] : 0u;
+      const uint32_t inc = (uint32_t)wave_inclusive_scan((int)c);
+      if (t < tiles) fcol[(int64_t)t * groups] = make_uint2(c, before + inc - c);
+      before += (uint32_t)__shfl((int)inc, kWave - 1, kWave);
+    }
+  }
 }
 
 }  // namespace pd3
