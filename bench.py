@@ -130,6 +130,15 @@ def map_proxy(model, model_cpu, max_voxels, frames, dev):
     model, model_cpu = copy.deepcopy(model), copy.deepcopy(model_cpu)
     with torch.no_grad():
         for m in (model, model_cpu):
+            # BatchNorm statistics like a trained net's (with the constructor's identity statistics the activations
+            # shrink layer by layer and no cell reaches the score threshold at all), the same values on both sides
+            g = torch.Generator().manual_seed(0)
+            for mod in m.modules():
+                if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                    mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+                    mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+                    mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)
+                    mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
             for task in m.bbox_head.tasks:
                 task.hm[-1].weight.mul_(30.0)
                 task.hm[-1].bias.fill_(-3.0)
