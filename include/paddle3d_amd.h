@@ -434,6 +434,18 @@ int pd3_conv3x3_winograd43_bias_relu(const float *x, const float *u_packed, cons
                                      int channels_per_tile, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * stable_argsort -- the index order the host glue of two reference functions needs, on the library's radix sort:
+ * rotate_nms_pcdet's `paddle.argsort(scores, descending=True)` (models/layers/layer_libs.py:230-236) and the re-sort
+ * by ranks_feat in front of bev_pool_v2_bkwd (models/transformers/bevdet_transformer.py:60-68).  Stable: equal keys
+ * keep their input order.
+ *   mode 0: keys int32 >= 0 (max_key bounds them: fewer passes), ascending;  mode 1: keys fp32, descending
+ *   order [n] int32 (device);  workspace: pd3_stable_argsort_workspace(n, max_key) bytes
+ */
+size_t pd3_stable_argsort_workspace(int64_t n, uint32_t max_key);
+int pd3_stable_argsort(const void *keys, int64_t n, int mode, uint32_t max_key, int32_t *order, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * conv3x3_f16_bias_relu -- the stride-1 3x3 / pad 1 convolutions of SecondBackbone and CenterHead in MIXED PRECISION:
  * fp16 activations and weights on the fp16 matrix cores, fp32 accumulation, bias + ReLU fused.  The reference's AMP
  * configuration of the model (configs/centerpoint/centerpoint_pillars_02voxel_nuscenes_10sweep_ampO2_ultra.yml:5-9,

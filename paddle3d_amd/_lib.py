@@ -103,6 +103,9 @@ _SIGNATURES = {
     "pd3_conv3x3_f16_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pd3_f32_nchw_to_f16_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_stable_argsort_workspace": (C.c_size_t, [C.c_int64, C.c_uint32]),
+    "pd3_stable_argsort": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]),
     "pd3_merge_sweeps_workspace": (C.c_size_t, [C.c_int64]),
     "pd3_merge_sweeps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

@@ -8,6 +8,7 @@ import math
 import torch
 
 from .ops import iou3d_nms
+from .ops.sort import stable_argsort
 
 __all__ = ["rotate_nms_pcdet"]
 
@@ -24,7 +25,7 @@ def rotate_nms_pcdet(boxes: torch.Tensor, scores: torch.Tensor, thresh: float, p
     cols = torch.tensor([0, 1, 2, 4, 3, 5, boxes.shape[1] - 1], device=boxes.device)
     b = boxes.index_select(1, cols).contiguous()       # transform back to pcdet's coordinate (:222-226)
     b[:, -1] = -b[:, -1] - math.pi / 2                 # fp32 tensor op with a scalar, as in the reference (:229)
-    order = torch.argsort(scores, dim=0, descending=True, stable=True)
+    order = stable_argsort(scores, descending=True)  # the library's radix sort (ties by index)
     if pre_max_size is not None:
         order = order[:pre_max_size]
     b = b[order].reshape(-1, 7).contiguous()

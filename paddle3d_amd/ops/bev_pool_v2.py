@@ -63,7 +63,9 @@ class BevPoolV2(torch.autograd.Function):
     @staticmethod
     def backward(ctx, out_grad):
         ranks_bev, depth, feat, ranks_feat, ranks_depth = ctx.saved_tensors
-        order = torch.argsort(ranks_feat.long(), stable=True)
+        from .sort import stable_argsort
+
+        order = stable_argsort(ranks_feat, descending=False)  # the library's radix sort
         rb, rd, rf = ranks_bev[order], ranks_depth[order], ranks_feat[order]
         kept = torch.ones(rb.shape[0], dtype=torch.bool, device=rb.device)
         kept[1:] = rf[1:] != rf[:-1]

@@ -192,3 +192,24 @@ def test_lds_atomic_lane_order():
             cnt[rows[live], idx[live]] += 1
     bad = int((old != want).sum())
     assert bad == 0, f"{bad} of {old.size} returning LDS adds out of lane order"
+
+
+@pytest.mark.parametrize("n", [1, 63, 1000, 16384, 358196])
+def test_stable_argsort_matches_torch(n):
+    """pd3_stable_argsort (radix sort) against torch.argsort(stable=True): descending fp32 scores with many ties,
+    negative values and infinities; ascending int32 ranks with runs of equal keys."""
+    from paddle3d_amd.ops.sort import stable_argsort
+
+    g = torch.Generator(device="cuda").manual_seed(n)
+    s = torch.randn(n, device="cuda", generator=g)
+    s = torch.round(s * 8) / 8            # ties
+    if n > 10:
+        s[3], s[5], s[7] = float("inf"), float("-inf"), 0.0
+    got = stable_argsort(s, descending=True)
+    want = torch.argsort(s, descending=True, stable=True)
+    assert torch.equal(got, want)
+    r = torch.randint(0, max(2, n // 7), (n,), device="cuda", generator=g, dtype=torch.int32)
+    got = stable_argsort(r, descending=False, max_key=int(max(2, n // 7)))
+    want = torch.argsort(r.long(), stable=True)
+    assert torch.equal(got, want)
+    assert torch.equal(stable_argsort(r.long()), want)
