@@ -9,14 +9,16 @@
 
 namespace pd3 {
 
-// mode 0: int32 keys >= 0, ascending.  mode 1: fp32 keys, descending (IEEE total order, NaN first like a descending
-// sort of torch / paddle puts it; -0 after +0): u = sign ? ~bits : bits | 0x80000000 is ascending, ~u descending.
+// mode 0: int32 keys >= 0, ascending.  mode 1: fp32 keys, descending (NaN first like a descending sort of torch /
+// paddle puts it; -0 and +0 tie): u = sign ? ~bits : bits | 0x80000000 is ascending, ~u descending.
 __global__ __launch_bounds__(256) void argsort_key_kernel(const uint32_t* __restrict__ in, int64_t n, int mode,
                                                           uint32_t* __restrict__ keys) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t b = in[i];
   if (mode == 1) {
+    if ((b & 0x7FFFFFFFu) == 0u) b = 0u;                   // -0 == +0: a tie, kept in input order
+    if ((b & 0x7FFFFFFFu) > 0x7F800000u) b = 0x7FC00000u;   // every NaN sorts as the largest value
     const uint32_t asc = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
     b = ~asc;
   }
