@@ -433,6 +433,13 @@ int pd3_conv3x3_winograd43_bias_relu(const float *x, const float *u_packed, cons
                                      int cin, int cout, int h, int w, int w_valid, int relu, float *out,
                                      int channels_per_tile, void *stream);
 
+/* conv3x3_winograd43_raw_bias_relu -- the same convolution, same F(4x4, 3x3) arithmetic, as a two-group ping-pong kernel
+ * that computes U = G g G^T in registers: w_raw is the plain folded [cout, cin, 3, 3] fp32 weight (no packing).
+ * requires cin % 8 == 0, cout % 64 == 0, w % 4 == 0; results agree with the packed form to the rounding of U (fp32 on the
+ * device here, fp64 on the host there: ~1e-7 relative). */
+int pd3_conv3x3_winograd43_raw_bias_relu(const float *x, const float *w_raw, const float *bias, int batch, int cin,
+                                         int cout, int h, int w, int w_valid, int relu, float *out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * stable_argsort -- the index order the host glue of two reference functions needs, on the library's radix sort:
  * rotate_nms_pcdet's `paddle.argsort(scores, descending=True)` (models/layers/layer_libs.py:230-236) and the re-sort

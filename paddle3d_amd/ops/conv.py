@@ -12,6 +12,7 @@ __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pitch4", "p
            "grouped_small_supported", "winograd_supported", "pack_winograd_weight", "conv3x3_winograd_bias_relu",
            "patch_mode", "patch_supported", "pack_patch_weight", "patch_conv_bias_relu",
            "winograd43_supported", "winograd43_tile", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu",
+           "winograd43_raw_supported", "conv3x3_winograd43_raw_bias_relu",
            "f16_supported", "f16_tile", "pack_conv3x3_f16_weight", "conv3x3_f16_bias_relu", "to_f16_nhwc"]
 
 
@@ -259,4 +260,24 @@ def conv3x3_f16_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: i
     check(lib().pd3_conv3x3_f16_bias_relu(ptr(x), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
                                           ptr(out), 1 if out_f32_nchw else 0, tile, stream_ptr(x.device)),
           "conv3x3_f16_bias_relu")
+    return out
+
+
+# ---- F(4x4, 3x3) as the ping-pong kernel that computes U on the fly (round 4) -------------------------------------------
+def winograd43_raw_supported(cin: int, cout: int, h: int, w: int) -> bool:
+    return cin % 8 == 0 and cout % 64 == 0
+
+
+def conv3x3_winograd43_raw_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias, cout: int, relu: bool = True,
+                                     out: torch.Tensor | None = None, w_valid: int | None = None) -> torch.Tensor:
+    """x [n, cin, h, pitch] fp32, weight the plain folded [cout, cin, 3, 3] tensor -> [n, cout, h, pitch]."""
+    xx = require_gpu(x, "conv3x3_winograd43_raw_bias_relu")
+    wt = require_gpu(weight, "conv3x3_winograd43_raw_bias_relu")
+    n, cin, h, w = xx.shape
+    if out is None:
+        out = torch.empty((n, cout, h, w), dtype=torch.float32, device=xx.device)
+    check(lib().pd3_conv3x3_winograd43_raw_bias_relu(ptr(xx), ptr(wt), ptr(bias), n, cin, cout, h, w,
+                                                     w if w_valid is None else int(w_valid), int(bool(relu)), ptr(out),
+                                                     stream_ptr(xx.device)),
+          "conv3x3_winograd43_raw_bias_relu")
     return out

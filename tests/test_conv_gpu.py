@@ -325,3 +325,31 @@ def test_conv3x3_f16_refuses_shapes_it_does_not_take():
     x = torch.zeros(1, 20, 32, 64, dtype=torch.float16, device="cuda")  # w % 32 != 0 as NHWC [1, 20, 32, 64]: h = 20
     with pytest.raises(Paddle3DAmdError, match="status -3"):
         conv.conv3x3_f16_bias_relu(x, torch.zeros(1, 4, 9, 64, 16, dtype=torch.float16, device="cuda"), None, 64)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 64), (1, 128, 128, 16, 128), (1, 8, 64, 24, 68), (1, 64, 192, 12, 64),
+                                           (1, 384, 64, 8, 128), (1, 64, 128, 90, 92)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_winograd43_pingpong_form(n, cin, cout, h, w, relu):
+    """The ping-pong F(4x4, 3x3) kernel with U computed on the fly against torch's fp32 convolution (1e-3 contract; the
+    packed form's measured error is ~1e-5) and against the packed-form kernel (same arithmetic up to the rounding of U):
+    partial border tiles, a zero-padded 90-wide map, channel counts of one to 48 slots."""
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wv = 90 if w == 92 else w
+    x[..., wv:] = 0
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x[..., :wv], wt, b, padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    assert conv.winograd43_raw_supported(cin, cout, h, wv)
+    got = conv.conv3x3_winograd43_raw_bias_relu(x.cuda(), wt.cuda(), b.cuda(), cout, relu, w_valid=wv)
+    assert got.shape == (n, cout, h, w)
+    assert (got[..., :wv].cpu() - ref).abs().max().item() < 1e-3
+    assert (got[..., wv:] == 0).all()
+    packed = conv.conv3x3_winograd43_bias_relu(x.cuda(), conv.pack_winograd43_weight(wt.cuda()), b.cuda(), cout, relu,
+                                               w_valid=wv)
+    assert (got - packed).abs().max().item() < 2e-5
