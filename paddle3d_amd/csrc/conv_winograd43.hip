@@ -344,8 +344,7 @@ __global__ __launch_bounds__(128 * CB, CB == 2 ? 2 : 1) void conv3x3_winograd43_
 //     registers: lane (co, ci) loads its 9 raw weights a slot ahead and computes U = G g G^T (36 values, ~90 VALU
 //     operations) in the shadow of the MFMAs -- a quarter of the ingest, no U in LDS (64 KB instead of 122 KB), no
 //     parking role.  The weights are the plain folded [cout][cin][3][3] tensor: no host-side packing.
-// Every workgroup-wide barrier is reached by both groups: two per slot (transform: raw patch staged | V written;
-// multiply: after the first trip | after the second).
+// One workgroup-wide barrier per slot, reached by both groups.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kPpKT = 2;                                   // trips per slot
 constexpr int kPpCi = kPpKT * kW4Ci;                       // 8 input channels per slot
@@ -489,43 +488,39 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
     b[0] = *reinterpret_cast<const w4_f32x4*>(vb);
     b[1] = *reinterpret_cast<const w4_f32x4*>(vb + 4);
 #pragma unroll
-    for (int g = 0; g < 9; ++g) {
+    for (int g = 0; g < 9; ++g) {  // (no scheduling fences: the U arithmetic of the later groups belongs between these MFMAs)
       if (g + 2 < 9) b[(g + 2) % 3] = *reinterpret_cast<const w4_f32x4*>(vb + (g + 2) * 4);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[g * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[g * 4 + j], b[g % 3][j], acc[g * 4 + j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  // group g runs T(0) M(0) T(1) M(1) ... one slot behind group g - 1: 2 * slots + 1 time slots, two barriers each
+  // group g runs T(0) M(0) T(1) M(1) ... one slot behind group g - 1: 2 * slots + 1 time slots, ONE barrier each.  A
+  // multiply slot ends by staging the raw rows of the group's next transform slot (fetched at its start), so a transform
+  // slot is the chain alone.  (A first version staged at the start of the transform slot behind a second barrier: the
+  // barrier lined the other group's first trip up with the staging and its second trip with the transform, i.e. the
+  // slot was one trip + the chain instead of their maximum: 15-20 % slower than the packed form.)
   fetch_x(0);
+  stash_x();
+  __syncthreads();
   const int nt = 2 * slots + 1;
   for (int tau = 0; tau < nt; ++tau) {
     const int k = tau - grp;
     const bool active = k >= 0 && k < 2 * slots;
     const int s = k >> 1;
     if (active && (k & 1) == 0) {  // transform slot s
-      stash_x();
-      fetch_g(s);  // needed by the multiply slot that follows
-      __syncthreads();
+      fetch_g(s);                  // needed by the multiply slot that follows
       transform();
-      __syncthreads();
     } else if (active) {           // multiply slot s
       if (s + 1 < slots) fetch_x(s + 1);  // the next transform slot's raw rows travel during the MFMAs
       __builtin_amdgcn_s_setprio(1);
       multiply(0);
-      __builtin_amdgcn_s_setprio(0);
-      __syncthreads();
-      __builtin_amdgcn_s_setprio(1);
       multiply(1);
       __builtin_amdgcn_s_setprio(0);
-      __syncthreads();
-    } else {
-      __syncthreads();
-      __syncthreads();
+      if (s + 1 < slots) stash_x();
     }
+    __syncthreads();
   }
 
   // epilogue (as above): Y = A^T M A; lane: tile column lane & 15, channels 4 (lane >> 4) + r of the co block

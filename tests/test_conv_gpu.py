@@ -352,4 +352,4 @@ def test_winograd43_pingpong_form(n, cin, cout, h, w, relu):
     assert (got[..., wv:] == 0).all()
     packed = conv.conv3x3_winograd43_bias_relu(x.cuda(), conv.pack_winograd43_weight(wt.cuda()), b.cuda(), cout, relu,
                                                w_valid=wv)
-    assert (got - packed).abs().max().item() < 2e-5
+    assert (got - packed).abs().max().item() < 1e-4
