@@ -439,6 +439,11 @@ int pd3_conv3x3_winograd43_bias_relu(const float *x, const float *u_packed, cons
  * device here, fp64 on the host there: ~1e-7 relative). */
 int pd3_conv3x3_winograd43_raw_bias_relu(const float *x, const float *w_raw, const float *bias, int batch, int cin,
                                          int cout, int h, int w, int w_valid, int relu, float *out, void *stream);
+/* the same with the kernel's scheduling variant named (measurement: bit 2 = scheduling fences around the MFMA groups,
+ * bits 0-1 = 0 no wave priorities / 1 multiply slots high / 2 transform slots high); identical results */
+int pd3_conv3x3_winograd43_raw_bias_relu_variant(const float *x, const float *w_raw, const float *bias, int batch,
+                                                 int cin, int cout, int h, int w, int w_valid, int relu, float *out,
+                                                 int variant, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * stable_argsort -- the index order the host glue of two reference functions needs, on the library's radix sort:

@@ -367,11 +367,12 @@ __device__ __forceinline__ void w4_gg(const float a, const float b, const float 
   t[5] = c;
 }
 
+template <bool FENCE>
 __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const float* __restrict__ x,
                                                                        const float* __restrict__ wraw,
                                                                        const float* __restrict__ bias,
                                                                        float* __restrict__ out, int cin, int cout, int h,
-                                                                       int w, int wv, int relu, int ptiles) {
+                                                                       int w, int wv, int relu, int ptiles, int prio) {
   constexpr int CO = 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = lane_id(), wave = wave_id();
@@ -488,11 +489,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
     b[0] = *reinterpret_cast<const w4_f32x4*>(vb);
     b[1] = *reinterpret_cast<const w4_f32x4*>(vb + 4);
 #pragma unroll
-    for (int g = 0; g < 9; ++g) {  // (no scheduling fences: the U arithmetic of the later groups belongs between these MFMAs)
+    for (int g = 0; g < 9; ++g) {  // (!FENCE: the U arithmetic of the later groups may move between these MFMAs)
       if (g + 2 < 9) b[(g + 2) % 3] = *reinterpret_cast<const w4_f32x4*>(vb + (g + 2) * 4);
+      if (FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[g * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[g * 4 + j], b[g % 3][j], acc[g * 4 + j], 0, 0, 0);
+      if (FENCE) __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -511,13 +514,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
     const int s = k >> 1;
     if (active && (k & 1) == 0) {  // transform slot s
       fetch_g(s);                  // needed by the multiply slot that follows
+      if (prio == 2) __builtin_amdgcn_s_setprio(2);
       transform();
+      if (prio == 2) __builtin_amdgcn_s_setprio(0);
     } else if (active) {           // multiply slot s
       if (s + 1 < slots) fetch_x(s + 1);  // the next transform slot's raw rows travel during the MFMAs
-      __builtin_amdgcn_s_setprio(1);
+      if (prio == 1) __builtin_amdgcn_s_setprio(1);
       multiply(0);
       multiply(1);
-      __builtin_amdgcn_s_setprio(0);
+      if (prio == 1) __builtin_amdgcn_s_setprio(0);
       if (s + 1 < slots) stash_x();
     }
     __syncthreads();
@@ -602,22 +607,43 @@ extern "C" int pd3_conv3x3_winograd43_bias_relu(const float* x, const float* u_p
 }
 
 // The ping-pong form: weights are the plain folded [cout][cin][3][3] tensor (U is computed in the kernel).
-extern "C" int pd3_conv3x3_winograd43_raw_bias_relu(const float* x, const float* w_raw, const float* bias, int batch,
-                                                    int cin, int cout, int h, int w, int w_valid, int relu, float* out,
-                                                    void* stream) {
+// variant (measurement): bit 2 = scheduling fences around the MFMA groups; bits 0-1 = 0 no priorities, 1 multiply slots
+// high, 2 transform slots high
+static int launch_wino43_pp(const float* x, const float* w_raw, const float* bias, int batch, int cin, int cout, int h,
+                            int w, int w_valid, int relu, float* out, int variant, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * (kPpRawSz + kPpVsz) * sizeof(float);
+  const bool fence = (variant & 4) != 0;
+  const void* fn = fence ? reinterpret_cast<const void*>(conv3x3_winograd43_pp_kernel<true>)
+                         : reinterpret_cast<const void*>(conv3x3_winograd43_pp_kernel<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  const int64_t ptiles = (int64_t)batch * ceil_div(h, 4 * kW4TR) * ceil_div(w, 4 * kW4TC);
+  const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / 64);
+  if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
+  if (fence)
+    conv3x3_winograd43_pp_kernel<true><<<(unsigned)nwg, 512, lds, s>>>(x, w_raw, bias, out, cin, cout, h, w, w_valid, relu,
+                                                                       (int)ptiles, variant & 3);
+  else
+    conv3x3_winograd43_pp_kernel<false><<<(unsigned)nwg, 512, lds, s>>>(x, w_raw, bias, out, cin, cout, h, w, w_valid, relu,
+                                                                        (int)ptiles, variant & 3);
+  return launch_status();
+}
+
+extern "C" int pd3_conv3x3_winograd43_raw_bias_relu_variant(const float* x, const float* w_raw, const float* bias,
+                                                            int batch, int cin, int cout, int h, int w, int w_valid,
+                                                            int relu, float* out, int variant, void* stream) {
   if (!x || !w_raw || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || w_valid <= 0 || w_valid > w)
     return PD3_EINVAL;
   if (cin % kPpCi != 0 || cout % 64 != 0 || w % 4 != 0) return PD3_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return PD3_EINVAL;
   if ((int64_t)cin * h * w >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
-  constexpr size_t lds = (size_t)2 * (kPpRawSz + kPpVsz) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_winograd43_pp_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
-  const int64_t ptiles = (int64_t)batch * ceil_div(h, 4 * kW4TR) * ceil_div(w, 4 * kW4TC);
-  const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / 64);
-  if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
-  conv3x3_winograd43_pp_kernel<<<(unsigned)nwg, 512, lds, static_cast<hipStream_t>(stream)>>>(
-      x, w_raw, bias, out, cin, cout, h, w, w_valid, relu, (int)ptiles);
-  return launch_status();
+  return launch_wino43_pp(x, w_raw, bias, batch, cin, cout, h, w, w_valid, relu, out, variant,
+                          static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pd3_conv3x3_winograd43_raw_bias_relu(const float* x, const float* w_raw, const float* bias, int batch,
+                                                    int cin, int cout, int h, int w, int w_valid, int relu, float* out,
+                                                    void* stream) {
+  return pd3_conv3x3_winograd43_raw_bias_relu_variant(x, w_raw, bias, batch, cin, cout, h, w, w_valid, relu, out, 1,
+                                                      stream);
 }

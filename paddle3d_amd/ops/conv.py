@@ -269,15 +269,22 @@ def winograd43_raw_supported(cin: int, cout: int, h: int, w: int) -> bool:
 
 
 def conv3x3_winograd43_raw_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias, cout: int, relu: bool = True,
-                                     out: torch.Tensor | None = None, w_valid: int | None = None) -> torch.Tensor:
+                                     out: torch.Tensor | None = None, w_valid: int | None = None,
+                                     variant: int | None = None) -> torch.Tensor:
     """x [n, cin, h, pitch] fp32, weight the plain folded [cout, cin, 3, 3] tensor -> [n, cout, h, pitch]."""
     xx = require_gpu(x, "conv3x3_winograd43_raw_bias_relu")
     wt = require_gpu(weight, "conv3x3_winograd43_raw_bias_relu")
     n, cin, h, w = xx.shape
     if out is None:
         out = torch.empty((n, cout, h, w), dtype=torch.float32, device=xx.device)
-    check(lib().pd3_conv3x3_winograd43_raw_bias_relu(ptr(xx), ptr(wt), ptr(bias), n, cin, cout, h, w,
-                                                     w if w_valid is None else int(w_valid), int(bool(relu)), ptr(out),
-                                                     stream_ptr(xx.device)),
-          "conv3x3_winograd43_raw_bias_relu")
+    if variant is None:
+        st = lib().pd3_conv3x3_winograd43_raw_bias_relu(ptr(xx), ptr(wt), ptr(bias), n, cin, cout, h, w,
+                                                        w if w_valid is None else int(w_valid), int(bool(relu)),
+                                                        ptr(out), stream_ptr(xx.device))
+    else:
+        st = lib().pd3_conv3x3_winograd43_raw_bias_relu_variant(ptr(xx), ptr(wt), ptr(bias), n, cin, cout, h, w,
+                                                                w if w_valid is None else int(w_valid),
+                                                                int(bool(relu)), ptr(out), int(variant),
+                                                                stream_ptr(xx.device))
+    check(st, "conv3x3_winograd43_raw_bias_relu")
     return out

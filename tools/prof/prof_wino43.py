@@ -17,8 +17,9 @@ for cin, cout, hw in shapes:
     out = torch.empty(B, cout, hw, hw, device="cuda")
     out2 = torch.empty(B, cout, hw, hw, device="cuda")
     up = conv.pack_winograd43_weight(w, 64)
-    forms = {"packed": lambda: conv.conv3x3_winograd43_bias_relu(x, up, b, cout, True, out=out),
-             "pingpong": lambda: conv.conv3x3_winograd43_raw_bias_relu(x, w, b, cout, True, out=out2)}
+    forms = {"packed": lambda: conv.conv3x3_winograd43_bias_relu(x, up, b, cout, True, out=out)}
+    for v in (0, 1, 2, 4, 5, 6):  # bit 2: fenced MFMA groups; 0 / 1 / 2: no priorities / multiply high / transform high
+        forms[f"pp{v}"] = (lambda v=v: conv.conv3x3_winograd43_raw_bias_relu(x, w, b, cout, True, out=out2, variant=v))
     res = {}
     for name, fn in list(forms.items()) * 2:
         for _ in range(2):
@@ -35,5 +36,5 @@ for cin, cout, hw in shapes:
     line = f"{cin:4d}->{cout:4d} @{hw:3d}:"
     for name, ms in res.items():
         m = min(ms)
-        line += f"  {name} {m:7.3f} ms ({fl / m / 1e9 / 4:5.1f} TFLOP/s executed)"
+        line += f"  {name} {m:6.3f}"
     print(line + f"  max|packed - pingpong| {diff:.1e}")
