@@ -441,6 +441,9 @@ int pd3_conv3x3_winograd43_raw_bias_relu(const float *x, const float *w_raw, con
                                          int cout, int h, int w, int w_valid, int relu, float *out, void *stream);
 /* the same with the kernel's scheduling variant named (measurement: bit 2 = scheduling fences around the MFMA groups,
  * bits 0-1 = 0 no wave priorities / 1 multiply slots high / 2 transform slots high); identical results */
+/* measurement hook: + per-wave phase cycle counters of one workgroup, dbg [8][4] int64 (device) */
+int pd3_conv3x3_winograd43_raw_trace(const float *x, const float *w_raw, const float *bias, int batch, int cin, int cout,
+                                     int h, int w, int relu, float *out, int variant, long long *dbg, void *stream);
 int pd3_conv3x3_winograd43_raw_bias_relu_variant(const float *x, const float *w_raw, const float *bias, int batch,
                                                  int cin, int cout, int h, int w, int w_valid, int relu, float *out,
                                                  int variant, void *stream);

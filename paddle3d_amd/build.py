@@ -42,10 +42,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# per-file additions: the ping-pong Winograd kernel computes U = G g G^T next to its MFMAs, where the SLP vectoriser's
+# v_pk_* forms (two issue passes each, plus the v_mov shuffles that feed them) cost more than scalar VALU
+EXTRA_FLAGS = {"conv_winograd43_pp.hip": ["-fno-slp-vectorize"]}
+
+
 def _compile(src, force):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
     if force or _stale(obj, [src] + _headers()):
-        cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+        cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
