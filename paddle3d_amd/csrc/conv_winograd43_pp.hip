@@ -165,8 +165,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
       for (int nu = 0; nu < 6; ++nu) u[xi * 6 + nu] = r6[nu];
     }
   };
-  // one trip: 9 LDS reads of V feed 36 MFMAs
-  auto mfma_trip = [&](int kt, const float (&u)[36]) {
+  // element xi of G applied to (a, b, c) (w4_gg, one output at a time: xi is a compile-time constant where it is used)
+  auto gg1 = [](int xi, float a, float b, float c) -> float {
+    switch (xi) {
+      case 0: return a * 0.25f;
+      case 1: return ((a + c) + b) * (-1.f / 6.f);
+      case 2: return ((a + c) - b) * (-1.f / 6.f);
+      case 3: return __builtin_fmaf(a, 1.f / 24.f, c * (1.f / 6.f)) + b * (1.f / 12.f);
+      case 4: return __builtin_fmaf(a, 1.f / 24.f, c * (1.f / 6.f)) - b * (1.f / 12.f);
+      default: return c;
+    }
+  };
+  // one trip: 9 LDS reads of V feed 36 MFMAs.  ROLL: behind every third group (12 MFMAs = 384 matrix-pipe cycles in
+  // flight) two rows of the NEXT trip's U are computed into the twelve registers those groups have just released --
+  // ~30 VALU operations that do not depend on the MFMAs and run in their shadow, so only a slot's first U is exposed.
+  auto mfma_trip = [&](int kt, float (&u)[36], bool roll) {
     const float* vb = Vs + kt * (kW4Ci * kW4TC * kW4Cs) + bbase;
     w4_f32x4 b[3];
     b[0] = *reinterpret_cast<const w4_f32x4*>(vb);
@@ -179,6 +192,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
       for (int j = 0; j < 4; ++j)
         acc[g * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[g * 4 + j], b[g % 3][j], acc[g * 4 + j], 0, 0, 0);
       if (FENCE) __builtin_amdgcn_sched_barrier(0);
+      if (roll && g % 3 == 2) {
+        const int xi0 = 2 * (g / 3);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int xi = xi0 + r;
+          float r6[6];
+          w4_gg(gg1(xi, gw[kt + 1][0], gw[kt + 1][3], gw[kt + 1][6]), gg1(xi, gw[kt + 1][1], gw[kt + 1][4], gw[kt + 1][7]),
+                gg1(xi, gw[kt + 1][2], gw[kt + 1][5], gw[kt + 1][8]), r6);
+#pragma unroll
+          for (int nu = 0; nu < 6; ++nu) u[xi * 6 + nu] = r6[nu];
+        }
+        if (FENCE) __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 
@@ -209,9 +235,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
       fetch_x(min(s + 1, slots - 1));  // the next transform slot's raw rows travel during the MFMAs (the last slot
                                        // re-reads its own: no branch, so the load counter stays exact)
       if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(1);
-      mfma_trip(0, u);
-      make_u(1, u);
-      mfma_trip(1, u);
+      mfma_trip(0, u, true);   // + U of trip 1, rolled in behind the MFMA groups
+      mfma_trip(1, u, false);
       if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(0);
       stash_x();
       if (dbg) t_mu += clock64() - c0;
