@@ -57,6 +57,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
                                                                        long long* __restrict__ dbg) {
   constexpr int CO = 64;
   long long t_tr = 0, t_mu = 0, t_ba = 0, t_all = dbg ? clock64() : 0;  // phase cycles of this wave (measurement)
+  long long t_u0 = 0, t_m0 = 0, t_m1 = 0, t_st = 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = lane_id(), wave = wave_id();
   const int grp = wave >> 2, cb = wave & 3;  // tile row / 16-channel block of this wave; waves w and w + 4 share a SIMD
@@ -234,11 +235,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
       make_u(0, u);  // (first use of the weights fetched a slot ago: the wait must not cover the loads issued next)
       fetch_x(min(s + 1, slots - 1));  // the next transform slot's raw rows travel during the MFMAs (the last slot
                                        // re-reads its own: no branch, so the load counter stays exact)
+      const long long c_a = dbg ? clock64() : 0;
       if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(1);
       mfma_trip(0, u, true);   // + U of trip 1, rolled in behind the MFMA groups
+      const long long c_b = dbg ? clock64() : 0;
       mfma_trip(1, u, false);
       if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(0);
+      const long long c_c = dbg ? clock64() : 0;
       stash_x();
+      if (dbg) {
+        const long long c_d = clock64();
+        t_u0 += c_a - c0, t_m0 += c_b - c_a, t_m1 += c_c - c_b, t_st += c_d - c_c;
+      }
       if (dbg) t_mu += clock64() - c0;
     }
     const long long c1 = dbg ? clock64() : 0;
@@ -250,6 +258,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
     dbg[wave * 4 + 1] = t_mu;
     dbg[wave * 4 + 2] = t_ba;
     dbg[wave * 4 + 3] = (clock64() - t_all) | ((long long)__builtin_amdgcn_s_getreg(2308) << 56);  // + SIMD id (HW_ID[5:4])
+    dbg[32 + wave * 4 + 0] = t_u0;
+    dbg[32 + wave * 4 + 1] = t_m0;
+    dbg[32 + wave * 4 + 2] = t_m1;
+    dbg[32 + wave * 4 + 3] = t_st;
   }
 
   // epilogue (as above): Y = A^T M A; lane: tile column lane & 15, channels 4 (lane >> 4) + r of the co block
