@@ -433,20 +433,23 @@ int pd3_conv3x3_winograd43_bias_relu(const float *x, const float *u_packed, cons
                                      int cin, int cout, int h, int w, int w_valid, int relu, float *out,
                                      int channels_per_tile, void *stream);
 
-/* conv3x3_winograd43_raw_bias_relu -- the same convolution, same F(4x4, 3x3) arithmetic, as a two-group ping-pong kernel
- * that computes U = G g G^T in registers: w_raw is the plain folded [cout, cin, 3, 3] fp32 weight (no packing).
- * requires cin % 8 == 0, cout % 64 == 0, w % 4 == 0; results agree with the packed form to the rounding of U (fp32 on the
- * device here, fp64 on the host there: ~1e-7 relative). */
-int pd3_conv3x3_winograd43_raw_bias_relu(const float *x, const float *w_raw, const float *bias, int batch, int cin,
-                                         int cout, int h, int w, int w_valid, int relu, float *out, void *stream);
-/* the same with the kernel's scheduling variant named (measurement: bit 2 = scheduling fences around the MFMA groups,
- * bits 0-1 = 0 no wave priorities / 1 multiply slots high / 2 transform slots high); identical results */
+/* conv3x3_winograd43_pp_bias_relu -- the same convolution, same F(4x4, 3x3) arithmetic, as a two-group ping-pong kernel
+ * whose multiply waves issue only MFMAs and LDS reads; U and the raw input rows reach LDS by buffer_load ... lds.
+ *   u_lane: U = G g G^T of the [cout, cin, 3, 3] weight in lane order, [cout/64][cin/8][2 trips][4 blocks][9][64 lanes][4]:
+ *           lane l of block cb holds channel 64 ct + 16 cb + (l & 15), input channel 8 slot + 4 trip + (l >> 4), float4 q =
+ *           components 4q .. 4q+3 of xi*6+nu (paddle3d_amd/ops/conv.py:pack_winograd43_lane_weight); 16-byte aligned
+ *   requires cin % 8 == 0, cout % 64 == 0, w % 4 == 0; the same U values as the packed form give the same sums up to the
+ *   order of accumulation over input channels (identical here: ascending) */
+int pd3_conv3x3_winograd43_pp_bias_relu(const float *x, const float *u_lane, const float *bias, int batch, int cin,
+                                        int cout, int h, int w, int w_valid, int relu, float *out, void *stream);
+/* the same with the kernel's scheduling variant named (measurement: 0 no wave priorities / 1 multiply slots high /
+ * 2 transform slots high); identical results */
+int pd3_conv3x3_winograd43_pp_bias_relu_variant(const float *x, const float *u_lane, const float *bias, int batch,
+                                                int cin, int cout, int h, int w, int w_valid, int relu, float *out,
+                                                int variant, void *stream);
 /* measurement hook: + per-wave phase cycle counters of one workgroup, dbg [8][4] int64 (device) */
-int pd3_conv3x3_winograd43_raw_trace(const float *x, const float *w_raw, const float *bias, int batch, int cin, int cout,
-                                     int h, int w, int relu, float *out, int variant, long long *dbg, void *stream);
-int pd3_conv3x3_winograd43_raw_bias_relu_variant(const float *x, const float *w_raw, const float *bias, int batch,
-                                                 int cin, int cout, int h, int w, int w_valid, int relu, float *out,
-                                                 int variant, void *stream);
+int pd3_conv3x3_winograd43_pp_trace(const float *x, const float *u_lane, const float *bias, int batch, int cin, int cout,
+                                    int h, int w, int relu, float *out, int variant, long long *dbg, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * stable_argsort -- the index order the host glue of two reference functions needs, on the library's radix sort:

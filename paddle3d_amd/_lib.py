@@ -106,12 +106,12 @@ _SIGNATURES = {
     "pd3_stable_argsort_workspace": (C.c_size_t, [C.c_int64, C.c_uint32]),
     "pd3_stable_argsort": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t,
                                      C.c_void_p]),
-    "pd3_conv3x3_winograd43_raw_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+    "pd3_conv3x3_winograd43_pp_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "pd3_conv3x3_winograd43_raw_bias_relu_variant": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+    "pd3_conv3x3_winograd43_pp_bias_relu_variant": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                                C.c_int, C.c_void_p]),
-    "pd3_conv3x3_winograd43_raw_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+    "pd3_conv3x3_winograd43_pp_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                    C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "pd3_merge_sweeps_workspace": (C.c_size_t, [C.c_int64]),
     "pd3_merge_sweeps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

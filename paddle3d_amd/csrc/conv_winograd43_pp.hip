@@ -1,31 +1,35 @@
 // 3x3 / stride 1 / pad 1 convolution + bias + ReLU by Winograd F(4x4, 3x3) on the fp32 matrix cores: the ping-pong form
-// (round 4).  Same arithmetic and tile shape as conv_winograd43.hip (reference layers: second_backbone.py:72-120,
-// center_head.py:43-220, cuDNN there); see the comment in front of the kernel for what differs.
-// Built with -fno-slp-vectorize (paddle3d_amd/build.py): packed v_pk_* arithmetic beside MFMAs costs more than it saves.
+// whose multiply waves issue nothing but MFMAs and LDS reads (round 4).  Same arithmetic and tile shape as
+// conv_winograd43.hip (reference layers: second_backbone.py:72-120, center_head.py:43-220, cuDNN there).
 #include "../../include/paddle3d_amd.h"
 #include "common.hpp"
 #include "conv_winograd43.hpp"
 
+#include <type_traits>
+
 namespace pd3 {
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Round 4: the ping-pong form with two-trip slots and U computed on the fly (`conv3x3_winograd43_pp_kernel`).
+// What the hardware does (tools/hwcheck/mfma_valu_overlap.hip, measured): a wave's own VALU instructions do NOT run in
+// the shadow of its MFMAs (36 v_mfma_f32_16x16x4_f32 with K fmas behind each: 32.4 / 36.9 / 44.5 / 51.2 cycles per MFMA
+// for K = 0 / 1 / 3 / 6), while a SECOND wave on the SIMD runs VALU + LDS work at about half speed beside an MFMA-only
+// wave that keeps its 32.4 cycles.  So the matrix pipe is full only if the wave feeding it issues MFMAs and LDS reads and
+// nothing else, and everything else lives in the partner wave.  The packed kernel (conv_winograd43.hip) has waves 0-3
+// transform AND multiply; round 4's first ping-pong form computed U = G g G^T in the multiply waves (tied with packed).
 //
-// What bounds the kernel above: a trip is the input-transform chain of waves 0-3 (~2300-2700 cycles whatever
-// the amount of data: LDS read -> row pass -> DPP exchange -> column pass -> LDS write, a latency chain on one wave per
-// SIMD) FOLLOWED by those waves' own 36 MFMAs (~1350), against 2304 cycles of matrix work per SIMD and trip.  Round 2's
-// ping-pong gave every group its own transform per trip and lost: a slot was as long as the chain (2700), not as its 1152
-// cycles of MFMAs, and there were two slots per trip.  Here a slot covers TWO trips (8 input channels):
-//   * group g (waves 4g .. 4g+3, one per SIMD) owns tile row g for all 64 channels; in a transform slot its 256 threads
-//     turn the 8 channels x 16 tiles of ITS tile row into V (one patch per thread pair: the same per-thread chain as above),
-//     in a multiply slot its waves issue 2 x 36 MFMAs (2304 cycles) -- while the other group, half a period off, does the
-//     opposite.  Per SIMD one wave always feeds the matrix pipe while its partner runs the chain; a slot lasts
-//     max(chain, 2304) and two slots cover two trips.
-//   * the A operand is no longer a 36.9 KB slice of pre-transformed U per trip through L2 -> registers -> LDS ->
-//     registers: lane (co, ci) loads its 9 raw weights a slot ahead and computes U = G g G^T (36 values, ~90 VALU
-//     operations) in the shadow of the MFMAs -- a quarter of the ingest, no U in LDS (64 KB instead of 122 KB), no
-//     parking role.  The weights are the plain folded [cout][cin][3][3] tensor: no host-side packing.
-// One workgroup-wide barrier per slot, reached by both groups.
+// Here: group g (waves 4g .. 4g+3, one per SIMD) owns tile row g for all 64 channels of the workgroup and alternates
+//   T(s): its 256 threads turn the 8 channels x 16 tiles of its tile row into V (one patch per thread pair) -- VALU, DPP,
+//         LDS: the partner role;
+//   M(s): 72 MFMAs (two trips of 4 input channels) fed by ds_read_b128 alone: B from the group's V, A from a per-lane
+//         packed copy of U in LDS.  No VALU, no waits on global memory in front of an MFMA.
+// The other group runs the opposite role, one time slot off; ONE workgroup barrier per slot.
+// Nothing goes through registers on its way into LDS: the raw rows of the next transform slot AND the next slot's U
+// (pre-transformed on the host into lane order, 73.7 KB per slot and workgroup) travel by buffer_load_dwordx4 ... lds.
+// U has ONE buffer (double buffering does not fit 160 KB): both groups read slot s's values in the same time slot (group
+// 0 during its multiply slot, group 1 into registers at the end of its transform slot), and group 0 refills the buffer
+// at the start of its next transform slot, a whole slot ahead of the barrier that publishes it.  The raw rows are private
+// to a wave (wave cb transforms channels 2 cb, 2 cb + 1 of the slot): it refetches them right after reading them, two
+// slots ahead of their use, and waits for them itself -- no barrier is involved.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kPpKT = 2;                                   // trips per slot
 constexpr int kPpCi = kPpKT * kW4Ci;                       // 8 input channels per slot
@@ -35,34 +39,28 @@ constexpr int kPpRawSz = kPpCi * kPpRawPl;                 // 3456 floats per gr
 constexpr int kPpVsz = kPpCi * kW4TC * kW4Cs;              // 4608 floats per group
 constexpr int kPpXN4 = kPpRawSz / 4;                       // 864 float4 per group
 constexpr int kPpXPT = (kPpXN4 + 255) / 256;               // 4 per thread
+constexpr int kPpUHalf = 9 * 64 * 4;                       // 2304 floats: U of one trip for one wave (9 float4 per lane)
+constexpr int kPpUsz = kPpKT * 4 * kPpUHalf;               // 18432 floats per slot: [trip][cb][q][lane][4]
 
-// G applied to three values (one column / one row of the 3x3 kernel): F(4x4, 3x3)'s kernel transform
-__device__ __forceinline__ void w4_gg(const float a, const float b, const float c, float (&t)[6]) {
-  const float s = a + c;
-  t[0] = a * 0.25f;
-  t[1] = (s + b) * (-1.f / 6.f);
-  t[2] = (s - b) * (-1.f / 6.f);
-  const float p = __builtin_fmaf(a, 1.f / 24.f, c * (1.f / 6.f)), q = b * (1.f / 12.f);
-  t[3] = p + q;
-  t[4] = p - q;
-  t[5] = c;
-}
-
-template <bool FENCE>
 __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const float* __restrict__ x,
-                                                                       const float* __restrict__ wraw,
+                                                                       const float* __restrict__ ulane,
                                                                        const float* __restrict__ bias,
                                                                        float* __restrict__ out, int cin, int cout, int h,
                                                                        int w, int wv, int relu, int ptiles, int prio,
                                                                        long long* __restrict__ dbg) {
   constexpr int CO = 64;
   long long t_tr = 0, t_mu = 0, t_ba = 0, t_all = dbg ? clock64() : 0;  // phase cycles of this wave (measurement)
-  long long t_u0 = 0, t_m0 = 0, t_m1 = 0, t_st = 0;
+  long long t_p[5] = {0, 0, 0, 0, 0}, t_c = 0;
+  const bool tl = dbg && blockIdx.x == 8 && lane_id() == 0;
+  auto stamp = [&](int wv, int s, int id) {
+    if (tl && s < 8) dbg[128 + (wv * 8 + s) * 8 + id] = clock64() - t_all;
+  };  // inside the transform slot: row wait, row reads, fetches, arithmetic, tail
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = lane_id(), wave = wave_id();
+  const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(wave_id());  // (uniform: scalar slot control)
   const int grp = wave >> 2, cb = wave & 3;  // tile row / 16-channel block of this wave; waves w and w + 4 share a SIMD
-  const int gt = threadIdx.x & 255;          // thread inside its group
-  float* Raw = smem + grp * (kPpRawSz + kPpVsz);  // [8 ci][6 rows][72 cols] of this group's tile row
+  const int gt = cb * 64 + lane;             // thread inside its group
+  float* Us = smem;                                          // [2 trips][4 cb][9][64 lanes][4]: U of the current slot
+  float* Raw = smem + kPpUsz + grp * (kPpRawSz + kPpVsz);    // [8 ci][6 rows][72 cols] of this group's tile row
   float* Vs = Raw + kPpRawSz;                      // [8 ci][16 tiles][36]
   const int tiles_x = (w + 4 * kW4TC - 1) / (4 * kW4TC), tiles_y = (h + 4 * kW4TR - 1) / (4 * kW4TR);
   const int nct = cout / CO;
@@ -75,61 +73,90 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
   const int64_t plane = (int64_t)h * w;
   const float* xin = x + (int64_t)n * cin * plane;
 
-  // staging pattern of this group's raw rows (identical for every slot)
-  int gofs[kPpXPT], ldst[kPpXPT];
-  unsigned live = 0;
+  // staging pattern of this WAVE's raw rows (identical for every slot).  Wave cb transforms channels 2 cb and 2 cb + 1 of
+  // the slot and nothing else, so those two planes of Raw ([2][6][72] = 216 float4) are private to it: it fetches them
+  // itself and needs no barrier between its reads and the next fetch.  float4 e = lane + 64 i comes from byte offset
+  // gofs[i] of the slot's 8 channel planes, or from beyond the buffer's range (-> zeros) for the padding.
+  constexpr int kWvN4 = 2 * kPpRawPl / 4;  // 216
+  unsigned gofs[kPpXPT];
 #pragma unroll
   for (int i = 0; i < kPpXPT; ++i) {
-    const int e = min(gt + i * 256, kPpXN4 - 1);
-    const int ci = e / (kPpRawR * (kW4RawW / 4)), rem = e - ci * (kPpRawR * (kW4RawW / 4));
+    const int e = min(lane + i * 64, kWvN4 - 1);
+    const int cl = e / (kPpRawR * (kW4RawW / 4)), rem = e - cl * (kPpRawR * (kW4RawW / 4));
     const int r = rem / (kW4RawW / 4), c4 = rem - r * (kW4RawW / 4);
     const int gy = y0 + 4 * grp - 1 + r, gx = x0 - 4 + c4 * 4;
     const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
-    gofs[i] = ok ? (int)(ci * plane + (int64_t)gy * w + gx) : 0;
-    live |= ok ? (1u << i) : 0u;
-    ldst[i] = e * 4;
+    gofs[i] = ok ? (unsigned)(4 * ((2 * cb + cl) * plane + (int64_t)gy * w + gx)) : 0x7ffffff0u;
   }
   // transform assignment: thread pair (2p, 2p+1) of the group owns patch p = (ci 0..7, tile column 0..15)
   const int pidx = gt >> 1, hf = gt & 1;
   const int pci = pidx >> 4, ptile = pidx & 15;
   const int rsrc = pci * kPpRawPl + 4 * ptile + 3 + 3 * hf;
   const int vdst = (pci * kW4TC + ptile) * kW4Cs + 18 * hf;
-  // MFMA operands: B = V[(trip * 4 + k) ci][tile][component]; A = U of (co, ci) = (lane & 15, lane >> 4), on the fly
+  // MFMA operands: B = V[(trip * 4 + k) ci][tile][component]; A = U of (co, ci) = (lane & 15, lane >> 4), float4 q of the
+  // lane's 36 components at Us[((trip * 4 + cb) * 9 + q) * 256 + 4 lane]
   const int bbase = ((lane >> 4) * kW4TC + (lane & 15)) * kW4Cs;
-  const float* wlane = wraw + ((int64_t)(ct * CO + cb * 16 + (lane & 15)) * cin + (lane >> 4)) * 9;
+  const float* uct = ulane + (int64_t)ct * slots * kPpUsz;  // this workgroup's 64 output channels, all slots
 
   w4_f32x4 acc[36];
 #pragma unroll
   for (int c = 0; c < 36; ++c) acc[c] = (w4_f32x4){0.f, 0.f, 0.f, 0.f};
-  w4_f32x4 xr[kPpXPT];
-  float gw[kPpKT][9];
 
+  // the wave's raw rows of slot s go from global memory straight into its planes of Raw (buffer_load_dwordx4 ... lds: no
+  // staging registers, no store pass)
   auto fetch_x = [&](int s) {
-    const float* xc = xin + (int64_t)s * kPpCi * plane;
-#pragma unroll
-    for (int i = 0; i < kPpXPT; ++i) xr[i] = *reinterpret_cast<const w4_f32x4*>(xc + gofs[i]);
-  };
-  auto fetch_g = [&](int s) {
-#pragma unroll
-    for (int kt = 0; kt < kPpKT; ++kt)
-#pragma unroll
-      for (int q = 0; q < 9; ++q) gw[kt][q] = wlane[(int64_t)(s * kPpCi + kt * kW4Ci) * 9 + q];
-  };
-  auto stash_x = [&]() {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(xin + (int64_t)s * kPpCi * plane), 0, (int)(kPpCi * plane * 4), 0x00020000);
 #pragma unroll
     for (int i = 0; i < kPpXPT; ++i) {
-      const w4_f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      if (kPpXN4 % 256 == 0 || gt + i * 256 < kPpXN4)
-        *reinterpret_cast<w4_f32x4*>(Raw + ldst[i]) = ((live >> i) & 1u) ? xr[i] : z;
+      if (lane + i * 64 < kWvN4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rs, (__attribute__((address_space(3))) void*)(Raw + 2 * cb * kPpRawPl + i * 256), 16, gofs[i], 0, 0, 0);
     }
   };
-  auto transform = [&]() {  // V = B^T d B of this thread pair's patch (as W4_TRANSFORM above)
-    float lo[3][3], hi[3][3];
+  // half hh of slot s of this wave's U block: 9 KB, contiguous in global memory and in LDS alike
+  const __amdgpu_buffer_rsrc_t urs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uct), 0, (int)((int64_t)slots * kPpUsz * 4), 0x00020000);
+  auto fetch_u = [&](int s, int hh) {
+    const int blk = (hh * 4 + cb) * kPpUHalf;
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (__attribute__((address_space(3))) void*)(Us + blk + q * 256), 16,
+                                               lane * 16, (s * kPpUsz + blk + q * 256) * 4, 0, 0);
+  };
+  // V = B^T d B of this thread pair's patch (as W4_TRANSFORM above).  The wave's raw rows are read first and the fetch of
+  // the NEXT slot's rows follows at once (slot sn): it has the rest of this slot and the whole multiply slot to land.
+  int cur_s = 0;
+  auto transform = [&](int sn, auto&& before_x) {
+    float rv[3][6];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
       const float* d = Raw + rsrc + b;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) rv[b][r] = d[r * kW4RawW];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the reads are done before the rows are overwritten
+    if (dbg) {
+      const long long c = clock64();
+      t_p[1] += c - t_c, t_c = c;
+    }
+    stamp(wave, cur_s, 1);
+    if (!(prio & 8)) {
+      before_x();
+      fetch_x(sn);
+    }
+    if (dbg) {
+      const long long c = clock64();
+      t_p[2] += c - t_c, t_c = c;
+    }
+    stamp(wave, cur_s, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    float lo[3][3], hi[3][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
       float t[6];
-      w4_in(d[0], d[kW4RawW], d[2 * kW4RawW], d[3 * kW4RawW], d[4 * kW4RawW], d[5 * kW4RawW], t);
+      w4_in(rv[b][0], rv[b][1], rv[b][2], rv[b][3], rv[b][4], rv[b][5], t);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         lo[a][b] = t[a];
@@ -153,115 +180,146 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
       *reinterpret_cast<w4_f32x2*>(v + a * 6 + 4) = (w4_f32x2){o[4], o[5]};
     }
   };
-  // U = G g G^T of this lane's (co, ci) for trip kt, in registers
-  auto make_u = [&](int kt, float (&u)[36]) {
-    float tc[3][6];  // G g: column j of the kernel through the transform
+  // a multiply slot: 72 MFMAs, one stream over both trips, fed by ds_read_b128 alone; B through a ring of three reads, two
+  // groups ahead.  No buffer_load ... lds here: one piece costs an MFMA stream 60-185 cycles of issue (measured: a group
+  // that issued 18 of them per slot took 4200 cycles for its 2304 cycles of MFMAs), a transform slot 25-60.
+  //   group 0: A through a second ring, straight from Us (whose refill landed before the barrier in front of this slot);
+  //   group 1: A from the registers ua[], read from Us at the end of its transform slot -- the SAME time slot in which
+  //            group 0 reads, so that Us is free for the refill one slot later.
+  auto vptr = [&](int g) { return Vs + (g / 9) * (kW4Ci * kW4TC * kW4Cs) + bbase + (g % 9) * 4; };
+  auto uptr = [&](int g) { return Us + (((g / 9) * 4 + cb) * 9 + (g % 9)) * 256 + lane * 4; };
+  w4_f32x4 ua[18];
+  auto multiply_ring = [&]() {
+    w4_f32x4 a[3], b[3];
+    a[0] = *reinterpret_cast<const w4_f32x4*>(uptr(0));
+    b[0] = *reinterpret_cast<const w4_f32x4*>(vptr(0));
+    a[1] = *reinterpret_cast<const w4_f32x4*>(uptr(1));
+    b[1] = *reinterpret_cast<const w4_f32x4*>(vptr(1));
 #pragma unroll
-    for (int j = 0; j < 3; ++j) w4_gg(gw[kt][j], gw[kt][3 + j], gw[kt][6 + j], tc[j]);
+    for (int t = 0; t < 2; ++t) {
 #pragma unroll
-    for (int xi = 0; xi < 6; ++xi) {
-      float r6[6];
-      w4_gg(tc[0][xi], tc[1][xi], tc[2][xi], r6);
-#pragma unroll
-      for (int nu = 0; nu < 6; ++nu) u[xi * 6 + nu] = r6[nu];
-    }
-  };
-  // element xi of G applied to (a, b, c) (w4_gg, one output at a time: xi is a compile-time constant where it is used)
-  auto gg1 = [](int xi, float a, float b, float c) -> float {
-    switch (xi) {
-      case 0: return a * 0.25f;
-      case 1: return ((a + c) + b) * (-1.f / 6.f);
-      case 2: return ((a + c) - b) * (-1.f / 6.f);
-      case 3: return __builtin_fmaf(a, 1.f / 24.f, c * (1.f / 6.f)) + b * (1.f / 12.f);
-      case 4: return __builtin_fmaf(a, 1.f / 24.f, c * (1.f / 6.f)) - b * (1.f / 12.f);
-      default: return c;
-    }
-  };
-  // one trip: 9 LDS reads of V feed 36 MFMAs.  ROLL: behind every third group (12 MFMAs = 384 matrix-pipe cycles in
-  // flight) two rows of the NEXT trip's U are computed into the twelve registers those groups have just released --
-  // ~30 VALU operations that do not depend on the MFMAs and run in their shadow, so only a slot's first U is exposed.
-  auto mfma_trip = [&](int kt, float (&u)[36], bool roll) {
-    const float* vb = Vs + kt * (kW4Ci * kW4TC * kW4Cs) + bbase;
-    w4_f32x4 b[3];
-    b[0] = *reinterpret_cast<const w4_f32x4*>(vb);
-    b[1] = *reinterpret_cast<const w4_f32x4*>(vb + 4);
-#pragma unroll
-    for (int g = 0; g < 9; ++g) {
-      if (g + 2 < 9) b[(g + 2) % 3] = *reinterpret_cast<const w4_f32x4*>(vb + (g + 2) * 4);
-      if (FENCE) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[g * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[g * 4 + j], b[g % 3][j], acc[g * 4 + j], 0, 0, 0);
-      if (FENCE) __builtin_amdgcn_sched_barrier(0);
-      if (roll && g % 3 == 2) {
-        const int xi0 = 2 * (g / 3);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int xi = xi0 + r;
-          float r6[6];
-          w4_gg(gg1(xi, gw[kt + 1][0], gw[kt + 1][3], gw[kt + 1][6]), gg1(xi, gw[kt + 1][1], gw[kt + 1][4], gw[kt + 1][7]),
-                gg1(xi, gw[kt + 1][2], gw[kt + 1][5], gw[kt + 1][8]), r6);
-#pragma unroll
-          for (int nu = 0; nu < 6; ++nu) u[xi * 6 + nu] = r6[nu];
+      for (int g9 = 0; g9 < 9; ++g9) {
+        const int g = t * 9 + g9;
+        if (g + 2 < 18 && !(prio & 4)) {
+          a[(g + 2) % 3] = *reinterpret_cast<const w4_f32x4*>(uptr(g + 2));
+          b[(g + 2) % 3] = *reinterpret_cast<const w4_f32x4*>(vptr(g + 2));
         }
-        if (FENCE) __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[g9 * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g % 3][j], b[g % 3][j], acc[g9 * 4 + j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (prio & 16) __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  };
+  auto multiply_regs = [&]() {
+    w4_f32x4 b[3];
+    b[0] = *reinterpret_cast<const w4_f32x4*>(vptr(0));
+    b[1] = *reinterpret_cast<const w4_f32x4*>(vptr(1));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int g9 = 0; g9 < 9; ++g9) {
+        const int g = t * 9 + g9;
+        if (g + 2 < 18 && !(prio & 4)) b[(g + 2) % 3] = *reinterpret_cast<const w4_f32x4*>(vptr(g + 2));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[g9 * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[g][j], b[g % 3][j], acc[g9 * 4 + j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (prio & 16) __builtin_amdgcn_s_sleep(1);
       }
     }
   };
 
-  // group g runs T(0) M(0) T(1) M(1) ... one slot behind group g - 1: 2 * slots + 1 time slots, ONE barrier each.  A
-  // multiply slot ends by staging the raw rows of the group's next transform slot (fetched at its start), so a transform
-  // slot is the chain alone.  (A first version staged at the start of the transform slot behind a second barrier: the
-  // barrier lined the other group's first trip up with the staging and its second trip with the transform, i.e. the
-  // slot was one trip + the chain instead of their maximum: 15-20 % slower than the packed form.)
+  // prologue: the raw rows of slot 0 (each wave its own) and slot 0's U (group 0's waves, as in the loop)
   fetch_x(0);
-  stash_x();
+  if (grp == 0) {
+    fetch_u(0, 0);
+    fetch_u(0, 1);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
   __syncthreads();
-  const int nt = 2 * slots + 1;
-  for (int tau = 0; tau < nt; ++tau) {
-    const int k = tau - grp;
-    const bool active = k >= 0 && k < 2 * slots;
-    const int s = k >> 1;
-    if (active && (k & 1) == 0) {  // transform slot s
-      const long long c0 = dbg ? clock64() : 0;
-      fetch_g(s);                  // needed by the multiply slot that follows
-      if ((prio & 3) == 2) __builtin_amdgcn_s_setprio(2);
-      transform();
-      if ((prio & 3) == 2) __builtin_amdgcn_s_setprio(0);
-      if (dbg) t_tr += clock64() - c0;
-    } else if (active) {           // multiply slot s
-      const long long c0 = dbg ? clock64() : 0;
-      float u[36];
-      make_u(0, u);  // (first use of the weights fetched a slot ago: the wait must not cover the loads issued next)
-      fetch_x(min(s + 1, slots - 1));  // the next transform slot's raw rows travel during the MFMAs (the last slot
-                                       // re-reads its own: no branch, so the load counter stays exact)
-      const long long c_a = dbg ? clock64() : 0;
-      if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(1);
-      mfma_trip(0, u, true);   // + U of trip 1, rolled in behind the MFMA groups
-      const long long c_b = dbg ? clock64() : 0;
-      mfma_trip(1, u, false);
-      if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(0);
-      const long long c_c = dbg ? clock64() : 0;
-      stash_x();
-      if (dbg) {
-        const long long c_d = clock64();
-        t_u0 += c_a - c0, t_m0 += c_b - c_a, t_m1 += c_c - c_b, t_st += c_d - c_c;
-      }
-      if (dbg) t_mu += clock64() - c0;
-    }
+  // (every wave passes 2 * slots + 1 barriers: group 1 waits out the first time slot, group 0 the last)
+  auto sync = [&]() {
     const long long c1 = dbg ? clock64() : 0;
     __syncthreads();
     if (dbg) t_ba += clock64() - c1;
-  }
+  };
+  // one straight-line loop per group (a single loop with the group's role chosen inside keeps two copies of the 144
+  // accumulators alive across the join and spills)
+  auto run = [&](auto is_g0) {
+    constexpr bool G0 = decltype(is_g0)::value;
+    if (!G0) sync();
+    for (int s = 0; s < slots; ++s) {
+      {  // transform slot s
+        const long long c0 = dbg ? clock64() : 0;
+        if ((prio & 3) == 2) __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the wave's own rows (fetched a transform slot ago) are in Raw
+        if (dbg) t_c = clock64(), t_p[0] += t_c - c0;
+        stamp(wave, s, 0);
+        const int sn = min(s + 1, slots - 1);  // (the last slot's refetch is never read)
+        cur_s = s;
+        if (G0) {
+          // Us is free: group 0 read slot s - 1 through its ring in the time slot before this one, group 1 into ua[].
+          // The refill goes first (in-order returns: it must not wait behind the raw rows, which come from HBM) and has
+          // landed before the barrier that ends the slot -- in front of group 0's multiply slot and group 1's read.
+          transform(sn, [&]() {
+            if (s > 0) {
+              fetch_u(s, 0);
+              fetch_u(s, 1);
+            }
+          });
+          if (dbg) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const long long c = clock64();
+            t_p[3] += c - t_c, t_c = c;
+          }
+          stamp(wave, s, 3);
+          __builtin_amdgcn_s_waitcnt(0x0f70 | 4);  // vmcnt(4): everything but the four raw-row pieces issued last
+        } else {
+          transform(sn, [&]() {});
+          if (dbg) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const long long c = clock64();
+            t_p[3] += c - t_c, t_c = c;
+          }
+          stamp(wave, s, 3);
+#pragma unroll
+          for (int g = 0; g < 18; ++g) ua[g] = *reinterpret_cast<const w4_f32x4*>(uptr(g));
+        }
+        if ((prio & 3) == 2) __builtin_amdgcn_s_setprio(0);
+        if (dbg) {
+          const long long c = clock64();
+          t_p[4] += c - t_c, t_tr += c - c0;
+        }
+        stamp(wave, s, 4);
+      }
+      sync();
+      {  // multiply slot s
+        const long long c0 = dbg ? clock64() : 0;
+        stamp(wave, s, 5);
+        if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(1);
+        if (G0) multiply_ring();
+        else multiply_regs();
+        if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(0);
+        if (dbg) t_mu += clock64() - c0;
+        stamp(wave, s, 6);
+      }
+      sync();
+    }
+    if (G0) sync();
+  };
+  if (grp == 0) run(std::true_type{});
+  else run(std::false_type{});
   if (dbg && blockIdx.x == 8 && lane == 0) {
     dbg[wave * 4 + 0] = t_tr;
     dbg[wave * 4 + 1] = t_mu;
     dbg[wave * 4 + 2] = t_ba;
     dbg[wave * 4 + 3] = (clock64() - t_all) | ((long long)__builtin_amdgcn_s_getreg(2308) << 56);  // + SIMD id (HW_ID[5:4])
-    dbg[32 + wave * 4 + 0] = t_u0;
-    dbg[32 + wave * 4 + 1] = t_m0;
-    dbg[32 + wave * 4 + 2] = t_m1;
-    dbg[32 + wave * 4 + 3] = t_st;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dbg[32 + wave * 5 + i] = t_p[i];
   }
 
   // epilogue (as above): Y = A^T M A; lane: tile column lane & 15, channels 4 (lane >> 4) + r of the co block
@@ -307,55 +365,58 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
 
 using namespace pd3;
 
-// The ping-pong form: weights are the plain folded [cout][cin][3][3] tensor (U is computed in the kernel).
-// variant (measurement): bit 2 = scheduling fences around the MFMA groups; bits 0-1 = 0 no priorities, 1 multiply slots
-// high, 2 transform slots high
-static int launch_wino43_pp(const float* x, const float* w_raw, const float* bias, int batch, int cin, int cout, int h,
+// variant (measurement): 0 no wave priorities, 1 multiply slots high, 2 transform slots high
+static int launch_wino43_pp(const float* x, const float* u_lane, const float* bias, int batch, int cin, int cout, int h,
                             int w, int w_valid, int relu, float* out, int variant, hipStream_t s,
                             long long* dbg = nullptr) {
-  constexpr size_t lds = (size_t)2 * (kPpRawSz + kPpVsz) * sizeof(float);
-  const bool fence = (variant & 4) != 0;
-  const void* fn = fence ? reinterpret_cast<const void*>(conv3x3_winograd43_pp_kernel<true>)
-                         : reinterpret_cast<const void*>(conv3x3_winograd43_pp_kernel<false>);
+  constexpr size_t lds = ((size_t)kPpUsz + 2 * (kPpRawSz + kPpVsz)) * sizeof(float);  // 138,240 B
+  const void* fn = reinterpret_cast<const void*>(conv3x3_winograd43_pp_kernel);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int64_t ptiles = (int64_t)batch * ceil_div(h, 4 * kW4TR) * ceil_div(w, 4 * kW4TC);
   const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / 64);
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
-  if (fence)
-    conv3x3_winograd43_pp_kernel<true><<<(unsigned)nwg, 512, lds, s>>>(x, w_raw, bias, out, cin, cout, h, w, w_valid, relu,
-                                                                       (int)ptiles, variant & 3, dbg);
-  else
-    conv3x3_winograd43_pp_kernel<false><<<(unsigned)nwg, 512, lds, s>>>(x, w_raw, bias, out, cin, cout, h, w, w_valid, relu,
-                                                                        (int)ptiles, variant & 3, dbg);
+  conv3x3_winograd43_pp_kernel<<<(unsigned)nwg, 512, lds, s>>>(x, u_lane, bias, out, cin, cout, h, w, w_valid, relu,
+                                                               (int)ptiles, variant, dbg);
   return launch_status();
 }
 
-extern "C" int pd3_conv3x3_winograd43_raw_bias_relu_variant(const float* x, const float* w_raw, const float* bias,
-                                                            int batch, int cin, int cout, int h, int w, int w_valid,
-                                                            int relu, float* out, int variant, void* stream) {
-  if (!x || !w_raw || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || w_valid <= 0 || w_valid > w)
+static int check_wino43_pp(const float* x, const float* u_lane, const float* out, int batch, int cin, int cout, int h,
+                           int w, int w_valid) {
+  if (!x || !u_lane || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || w_valid <= 0 || w_valid > w)
     return PD3_EINVAL;
   if (cin % kPpCi != 0 || cout % 64 != 0 || w % 4 != 0) return PD3_EUNSUPPORTED;
-  if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0) return PD3_EINVAL;
-  if ((int64_t)cin * h * w >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
-  return launch_wino43_pp(x, w_raw, bias, batch, cin, cout, h, w, w_valid, relu, out, variant,
+  if (reinterpret_cast<uintptr_t>(x) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0 ||
+      reinterpret_cast<uintptr_t>(u_lane) % 16 != 0)
+    return PD3_EINVAL;
+  if ((int64_t)kPpCi * h * w >= (int64_t)1 << 29) return PD3_EUNSUPPORTED;       // 32-bit byte offsets inside a slot
+  if ((int64_t)(cin / kPpCi) * kPpUsz >= (int64_t)1 << 29) return PD3_EUNSUPPORTED;  // and inside a channel tile's U
+  return PD3_OK;
+}
+
+extern "C" int pd3_conv3x3_winograd43_pp_bias_relu_variant(const float* x, const float* u_lane, const float* bias,
+                                                           int batch, int cin, int cout, int h, int w, int w_valid,
+                                                           int relu, float* out, int variant, void* stream) {
+  const int st = check_wino43_pp(x, u_lane, out, batch, cin, cout, h, w, w_valid);
+  if (st != PD3_OK) return st;
+  return launch_wino43_pp(x, u_lane, bias, batch, cin, cout, h, w, w_valid, relu, out, variant,
                           static_cast<hipStream_t>(stream));
 }
 
-extern "C" int pd3_conv3x3_winograd43_raw_bias_relu(const float* x, const float* w_raw, const float* bias, int batch,
-                                                    int cin, int cout, int h, int w, int w_valid, int relu, float* out,
-                                                    void* stream) {
-  return pd3_conv3x3_winograd43_raw_bias_relu_variant(x, w_raw, bias, batch, cin, cout, h, w, w_valid, relu, out, 1,
-                                                      stream);
+extern "C" int pd3_conv3x3_winograd43_pp_bias_relu(const float* x, const float* u_lane, const float* bias, int batch,
+                                                   int cin, int cout, int h, int w, int w_valid, int relu, float* out,
+                                                   void* stream) {
+  return pd3_conv3x3_winograd43_pp_bias_relu_variant(x, u_lane, bias, batch, cin, cout, h, w, w_valid, relu, out, 0,
+                                                     stream);
 }
 
 // measurement hook: the variant entry + per-wave phase cycle counters of one workgroup (dbg [8 waves][4]: transform,
 // multiply, barrier wait, whole kernel; device memory)
-extern "C" int pd3_conv3x3_winograd43_raw_trace(const float* x, const float* w_raw, const float* bias, int batch, int cin,
-                                                int cout, int h, int w, int relu, float* out, int variant,
-                                                long long* dbg, void* stream) {
-  if (!x || !w_raw || !out || !dbg || cin % kPpCi != 0 || cout % 64 != 0 || w % 4 != 0) return PD3_EINVAL;
-  return launch_wino43_pp(x, w_raw, bias, batch, cin, cout, h, w, w, relu, out, variant, static_cast<hipStream_t>(stream),
+extern "C" int pd3_conv3x3_winograd43_pp_trace(const float* x, const float* u_lane, const float* bias, int batch, int cin,
+                                               int cout, int h, int w, int relu, float* out, int variant, long long* dbg,
+                                               void* stream) {
+  const int st = check_wino43_pp(x, u_lane, out, batch, cin, cout, h, w, w);
+  if (st != PD3_OK || !dbg) return st != PD3_OK ? st : PD3_EINVAL;
+  return launch_wino43_pp(x, u_lane, bias, batch, cin, cout, h, w, w, relu, out, variant, static_cast<hipStream_t>(stream),
                           dbg);
 }

@@ -12,7 +12,7 @@ __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pitch4", "p
            "grouped_small_supported", "winograd_supported", "pack_winograd_weight", "conv3x3_winograd_bias_relu",
            "patch_mode", "patch_supported", "pack_patch_weight", "patch_conv_bias_relu",
            "winograd43_supported", "winograd43_tile", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu",
-           "winograd43_raw_supported", "conv3x3_winograd43_raw_bias_relu",
+           "winograd43_pp_supported", "pack_winograd43_lane_weight", "conv3x3_winograd43_pp_bias_relu",
            "f16_supported", "f16_tile", "pack_conv3x3_f16_weight", "conv3x3_f16_bias_relu", "to_f16_nhwc"]
 
 
@@ -263,28 +263,43 @@ def conv3x3_f16_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: i
     return out
 
 
-# ---- F(4x4, 3x3) as the ping-pong kernel that computes U on the fly (round 4) -------------------------------------------
-def winograd43_raw_supported(cin: int, cout: int, h: int, w: int) -> bool:
-    return cin % 8 == 0 and cout % 64 == 0
+# ---- F(4x4, 3x3) as the ping-pong kernel fed by LDS alone (round 4) ------------------------------------------------------
+def winograd43_pp_supported(cin: int, cout: int, h: int, w: int) -> bool:
+    return cin % 8 == 0 and cout % 64 == 0 and w % 4 == 0
 
 
-def conv3x3_winograd43_raw_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias, cout: int, relu: bool = True,
-                                     out: torch.Tensor | None = None, w_valid: int | None = None,
-                                     variant: int | None = None) -> torch.Tensor:
-    """x [n, cin, h, pitch] fp32, weight the plain folded [cout, cin, 3, 3] tensor -> [n, cout, h, pitch]."""
-    xx = require_gpu(x, "conv3x3_winograd43_raw_bias_relu")
-    wt = require_gpu(weight, "conv3x3_winograd43_raw_bias_relu")
+def pack_winograd43_lane_weight(weight: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> U = G g G^T (the values of pack_winograd43_weight) in the lane order of the ping-pong kernel:
+    [Cout/64][Cin/8][2 trips][4 blocks][9][64 lanes][4], lane = 16 (ci % 4) + (co % 16)."""
+    cout, cin = weight.shape[:2]
+    assert weight.shape[2:] == (3, 3) and cout % 64 == 0 and cin % 8 == 0
+    g = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                      [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64, device=weight.device)
+    u = torch.einsum("ij,ocjk,lk->ocil", g, weight.double(), g).float()  # [cout, cin, 6, 6]
+    #          ct          cb 16co  slot      trip ci4 q  j
+    u = u.reshape(cout // 64, 4, 16, cin // 8, 2, 4, 9, 4).permute(0, 3, 4, 1, 6, 5, 2, 7)
+    return u.contiguous()
+
+
+def conv3x3_winograd43_pp_bias_relu(x: torch.Tensor, u_lane: torch.Tensor, bias, cout: int, relu: bool = True,
+                                    out: torch.Tensor | None = None, w_valid: int | None = None,
+                                    variant: int | None = None) -> torch.Tensor:
+    """x [n, cin, h, pitch] fp32, u_lane from pack_winograd43_lane_weight -> [n, cout, h, pitch]."""
+    xx = require_gpu(x, "conv3x3_winograd43_pp_bias_relu")
+    ul = require_gpu(u_lane, "conv3x3_winograd43_pp_bias_relu")
     n, cin, h, w = xx.shape
+    if ul.numel() != cout * cin * 36:
+        raise RuntimeError("conv3x3_winograd43_pp_bias_relu: u_lane does not belong to a [cout, cin, 3, 3] weight")
     if out is None:
         out = torch.empty((n, cout, h, w), dtype=torch.float32, device=xx.device)
     if variant is None:
-        st = lib().pd3_conv3x3_winograd43_raw_bias_relu(ptr(xx), ptr(wt), ptr(bias), n, cin, cout, h, w,
-                                                        w if w_valid is None else int(w_valid), int(bool(relu)),
-                                                        ptr(out), stream_ptr(xx.device))
+        st = lib().pd3_conv3x3_winograd43_pp_bias_relu(ptr(xx), ptr(ul), ptr(bias), n, cin, cout, h, w,
+                                                       w if w_valid is None else int(w_valid), int(bool(relu)),
+                                                       ptr(out), stream_ptr(xx.device))
     else:
-        st = lib().pd3_conv3x3_winograd43_raw_bias_relu_variant(ptr(xx), ptr(wt), ptr(bias), n, cin, cout, h, w,
-                                                                w if w_valid is None else int(w_valid),
-                                                                int(bool(relu)), ptr(out), int(variant),
-                                                                stream_ptr(xx.device))
-    check(st, "conv3x3_winograd43_raw_bias_relu")
+        st = lib().pd3_conv3x3_winograd43_pp_bias_relu_variant(ptr(xx), ptr(ul), ptr(bias), n, cin, cout, h, w,
+                                                               w if w_valid is None else int(w_valid),
+                                                               int(bool(relu)), ptr(out), int(variant),
+                                                               stream_ptr(xx.device))
+    check(st, "conv3x3_winograd43_pp_bias_relu")
     return out

@@ -1,5 +1,5 @@
 """Timing driver (not a test): the F(4x4,3x3) kernels on the stride-1 layer shapes of CenterPoint-Pillars, batch 16:
-the packed form (pre-transformed U through LDS) and the ping-pong form of round 4 (two-trip slots, U on the fly)."""
+the packed form (waves 0-3 transform and multiply) and the ping-pong form of round 4 (multiply waves fed by LDS alone)."""
 import os
 import sys
 
@@ -10,6 +10,8 @@ from paddle3d_amd.ops import conv  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 shapes = [(64, 64, 256), (128, 128, 128), (256, 256, 64), (384, 64, 128), (64, 1152, 128)]
+if len(sys.argv) > 3:
+    shapes = shapes[1:2]
 for cin, cout, hw in shapes:
     x = torch.randn(B, cin, hw, hw, device="cuda")
     w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
@@ -18,8 +20,9 @@ for cin, cout, hw in shapes:
     out2 = torch.empty(B, cout, hw, hw, device="cuda")
     up = conv.pack_winograd43_weight(w, 64)
     forms = {"packed": lambda: conv.conv3x3_winograd43_bias_relu(x, up, b, cout, True, out=out)}
-    for v in (0, 1, 2, 4, 5, 6):  # bit 2: fenced MFMA groups; 0 / 1 / 2: no priorities / multiply high / transform high
-        forms[f"pp{v}"] = (lambda v=v: conv.conv3x3_winograd43_raw_bias_relu(x, w, b, cout, True, out=out2, variant=v))
+    ul = conv.pack_winograd43_lane_weight(w)
+    for v in ([int(a) for a in sys.argv[2].split(',')] if len(sys.argv) > 2 else (0, 1, 2)):  # 0 / 1 / 2: no wave priorities / multiply slots high / transform slots high
+        forms[f"pp{v}"] = (lambda v=v: conv.conv3x3_winograd43_pp_bias_relu(x, ul, b, cout, True, out=out2, variant=v))
     res = {}
     for name, fn in list(forms.items()) * 2:
         for _ in range(2):
