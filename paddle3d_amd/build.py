@@ -44,7 +44,7 @@ def _stale(target, deps):
 
 # per-file additions: the ping-pong Winograd kernel computes U = G g G^T next to its MFMAs, where the SLP vectoriser's
 # v_pk_* forms (two issue passes each, plus the v_mov shuffles that feed them) cost more than scalar VALU
-EXTRA_FLAGS = {"conv_winograd43_pp.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {}
 
 
 def _compile(src, force):

@@ -142,10 +142,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
       t_p[1] += c - t_c, t_c = c;
     }
     stamp(wave, cur_s, 1);
-    if (!(prio & 8)) {
-      before_x();
-      fetch_x(sn);
-    }
+    before_x();
+    fetch_x(sn);
     if (dbg) {
       const long long c = clock64();
       t_p[2] += c - t_c, t_c = c;
@@ -200,7 +198,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
 #pragma unroll
       for (int g9 = 0; g9 < 9; ++g9) {
         const int g = t * 9 + g9;
-        if (g + 2 < 18 && !(prio & 4)) {
+        if (g + 2 < 18) {
           a[(g + 2) % 3] = *reinterpret_cast<const w4_f32x4*>(uptr(g + 2));
           b[(g + 2) % 3] = *reinterpret_cast<const w4_f32x4*>(vptr(g + 2));
         }
@@ -209,7 +207,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
         for (int j = 0; j < 4; ++j)
           acc[g9 * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g % 3][j], b[g % 3][j], acc[g9 * 4 + j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (prio & 16) __builtin_amdgcn_s_sleep(1);
       }
     }
   };
@@ -222,13 +219,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
 #pragma unroll
       for (int g9 = 0; g9 < 9; ++g9) {
         const int g = t * 9 + g9;
-        if (g + 2 < 18 && !(prio & 4)) b[(g + 2) % 3] = *reinterpret_cast<const w4_f32x4*>(vptr(g + 2));
+        if (g + 2 < 18) b[(g + 2) % 3] = *reinterpret_cast<const w4_f32x4*>(vptr(g + 2));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[g9 * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[g][j], b[g % 3][j], acc[g9 * 4 + j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (prio & 16) __builtin_amdgcn_s_sleep(1);
       }
     }
   };
@@ -256,17 +252,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
       {  // transform slot s
         const long long c0 = dbg ? clock64() : 0;
         if ((prio & 3) == 2) __builtin_amdgcn_s_setprio(2);
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the wave's own rows (fetched a transform slot ago) are in Raw
-        if (dbg) t_c = clock64(), t_p[0] += t_c - c0;
-        stamp(wave, s, 0);
         const int sn = min(s + 1, slots - 1);  // (the last slot's refetch is never read)
         cur_s = s;
         if (G0) {
           // Us is free: group 0 read slot s - 1 through its ring in the time slot before this one, group 1 into ua[].
-          // The refill goes first (in-order returns: it must not wait behind the raw rows, which come from HBM) and has
-          // landed before the barrier that ends the slot -- in front of group 0's multiply slot and group 1's read.
+          // The refill goes out at once -- the other group's MFMAs hold this SIMD for most of the slot (a dense fp32 MFMA
+          // stream starves its partner of VALU issue and LDS returns: tools/hwcheck/pingpong_skeleton.hip), the memory
+          // pipe takes the eighteen pieces meanwhile -- and lands before the barrier that ends the slot, in front of
+          // group 0's multiply slot and group 1's read.
+          if (s > 0 && !(prio & 4)) {
+            fetch_u(s, 0);
+            fetch_u(s, 1);
+            __builtin_amdgcn_s_waitcnt(0x4f72);  // vmcnt(18): the wave's own rows, fetched a transform slot ago, are in Raw
+          } else {
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+          }
+          if (dbg) t_c = clock64(), t_p[0] += t_c - c0;
+          stamp(wave, s, 0);
           transform(sn, [&]() {
-            if (s > 0) {
+            if (s > 0 && (prio & 4)) {
               fetch_u(s, 0);
               fetch_u(s, 1);
             }
@@ -279,6 +283,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
           stamp(wave, s, 3);
           __builtin_amdgcn_s_waitcnt(0x0f70 | 4);  // vmcnt(4): everything but the four raw-row pieces issued last
         } else {
+          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the wave's own rows (fetched a transform slot ago) are in Raw
+          if (dbg) t_c = clock64(), t_p[0] += t_c - c0;
+          stamp(wave, s, 0);
           transform(sn, [&]() {});
           if (dbg) {
             __builtin_amdgcn_s_waitcnt(0xc07f);

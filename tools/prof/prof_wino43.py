@@ -24,16 +24,16 @@ for cin, cout, hw in shapes:
     for v in ([int(a) for a in sys.argv[2].split(',')] if len(sys.argv) > 2 else (0, 1, 2)):  # 0 / 1 / 2: no wave priorities / multiply slots high / transform slots high
         forms[f"pp{v}"] = (lambda v=v: conv.conv3x3_winograd43_pp_bias_relu(x, ul, b, cout, True, out=out2, variant=v))
     res = {}
-    for name, fn in list(forms.items()) * 2:
+    for name, fn in list(forms.items()) * 4:
         for _ in range(2):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5):
+        for _ in range(20):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        res.setdefault(name, []).append(e0.elapsed_time(e1) / 5)
+        res.setdefault(name, []).append(e0.elapsed_time(e1) / 20)
     fl = 2.0 * B * hw * hw * cin * cout * 9
     diff = (out - out2).abs().max().item()
     line = f"{cin:4d}->{cout:4d} @{hw:3d}:"
