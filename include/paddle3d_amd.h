@@ -451,6 +451,14 @@ int pd3_conv3x3_winograd43_pp_bias_relu_variant(const float *x, const float *u_l
 int pd3_conv3x3_winograd43_pp_trace(const float *x, const float *u_lane, const float *bias, int batch, int cin, int cout,
                                     int h, int w, int relu, float *out, int variant, long long *dbg, void *stream);
 
+/* conv3x3_winograd43_pl_bias_relu -- the pipelined form: the input transform of the next slot in micro-steps behind the
+ * MFMAs of the current one, all eight waves in one role; same u_lane, requirements and bytes as the ping-pong form */
+int pd3_conv3x3_winograd43_pl_bias_relu(const float *x, const float *u_lane, const float *bias, int batch, int cin,
+                                        int cout, int h, int w, int w_valid, int relu, float *out, void *stream);
+/* measurement hook: + cycle stamps of one workgroup's first eight slots, dbg [8 waves][8 slots][8] int64 (device) */
+int pd3_conv3x3_winograd43_pl_trace(const float *x, const float *u_lane, const float *bias, int batch, int cin, int cout,
+                                    int h, int w, int relu, float *out, long long *dbg, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * stable_argsort -- the index order the host glue of two reference functions needs, on the library's radix sort:
  * rotate_nms_pcdet's `paddle.argsort(scores, descending=True)` (models/layers/layer_libs.py:230-236) and the re-sort

@@ -108,6 +108,10 @@ _SIGNATURES = {
                                      C.c_void_p]),
     "pd3_conv3x3_winograd43_pp_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_conv3x3_winograd43_pl_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_conv3x3_winograd43_pl_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pd3_conv3x3_winograd43_pp_bias_relu_variant": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                                C.c_int, C.c_void_p]),

@@ -45,4 +45,10 @@ __device__ __forceinline__ float w4_swap_pair(float v) {  // value of the neighb
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() makes the compiler drain vmcnt as well -- a pending
+// buffer_load ... lds counts as a store to LDS -- which puts the full latency of every fetch in flight in front of the
+// barrier.  The kernels that use this wait for exactly the fetches a barrier has to publish (explicit s_waitcnt vmcnt(N))
+// and let the others travel across it (LDS-DMA requests stay in flight across s_barrier).
+__device__ __forceinline__ void w4_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 }  // namespace pd3

@@ -236,11 +236,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
     fetch_u(0, 1);
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-  __syncthreads();
+  w4_lds_barrier();
   // (every wave passes 2 * slots + 1 barriers: group 1 waits out the first time slot, group 0 the last)
   auto sync = [&]() {
     const long long c1 = dbg ? clock64() : 0;
-    __syncthreads();
+    w4_lds_barrier();
     if (dbg) t_ba += clock64() - c1;
   };
   // one straight-line loop per group (a single loop with the group's role chosen inside keeps two copies of the 144

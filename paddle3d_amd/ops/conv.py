@@ -12,7 +12,7 @@ __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pitch4", "p
            "grouped_small_supported", "winograd_supported", "pack_winograd_weight", "conv3x3_winograd_bias_relu",
            "patch_mode", "patch_supported", "pack_patch_weight", "patch_conv_bias_relu",
            "winograd43_supported", "winograd43_tile", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu",
-           "winograd43_pp_supported", "pack_winograd43_lane_weight", "conv3x3_winograd43_pp_bias_relu",
+           "winograd43_pp_supported", "pack_winograd43_lane_weight", "conv3x3_winograd43_pp_bias_relu", "conv3x3_winograd43_pl_bias_relu",
            "f16_supported", "f16_tile", "pack_conv3x3_f16_weight", "conv3x3_f16_bias_relu", "to_f16_nhwc"]
 
 
@@ -302,4 +302,21 @@ def conv3x3_winograd43_pp_bias_relu(x: torch.Tensor, u_lane: torch.Tensor, bias,
                                                                int(bool(relu)), ptr(out), int(variant),
                                                                stream_ptr(xx.device))
     check(st, "conv3x3_winograd43_pp_bias_relu")
+    return out
+
+
+def conv3x3_winograd43_pl_bias_relu(x: torch.Tensor, u_lane: torch.Tensor, bias, cout: int, relu: bool = True,
+                                    out: torch.Tensor | None = None, w_valid: int | None = None) -> torch.Tensor:
+    """The pipelined form (same operands as conv3x3_winograd43_pp_bias_relu)."""
+    xx = require_gpu(x, "conv3x3_winograd43_pl_bias_relu")
+    ul = require_gpu(u_lane, "conv3x3_winograd43_pl_bias_relu")
+    n, cin, h, w = xx.shape
+    if ul.numel() != cout * cin * 36:
+        raise RuntimeError("conv3x3_winograd43_pl_bias_relu: u_lane does not belong to a [cout, cin, 3, 3] weight")
+    if out is None:
+        out = torch.empty((n, cout, h, w), dtype=torch.float32, device=xx.device)
+    check(lib().pd3_conv3x3_winograd43_pl_bias_relu(ptr(xx), ptr(ul), ptr(bias), n, cin, cout, h, w,
+                                                    w if w_valid is None else int(w_valid), int(bool(relu)),
+                                                    ptr(out), stream_ptr(xx.device)),
+          "conv3x3_winograd43_pl_bias_relu")
     return out

@@ -356,3 +356,5 @@ def test_winograd43_pingpong_form(n, cin, cout, h, w, relu):
         assert (got[..., :wv].cpu() - ref).abs().max().item() < 1e-3
         assert (got[..., wv:] == 0).all()
         assert torch.equal(got, packed)  # the same U, the same order of accumulation
+    got = conv.conv3x3_winograd43_pl_bias_relu(x.cuda(), ul, b.cuda(), cout, relu, w_valid=wv)
+    assert torch.equal(got, packed)      # the pipelined form: the same bytes again
