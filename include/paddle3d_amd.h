@@ -442,21 +442,10 @@ int pd3_conv3x3_winograd43_bias_relu(const float *x, const float *u_packed, cons
  *   order of accumulation over input channels (identical here: ascending) */
 int pd3_conv3x3_winograd43_pp_bias_relu(const float *x, const float *u_lane, const float *bias, int batch, int cin,
                                         int cout, int h, int w, int w_valid, int relu, float *out, void *stream);
-/* the same with the kernel's scheduling variant named (measurement: 0 no wave priorities / 1 multiply slots high /
- * 2 transform slots high); identical results */
-int pd3_conv3x3_winograd43_pp_bias_relu_variant(const float *x, const float *u_lane, const float *bias, int batch,
-                                                int cin, int cout, int h, int w, int w_valid, int relu, float *out,
-                                                int variant, void *stream);
-/* measurement hook: + per-wave phase cycle counters of one workgroup, dbg [8][4] int64 (device) */
+/* measurement hook: + cycle counters of one workgroup (blockIdx 8), dbg int64 [640] (device): [8 waves][4] transform /
+ * multiply / barrier-wait / kernel cycles, from [32] [8 waves][5] the parts of the transform slot, from [128]
+ * [8 waves][8 slots][8] time stamps of the first slots (tools/prof/prof_wino_trace.py prints them) */
 int pd3_conv3x3_winograd43_pp_trace(const float *x, const float *u_lane, const float *bias, int batch, int cin, int cout,
-                                    int h, int w, int relu, float *out, int variant, long long *dbg, void *stream);
-
-/* conv3x3_winograd43_pl_bias_relu -- the pipelined form: the input transform of the next slot in micro-steps behind the
- * MFMAs of the current one, all eight waves in one role; same u_lane, requirements and bytes as the ping-pong form */
-int pd3_conv3x3_winograd43_pl_bias_relu(const float *x, const float *u_lane, const float *bias, int batch, int cin,
-                                        int cout, int h, int w, int w_valid, int relu, float *out, void *stream);
-/* measurement hook: + cycle stamps of one workgroup's first eight slots, dbg [8 waves][8 slots][8] int64 (device) */
-int pd3_conv3x3_winograd43_pl_trace(const float *x, const float *u_lane, const float *bias, int batch, int cin, int cout,
                                     int h, int w, int relu, float *out, long long *dbg, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

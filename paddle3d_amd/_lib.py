@@ -108,15 +108,8 @@ _SIGNATURES = {
                                      C.c_void_p]),
     "pd3_conv3x3_winograd43_pp_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "pd3_conv3x3_winograd43_pl_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "pd3_conv3x3_winograd43_pl_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "pd3_conv3x3_winograd43_pp_bias_relu_variant": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                                               C.c_int, C.c_void_p]),
     "pd3_conv3x3_winograd43_pp_trace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                                   C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+                                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pd3_merge_sweeps_workspace": (C.c_size_t, [C.c_int64]),
     "pd3_merge_sweeps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

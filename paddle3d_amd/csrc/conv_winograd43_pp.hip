@@ -1,6 +1,6 @@
 // 3x3 / stride 1 / pad 1 convolution + bias + ReLU by Winograd F(4x4, 3x3) on the fp32 matrix cores: the ping-pong form
-// whose multiply waves issue nothing but MFMAs and LDS reads (round 4).  Same arithmetic and tile shape as
-// conv_winograd43.hip (reference layers: second_backbone.py:72-120, center_head.py:43-220, cuDNN there).
+// whose multiply waves issue nothing but MFMAs and LDS reads (round 4).  Same arithmetic, tile shape and results (bit for
+// bit) as conv_winograd43.hip (reference layers: second_backbone.py:72-120, center_head.py:43-220, cuDNN there).
 #include "../../include/paddle3d_amd.h"
 #include "common.hpp"
 #include "conv_winograd43.hpp"
@@ -10,19 +10,27 @@
 namespace pd3 {
 
 // ---------------------------------------------------------------------------------------------------------------------
-// What the hardware does (tools/hwcheck/mfma_valu_overlap.hip, measured): a wave's own VALU instructions do NOT run in
-// the shadow of its MFMAs (36 v_mfma_f32_16x16x4_f32 with K fmas behind each: 32.4 / 36.9 / 44.5 / 51.2 cycles per MFMA
-// for K = 0 / 1 / 3 / 6), while a SECOND wave on the SIMD runs VALU + LDS work at about half speed beside an MFMA-only
-// wave that keeps its 32.4 cycles.  So the matrix pipe is full only if the wave feeding it issues MFMAs and LDS reads and
-// nothing else, and everything else lives in the partner wave.  The packed kernel (conv_winograd43.hip) has waves 0-3
-// transform AND multiply; round 4's first ping-pong form computed U = G g G^T in the multiply waves (tied with packed).
+// What the hardware does (gfx950, measured: tools/hwcheck/mfma_valu_overlap.hip, pingpong_skeleton.hip):
+//   * a wave's own VALU instructions are not hidden behind its v_mfma_f32_16x16x4_f32: 36 MFMAs with K fmas behind each
+//     run at 32.4 / 36.9 / 44.5 / 51.2 cycles per MFMA for K = 0 / 1 / 3 / 6 (a filler costs its issue time);
+//   * a wave that streams these MFMAs back to back starves its partner on the SIMD: the partner's LDS reads return and
+//     its VALU instructions issue when the stream ends (a transform-like phase of 1700 cycles beside a 2370-cycle stream
+//     takes 3700).  Two waves with the same mixed stream do not interleave either: the older one runs first.
+// So a SIMD's time is close to the SUM of its MFMAs (32 cycles each) and of everything else its waves issue, however
+// the work is arranged.  Three arrangements of this convolution were built and measured in round 4 (same bytes out):
+// this one; one with U computed in registers behind the MFMAs; one with the transform cut into micro-steps behind the
+// MFMAs of the same wave, all eight waves in one role (git history: conv_winograd43_pl.hip).  Batch 16, 128 -> 128 @
+// 128 x 128: packed form (conv_winograd43.hip) 0.255 ms, this 0.244-0.250, the others 0.254-0.259: 55-57 % of the
+// fp32 matrix peak each.  This one is kept for the layers where it wins (cin >= 128: 2-5 %).
 //
-// Here: group g (waves 4g .. 4g+3, one per SIMD) owns tile row g for all 64 channels of the workgroup and alternates
-//   T(s): its 256 threads turn the 8 channels x 16 tiles of its tile row into V (one patch per thread pair) -- VALU, DPP,
-//         LDS: the partner role;
+// The arrangement: group g (waves 4g .. 4g+3, one per SIMD) owns tile row g for all 64 channels of the workgroup and
+// alternates
+//   T(s): its 256 threads turn the 8 channels x 16 tiles of its tile row into V (one patch per thread pair);
 //   M(s): 72 MFMAs (two trips of 4 input channels) fed by ds_read_b128 alone: B from the group's V, A from a per-lane
-//         packed copy of U in LDS.  No VALU, no waits on global memory in front of an MFMA.
-// The other group runs the opposite role, one time slot off; ONE workgroup barrier per slot.
+//         packed copy of U in LDS.  No VALU, no fetches (one buffer_load ... lds costs an MFMA stream 60-185 cycles of
+//         issue, a transform slot 25-60), no waits on global memory.
+// The other group runs the opposite role, one time slot off; ONE workgroup barrier per slot (w4_lds_barrier: LDS
+// traffic only, fetches travel across it).
 // Nothing goes through registers on its way into LDS: the raw rows of the next transform slot AND the next slot's U
 // (pre-transformed on the host into lane order, 73.7 KB per slot and workgroup) travel by buffer_load_dwordx4 ... lds.
 // U has ONE buffer (double buffering does not fit 160 KB): both groups read slot s's values in the same time slot (group
@@ -46,7 +54,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
                                                                        const float* __restrict__ ulane,
                                                                        const float* __restrict__ bias,
                                                                        float* __restrict__ out, int cin, int cout, int h,
-                                                                       int w, int wv, int relu, int ptiles, int prio,
+                                                                       int w, int wv, int relu, int ptiles,
                                                                        long long* __restrict__ dbg) {
   constexpr int CO = 64;
   long long t_tr = 0, t_mu = 0, t_ba = 0, t_all = dbg ? clock64() : 0;  // phase cycles of this wave (measurement)
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
   // V = B^T d B of this thread pair's patch (as W4_TRANSFORM above).  The wave's raw rows are read first and the fetch of
   // the NEXT slot's rows follows at once (slot sn): it has the rest of this slot and the whole multiply slot to land.
   int cur_s = 0;
-  auto transform = [&](int sn, auto&& before_x) {
+  auto transform = [&](int sn) {
     float rv[3][6];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
@@ -142,7 +150,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
       t_p[1] += c - t_c, t_c = c;
     }
     stamp(wave, cur_s, 1);
-    before_x();
     fetch_x(sn);
     if (dbg) {
       const long long c = clock64();
@@ -251,7 +258,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
     for (int s = 0; s < slots; ++s) {
       {  // transform slot s
         const long long c0 = dbg ? clock64() : 0;
-        if ((prio & 3) == 2) __builtin_amdgcn_s_setprio(2);
         const int sn = min(s + 1, slots - 1);  // (the last slot's refetch is never read)
         cur_s = s;
         if (G0) {
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
           // stream starves its partner of VALU issue and LDS returns: tools/hwcheck/pingpong_skeleton.hip), the memory
           // pipe takes the eighteen pieces meanwhile -- and lands before the barrier that ends the slot, in front of
           // group 0's multiply slot and group 1's read.
-          if (s > 0 && !(prio & 4)) {
+          if (s > 0) {
             fetch_u(s, 0);
             fetch_u(s, 1);
             __builtin_amdgcn_s_waitcnt(0x4f72);  // vmcnt(18): the wave's own rows, fetched a transform slot ago, are in Raw
@@ -269,12 +275,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
           }
           if (dbg) t_c = clock64(), t_p[0] += t_c - c0;
           stamp(wave, s, 0);
-          transform(sn, [&]() {
-            if (s > 0 && (prio & 4)) {
-              fetch_u(s, 0);
-              fetch_u(s, 1);
-            }
-          });
+          transform(sn);
           if (dbg) {
             __builtin_amdgcn_s_waitcnt(0xc07f);
             const long long c = clock64();
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
           __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the wave's own rows (fetched a transform slot ago) are in Raw
           if (dbg) t_c = clock64(), t_p[0] += t_c - c0;
           stamp(wave, s, 0);
-          transform(sn, [&]() {});
+          transform(sn);
           if (dbg) {
             __builtin_amdgcn_s_waitcnt(0xc07f);
             const long long c = clock64();
@@ -296,7 +297,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
 #pragma unroll
           for (int g = 0; g < 18; ++g) ua[g] = *reinterpret_cast<const w4_f32x4*>(uptr(g));
         }
-        if ((prio & 3) == 2) __builtin_amdgcn_s_setprio(0);
         if (dbg) {
           const long long c = clock64();
           t_p[4] += c - t_c, t_tr += c - c0;
@@ -307,10 +307,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
       {  // multiply slot s
         const long long c0 = dbg ? clock64() : 0;
         stamp(wave, s, 5);
-        if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(1);
         if (G0) multiply_ring();
         else multiply_regs();
-        if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(0);
         if (dbg) t_mu += clock64() - c0;
         stamp(wave, s, 6);
       }
@@ -372,10 +370,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
 
 using namespace pd3;
 
-// variant (measurement): 0 no wave priorities, 1 multiply slots high, 2 transform slots high
 static int launch_wino43_pp(const float* x, const float* u_lane, const float* bias, int batch, int cin, int cout, int h,
-                            int w, int w_valid, int relu, float* out, int variant, hipStream_t s,
-                            long long* dbg = nullptr) {
+                            int w, int w_valid, int relu, float* out, hipStream_t s, long long* dbg = nullptr) {
   constexpr size_t lds = ((size_t)kPpUsz + 2 * (kPpRawSz + kPpVsz)) * sizeof(float);  // 138,240 B
   const void* fn = reinterpret_cast<const void*>(conv3x3_winograd43_pp_kernel);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -384,7 +380,7 @@ static int launch_wino43_pp(const float* x, const float* u_lane, const float* bi
   const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / 64);
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
   conv3x3_winograd43_pp_kernel<<<(unsigned)nwg, 512, lds, s>>>(x, u_lane, bias, out, cin, cout, h, w, w_valid, relu,
-                                                               (int)ptiles, variant, dbg);
+                                                               (int)ptiles, dbg);
   return launch_status();
 }
 
@@ -401,29 +397,19 @@ static int check_wino43_pp(const float* x, const float* u_lane, const float* out
   return PD3_OK;
 }
 
-extern "C" int pd3_conv3x3_winograd43_pp_bias_relu_variant(const float* x, const float* u_lane, const float* bias,
-                                                           int batch, int cin, int cout, int h, int w, int w_valid,
-                                                           int relu, float* out, int variant, void* stream) {
-  const int st = check_wino43_pp(x, u_lane, out, batch, cin, cout, h, w, w_valid);
-  if (st != PD3_OK) return st;
-  return launch_wino43_pp(x, u_lane, bias, batch, cin, cout, h, w, w_valid, relu, out, variant,
-                          static_cast<hipStream_t>(stream));
-}
-
 extern "C" int pd3_conv3x3_winograd43_pp_bias_relu(const float* x, const float* u_lane, const float* bias, int batch,
                                                    int cin, int cout, int h, int w, int w_valid, int relu, float* out,
                                                    void* stream) {
-  return pd3_conv3x3_winograd43_pp_bias_relu_variant(x, u_lane, bias, batch, cin, cout, h, w, w_valid, relu, out, 0,
-                                                     stream);
+  const int st = check_wino43_pp(x, u_lane, out, batch, cin, cout, h, w, w_valid);
+  if (st != PD3_OK) return st;
+  return launch_wino43_pp(x, u_lane, bias, batch, cin, cout, h, w, w_valid, relu, out, static_cast<hipStream_t>(stream));
 }
 
-// measurement hook: the variant entry + per-wave phase cycle counters of one workgroup (dbg [8 waves][4]: transform,
-// multiply, barrier wait, whole kernel; device memory)
+// measurement hook: + cycle counters of one workgroup (see include/paddle3d_amd.h for the layout of dbg)
 extern "C" int pd3_conv3x3_winograd43_pp_trace(const float* x, const float* u_lane, const float* bias, int batch, int cin,
-                                               int cout, int h, int w, int relu, float* out, int variant, long long* dbg,
+                                               int cout, int h, int w, int relu, float* out, long long* dbg,
                                                void* stream) {
   const int st = check_wino43_pp(x, u_lane, out, batch, cin, cout, h, w, w);
   if (st != PD3_OK || !dbg) return st != PD3_OK ? st : PD3_EINVAL;
-  return launch_wino43_pp(x, u_lane, bias, batch, cin, cout, h, w, w, relu, out, variant, static_cast<hipStream_t>(stream),
-                          dbg);
+  return launch_wino43_pp(x, u_lane, bias, batch, cin, cout, h, w, w, relu, out, static_cast<hipStream_t>(stream), dbg);
 }

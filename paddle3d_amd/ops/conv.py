@@ -12,7 +12,7 @@ __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pitch4", "p
            "grouped_small_supported", "winograd_supported", "pack_winograd_weight", "conv3x3_winograd_bias_relu",
            "patch_mode", "patch_supported", "pack_patch_weight", "patch_conv_bias_relu",
            "winograd43_supported", "winograd43_tile", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu",
-           "winograd43_pp_supported", "pack_winograd43_lane_weight", "conv3x3_winograd43_pp_bias_relu", "conv3x3_winograd43_pl_bias_relu",
+           "WINOGRAD43_PP_MIN_CIN", "winograd43_pp_supported", "pack_winograd43_lane_weight", "conv3x3_winograd43_pp_bias_relu",
            "f16_supported", "f16_tile", "pack_conv3x3_f16_weight", "conv3x3_f16_bias_relu", "to_f16_nhwc"]
 
 
@@ -264,6 +264,9 @@ def conv3x3_f16_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: i
 
 
 # ---- F(4x4, 3x3) as the ping-pong kernel fed by LDS alone (round 4) ------------------------------------------------------
+WINOGRAD43_PP_MIN_CIN = 64  # from here on the ping-pong form beats the packed one (measured per layer shape)
+
+
 def winograd43_pp_supported(cin: int, cout: int, h: int, w: int) -> bool:
     return cin % 8 == 0 and cout % 64 == 0 and w % 4 == 0
 
@@ -282,8 +285,7 @@ def pack_winograd43_lane_weight(weight: torch.Tensor) -> torch.Tensor:
 
 
 def conv3x3_winograd43_pp_bias_relu(x: torch.Tensor, u_lane: torch.Tensor, bias, cout: int, relu: bool = True,
-                                    out: torch.Tensor | None = None, w_valid: int | None = None,
-                                    variant: int | None = None) -> torch.Tensor:
+                                    out: torch.Tensor | None = None, w_valid: int | None = None) -> torch.Tensor:
     """x [n, cin, h, pitch] fp32, u_lane from pack_winograd43_lane_weight -> [n, cout, h, pitch]."""
     xx = require_gpu(x, "conv3x3_winograd43_pp_bias_relu")
     ul = require_gpu(u_lane, "conv3x3_winograd43_pp_bias_relu")
@@ -292,31 +294,8 @@ def conv3x3_winograd43_pp_bias_relu(x: torch.Tensor, u_lane: torch.Tensor, bias,
         raise RuntimeError("conv3x3_winograd43_pp_bias_relu: u_lane does not belong to a [cout, cin, 3, 3] weight")
     if out is None:
         out = torch.empty((n, cout, h, w), dtype=torch.float32, device=xx.device)
-    if variant is None:
-        st = lib().pd3_conv3x3_winograd43_pp_bias_relu(ptr(xx), ptr(ul), ptr(bias), n, cin, cout, h, w,
-                                                       w if w_valid is None else int(w_valid), int(bool(relu)),
-                                                       ptr(out), stream_ptr(xx.device))
-    else:
-        st = lib().pd3_conv3x3_winograd43_pp_bias_relu_variant(ptr(xx), ptr(ul), ptr(bias), n, cin, cout, h, w,
-                                                               w if w_valid is None else int(w_valid),
-                                                               int(bool(relu)), ptr(out), int(variant),
-                                                               stream_ptr(xx.device))
-    check(st, "conv3x3_winograd43_pp_bias_relu")
-    return out
-
-
-def conv3x3_winograd43_pl_bias_relu(x: torch.Tensor, u_lane: torch.Tensor, bias, cout: int, relu: bool = True,
-                                    out: torch.Tensor | None = None, w_valid: int | None = None) -> torch.Tensor:
-    """The pipelined form (same operands as conv3x3_winograd43_pp_bias_relu)."""
-    xx = require_gpu(x, "conv3x3_winograd43_pl_bias_relu")
-    ul = require_gpu(u_lane, "conv3x3_winograd43_pl_bias_relu")
-    n, cin, h, w = xx.shape
-    if ul.numel() != cout * cin * 36:
-        raise RuntimeError("conv3x3_winograd43_pl_bias_relu: u_lane does not belong to a [cout, cin, 3, 3] weight")
-    if out is None:
-        out = torch.empty((n, cout, h, w), dtype=torch.float32, device=xx.device)
-    check(lib().pd3_conv3x3_winograd43_pl_bias_relu(ptr(xx), ptr(ul), ptr(bias), n, cin, cout, h, w,
+    check(lib().pd3_conv3x3_winograd43_pp_bias_relu(ptr(xx), ptr(ul), ptr(bias), n, cin, cout, h, w,
                                                     w if w_valid is None else int(w_valid), int(bool(relu)),
                                                     ptr(out), stream_ptr(xx.device)),
-          "conv3x3_winograd43_pl_bias_relu")
+          "conv3x3_winograd43_pp_bias_relu")
     return out

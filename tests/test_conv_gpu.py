@@ -349,12 +349,8 @@ def test_winograd43_pingpong_form(n, cin, cout, h, w, relu):
     ul = conv.pack_winograd43_lane_weight(wt.cuda())
     packed = conv.conv3x3_winograd43_bias_relu(x.cuda(), conv.pack_winograd43_weight(wt.cuda()), b.cuda(), cout, relu,
                                                w_valid=wv)
-    for variant in (None, 1, 2):  # the default and the wave-priority variants (measurement)
-        kw = {} if variant is None else {"variant": variant}
-        got = conv.conv3x3_winograd43_pp_bias_relu(x.cuda(), ul, b.cuda(), cout, relu, w_valid=wv, **kw)
-        assert got.shape == (n, cout, h, w)
-        assert (got[..., :wv].cpu() - ref).abs().max().item() < 1e-3
-        assert (got[..., wv:] == 0).all()
-        assert torch.equal(got, packed)  # the same U, the same order of accumulation
-    got = conv.conv3x3_winograd43_pl_bias_relu(x.cuda(), ul, b.cuda(), cout, relu, w_valid=wv)
-    assert torch.equal(got, packed)      # the pipelined form: the same bytes again
+    got = conv.conv3x3_winograd43_pp_bias_relu(x.cuda(), ul, b.cuda(), cout, relu, w_valid=wv)
+    assert got.shape == (n, cout, h, w)
+    assert (got[..., :wv].cpu() - ref).abs().max().item() < 1e-3
+    assert (got[..., wv:] == 0).all()
+    assert torch.equal(got, packed)  # the same U, the same order of accumulation: the same bytes
