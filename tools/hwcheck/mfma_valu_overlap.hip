@@ -79,8 +79,8 @@ void run(float* out, long long* cyc) {
   }
   long long h[8];
   (void)hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
-  printf("K %d fmas per MFMA, partner %d, swap %d, mfma-lds %d: %.1f cycles per MFMA; partner: %.1f cycles per iteration\n", K,
-         P, SWAP, MLDS, (double)h[SWAP ? 4 : 0] / (iters * 36), (double)h[SWAP ? 0 : 4] / (iters * 36));
+  printf("K %d fmas behind every v_mfma_f32_16x16x4_f32 (36 accumulators, one wave per SIMD): %.1f cycles per MFMA\n", K,
+         (double)h[SWAP ? 4 : 0] / (iters * 36));
 }
 
 int main() {
@@ -88,6 +88,8 @@ int main() {
   long long* cyc;
   (void)hipMalloc(&out, 256 * 512 * 4);
   (void)hipMalloc(&cyc, 64);
+  // (the partner modes are for use under a profiler: the partner loop outlives the MFMA wave, so its mean says nothing
+  // about the overlap -- tools/hwcheck/pingpong_skeleton.hip measures that with barrier-bounded phases)
   run<0, 0>(out, cyc);
   run<1, 0>(out, cyc);
   run<2, 0>(out, cyc);
@@ -95,15 +97,5 @@ int main() {
   run<4, 0>(out, cyc);
   run<6, 0>(out, cyc);
   run<8, 0>(out, cyc);
-  run<0, 1>(out, cyc);
-  run<3, 1>(out, cyc);
-  run<0, 2>(out, cyc);
-  run<3, 2>(out, cyc);
-  run<0, 3>(out, cyc);
-  run<0, 3, 1>(out, cyc);
-  run<0, 3, 0, 1>(out, cyc);
-  run<0, 3, 1, 1>(out, cyc);
-  run<0, 2, 1, 1>(out, cyc);
-  run<0, 0, 0, 1>(out, cyc);
   return 0;
 }

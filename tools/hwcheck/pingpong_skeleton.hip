@@ -136,12 +136,26 @@ int main() {
   long long* cyc;
   (void)hipMalloc(&out, 256 * 512 * 4);
   (void)hipMalloc(&cyc, 128);
+  // the transform-like phase alone and beside the other group's MFMA stream
+  run<150, true, true>(out, cyc);
+  run<150, false, true>(out, cyc);
+  run<30, false, true>(out, cyc);
+  run<300, false, true>(out, cyc);
+  // which part of it is held up: LDS reads only (18 / 8 / 4 / 2), LDS writes only, VALU only
+  run<0, true, true, 0, 18, 0>(out, cyc);
   run<0, false, true, 0, 18, 0>(out, cyc);
+  run<0, false, true, 0, 8, 0>(out, cyc);
+  run<0, false, true, 0, 4, 0>(out, cyc);
+  run<0, false, true, 0, 2, 0>(out, cyc);
+  run<0, true, true, 0, 2, 9>(out, cyc);
+  run<0, false, true, 0, 2, 9>(out, cyc);
+  run<150, true, true, 0, 2, 1>(out, cyc);
+  run<150, false, true, 0, 2, 1>(out, cyc);
+  // the multiply phase without any LDS read of its own; a VALU stream of the same length in its place
   run<0, false, true, 32, 18, 0>(out, cyc);
   run<0, false, true, 64, 18, 0>(out, cyc);
-  run<0, false, true, 0, 4, 0>(out, cyc);
-  run<0, false, true, 0, 8, 0>(out, cyc);
-  run<150, false, true, 32>(out, cyc);
   run<150, false, true, 64>(out, cyc);
+  // the transform-like phase at wave priority 3
+  run<150, false, true, 8>(out, cyc);
   return 0;
 }
