@@ -442,9 +442,8 @@ int pd3_conv3x3_winograd43_bias_relu(const float *x, const float *u_packed, cons
  *   order of accumulation over input channels (identical here: ascending) */
 int pd3_conv3x3_winograd43_pp_bias_relu(const float *x, const float *u_lane, const float *bias, int batch, int cin,
                                         int cout, int h, int w, int w_valid, int relu, float *out, void *stream);
-/* measurement hook: + cycle counters of one workgroup (blockIdx 8), dbg int64 [640] (device): [8 waves][4] transform /
- * multiply / barrier-wait / kernel cycles, from [32] [8 waves][5] the parts of the transform slot, from [128]
- * [8 waves][8 slots][8] time stamps of the first slots (tools/prof/prof_wino_trace.py prints them) */
+/* measurement hook: + cycle counters of one workgroup (blockIdx 8), dbg int64 [8 waves][4] (device): transform /
+ * multiply / barrier-wait / kernel cycles (the last with the SIMD id in bits 56+; tools/prof/prof_wino_trace.py) */
 int pd3_conv3x3_winograd43_pp_trace(const float *x, const float *u_lane, const float *bias, int batch, int cin, int cout,
                                     int h, int w, int relu, float *out, long long *dbg, void *stream);
 

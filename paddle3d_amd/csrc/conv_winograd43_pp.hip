@@ -58,11 +58,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
                                                                        long long* __restrict__ dbg) {
   constexpr int CO = 64;
   long long t_tr = 0, t_mu = 0, t_ba = 0, t_all = dbg ? clock64() : 0;  // phase cycles of this wave (measurement)
-  long long t_p[5] = {0, 0, 0, 0, 0}, t_c = 0;
-  const bool tl = dbg && blockIdx.x == 8 && lane_id() == 0;
-  auto stamp = [&](int wv, int s, int id) {
-    if (tl && s < 8) dbg[128 + (wv * 8 + s) * 8 + id] = clock64() - t_all;
-  };  // inside the transform slot: row wait, row reads, fetches, arithmetic, tail
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(wave_id());  // (uniform: scalar slot control)
   const int grp = wave >> 2, cb = wave & 3;  // tile row / 16-channel block of this wave; waves w and w + 4 share a SIMD
@@ -132,30 +127,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
       __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (__attribute__((address_space(3))) void*)(Us + blk + q * 256), 16,
                                                lane * 16, (s * kPpUsz + blk + q * 256) * 4, 0, 0);
   };
-  // V = B^T d B of this thread pair's patch (as W4_TRANSFORM above).  The wave's raw rows are read first and the fetch of
-  // the NEXT slot's rows follows at once (slot sn): it has the rest of this slot and the whole multiply slot to land.
-  int cur_s = 0;
-  auto transform = [&](int sn) {
-    float rv[3][6];
+  // The wave's raw rows of the NEXT transform slot are read into registers at the end of the wave's multiply slot, in front
+  // of the barrier: behind it the other group's MFMAs hold the SIMD, and LDS reads issued then return when that stream
+  // ends (pingpong_skeleton: more than four reads wait for it) -- 340-450 cycles of every time slot.
+  float rv[3][6];
+  auto read_rows = [&]() {
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
       const float* d = Raw + rsrc + b;
 #pragma unroll
       for (int r = 0; r < 6; ++r) rv[b][r] = d[r * kW4RawW];
     }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the reads are done before the rows are overwritten
-    if (dbg) {
-      const long long c = clock64();
-      t_p[1] += c - t_c, t_c = c;
-    }
-    stamp(wave, cur_s, 1);
+  };
+  // V = B^T d B of this thread pair's patch (as W4_TRANSFORM above), from the rows in rv[].  The fetch of the NEXT slot's
+  // rows (slot sn) goes out first -- the memory pipe takes it while the SIMD is held -- and has the rest of this slot and
+  // the wave's multiply slot to land.
+  auto transform = [&](int sn, auto&& after_fetch) {
     fetch_x(sn);
-    if (dbg) {
-      const long long c = clock64();
-      t_p[2] += c - t_c, t_c = c;
-    }
-    stamp(wave, cur_s, 2);
+    after_fetch();
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_sched_barrier(0);
     float lo[3][3], hi[3][3];
 #pragma unroll
@@ -214,6 +204,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
         for (int j = 0; j < 4; ++j)
           acc[g9 * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g % 3][j], b[g % 3][j], acc[g9 * 4 + j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (g == 15) {  // the rows of the wave's next transform slot (fetched a slot ago), behind the last ring reads
+          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+          read_rows();
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   };
@@ -232,6 +227,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
         for (int j = 0; j < 4; ++j)
           acc[g9 * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[g][j], b[g % 3][j], acc[g9 * 4 + j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if (g == 16) {  // as above, one group later: by then all but four of the 72 registers of ua[] are free
+          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+          read_rows();
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   };
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
     fetch_u(0, 1);
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+  read_rows();
   w4_lds_barrier();
   // (every wave passes 2 * slots + 1 barriers: group 1 waits out the first time slot, group 0 the last)
   auto sync = [&]() {
@@ -259,7 +260,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
       {  // transform slot s
         const long long c0 = dbg ? clock64() : 0;
         const int sn = min(s + 1, slots - 1);  // (the last slot's refetch is never read)
-        cur_s = s;
         if (G0) {
           // Us is free: group 0 read slot s - 1 through its ring in the time slot before this one, group 1 into ua[].
           // The refill goes out at once -- the other group's MFMAs hold this SIMD for most of the slot (a dense fp32 MFMA
@@ -269,48 +269,27 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
           if (s > 0) {
             fetch_u(s, 0);
             fetch_u(s, 1);
-            __builtin_amdgcn_s_waitcnt(0x4f72);  // vmcnt(18): the wave's own rows, fetched a transform slot ago, are in Raw
-          } else {
-            __builtin_amdgcn_s_waitcnt(0x0f70);
           }
-          if (dbg) t_c = clock64(), t_p[0] += t_c - c0;
-          stamp(wave, s, 0);
-          transform(sn);
-          if (dbg) {
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            const long long c = clock64();
-            t_p[3] += c - t_c, t_c = c;
-          }
-          stamp(wave, s, 3);
+          transform(sn, [&]() {});
           __builtin_amdgcn_s_waitcnt(0x0f70 | 4);  // vmcnt(4): everything but the four raw-row pieces issued last
         } else {
-          __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the wave's own rows (fetched a transform slot ago) are in Raw
-          if (dbg) t_c = clock64(), t_p[0] += t_c - c0;
-          stamp(wave, s, 0);
-          transform(sn);
-          if (dbg) {
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            const long long c = clock64();
-            t_p[3] += c - t_c, t_c = c;
-          }
-          stamp(wave, s, 3);
+          // U of this slot into registers: trip 0's half goes out in front of the arithmetic (the reads return when the
+          // other group's stream ends, the arithmetic does not wait for them), trip 1's half behind it (registers)
+          transform(sn, [&]() {
 #pragma unroll
-          for (int g = 0; g < 18; ++g) ua[g] = *reinterpret_cast<const w4_f32x4*>(uptr(g));
+            for (int g = 0; g < 9; ++g) ua[g] = *reinterpret_cast<const w4_f32x4*>(uptr(g));
+          });
+#pragma unroll
+          for (int g = 9; g < 18; ++g) ua[g] = *reinterpret_cast<const w4_f32x4*>(uptr(g));
         }
-        if (dbg) {
-          const long long c = clock64();
-          t_p[4] += c - t_c, t_tr += c - c0;
-        }
-        stamp(wave, s, 4);
+        if (dbg) t_tr += clock64() - c0;
       }
       sync();
       {  // multiply slot s
         const long long c0 = dbg ? clock64() : 0;
-        stamp(wave, s, 5);
         if (G0) multiply_ring();
         else multiply_regs();
         if (dbg) t_mu += clock64() - c0;
-        stamp(wave, s, 6);
       }
       sync();
     }
@@ -323,8 +302,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_pp_kernel(const flo
     dbg[wave * 4 + 1] = t_mu;
     dbg[wave * 4 + 2] = t_ba;
     dbg[wave * 4 + 3] = (clock64() - t_all) | ((long long)__builtin_amdgcn_s_getreg(2308) << 56);  // + SIMD id (HW_ID[5:4])
-#pragma unroll
-    for (int i = 0; i < 5; ++i) dbg[32 + wave * 5 + i] = t_p[i];
   }
 
   // epilogue (as above): Y = A^T M A; lane: tile column lane & 15, channels 4 (lane >> 4) + r of the co block

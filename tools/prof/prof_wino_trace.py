@@ -14,24 +14,15 @@ x = torch.randn(B, cin, hw, hw, device="cuda")
 w = torch.randn(cout, cin, 3, 3, device="cuda") / (cin * 9) ** 0.5
 out = torch.empty(B, cout, hw, hw, device="cuda")
 ul = conv.pack_winograd43_lane_weight(w)
-for variant in (0,):
-    dbg = torch.zeros(160, 4, dtype=torch.int64, device="cuda")
+for _once in (0,):
+    dbg = torch.zeros(8, 4, dtype=torch.int64, device="cuda")
     for _ in range(2):
         check(lib().pd3_conv3x3_winograd43_pp_trace(ptr(x), ptr(ul), None, B, cin, cout, hw, hw, 1, ptr(out),
                                                      ptr(dbg), stream_ptr(x.device)), "trace")
     torch.cuda.synchronize()
     d = dbg.cpu().tolist()
-    tp = dbg.cpu().reshape(-1)[32:72].reshape(8, 5).tolist()
-    print(f"variant {variant}: slots {cin // 8} per group; per wave [transform, multiply, barrier wait, kernel] cycles:")
+    print(f"slots {cin // 8} per group; per wave [transform, multiply, barrier wait, kernel] cycles:")
     ns = cin // 8
     for wv, r in enumerate(d[:8]):
         print(f"  wave {wv} (group {wv >> 2}): T {r[0]:7d} ({r[0] // (cin // 8):5d}/slot)  M {r[1]:7d} ({r[1] // (cin // 8):5d}/slot)  "
               f"barrier {r[2]:7d}  total {r[3] & ((1 << 56) - 1):7d}  SIMD {r[3] >> 56}")
-    for wv in (0, 4):
-        print(f"  wave {wv} transform slot, cycles per slot: row wait {tp[wv][0] // ns}  row reads {tp[wv][1] // ns}  fetch issue "
-              f"{tp[wv][2] // ns}  arithmetic + V stores {tp[wv][3] // ns}  tail (U wait / U reads) {tp[wv][4] // ns}")
-    tlv = dbg.cpu().reshape(-1)[128:128 + 512].reshape(8, 8, 8).tolist()
-    names = ["rows in", "rows read", "fetches out", "V stored", "T end", "M start", "M end"]
-    for wv in (0, 4):
-        for sl in range(4):
-            print(f"  wave {wv} slot {sl}: " + "  ".join(f"{n} {tlv[wv][sl][i]}" for i, n in enumerate(names)))
