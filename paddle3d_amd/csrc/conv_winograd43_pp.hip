@@ -13,31 +13,37 @@ namespace pd3 {
 // What the hardware does (gfx950, measured: tools/hwcheck/mfma_valu_overlap.hip, pingpong_skeleton.hip):
 //   * a wave's own VALU instructions are not hidden behind its v_mfma_f32_16x16x4_f32: 36 MFMAs with K fmas behind each
 //     run at 32.4 / 36.9 / 44.5 / 51.2 cycles per MFMA for K = 0 / 1 / 3 / 6 (a filler costs its issue time);
-//   * a wave that streams these MFMAs back to back starves its partner on the SIMD: the partner's LDS reads return and
-//     its VALU instructions issue when the stream ends (a transform-like phase of 1700 cycles beside a 2370-cycle stream
-//     takes 3700).  Two waves with the same mixed stream do not interleave either: the older one runs first.
+//   * a wave that streams these MFMAs back to back starves its partner on the SIMD: beyond the first four, the partner's
+//     LDS reads return when the stream ends, its LDS stores likewise, its VALU instructions crawl (a transform-like phase
+//     of 1700 cycles beside a 2370-cycle stream takes 3700); its buffer_load ... lds pieces do go out.  Two waves with the
+//     same mixed stream do not interleave either: the older one runs first.
 // So a SIMD's time is close to the SUM of its MFMAs (32 cycles each) and of everything else its waves issue, however
 // the work is arranged.  Three arrangements of this convolution were built and measured in round 4 (same bytes out):
 // this one; one with U computed in registers behind the MFMAs; one with the transform cut into micro-steps behind the
 // MFMAs of the same wave, all eight waves in one role (git history: conv_winograd43_pl.hip).  Batch 16, 128 -> 128 @
-// 128 x 128: packed form (conv_winograd43.hip) 0.255 ms, this 0.244-0.250, the others 0.254-0.259: 55-57 % of the
-// fp32 matrix peak each.  This one is kept for the layers where it wins (cin >= 128: 2-5 %).
+// 128 x 128: packed form (conv_winograd43.hip) 0.254 ms, the others 0.254-0.259, this one 0.239 -- and 0.214 once what
+// the partner's stream blocks HARD (LDS returns and LDS stores, not VALU issue, which only slows down) was moved out of
+// its way: a wave reads the rows of its next transform slot at the END of its own multiply slot, in front of the barrier,
+// sends its fetches first thing in the transform slot, and group 1 reads half of its U in front of the arithmetic.
 //
 // The arrangement: group g (waves 4g .. 4g+3, one per SIMD) owns tile row g for all 64 channels of the workgroup and
 // alternates
-//   T(s): its 256 threads turn the 8 channels x 16 tiles of its tile row into V (one patch per thread pair);
+//   T(s): its 256 threads turn the 8 channels x 16 tiles of its tile row into V (one patch per thread pair), from rows
+//         that are already in registers; the slot opens with the fetches (U of slot s by group 0, the wave's rows of
+//         slot s + 1), which the memory pipe takes while the other group's MFMAs hold the SIMD;
 //   M(s): 72 MFMAs (two trips of 4 input channels) fed by ds_read_b128 alone: B from the group's V, A from a per-lane
 //         packed copy of U in LDS.  No VALU, no fetches (one buffer_load ... lds costs an MFMA stream 60-185 cycles of
-//         issue, a transform slot 25-60), no waits on global memory.
+//         issue, a transform slot 25-60); behind its sixteenth group of MFMAs the wave reads the rows of T(s + 1) from
+//         its planes of Raw into registers (fetched in T(s): they have landed).
 // The other group runs the opposite role, one time slot off; ONE workgroup barrier per slot (w4_lds_barrier: LDS
 // traffic only, fetches travel across it).
 // Nothing goes through registers on its way into LDS: the raw rows of the next transform slot AND the next slot's U
 // (pre-transformed on the host into lane order, 73.7 KB per slot and workgroup) travel by buffer_load_dwordx4 ... lds.
 // U has ONE buffer (double buffering does not fit 160 KB): both groups read slot s's values in the same time slot (group
-// 0 during its multiply slot, group 1 into registers at the end of its transform slot), and group 0 refills the buffer
+// 0 during its multiply slot, group 1 into registers during its transform slot), and group 0 refills the buffer
 // at the start of its next transform slot, a whole slot ahead of the barrier that publishes it.  The raw rows are private
-// to a wave (wave cb transforms channels 2 cb, 2 cb + 1 of the slot): it refetches them right after reading them, two
-// slots ahead of their use, and waits for them itself -- no barrier is involved.
+// to a wave (wave cb transforms channels 2 cb, 2 cb + 1 of the slot): it reads, refetches and waits for them itself -- no
+// barrier is involved.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kPpKT = 2;                                   // trips per slot
 constexpr int kPpCi = kPpKT * kW4Ci;                       // 8 input channels per slot
