@@ -486,3 +486,37 @@ def test_amp_graph_close_to_fp32():
     assert f16.dtype == torch.float32 and f16.shape == f32.shape
     assert 0 < rel_f < 2e-2 and rel_p < 5e-2
     assert m > 0.97
+
+
+def test_pingpong_and_packed_winograd_graphs_are_identical():
+    """The stride-1 layers run the ping-pong Winograd kernel (round 4) where it applies; switched off, the packed kernel
+    runs them.  Same U, same order of accumulation: the FPN features and every head map of the two graphs are the same
+    bytes (the golden and oracle tests above therefore hold for both)."""
+    from paddle3d_amd import centerpoint as cpm
+    from paddle3d_amd.ops import conv
+
+    torch.manual_seed(3)
+    model = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(30000, 30000)).cuda().eval()
+    _randomise_bn(model)
+    pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(700 + i) for i in range(2)])).cuda()
+
+    def run():
+        model.invalidate()
+        with torch.no_grad():
+            canvas = model.extract_pillars(pts, dense=False)
+            feats = model.dense_forward(canvas)
+            preds, _ = model.bbox_head(feats)
+        return feats.clone(), [{k: v.clone() for k, v in p.items()} for p in preds]
+
+    saved = conv.WINOGRAD43_PP_MIN_CIN
+    try:
+        f_pp, p_pp = run()
+        conv.WINOGRAD43_PP_MIN_CIN = 1 << 30
+        f_pk, p_pk = run()
+    finally:
+        conv.WINOGRAD43_PP_MIN_CIN = saved
+        model.invalidate()
+    assert torch.equal(f_pp, f_pk)
+    for a, b in zip(p_pp, p_pk):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
