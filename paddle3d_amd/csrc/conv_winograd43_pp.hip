@@ -51,8 +51,7 @@ constexpr int kPpRawR = 6;                                 // staged input rows 
 constexpr int kPpRawPl = kPpRawR * kW4RawW;                // 432 floats per channel
 constexpr int kPpRawSz = kPpCi * kPpRawPl;                 // 3456 floats per group
 constexpr int kPpVsz = kPpCi * kW4TC * kW4Cs;              // 4608 floats per group
-constexpr int kPpXN4 = kPpRawSz / 4;                       // 864 float4 per group
-constexpr int kPpXPT = (kPpXN4 + 255) / 256;               // 4 per thread
+constexpr int kPpXPT = (2 * kPpRawPl / 4 + 63) / 64;       // 4 fetch pieces per wave: its two planes are 216 float4
 constexpr int kPpUHalf = 9 * 64 * 4;                       // 2304 floats: U of one trip for one wave (9 float4 per lane)
 constexpr int kPpUsz = kPpKT * 4 * kPpUHalf;               // 18432 floats per slot: [trip][cb][q][lane][4]
 
