@@ -494,6 +494,166 @@ def sparse_encoder_dense_torch(net, feats, coords, batch):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# The same sparse encoders WITHOUT a dense grid (round 5): index sets are sorted int64 key arrays
+# ((b * D + z) * H + y) * W + x, a neighbour is found with np.searchsorted, the sum over kernel offsets runs in
+# ascending offset order in fp32.  Needs no [B, C, D, H, W] tensor, so it runs at the full config-4 grid
+# (41 x 1440 x 1440, ~130 k voxels per scene) where the dense statement above cannot.  Same public definition of
+# paddle.sparse.nn.SubmConv3D / Conv3D as above (Paddle core arithmetic absent: parity unpinned against Paddle's
+# own kernels); tests/test_oracle.py pins this statement to the dense one on small grids.
+# ---------------------------------------------------------------------------------------------------------
+def _sp_decode(keys, shape):
+    d, h, w = (int(v) for v in shape)
+    x = keys % w
+    r = keys // w
+    y = r % h
+    r = r // h
+    return r // d, r % d, y, x  # b, z, y, x
+
+
+def sparse_keys_numpy(coords, shape):
+    """coords [n, 4] (b, z, y, x) -> (sorted unique int64 keys, order) with keys[i] = key of coords[order[i]]."""
+    c = np.asarray(coords).astype(np.int64)
+    d, h, w = (int(v) for v in shape)
+    keys = ((c[:, 0] * d + c[:, 1]) * h + c[:, 2]) * w + c[:, 3]
+    order = np.argsort(keys, kind="stable")
+    keys = keys[order]
+    if keys.size > 1 and (np.diff(keys) <= 0).any():
+        raise ValueError("duplicate voxel coordinates")
+    return keys, order
+
+
+def sparse_conv_numpy(feats, keys, batch, shape, weight, stride=(1, 1, 1), padding=(0, 0, 0), subm=False, bias=None):
+    """One sparse convolution on a sorted key set.  feats [n, cin] fp32 (row i at keys[i]), weight [kd, kh, kw, cin,
+    cout] (Paddle layout).  Submanifold: the output set is the input set ("same" padding k // 2, stride 1);
+    regular: every output cell some input reaches, in raster order.  Returns (out_feats, out_keys, out_shape, pairs)
+    -- pairs = the number of (output row, offset) pairs that exist."""
+    feats = np.ascontiguousarray(feats, _f)
+    weight = np.asarray(weight, _f)
+    kd, kh, kw, cin, cout = weight.shape
+    d, h, w = (int(v) for v in shape)
+    if subm:
+        stride, padding = (1, 1, 1), (kd // 2, kh // 2, kw // 2)
+        oshape, okeys = (d, h, w), keys
+    else:
+        stride, padding = tuple(int(v) for v in stride), tuple(int(v) for v in padding)
+        oshape = tuple((s + 2 * p - k) // st + 1 for s, k, st, p in zip((d, h, w), (kd, kh, kw), stride, padding))
+        b, z, y, x = _sp_decode(keys, shape)
+        cand = []
+        for kz in range(kd):
+            for ky in range(kh):
+                for kx in range(kw):
+                    nz, ny, nx = z + padding[0] - kz, y + padding[1] - ky, x + padding[2] - kx  # = q * stride
+                    ok = (nz >= 0) & (ny >= 0) & (nx >= 0) & (nz % stride[0] == 0) & (ny % stride[1] == 0) & \
+                        (nx % stride[2] == 0)
+                    qz, qy, qx = nz // stride[0], ny // stride[1], nx // stride[2]
+                    ok &= (qz < oshape[0]) & (qy < oshape[1]) & (qx < oshape[2])
+                    cand.append((((b[ok] * oshape[0] + qz[ok]) * oshape[1] + qy[ok]) * oshape[2] + qx[ok]))
+        okeys = np.unique(np.concatenate(cand)) if cand else np.zeros((0,), np.int64)
+    ob, oz, oy, ox = _sp_decode(okeys, oshape)
+    out = np.zeros((okeys.shape[0], cout), _f)
+    pairs = 0
+    n = keys.shape[0]
+    for kz in range(kd):
+        for ky in range(kh):
+            for kx in range(kw):
+                iz = oz * stride[0] - padding[0] + kz
+                iy = oy * stride[1] - padding[1] + ky
+                ix = ox * stride[2] - padding[2] + kx
+                ok = (iz >= 0) & (iz < d) & (iy >= 0) & (iy < h) & (ix >= 0) & (ix < w)
+                rows = np.nonzero(ok)[0]
+                if rows.size == 0 or n == 0:
+                    continue
+                want = ((ob[rows] * d + iz[rows]) * h + iy[rows]) * w + ix[rows]
+                pos = np.searchsorted(keys, want)
+                hit = (pos < n) & (keys[np.minimum(pos, n - 1)] == want)
+                rows, src = rows[hit], pos[hit]
+                if rows.size == 0:
+                    continue
+                pairs += int(rows.size)
+                out[rows] += feats[src] @ weight[kz, ky, kx]  # an output row occurs at most once per offset
+    if bias is not None:
+        out += np.asarray(bias, _f)
+    return out, okeys, oshape, pairs
+
+
+def sparse_to_dense_numpy(feats, keys, batch, shape):
+    """to_dense + transpose([0, 4, 1, 2, 3]) + reshape [N, C * D, H, W] (sparse_resnet.py:202-205)."""
+    d, h, w = (int(v) for v in shape)
+    c = feats.shape[1]
+    out = np.zeros((batch, c, d, h, w), _f)
+    b, z, y, x = _sp_decode(keys, shape)
+    out[b, :, z, y, x] = feats
+    return out.reshape(batch, c * d, h, w)
+
+
+def sparse_encoder_numpy(net, feats, coords, batch, trace=None):
+    """SparseResNet3D.forward (sparse_resnet.py:184-206) / SparseNet3D.forward (sparsenet.py:140-182) for the module
+    mirrors in paddle3d_amd/sparse.py, on sorted key sets (no dense grid).  Rows of `coords` with a negative batch
+    index are padding.  Returns the [B, C * D, H, W] map; `trace` (a dict) receives, per convolution module name,
+    dict(keys, shape, feats, pairs) with feats AFTER the BatchNorm / ReLU / residual add that follow the
+    convolution in the reference's Sequential (the point where the device's fused kernel writes its output)."""
+    import torch.nn as nn
+
+    coords = np.asarray(coords)
+    live = coords[:, 0] >= 0
+    keys, order = sparse_keys_numpy(coords[live], net.sparse_shape)
+    x = np.ascontiguousarray(np.asarray(feats, _f)[live][order])
+    shape = tuple(net.sparse_shape)
+    names = {id(m): n for n, m in net.named_modules()}
+
+    def fold(bn):
+        sc = (bn.weight / (bn.running_var + bn.eps).sqrt()).detach().cpu().numpy().astype(_f)
+        sh = (bn.bias.detach().cpu().numpy().astype(_f) - bn.running_mean.detach().cpu().numpy().astype(_f) * sc)
+        return sc, sh
+
+    def conv(m, x, keys, shape):
+        wt = m.weight.detach().cpu().numpy()
+        b = None if m.bias is None else m.bias.detach().cpu().numpy()
+        return sparse_conv_numpy(x, keys, batch, shape, wt, m.stride, m.padding, m.subm, b)
+
+    def note(m, x, keys, shape, pairs):
+        if trace is not None:
+            trace[names[id(m)]] = dict(keys=keys, shape=shape, feats=x.copy(), pairs=pairs)
+
+    def run(mod, x, keys, shape):
+        if isinstance(mod, nn.Sequential):
+            mods = list(mod)
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                if hasattr(m, "subm"):  # a convolution, then the BatchNorm / ReLU that follow it
+                    x, keys, shape, pairs = conv(m, x, keys, shape)
+                    i += 1
+                    if i < len(mods) and isinstance(mods[i], nn.BatchNorm1d):
+                        sc, sh = fold(mods[i])
+                        x = x * sc + sh
+                        i += 1
+                        if i < len(mods) and isinstance(mods[i], nn.ReLU):
+                            x = np.maximum(x, 0)
+                            i += 1
+                    note(m, x, keys, shape, pairs)
+                else:
+                    x, keys, shape = run(m, x, keys, shape)
+                    i += 1
+            return x, keys, shape
+        if hasattr(mod, "conv1") and hasattr(mod, "bn2"):  # SparseBasicBlock, sparse_resnet.py:92-111
+            o, _, _, p1 = conv(mod.conv1, x, keys, shape)
+            sc, sh = fold(mod.bn1)
+            o = np.maximum(o * sc + sh, 0)
+            note(mod.conv1, o, keys, shape, p1)
+            o, _, _, p2 = conv(mod.conv2, o, keys, shape)
+            sc, sh = fold(mod.bn2)
+            o = np.maximum(o * sc + sh + x, 0)
+            note(mod.conv2, o, keys, shape, p2)
+            return o, keys, shape
+        raise TypeError(f"sparse_encoder_numpy: unexpected module {type(mod).__name__}")
+
+    for stage in (net.conv_input, net.conv1, net.conv2, net.conv3, net.conv4, net.extra_conv):
+        x, keys, shape = run(stage, x, keys, shape)
+    return sparse_to_dense_numpy(x, keys, batch, shape)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # NumPy restatements of the reference's Python glue around the ops (pinned to the reference's own Python by
 # tests/golden/python_layers.npz, made by tests/golden/make_python_golden.py through the paddle shim).
 # ---------------------------------------------------------------------------------------------------------

@@ -428,12 +428,11 @@ def test_map_proxy_64_frames(oracle):
     # 2e-6 perturbation of the CPU maps alone moves this figure to 0.996 (measured, CPU against CPU).  With the last
     # heat-map convolution scaled by 30 the scores spread over 0.10 .. 0.77 like a trained head's, and the same
     # perturbation leaves the figure at 1.0: what is left is what the two pipelines really disagree on.
-    with torch.no_grad():
-        for task in model.bbox_head.tasks:
-            task.hm[-1].weight.mul_(30.0)
-            task.hm[-1].bias.fill_(-3.0)
+    # (round 5: the bias per class, from the heat maps of two frames, so that every class of every task crosses the
+    # threshold in 1 % of the cells -- with one common bias three of the six tasks never fired and 3 classes were scored)
     frames = 64
     pts = np.stack([synth.nuscenes_sweep(300 + i) for i in range(frames)])
+    synth.trained_like_heads(model, torch.from_numpy(pts[:2]).cuda())
     dev = []
     for b0 in range(0, frames, 16):
         for d in model.test_forward(torch.from_numpy(pts[b0:b0 + 16]).cuda()):
@@ -444,7 +443,7 @@ def test_map_proxy_64_frames(oracle):
     res = nb.nuscenes_style_map(dev, ref)
     n_ref = sum(len(r["scores"]) for r in ref)
     print(f"mAP proxy over {frames} frames: {res['mAP']:.6f} ({res['classes_scored']} classes, {n_ref} oracle detections)")
-    assert n_ref > 64 * 50 and res["classes_scored"] >= 4
+    assert n_ref > 64 * 50 and res["classes_scored"] == 10, res
     assert res["mAP"] >= 0.999, res
     # and the other way round (the oracle's detections scored against the device's): symmetric evidence
     back = nb.nuscenes_style_map(ref, dev)
@@ -454,38 +453,46 @@ def test_map_proxy_64_frames(oracle):
 def test_amp_graph_close_to_fp32():
     """set_amp(True): the stride-1 3x3 layers of backbone and head on the fp16 matrix cores (the reference's amp_cfg O2
     configuration) -- head maps stay within fp16's resolution of the fp32 graph's, and the detections of the two
-    graphs (spread heat maps, see test_map_proxy_64_frames) agree on the mAP scale."""
+    graphs (spread heat maps, see test_map_proxy_64_frames) agree on the mAP scale: 64 frames, all ten classes scored."""
     from paddle3d_amd import centerpoint as cpm
     from paddle3d_amd import nuscenes_bridge as nb
 
     torch.manual_seed(12)
     model = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(30000, 30000)).cuda().eval()
     _randomise_bn(model)
-    with torch.no_grad():
-        for task in model.bbox_head.tasks:
-            task.hm[-1].weight.mul_(30.0)
-            task.hm[-1].bias.fill_(-3.0)
-    pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(400 + i) for i in range(4)])).cuda()
+    frames = 64
+    host = np.stack([synth.nuscenes_sweep(400 + i) for i in range(frames)])
+    synth.trained_like_heads(model, torch.from_numpy(host[:2]).cuda())
 
     def run(flag):
         model.set_amp(flag)
+        rel_f = rel_p = 0.0
+        dets = []
         with torch.no_grad():
-            canvas = model.extract_pillars(pts, dense=False)
-            feats = model.dense_forward(canvas)
-            preds, _ = model.bbox_head(feats)
-            dets = model.bbox_head.predict_by_custom_op(preds, model.test_cfg)
-        return feats, preds, [{k: d[k].cpu().numpy() for k in ("box3d_lidar", "scores", "label_preds")} for d in dets]
+            for b0 in range(0, frames, 16):
+                pts = torch.from_numpy(host[b0:b0 + 16]).cuda()
+                feats = model.dense_forward(model.extract_pillars(pts, dense=False))
+                preds, _ = model.bbox_head(feats)
+                dets += [{k: d[k].cpu().numpy() for k in ("box3d_lidar", "scores", "label_preds")}
+                         for d in model.bbox_head.predict_by_custom_op(preds, model.test_cfg)]
+                if b0 == 0:
+                    first = feats.clone(), [{k: v.clone() for k, v in p.items()} for p in preds]
+        return first[0], first[1], dets
 
     f32, p32, d32 = run(False)
     f16, p16, d16 = run(True)
     model.set_amp(False)
     rel_f = ((f16 - f32).abs().max() / f32.abs().max()).item()
     rel_p = max(((a[k] - b[k]).abs().max() / b[k].abs().max().clamp(min=1e-3)).item() for a, b in zip(p16, p32) for k in a)
-    m = nb.nuscenes_style_map(d16, d32)["mAP"]
-    print(f"AMP vs fp32: FPN features {rel_f:.2e} of max, head maps {rel_p:.2e} of max, mAP proxy {m:.4f}")
+    res = nb.nuscenes_style_map(d16, d32)
+    m = res["mAP"]
+    worst = min(res["per_class"].values())
+    print(f"AMP vs fp32 over {frames} frames: FPN features {rel_f:.2e} of max, head maps {rel_p:.2e} of max, "
+          f"mAP proxy {m:.4f} ({res['classes_scored']} classes, worst class {worst:.4f})")
     assert f16.dtype == torch.float32 and f16.shape == f32.shape
     assert 0 < rel_f < 2e-2 and rel_p < 5e-2
-    assert m > 0.97
+    assert res["classes_scored"] == 10, res
+    assert m >= 0.99, res
 
 
 def test_pingpong_and_packed_winograd_graphs_are_identical():

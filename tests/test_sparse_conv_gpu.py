@@ -248,3 +248,67 @@ def test_plan_large_tiles_and_empty():
     assert torch.equal(ref1.out_coords, pl.indices[1].out_coords) and torch.equal(ref1.nbr, pl.indices[1].nbr)
     empty = sp.plan(torch.full((10, 4), -1, dtype=torch.int32).cuda(), 1, shape, specs)
     assert empty.n_in == 0 and all(i.n_out == 0 for i in empty.indices)
+
+
+def _keys_of(indices, shape):
+    c = indices.cpu().numpy().astype(np.int64)
+    d, h, w = shape
+    return ((c[:, 0] * d + c[:, 1]) * h + c[:, 2]) * w + c[:, 3]
+
+
+def test_sparse_encoder_full_c4_grid_vs_keyset_oracle(oracle):
+    """Config 4 at the size the bench runs (configs/centerpoint/centerpoint_voxels_0075voxel_nuscenes_10sweep.yml:
+    111-173: 41 x 1440 x 1440 cells of 0.075 m, two real synth.nuscenes_sweep frames, ~130 k voxels each, LiDAR-shaped
+    occupancy: dense near-sensor neighbourhoods and sparse far rings) against oracle.sparse_encoder_numpy, which
+    needs no dense grid.  EVERY convolution of SparseResNet3D (sparse_resnet.py:115-206) -- the input layer (5 -> 16),
+    submanifold 16 / 32 / 64 / 128, the three strided 3x3x3 layers, the final (3, 1, 1) / (2, 1, 1) layer -- is
+    compared where the device's fused kernel writes: index set exact and in the same (raster) order, features within
+    1e-3 of the largest magnitude of the layer; then the [2, 256, 180, 180] map."""
+    from paddle3d_amd import centerpoint as cpm
+    from paddle3d_amd import sparse as S
+    from paddle3d_amd import synth
+
+    torch.manual_seed(3)
+    model = cpm.centerpoint_voxels_nuscenes().cuda().eval()
+    net = model.middle_encoder
+    _randomise(net)
+    assert net.sparse_shape == (41, 1440, 1440)
+    pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(93), synth.nuscenes_sweep(94)])).cuda()
+    voxels, coors, npv, nv = model.voxelizer(pts)
+    b, v, p, d = voxels.shape
+    coors = coors.view(b * v, 4)
+    feats = model.voxel_encoder(voxels.view(b * v, p, d), npv.view(b * v), coors)
+    assert int((coors[:, 0] >= 0).sum()) == int(nv.sum()) > 200_000  # padding rows travel along (batch -1)
+
+    got = {}
+    names = {id(m): n for n, m in net.named_modules()}
+    hooks = [m.register_forward_hook(lambda mod, inp, out: got.__setitem__(names[id(mod)], out))
+             for m in net.modules() if isinstance(m, S._SparseConv)]
+    try:
+        bev = net(feats, coors, b)
+    finally:
+        for h in hooks:
+            h.remove()
+    trace = {}
+    ref_bev = oracle.sparse_encoder_numpy(net, feats.cpu().numpy(), coors.cpu().numpy(), b, trace=trace)
+    assert sorted(trace) == sorted(got) and len(got) == 21
+    kinds = set()
+    for name, want in trace.items():
+        t = got[name]
+        mod = dict(net.named_modules())[name]
+        kinds.add((mod.subm, tuple(mod.weight.shape[-2:]), mod.ks))
+        assert tuple(t.spatial_shape) == tuple(want["shape"]), name
+        np.testing.assert_array_equal(_keys_of(t.indices, t.spatial_shape), want["keys"], err_msg=name)
+        f = t.features.cpu().numpy()
+        scale = max(1.0, float(np.abs(want["feats"]).max()))
+        err = float(np.abs(f - want["feats"]).max())
+        assert err < 1e-3 * scale, (name, err, scale)
+    # every layer type of the encoder was in the comparison
+    assert {(True, (5, 16), (3, 3, 3)), (True, (16, 16), (3, 3, 3)), (True, (32, 32), (3, 3, 3)),
+            (True, (64, 64), (3, 3, 3)), (True, (128, 128), (3, 3, 3)), (False, (16, 32), (3, 3, 3)),
+            (False, (32, 64), (3, 3, 3)), (False, (64, 128), (3, 3, 3)), (False, (128, 128), (3, 1, 1))} <= kinds
+    assert bev.shape == ref_bev.shape == (2, 256, 180, 180)
+    err = float(np.abs(bev.cpu().numpy() - ref_bev).max())
+    assert err < 1e-3 * max(1.0, float(np.abs(ref_bev).max())), err
+    # the dense neighbourhoods the bench's tiles see are in this input: > 10 existing pairs per row on the 32+ layers
+    assert trace["conv2.3.conv1"]["pairs"] > 10 * trace["conv2.3.conv1"]["keys"].shape[0]
