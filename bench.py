@@ -519,7 +519,8 @@ def bench_pillars(args, rank, world, dev):
     def finish(out):
         return pipe.flush() if pipe is not None else out
 
-    def run(points, events):
+    def compute(points, events):
+        """One step up to the operator's own record: (rec [B, max_per_img, 11], cnt [B]) of THIS batch."""
         def mark(i):
             if events is not None:
                 events[i].record()
@@ -538,8 +539,13 @@ def bench_pillars(args, rank, world, dev):
         _bx, _sc, _lb, cnt, rec = model.bbox_head.predict_by_custom_op(preds, cfg, device_only=True,
                                                                       records=max_per_img)
         mark(5)
+        return rec, cnt
+
+    def run(points, events):
+        rec, cnt = compute(points, events)
         all_rec, all_cnt = hand_off(rec, cnt)  # the record comes out of the operator itself
-        mark(6)
+        if events is not None:
+            events[6].record()
         return all_rec, all_cnt
 
     # --graph: the step as five HIP graphs (one per op, so that the per-op HIP events stay between them): ~60 kernel
@@ -603,9 +609,13 @@ def bench_pillars(args, rank, world, dev):
                         events[6].record()
                     return res
 
-                ref = run(pts, None)
-                got = run_graphs(None)
+                # the guard compares THIS batch's records of the two launch paths (not what hand_off returns: with
+                # --gather overlap that is the previous batch's result, which would compare eager with eager)
+                ref = [t.clone() for t in compute(pts, None)]
+                for g in graphs:
+                    g.replay()
                 torch.cuda.synchronize()
+                got = (st["post"][4], st["post"][3])
                 if not (torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])):
                     raise RuntimeError("graph replay and eager step disagree")
                 step, launch = run_graphs, f"hip graphs ({len(graphs)} per step, one per op) + eager result hand-off"

@@ -589,7 +589,9 @@ class CenterHead(_InferenceCache, nn.Module):
             rets = [dict() for _ in self.tasks]
             for g, (t, head) in enumerate(f["plan"]):
                 rets[t][head] = z[:, g * f["cmax"]:g * f["cmax"] + f["ncls"][g]]
-            return rets, x
+            # the shared map in the reference's layout and dtype in both modes (center_head.py:212-220 returns
+            # `ret_dicts, x` with x fp32 [n, 64, h, w]); one 16 MB elementwise pass per 16 frames
+            return rets, x.permute(0, 3, 1, 2).float()
         chunked = (k < groups and f["hc"] == 64 and first.stride == 1 and _conv.winograd43_supported(first.cin, first.cout, h, w)
                    and w % 4 == 0)
         if chunked:

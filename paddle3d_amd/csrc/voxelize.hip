@@ -480,14 +480,24 @@ static int run_wave_split(const float* points, const int32_t* num_points, int ba
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev || batch < 2)
     return run_wave(points, num_points, batch, n, dim, g, max_pts, max_voxels, plan, voxels, coords, num_pts,
                     num_voxels, coors4, workspace, s, variant);
-  {
-    std::lock_guard<std::mutex> lock(mu);
-    if (!side[dev]) {
-      if (hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&fork_ev[dev], hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&join_ev[dev], hipEventDisableTiming) != hipSuccess)
-        return PD3_EINVAL;
+  // One side stream and one fork / join event pair per device, shared by every caller: the lock is held from the fork
+  // to the join so that two host threads on different streams of one device cannot interleave their records and waits
+  // (this is a measurement form; the library's own choice never takes it).
+  std::lock_guard<std::mutex> lock(mu);
+  if (!side[dev]) {  // the slot counts as initialised only when all three objects exist
+    hipStream_t st = nullptr;
+    hipEvent_t ef = nullptr, ej = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ef, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ej, hipEventDisableTiming) != hipSuccess) {
+      if (ej) (void)hipEventDestroy(ej);
+      if (ef) (void)hipEventDestroy(ef);
+      if (st) (void)hipStreamDestroy(st);
+      return PD3_EINVAL;
     }
+    fork_ev[dev] = ef;
+    join_ev[dev] = ej;
+    side[dev] = st;
   }
   const int b0 = batch / 2, b1 = batch - b0;
   const size_t half_bytes = align_up(vw_carve(nullptr, b0, n, max_voxels, plan).bytes, 256);

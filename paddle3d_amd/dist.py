@@ -91,19 +91,21 @@ class GatherPipeline:
     """The per-batch result hand-off, one batch deep: `submit(records, counts)` starts the all-gather of THIS batch
     without waiting for it (async_op: RCCL's own stream, ordered after the producing kernels of the current stream)
     and returns the gathered (records, counts) of the PREVIOUS batch (None the first time); `flush()` waits for the
-    batch in flight and returns it.  With one rank it degenerates to handing the tensors through one batch late, so
-    the calling code is the same for any world size.  The input tensors stay referenced until their collective has
-    completed."""
+    batch in flight and returns it.  With one rank it degenerates to handing the result through one batch late, so
+    the calling code is the same for any world size.  `submit` takes a private copy of its inputs (22 KB per frame,
+    on the current stream): the caller may overwrite `records` / `counts` as soon as submit returns -- a captured HIP
+    graph replays into the same static buffers every step, and a preallocated record buffer is reused the same way."""
 
     def __init__(self):
         self._pending = None
 
     @staticmethod
     def _start(records, counts):
+        records, counts = records.clone(memory_format=torch.contiguous_format), counts.clone(
+            memory_format=torch.contiguous_format)
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return (None, None, records, counts, records, counts)
         world = dist.get_world_size()
-        records, counts = records.contiguous(), counts.contiguous()
         out_r = torch.empty((world * records.shape[0],) + tuple(records.shape[1:]), dtype=records.dtype,
                             device=records.device)
         out_c = torch.empty((world * counts.shape[0],), dtype=counts.dtype, device=counts.device)

@@ -12,7 +12,7 @@ __all__ = ["stable_argsort"]
 
 def stable_argsort(keys: torch.Tensor, descending: bool = False, max_key: int | None = None) -> torch.Tensor:
     """keys [n] on the GPU: float32 with descending=True (scores), or int32 / int64 >= 0 ascending (ranks; int64 is
-    narrowed, values must fit 31 bits).  Returns int64 indices like torch.argsort(stable=True)."""
+    narrowed; values outside [0, max_key] raise).  Returns int64 indices like torch.argsort(stable=True)."""
     if keys.dim() != 1:
         raise RuntimeError("stable_argsort: keys must be one-dimensional")
     n = int(keys.shape[0])
@@ -25,8 +25,16 @@ def stable_argsort(keys: torch.Tensor, descending: bool = False, max_key: int | 
     else:
         if keys.dtype not in (torch.int32, torch.int64):
             raise RuntimeError("stable_argsort: ascending keys must be int32 / int64")
-        k = require_gpu(keys.to(torch.int32), "stable_argsort", torch.int32)
         mode, mk = 0, (0x7FFFFFFF if max_key is None else int(max_key))
+        if not 0 <= mk <= 0x7FFFFFFF:
+            raise RuntimeError("stable_argsort: max_key must lie in [0, 2^31)")
+        require_gpu(keys, "stable_argsort")
+        # a key outside [0, max_key] would be narrowed / sorted on too few digits without any error: one read-back of
+        # (min, max) -- this mode serves BevPoolV2.backward (training glue), not an inference step
+        lo, hi = (int(v) for v in torch.stack([keys.amin(), keys.amax()]).tolist())
+        if lo < 0 or hi > mk:
+            raise RuntimeError(f"stable_argsort: ascending keys must lie in [0, {mk}] (found [{lo}, {hi}])")
+        k = require_gpu(keys.to(torch.int32), "stable_argsort", torch.int32)
     order = torch.empty((n,), dtype=torch.int32, device=dev)
     L = lib()
     ws = workspace(L.pd3_stable_argsort_workspace(n, mk), dev)

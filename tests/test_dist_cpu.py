@@ -130,3 +130,22 @@ def test_gather_pipeline_single_rank_is_one_batch_late():
     got = pipe.flush()
     assert torch.equal(got[0], b[0]) and torch.equal(got[1], b[1])
     assert pipe.flush() is None
+
+
+def test_gather_pipeline_inputs_may_be_reused_after_submit():
+    """A captured HIP graph (or a preallocated record buffer) writes every batch into the same tensors: what submit
+    hands back one batch later must be the values at submit time, not the buffer's later contents."""
+    from paddle3d_amd import dist as pdist
+
+    pipe = pdist.GatherPipeline()
+    rec, cnt = torch.zeros(2, 3, 11), torch.zeros(2, dtype=torch.int32)
+    rec.fill_(1.0)
+    cnt.fill_(1)
+    assert pipe.submit(rec, cnt) is None
+    rec.fill_(2.0)  # batch k + 1 overwrites the static buffers ...
+    cnt.fill_(2)
+    got = pipe.submit(rec, cnt)
+    assert (got[0] == 1.0).all() and (got[1] == 1).all()  # ... batch k's result is untouched
+    rec.fill_(3.0)
+    got = pipe.flush()
+    assert (got[0] == 2.0).all() and (got[1] == 2).all()
