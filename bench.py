@@ -1034,6 +1034,9 @@ def bench_voxel(args, rank, world, dev):
         return all_rec, all_cnt
 
     dt, per_op_ms, out, info = _timed_loop(run, args, world, dev, names)
+    # the encoder planned every timed step from remembered capacities (no host round trip inside the step); did a set
+    # outgrow its capacity?  (one read-back, after the timed region)
+    overflow = bool(model.middle_encoder.take_overflow())
     if rank != 0:
         return None
     alg = 4 * N_POINTS * DIMS + 4 * V * 10 * DIMS + 16 * V + 4
@@ -1059,11 +1062,16 @@ def bench_voxel(args, rank, world, dev):
                    "frames_per_gpu_per_step": B, "max_voxels": V, "parallelism": f"dp{world} (frames)"},
         "roofline": dict(bound="hbm", achieved=a, peak=HBM_PEAK_GBPS, unit="GB/s", frac=a / HBM_PEAK_GBPS, traffic=None,
                          ms_per_launch=per_op_ms["hard_voxelize"], units_per_launch=B, algorithmic_bytes_per_unit=alg,
-                         kernel="hard_voxelize launch sequence, generic path (cell_key + radix sort + seg_head + scan "
-                                "+ gather): the 82.9 M-cell grid is beyond the tiled path"),
+                         kernel="hard_voxelize launch sequence, 3-D wave form (voxelize_wave3d.hpp: route + group with an "
+                                "LDS hash table per wave + assign + rows) on the 82.9 M-cell grid"),
         "per_op_ms": per_op_ms, "active_voxels_per_batch": stats.get("active_voxels"),
         "detections_first_frame": int(out[1][0].item()),
+        "sparse_plan": dict(host_syncs_per_step=0, capacity_overflow=overflow,
+                            note="index sets planned from remembered capacities (first forward of the shape: one "
+                                 "sync); an overflow would make the timed steps invalid"),
     }
+    if overflow:
+        line["error"] = "sparse plan: an index set outgrew its remembered capacity during the timed steps"
     if sp:
         ms = per_op_ms["voxel_mean_sparse_encoder"]
         line["rooflines"] = {"sparse_encoder": dict(

@@ -343,6 +343,22 @@ int pd3_sparse_conv3d_features(const float *in_feats, const int32_t *nbr, const 
                                const float *weight, const float *bias, const float *scale,
                                const float *shift, const float *residual, int relu, float *out,
                                void *stream);
+/* Tile order (a scheduling hint, never a change of results): the rows of every window of 8192 consecutive output
+ * rows sorted by their neighbour mask, so that the 16-row blocks of the gather-GEMM hold rows that need the same
+ * kernel offsets (a block runs an offset if ANY of its rows has that neighbour: 1.3x - 7x more steps than pairs
+ * exist with rows in raster order, 1.2x - 2x in tile order).
+ *   order [pd3_sparse_tile_order_entries(n_out_cap)] int32: slot -> output row, -1 past the row count
+ *   n_out may be NULL (= n_out_cap); kernel_volume <= 32
+ * pd3_sparse_conv3d_features_ordered = pd3_sparse_conv3d_features taking `order` (NULL: raster order); same bytes
+ * out for any order. */
+int64_t pd3_sparse_tile_order_entries(int n_out_cap);
+int pd3_sparse_tile_order(const int32_t *nbr, const int32_t *n_out, int n_out_cap, int kernel_volume,
+                          int32_t *order, void *stream);
+int pd3_sparse_conv3d_features_ordered(const float *in_feats, const int32_t *nbr, const int32_t *n_out,
+                                       int n_out_cap, int kernel_volume, int cin, int cout,
+                                       const float *weight, const float *bias, const float *scale,
+                                       const float *shift, const float *residual, int relu,
+                                       const int32_t *order, float *out, void *stream);
 /* Plan path: the index sets of a whole encoder without a host round trip between the convolutions (the
  * reference's layers read nnz on the host after every sparse op).  An index set is a SORTED array of keys
  * ((b*D + z)*H + y)*W + x (raster order; 0xFFFFFFFF = padding, at the end) with its length in device memory.

@@ -730,10 +730,18 @@ class CenterPoint(nn.Module):
     @torch.no_grad()
     def test_forward(self, points, device_only=False):
         pts, lens = self._pack(points)
-        x = self.extract_pillars(pts, lens, dense=False)
-        x = self.dense_forward(x)
-        preds, _ = self.bbox_head(x)
-        return self.bbox_head.predict_by_custom_op(preds, self.test_cfg, device_only=device_only)
+        for _attempt in range(2):
+            x = self.extract_pillars(pts, lens, dense=False)
+            x = self.dense_forward(x)
+            preds, _ = self.bbox_head(x)
+            out = self.bbox_head.predict_by_custom_op(preds, self.test_cfg, device_only=device_only)
+            # A sparse middle encoder that planned from remembered capacities (no host sync) reports here, after the
+            # host has read the detections anyway, whether an index set outgrew its capacity; then the frame is run
+            # again with exact sizes.  device_only callers ask `middle_encoder.take_overflow()` where they synchronise.
+            take = getattr(self.middle_encoder, "take_overflow", None)
+            if device_only or take is None or not take():
+                break
+        return out
 
     forward = test_forward
 

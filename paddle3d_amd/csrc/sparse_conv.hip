@@ -193,6 +193,8 @@ struct SpGemmArgs {
   float* out;            // [n_out, cout]
   const int* n_out_dev;  // device row count or null
   int n_out_cap, K, cin, cout, relu;
+  const int32_t* order;  // optional tile order (sp_tile_order_kernel): slot -> output row or -1; a scheduling
+                         // hint only -- which rows share a tile never changes a row's result
 };
 
 template <int COUT_PER_LANE>
@@ -435,15 +437,33 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_kernel(SpGemmArgs a) {
   float* Ws = sp_smem;                                        // [2][WSZ]
   int* nbs = reinterpret_cast<int*>(Ws + 2 * WSZ);            // [128][K]
   uint32_t* masks = reinterpret_cast<uint32_t*>(nbs + kSg2Rows * a.K);  // [0] workgroup, [1 + row block]
+  int* rows = reinterpret_cast<int*>(masks + 16);             // [128] output row of a slot (-1: none)
   const int lane = lane_id(), wave = wave_id();
   const int K = a.K, cin = a.cin;
   const int n_out = a.n_out_dev ? min(*a.n_out_dev, a.n_out_cap) : a.n_out_cap;
   const int row0 = blockIdx.x * kSg2Rows;
-  if (row0 >= n_out) return;
-  {
+  if (row0 >= n_out) return;  // (ordered: rows past n_out sort last in the last window, so this still holds)
+  if (a.order) {
+    // the tile's rows come from the tile order: rows of one window with similar neighbour masks share a 16-row
+    // block, so fewer (block, offset) steps run on rows that lack the neighbour
+    if (threadIdx.x < kSg2Rows) {
+      const int r = a.order[row0 + threadIdx.x];
+      rows[threadIdx.x] = r >= 0 && r < n_out ? r : -1;
+    }
+    if (threadIdx.x < 9) masks[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int e = threadIdx.x; e < kSg2Rows * 32; e += 256) {
+      const int i = e >> 5, k = e & 31;
+      if (k < K) {
+        const int r = rows[i];
+        nbs[i * K + k] = r >= 0 ? a.nbr[(int64_t)r * K + k] : -1;
+      }
+    }
+  } else {
     const int live = min(kSg2Rows, n_out - row0) * K;
     const int32_t* src = a.nbr + (int64_t)row0 * K;
     for (int e = threadIdx.x; e < kSg2Rows * K; e += 256) nbs[e] = e < live ? src[e] : -1;
+    if (threadIdx.x < kSg2Rows) rows[threadIdx.x] = row0 + (int)threadIdx.x < n_out ? row0 + (int)threadIdx.x : -1;
     if (threadIdx.x < 9) masks[threadIdx.x] = 0u;
   }
   __syncthreads();
@@ -459,7 +479,8 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_kernel(SpGemmArgs a) {
   }
   __syncthreads();
   const uint32_t wg_mask = masks[0];
-  const uint32_t wave_mask = masks[1 + 2 * wave] | masks[2 + 2 * wave];
+  const uint32_t blk_mask[2] = {masks[1 + 2 * wave], masks[2 + 2 * wave]};  // per 16-row block of this wave
+  const uint32_t wave_mask = blk_mask[0] | blk_mask[1];
   const int nchunks = cin / CH;
   const int cout = NB * 16;
   const int ai = lane & 15, akk = lane >> 4;
@@ -468,6 +489,10 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_kernel(SpGemmArgs a) {
 #pragma unroll
   for (int u = 0; u < NB; ++u) acc[u][0] = acc[u][1] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
   sp_f32x4 wreg[WPT], acur[2][AQ], anext[2][AQ];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int q = 0; q < AQ; ++q) acur[rb][q] = anext[rb][q] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto fetch_w = [&](int k, int c) {
     const float* wk = a.weight + ((int64_t)k * cin + (int64_t)c * CH) * cout;
@@ -495,6 +520,7 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_kernel(SpGemmArgs a) {
   auto fetch_a = [&](int k, int c, sp_f32x4 (&dst)[2][AQ]) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
+      if (!((blk_mask[rb] >> k) & 1u)) continue;  // (block-uniform: no row of the block has this neighbour)
       const int j = nbs[(wave * 32 + rb * 16 + ai) * K + k];
 #pragma unroll
       for (int q = 0; q < AQ; ++q) dst[rb][q] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -527,6 +553,7 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_kernel(SpGemmArgs a) {
     if (more) fetch_w(k2, c2);
     if (need2) fetch_a(k2, c2, anext);
     if (need) {
+      const bool need_b0 = (blk_mask[0] >> k) & 1u, both = need_b0 && ((blk_mask[1] >> k) & 1u);
       const float* wl = Ws + buf * WSZ + lane * S;
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
@@ -539,10 +566,21 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_kernel(SpGemmArgs a) {
           b[q * 4 + 2] = v[2];
           b[q * 4 + 3] = v[3];
         }
+        // a 16-row block whose rows all lack this neighbour is skipped (its A registers hold stale values)
+        if (both) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-          acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[0][t >> 2][t & 3], b[t], acc[u][0], 0, 0, 0);
-          acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[1][t >> 2][t & 3], b[t], acc[u][1], 0, 0, 0);
+          for (int t = 0; t < T; ++t) {
+            acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[0][t >> 2][t & 3], b[t], acc[u][0], 0, 0, 0);
+            acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[1][t >> 2][t & 3], b[t], acc[u][1], 0, 0, 0);
+          }
+        } else if (need_b0) {
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+            acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[0][t >> 2][t & 3], b[t], acc[u][0], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+            acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[1][t >> 2][t & 3], b[t], acc[u][1], 0, 0, 0);
         }
       }
     }
@@ -568,8 +606,8 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_kernel(SpGemmArgs a) {
     for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = row0 + wave * 32 + rb * 16 + (lane >> 4) * 4 + r;
-        if (row >= n_out) continue;
+        const int row = rows[wave * 32 + rb * 16 + (lane >> 4) * 4 + r];
+        if (row < 0) continue;
         float v = acc[u][rb][r];
         if (a.bias) v += bias;
         if (a.scale) v = fmaf(v, sc, sh);
@@ -578,6 +616,65 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_kernel(SpGemmArgs a) {
         a.out[(int64_t)row * cout + co] = v;
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Tile order (round 5).  sp_gemm_rows_kernel runs a (16-row block, kernel offset) step whenever ANY row of the block
+// has that neighbour; with rows in raster order a block's rows have different neighbour masks and 1.3x (128 -> 128)
+// to 7x (the strided layers) more steps run than (row, offset) pairs exist.  Which rows share a tile is free -- a
+// row's result does not depend on it -- so the rows of one WINDOW of kSpWindow consecutive rows are sorted by their
+// 27-bit neighbour mask (ties by row: a deterministic order) and tiles take their rows from that order: rows with
+// equal or similar masks end up in one block.  A window is still a piece of the raster order (a few neighbouring
+// lines), so a tile's gathers keep their cache locality.  One workgroup per window: masks from the rulebook, a
+// bitonic sort of (mask << 32 | index in window) in LDS, order[window slot] = row (or -1 past n_out).
+// Measured on config 4 (two frames): steps / pairs 1.73 -> 1.31 (64 -> 64), 2.15 -> 1.41 (32 -> 32), 1.29 -> 1.17
+// (128 -> 128), 4.8 - 7.0 -> 1.9 - 2.0 on the strided layers.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSpWindow = 8192;
+constexpr int kSpOrderThreads = 1024;
+
+__global__ __launch_bounds__(kSpOrderThreads) void sp_tile_order_kernel(
+    const int32_t* __restrict__ nbr, const int* __restrict__ n_out_dev, int n_out_cap, int K,
+    int32_t* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sp_order_smem[];
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(sp_order_smem);  // [kSpWindow]
+  const int n_out = n_out_dev ? min(*n_out_dev, n_out_cap) : n_out_cap;
+  const int win0 = blockIdx.x * kSpWindow;
+  if (win0 >= n_out) {  // a window of padding only
+    for (int i = threadIdx.x; i < kSpWindow; i += kSpOrderThreads) order[win0 + i] = -1;
+    return;
+  }
+  for (int i = threadIdx.x; i < kSpWindow; i += kSpOrderThreads) {
+    const int row = win0 + i;
+    unsigned long long kv = ~0ull;
+    if (row < n_out) {
+      uint32_t m = 0;
+      const int32_t* src = nbr + (int64_t)row * K;
+      for (int k = 0; k < K; ++k) m |= src[k] >= 0 ? 1u << (k & 31) : 0u;
+      kv = ((unsigned long long)m << 32) | (unsigned long long)i;
+    }
+    key[i] = kv;
+  }
+  __syncthreads();
+  for (int size = 2; size <= kSpWindow; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < kSpWindow / 2; t += kSpOrderThreads) {
+        const int lo = ((t / stride) * stride * 2) + (t % stride);  // (stride is a power of two: shifts)
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = key[lo], b = key[hi];
+        if ((a > b) == up) {
+          key[lo] = b;
+          key[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < kSpWindow; i += kSpOrderThreads) {
+    const unsigned long long kv = key[i];
+    order[win0 + i] = kv == ~0ull ? -1 : win0 + (int)(kv & 0xFFFFFFFFull);
   }
 }
 
@@ -1069,18 +1166,36 @@ extern "C" int pd3_sparse_rulebook(const uint32_t* in_keys, const int32_t* n_in,
   return launch_status();
 }
 
+extern "C" int pd3_sparse_conv3d_features_ordered(const float* in_feats, const int32_t* nbr,
+                                                  const int32_t* n_out, int n_out_cap, int kernel_volume,
+                                                  int cin, int cout, const float* weight, const float* bias,
+                                                  const float* scale, const float* shift,
+                                                  const float* residual, int relu, const int32_t* order,
+                                                  float* out, void* stream);
+
 extern "C" int pd3_sparse_conv3d_features(const float* in_feats, const int32_t* nbr,
                                           const int32_t* n_out, int n_out_cap, int kernel_volume,
                                           int cin, int cout, const float* weight, const float* bias,
                                           const float* scale, const float* shift,
                                           const float* residual, int relu, float* out, void* stream) {
+  return pd3_sparse_conv3d_features_ordered(in_feats, nbr, n_out, n_out_cap, kernel_volume, cin, cout, weight, bias,
+                                            scale, shift, residual, relu, nullptr, out, stream);
+}
+
+extern "C" int pd3_sparse_conv3d_features_ordered(const float* in_feats, const int32_t* nbr,
+                                                  const int32_t* n_out, int n_out_cap, int kernel_volume,
+                                                  int cin, int cout, const float* weight, const float* bias,
+                                                  const float* scale, const float* shift,
+                                                  const float* residual, int relu, const int32_t* order,
+                                                  float* out, void* stream) {
   if (!in_feats || !nbr || !weight || !out || n_out_cap <= 0 || kernel_volume <= 0 || cin <= 0 ||
       cout <= 0)
     return PD3_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return PD3_EINVAL;
   if (cout > 128) return PD3_EUNSUPPORTED;
+  // `order` (pd3_sparse_tile_order) is a scheduling hint for the 128-row kernel; the other kernels ignore it
   SpGemmArgs a{in_feats, nbr, weight, bias, scale, shift, residual, out, n_out, n_out_cap,
-               kernel_volume, cin, cout, relu ? 1 : 0};
+               kernel_volume, cin, cout, relu ? 1 : 0, order};
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e;
   if (cin % 16 == 0 && kernel_volume <= kSg2MaxK && (cout == 16 || cout == 32 || cout == 64 || cout == 128) &&
@@ -1088,7 +1203,7 @@ extern "C" int pd3_sparse_conv3d_features(const float* in_feats, const int32_t* 
     // the encoder's shapes: 128-row tiles, A operand straight from global memory
     const int t = cin % 32 == 0 ? 8 : 4, nb = cout / 16;
     const size_t lds = (size_t)2 * 64 * (nb * t + 4) * sizeof(float) +
-                       ((size_t)kSg2Rows * kernel_volume + 16) * sizeof(int);
+                       ((size_t)kSg2Rows * kernel_volume + 16 + kSg2Rows) * sizeof(int);
     const unsigned grid = (unsigned)ceil_div(n_out_cap, kSg2Rows);
 #define PD3_SP_ROWS(NBV, TV)                                                                      \
   do {                                                                                            \
@@ -1161,6 +1276,28 @@ valu_path:
       sp_gather_gemm_kernel<2><<<grid, 256, lds, s>>>(a);
     }
   }
+  return launch_status();
+}
+
+extern "C" int64_t pd3_sparse_tile_order_entries(int n_out_cap) {
+  if (n_out_cap <= 0) return 0;
+  return ceil_div(n_out_cap, kSpWindow) * (int64_t)kSpWindow;
+}
+
+extern "C" int pd3_sparse_tile_order(const int32_t* nbr, const int32_t* n_out, int n_out_cap, int kernel_volume,
+                                     int32_t* order, void* stream) {
+  if (!nbr || !order || n_out_cap <= 0 || kernel_volume <= 0 || kernel_volume > 32) return PD3_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t lds = (size_t)kSpWindow * sizeof(unsigned long long);
+  static bool raised = false;  // (the attribute is per function, not per device state that could go stale)
+  if (!raised) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_tile_order_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  sp_tile_order_kernel<<<(unsigned)ceil_div(n_out_cap, kSpWindow), kSpOrderThreads, lds, s>>>(
+      nbr, n_out, n_out_cap, kernel_volume, order);
   return launch_status();
 }
 

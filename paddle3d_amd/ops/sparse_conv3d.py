@@ -4,6 +4,8 @@ has no `paddle3d.ops.sparse_conv3d` module -- the arithmetic is Paddle core -- s
 
   indices(coords, batch, spatial_shape, kernel_size, stride, padding, subm) -> SparseIndices
   plan(coords, batch, spatial_shape, specs) -> SparsePlan   (all index sets of an encoder, ONE host sync)
+  plan(..., caps=plan_caps(earlier plan)) -> SparsePlan     (the same WITHOUT a host sync: remembered capacities,
+                                                             device row counts, one overflow word to check later)
   features(in_feats, idx, weight, bias=None, scale=None, shift=None, residual=None, relu=False) -> out_feats
   to_dense(feats, coords, batch, spatial_shape) -> [B, C*D, H, W]
 """
@@ -16,7 +18,7 @@ import torch
 
 from ._common import check, host_i32, lib, ptr, require_gpu, stream_ptr, workspace
 
-__all__ = ["SparseIndices", "ConvSpec", "SparsePlan", "indices", "plan", "features", "to_dense",
+__all__ = ["SparseIndices", "ConvSpec", "SparsePlan", "indices", "plan", "plan_caps", "features", "to_dense",
            "out_spatial_shape"]
 
 
@@ -24,9 +26,15 @@ __all__ = ["SparseIndices", "ConvSpec", "SparsePlan", "indices", "plan", "featur
 class SparseIndices:
     out_coords: torch.Tensor   # [n_out, 4] int32 (b, z, y, x)
     nbr: torch.Tensor          # [n_out, K] int32, input row or -1
-    n_out: int
+    n_out: int                 # rows of the arrays (a capacity when n_out_dev is set)
     out_shape: tuple           # (D, H, W)
     kernel_volume: int
+    order: torch.Tensor = None      # tile order of the rows (pd3_sparse_tile_order): a scheduling hint for `features`
+    n_out_dev: torch.Tensor = None  # [1] int32 on the device: the real row count of a plan made without a host sync
+
+
+# tile order on / off (the GPU tests run both: the results are the same bytes)
+TILE_ORDER = True
 
 
 def out_spatial_shape(spatial_shape, kernel_size, stride, padding):
@@ -90,13 +98,27 @@ class SparsePlan:
     coords: torch.Tensor      # [n_in, 4] int32 coordinates of the first index set (raster order)
     n_in: int
     indices: list             # one SparseIndices per ConvSpec (shared objects where rulebooks are shared)
+    counts: list = None       # rows of every index set (host ints; None for a plan made without a host sync)
+    n_in_dev: torch.Tensor = None   # [1] int32: rows of the first set (a plan made without a host sync)
+    overflow: torch.Tensor = None   # [] bool on the device: some set reached its capacity (results truncated)
 
 
-def plan(coords: torch.Tensor, batch: int, spatial_shape, specs) -> SparsePlan:
+def plan_caps(pl: SparsePlan, margin: float = 1.25, quantum: int = 8192):
+    """Capacities for later plans of the same encoder and batch size, from a plan made WITH the host sync: every
+    set's row count times `margin`, rounded up to `quantum` rows."""
+    return [int(-(-int(n * margin + 1) // quantum) * quantum) for n in pl.counts]
+
+
+def plan(coords: torch.Tensor, batch: int, spatial_shape, specs, caps=None) -> SparsePlan:
     """Index sets and rulebooks of a chain of sparse convolutions (an encoder).  Every index set is a sorted key
     array whose length stays on the device while the chain is enqueued; the lengths are read back ONCE, then the
     rulebooks are built at their exact sizes (LDS-staged hash lookups).  `coords` may contain padding rows
-    (batch < 0), e.g. the voxelizer's fixed-shape output; row i of the first set is input row order[i]."""
+    (batch < 0), e.g. the voxelizer's fixed-shape output; row i of the first set is input row order[i].
+
+    caps (plan_caps of an earlier plan): NO host sync.  Rulebooks and feature rows are allocated at the remembered
+    capacities, every kernel reads its row count from device memory, and `overflow` says (on the device) whether a
+    set filled its capacity -- the caller reads it wherever it synchronises anyway (where detections are read) and
+    replans with the sync if it is set."""
     c = require_gpu(coords, "sparse_conv3d", torch.int32)
     if c.dim() != 2 or c.shape[1] != 4:
         raise RuntimeError("sparse_conv3d: coords must be [N, 4] int32 (batch, z, y, x)")
@@ -125,6 +147,8 @@ def plan(coords: torch.Tensor, batch: int, spatial_shape, specs) -> SparsePlan:
             raise RuntimeError("sparse_conv3d: empty output shape")
         per_in = math.prod(-(-k // s) for k, s in zip(ks, st))
         cap = int(min(sets[cur]["cap"] * per_in, batch * math.prod(shape)))
+        if caps is not None:
+            cap = min(cap, int(caps[len(sets)]))
         new = dict(keys=torch.empty((max(cap, 1),), dtype=torch.int32, device=dev), cap=cap, shape=shape)
         if cap > 0 and sets[cur]["cap"] > 0:
             j = len(sets)
@@ -137,10 +161,16 @@ def plan(coords: torch.Tensor, batch: int, spatial_shape, specs) -> SparsePlan:
         sets.append(new)
         pairs.append((cur, len(sets) - 1))
         cur = len(sets) - 1
-    n = [int(v) for v in counts.cpu().tolist()]  # the one host sync of the encoder
-    for st_, nn_ in zip(sets, n):
+    if caps is None:
+        n = [int(v) for v in counts.cpu().tolist()]  # the one host sync of the encoder
+    else:
+        if len(caps) != n_sets:
+            raise RuntimeError("sparse_conv3d.plan: caps must hold one capacity per index set")
+        n = [st_["cap"] for st_ in sets]  # arrays at capacity, the real counts stay on the device
+    for j, (st_, nn_) in enumerate(zip(sets, n)):
         st_["n"] = min(nn_, st_["cap"])
         st_["coords"] = None
+        st_["n_dev"] = counts[j:j + 1] if caps is not None else None
     books, out = {}, []
     for sp, (i, o) in zip(specs, pairs):
         ks, st, pd = _triple(sp.kernel_size), _triple(sp.stride), _triple(sp.padding)
@@ -156,21 +186,32 @@ def plan(coords: torch.Tensor, batch: int, spatial_shape, specs) -> SparsePlan:
             if n_out > 0 and n_in > 0:
                 hsh, hk, hs, hp = host_i32(sets[i]["shape"]), host_i32(ks), host_i32(st), host_i32(pd)
                 ws = workspace(L.pd3_sparse_rulebook_workspace(batch, ptr(hsh)), dev)
-                check(L.pd3_sparse_rulebook(ptr(sets[i]["keys"]), None, n_in, ptr(sets[o]["keys"]), None, n_out,
-                                            batch, ptr(hsh), ptr(hk), ptr(hs), ptr(hp), int(sp.subm), ptr(nbr),
-                                            ptr(oc) if want_coords else None, ptr(ws), ws.numel(),
-                                            stream_ptr(dev)),
+                check(L.pd3_sparse_rulebook(ptr(sets[i]["keys"]), ptr(sets[i]["n_dev"]), n_in, ptr(sets[o]["keys"]),
+                                            ptr(sets[o]["n_dev"]), n_out, batch, ptr(hsh), ptr(hk), ptr(hs), ptr(hp),
+                                            int(sp.subm), ptr(nbr), ptr(oc) if want_coords else None, ptr(ws),
+                                            ws.numel(), stream_ptr(dev)),
                       "sparse_rulebook")
             elif n_out > 0:
                 nbr.fill_(-1)
             sets[o]["coords"] = oc
-            books[tag] = SparseIndices(oc, nbr, n_out, sets[o]["shape"], kvol)
+            order = None
+            if TILE_ORDER and n_out > 0 and kvol <= 32:
+                order = torch.empty((int(L.pd3_sparse_tile_order_entries(n_out)),), dtype=torch.int32, device=dev)
+                check(L.pd3_sparse_tile_order(ptr(nbr), ptr(sets[o]["n_dev"]), n_out, kvol, ptr(order),
+                                              stream_ptr(dev)), "sparse_tile_order")
+            books[tag] = SparseIndices(oc, nbr, n_out, sets[o]["shape"], kvol, order, sets[o]["n_dev"])
         out.append(books[tag])
     if sets[0]["coords"] is None:  # a chain that starts with a regular convolution: decode the first set here
         k = sets[0]["keys"][: sets[0]["n"]].long() & 0xFFFFFFFF
         d, h, w = sets[0]["shape"]
         sets[0]["coords"] = torch.stack([k // (d * h * w), (k // (h * w)) % d, (k // w) % h, k % w], 1).int()
-    return SparsePlan(order[: sets[0]["n"]].long(), sets[0]["coords"], sets[0]["n"], out)
+    if caps is None:
+        return SparsePlan(order[: sets[0]["n"]].long(), sets[0]["coords"], sets[0]["n"], out, counts=n)
+    # a set that filled its capacity may have lost rows (the first set's capacity is the input's own row count)
+    limit = torch.tensor([st_["cap"] for st_ in sets[1:]], dtype=torch.int32, device=dev)
+    over = (counts[1:] >= limit).any() if n_sets > 1 else torch.zeros((), dtype=torch.bool, device=dev)
+    return SparsePlan(order[: sets[0]["n"]].long(), sets[0]["coords"], sets[0]["n"], out, n_in_dev=counts[0:1],
+                      overflow=over)
 
 
 def features(in_feats: torch.Tensor, idx: SparseIndices, weight: torch.Tensor, bias=None, scale=None,
@@ -185,14 +226,14 @@ def features(in_feats: torch.Tensor, idx: SparseIndices, weight: torch.Tensor, b
     if idx.n_out == 0:
         return out
     opt = [None if t is None else require_gpu(t, "sparse_conv3d") for t in (bias, scale, shift, residual)]
-    check(lib().pd3_sparse_conv3d_features(ptr(f), ptr(idx.nbr), None, idx.n_out, idx.kernel_volume, cin, cout,
-                                           ptr(w), ptr(opt[0]), ptr(opt[1]), ptr(opt[2]), ptr(opt[3]),
-                                           int(bool(relu)), ptr(out), stream_ptr(f.device)),
-          "sparse_conv3d_features")
+    check(lib().pd3_sparse_conv3d_features_ordered(
+        ptr(f), ptr(idx.nbr), ptr(idx.n_out_dev), idx.n_out, idx.kernel_volume, cin, cout, ptr(w), ptr(opt[0]),
+        ptr(opt[1]), ptr(opt[2]), ptr(opt[3]), int(bool(relu)), ptr(idx.order) if TILE_ORDER else None, ptr(out),
+        stream_ptr(f.device)), "sparse_conv3d_features")
     return out
 
 
-def to_dense(feats: torch.Tensor, coords: torch.Tensor, batch: int, spatial_shape) -> torch.Tensor:
+def to_dense(feats: torch.Tensor, coords: torch.Tensor, batch: int, spatial_shape, n_dev=None) -> torch.Tensor:
     f = require_gpu(feats, "sparse_to_dense")
     c = require_gpu(coords, "sparse_to_dense", torch.int32)
     d, h, w = (int(x) for x in spatial_shape)
@@ -202,6 +243,6 @@ def to_dense(feats: torch.Tensor, coords: torch.Tensor, batch: int, spatial_shap
     if n == 0:
         return out.zero_()
     hsh = host_i32(spatial_shape)
-    check(lib().pd3_sparse_to_dense(ptr(f), ptr(c), None, n, ch, batch, ptr(hsh), ptr(out),
+    check(lib().pd3_sparse_to_dense(ptr(f), ptr(c), ptr(n_dev), n, ch, batch, ptr(hsh), ptr(out),
                                     stream_ptr(f.device)), "sparse_to_dense")
     return out

@@ -18,19 +18,23 @@ __all__ = ["SparseConvTensor", "SubmConv3D", "Conv3D", "SparseBasicBlock", "Spar
 class SparseConvTensor:
     """features [N, C] fp32 + indices [N, 4] int32 (b, z, y, x) + dense spatial shape (D, H, W)."""
 
-    def __init__(self, features, indices, spatial_shape, batch_size, cache=None, plan=None):
+    def __init__(self, features, indices, spatial_shape, batch_size, cache=None, plan=None, n_dev=None):
         self.features = features
         self.indices = indices
         self.spatial_shape = tuple(int(s) for s in spatial_shape)
         self.batch_size = int(batch_size)
         self.cache = {} if cache is None else cache  # indice_key -> SparseIndices
         self.plan = plan  # id(conv module) -> SparseIndices, when the encoder planned its index sets up front
+        # [1] int32 on the device: the real row count when the arrays are at a remembered capacity (a plan made
+        # without a host sync); rows past it hold nothing
+        self.n_dev = n_dev
 
     def replace(self, features):
-        return SparseConvTensor(features, self.indices, self.spatial_shape, self.batch_size, self.cache, self.plan)
+        return SparseConvTensor(features, self.indices, self.spatial_shape, self.batch_size, self.cache, self.plan,
+                                self.n_dev)
 
     def dense(self):
-        return _sp.to_dense(self.features, self.indices, self.batch_size, self.spatial_shape)
+        return _sp.to_dense(self.features, self.indices, self.batch_size, self.spatial_shape, self.n_dev)
 
 
 def _triple(v):
@@ -45,11 +49,16 @@ def count_flops(encoder, voxel_features, coors, batch_size) -> dict:
     pair, `dense` = the same with all kernel offsets counted.  Host syncs per convolution: not for timed code."""
     global _STATS
     _STATS = dict(pairs=0, dense=0)
+    keep = getattr(encoder, "remember_capacities", None)
+    if keep is not None:
+        encoder.remember_capacities = False  # exact-size rulebooks: every row of `nbr` is a real row
     try:
         encoder(voxel_features, coors, batch_size)
         return dict(_STATS)
     finally:
         _STATS = None
+        if keep is not None:
+            encoder.remember_capacities = keep
 
 
 class _SparseConv(nn.Module):
@@ -87,7 +96,7 @@ class _SparseConv(nn.Module):
         out = _sp.features(x.features, idx, self.weight, self.bias, scale, shift, residual, relu)
         if self.subm:
             return x.replace(out)
-        return SparseConvTensor(out, idx.out_coords, idx.out_shape, x.batch_size, plan=x.plan)
+        return SparseConvTensor(out, idx.out_coords, idx.out_shape, x.batch_size, plan=x.plan, n_dev=idx.n_out_dev)
 
 
 class SubmConv3D(_SparseConv):
@@ -120,16 +129,16 @@ def _fold(bn: nn.BatchNorm1d):
     return scale, shift
 
 
-def _planned_input(encoder, voxel_features, coors, batch_size):
+def _planned_input(encoder, voxel_features, coors, batch_size, caps=None):
     """The encoder's index sets are planned before any feature is touched (ops.sparse_conv3d.plan: sorted key
     sets, one host sync, exact-size rulebooks); rows travel in raster order, so tiles of consecutive rows are
     spatial neighbours (a tile's kernel offsets are mostly all-present or all-absent, its gathers share cache
     lines).  `coors` may carry the voxelizer's padding rows (batch = -1)."""
     convs = [m for m in encoder.modules() if isinstance(m, _SparseConv)]
-    pl = _sp.plan(coors, batch_size, encoder.sparse_shape, [m.spec() for m in convs])
+    pl = _sp.plan(coors, batch_size, encoder.sparse_shape, [m.spec() for m in convs], caps=caps)
     feats = voxel_features.index_select(0, pl.order)
     return SparseConvTensor(feats, pl.coords, encoder.sparse_shape, batch_size,
-                            plan={id(m): idx for m, idx in zip(convs, pl.indices)})
+                            plan={id(m): idx for m, idx in zip(convs, pl.indices)}, n_dev=pl.n_in_dev), pl
 
 
 def _bn(channels):
@@ -215,9 +224,41 @@ class SparseResNet3D(nn.Module):
 
     accepts_padding_rows = True  # rows with batch index < 0 are ignored (no boolean-mask sync in the caller)
 
+    # remember_capacities: the first forward of a (batch size, input rows) shape plans with the ONE host sync and
+    # remembers every index set's row count (x 1.25); later forwards of that shape plan without any host round trip
+    # (sparse_conv3d.plan(caps=...)), and `take_overflow()` -- read where the caller synchronises anyway, e.g. where
+    # detections reach the host -- says whether a set outgrew its capacity (then the result is to be recomputed: the
+    # capacities are dropped and the next forward plans with the sync again).  The reference's layers read nnz on the
+    # host after every sparse op.
+    remember_capacities = True
+
+    def _plan_input(self, voxel_features, coors, batch_size):
+        shape_key = (int(batch_size), int(coors.shape[0]))
+        caps = getattr(self, "_caps", {}).get(shape_key) if self.remember_capacities else None
+        x, pl = _planned_input(self, voxel_features, coors, batch_size, caps)
+        if caps is None:
+            if self.remember_capacities:
+                if not hasattr(self, "_caps"):
+                    object.__setattr__(self, "_caps", {})
+                self._caps[shape_key] = _sp.plan_caps(pl)
+        else:
+            prev = getattr(self, "_overflow", None)
+            object.__setattr__(self, "_overflow", pl.overflow if prev is None else (prev | pl.overflow))
+        return x
+
+    def take_overflow(self) -> bool:
+        """True if an index set of a forward since the last call outgrew its remembered capacity (ONE host sync; the
+        capacities are dropped so that the next forward plans with exact sizes).  False when nothing ran unsynced."""
+        flag = getattr(self, "_overflow", None)
+        object.__setattr__(self, "_overflow", None)
+        if flag is None or not bool(flag.item()):
+            return False
+        object.__setattr__(self, "_caps", {})
+        return True
+
     @torch.no_grad()
     def forward(self, voxel_features, coors, batch_size):
-        x = _planned_input(self, voxel_features, coors, batch_size)
+        x = self._plan_input(voxel_features, coors, batch_size)
         for stage in (self.conv_input, self.conv1, self.conv2, self.conv3, self.conv4, self.extra_conv):
             x = _run_sequential(stage, x)
         return _densify(x)
@@ -259,7 +300,8 @@ class SparseNet3D(nn.Module):
 
     @torch.no_grad()
     def forward(self, voxel_features, coors, batch_size):
-        x = _planned_input(self, voxel_features, coors, batch_size)
+        # (always the synced plan: the intermediate sparse tensors are part of the result, at their exact sizes)
+        x, _ = _planned_input(self, voxel_features, coors, batch_size)
         x = _run_sequential(self.conv_input, x)
         x1 = _run_sequential(self.conv1, x)
         x2 = _run_sequential(self.conv2, x1)

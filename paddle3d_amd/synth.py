@@ -201,30 +201,37 @@ def camera_rig(seed: int, n_cam: int = 6, input_size=(256, 704), batch: int = 1)
                 post_trans=np.asarray(ptran, f32).reshape(*sh, 3), bda=np.tile(np.eye(3, dtype=f32), (batch, 1, 1)))
 
 
-def trained_like_heads(model, points, gain: float = 30.0, fraction: float = 0.01):
+def trained_like_heads(model, points, fraction: float = 0.01, top_fraction: float = 0.001, top_score: float = 0.35):
     """Measurement aid for RANDOM-INIT weights (bench.py's mAP proxy, tests/test_model_gpu.py): gives every class of
     every task of a CenterPoint head a heat map that behaves like a trained one's, so that all tasks emit detections
-    and every class is scored.  The last heat-map convolution of each task is scaled by `gain` (plain random-init
-    heads put all scores of a class into a band 0.003 wide, where the top-K cut and the NMS order are thousands of
-    near-ties) and its bias is set PER CLASS so that `fraction` of the cells of `points` (a [B, N, D] device tensor,
-    one or two frames are enough) score above the model's score threshold -- with one common bias (-3, rounds 3-4)
-    three of the six nuScenes tasks never crossed the threshold.  In place; the caller copies the state dict to a CPU
-    twin afterwards."""
+    and every class is scored.  Plain random-init heads put all scores of a class into a band 0.003 wide, where the
+    top-K cut and the NMS order are thousands of near-ties; one common gain and bias (30 / -3, rounds 3-4) left three
+    of the six nuScenes tasks under the threshold, and with a bias per class alone the class with the heavier tail
+    still took all 83 post-NMS places of its task.  So the last heat-map convolution of each task gets a gain AND a
+    bias PER CLASS that put two quantiles of the class's map over the cells of `points` (a [B, N, D] device tensor,
+    two frames are enough) at fixed scores: `fraction` of the cells score above the model's score threshold and
+    `top_fraction` of them above `top_score`.  In place; the caller copies the state dict to a CPU twin afterwards."""
     import math
 
     import torch
 
+    def logit(p):
+        return math.log(p / (1.0 - p))
+
     thr = float(model.test_cfg["score_threshold"])
     with torch.no_grad():
         for task in model.bbox_head.tasks:
-            task.hm[-1].weight.mul_(gain)
             task.hm[-1].bias.zero_()
         model.invalidate()
         preds, _ = model.bbox_head(model.dense_forward(model.extract_pillars(points, dense=False)))
         for task, p in zip(model.bbox_head.tasks, preds):
             hm = p["hm"].float().transpose(0, 1).reshape(p["hm"].shape[1], -1)  # [classes, B * H * W] logits, bias 0
-            k = max(1, int(round(hm.shape[1] * (1.0 - fraction))))
-            cut = hm.kthvalue(k, dim=1).values
-            task.hm[-1].bias.copy_(math.log(thr / (1.0 - thr)) - cut)
+            n = hm.shape[1]
+            lo = hm.kthvalue(max(1, int(round(n * (1.0 - fraction)))), dim=1).values
+            hi = hm.kthvalue(max(1, int(round(n * (1.0 - top_fraction)))), dim=1).values
+            gain = (logit(top_score) - logit(thr)) / (hi - lo).clamp(min=1e-12)
+            conv = task.hm[-1]
+            conv.weight.mul_(gain.to(conv.weight.dtype).view(-1, 1, 1, 1))
+            conv.bias.copy_(logit(thr) - gain * lo)
         model.invalidate()
     return model

@@ -310,5 +310,120 @@ def test_sparse_encoder_full_c4_grid_vs_keyset_oracle(oracle):
     assert bev.shape == ref_bev.shape == (2, 256, 180, 180)
     err = float(np.abs(bev.cpu().numpy() - ref_bev).max())
     assert err < 1e-3 * max(1.0, float(np.abs(ref_bev).max())), err
+    # the same map with the rows in raster order (no tile order) and from the unsynced plan: identical bytes
+    from paddle3d_amd.ops import sparse_conv3d as sp
+    assert torch.equal(net(feats, coors, b), bev) and not net.take_overflow()
+    sp.TILE_ORDER = False
+    try:
+        net.remember_capacities = False
+        assert torch.equal(net(feats, coors, b), bev)
+    finally:
+        sp.TILE_ORDER = True
+        net.remember_capacities = True
     # the dense neighbourhoods the bench's tiles see are in this input: > 10 existing pairs per row on the 32+ layers
     assert trace["conv2.3.conv1"]["pairs"] > 10 * trace["conv2.3.conv1"]["keys"].shape[0]
+
+
+@pytest.mark.parametrize("layer", [(16, 16, True), (32, 64, False), (64, 64, True), (128, 128, True)],
+                         ids=lambda l: f"{l[0]}to{l[1]}{'subm' if l[2] else 'down'}")
+def test_tile_order_changes_no_byte(layer):
+    """The tile order (rows of a window sorted by neighbour mask, pd3_sparse_tile_order) only decides which rows share
+    a 16-row block of the gather-GEMM: the order array is a permutation of every window's rows (-1 past the row
+    count) and the features are the same bytes with and without it."""
+    from paddle3d_amd.ops import sparse_conv3d as sp
+
+    cin, cout, subm = layer
+    rng = np.random.default_rng(cin + cout)
+    shape = (9, 120, 130)
+    n = 20000  # 2.4 windows of 8192 rows: a full window, a partial one, padding
+    coords, feats = _random_sparse(rng, 2, shape, n, cin)
+    # clustered occupancy as well: half of the rows in a dense slab, so that masks range from 1 to 27 neighbours
+    slab = np.stack(np.meshgrid(np.arange(2), np.arange(3, 6), np.arange(40, 90), np.arange(30, 60), indexing="ij"),
+                    -1).reshape(-1, 4).astype(np.int32)
+    coords = np.unique(np.concatenate([coords, slab]), axis=0)
+    feats = rng.normal(size=(len(coords), cin)).astype(np.float32)
+    spec = sp.ConvSpec((3, 3, 3), (1, 1, 1), (1, 1, 1), True) if subm else sp.ConvSpec((3, 3, 3), (2, 2, 2), (1, 1, 1))
+    w = torch.from_numpy((rng.normal(size=(3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)).cuda()
+    res = torch.from_numpy(rng.normal(size=(len(coords) * 8, cout)).astype(np.float32)).cuda()
+    outs = []
+    for flag in (True, False):
+        sp.TILE_ORDER = flag
+        try:
+            pl = sp.plan(torch.from_numpy(coords).cuda(), 2, shape, [spec])
+            idx = pl.indices[0]
+            f = torch.from_numpy(feats).cuda().index_select(0, pl.order)
+            outs.append(sp.features(f, idx, w, None, None, None, res[: idx.n_out].contiguous(), True))
+            if flag:
+                order = idx.order.cpu().numpy()
+                assert len(order) % 8192 == 0 and len(order) >= idx.n_out
+                live = order[order >= 0]
+                assert len(live) == idx.n_out and np.array_equal(np.sort(live), np.arange(idx.n_out))
+                for w0 in range(0, len(order), 8192):  # every window holds ITS rows, the padding last
+                    piece = order[w0:w0 + 8192]
+                    k = int((piece >= 0).sum())
+                    assert (piece[:k] >= w0).all() and (piece[:k] < w0 + 8192).all() and (piece[k:] == -1).all()
+                # rows of one block are neighbours in mask order: fewer (block, offset) steps than in raster order
+                nb = idx.nbr.cpu().numpy() >= 0
+                def steps(rows):
+                    pad = (-len(rows)) % 16
+                    m = np.concatenate([nb[rows], np.zeros((pad, nb.shape[1]), bool)]).reshape(-1, 16, nb.shape[1])
+                    return int(m.any(1).sum())
+                assert steps(live) < steps(np.arange(idx.n_out))
+            else:
+                assert idx.order is None
+        finally:
+            sp.TILE_ORDER = True
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_plan_without_host_sync_and_overflow(oracle):
+    """SparseResNet3D plans its first forward of a shape with the one host sync and remembers the index sets' sizes;
+    the next forward of that shape plans from the remembered capacities with NO host round trip (device row counts,
+    arrays at capacity) and gives the same bytes.  A capacity that is too small is reported by take_overflow() and
+    CenterPoint.test_forward then recomputes the frame with exact sizes."""
+    from paddle3d_amd import centerpoint as cpm
+    from paddle3d_amd import synth
+
+    torch.manual_seed(5)
+    pcr = [-9.6, -9.6, -5.0, 9.6, 9.6, 3.0]
+    model = cpm.centerpoint_voxels_nuscenes(max_num_voxels=(40000, 40000), point_cloud_range=pcr).cuda().eval()
+    net = model.middle_encoder
+    _randomise(net)
+    with torch.no_grad():
+        for task in model.bbox_head.tasks:
+            task.hm[-1].bias.fill_(-1.0)
+    pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(93, n_points=120_000),
+                                     synth.nuscenes_sweep(94, n_points=120_000)])).cuda()
+    voxels, coors, npv, nv = model.voxelizer(pts)
+    b, v, p, d = voxels.shape
+    coors = coors.view(b * v, 4)
+    feats = model.voxel_encoder(voxels.view(b * v, p, d), npv.view(b * v), coors)
+    first = net(feats, coors, b)          # synced plan, capacities remembered
+    assert len(net._caps) == 1 and not net.take_overflow()
+    caps = next(iter(net._caps.values()))
+    second = net(feats, coors, b)         # planned from the capacities
+    assert net._overflow is not None and torch.equal(first, second)
+    assert not net.take_overflow()
+    ref = oracle.sparse_encoder_numpy(net, feats.cpu().numpy(), coors.cpu().numpy(), b)
+    assert np.abs(second.cpu().numpy() - ref).max() < 1e-3 * max(1.0, np.abs(ref).max())
+    # another frame of the same shape (other row counts) through the unsynced plan
+    pts2 = torch.from_numpy(np.stack([synth.nuscenes_sweep(95, n_points=120_000),
+                                      synth.nuscenes_sweep(96, n_points=120_000)])).cuda()
+    dets_a = model.test_forward(pts2)
+    net.remember_capacities = False
+    dets_b = model.test_forward(pts2)
+    net.remember_capacities = True
+    for a, c in zip(dets_a, dets_b):
+        assert torch.equal(a["box3d_lidar"], c["box3d_lidar"]) and torch.equal(a["scores"], c["scores"])
+    # capacities far too small: the unsynced forward truncates, says so, and test_forward recomputes
+    key = next(iter(net._caps))
+    net._caps[key] = [caps[0]] + [max(8192, c // 8) for c in caps[1:]]
+    truncated = net(feats, coors, b)
+    assert net.take_overflow() and net._caps == {}
+    assert not torch.equal(truncated, first)
+    net(feats, coors, b)
+    key = next(iter(net._caps))
+    net._caps[key] = [net._caps[key][0]] + [max(8192, c // 8) for c in net._caps[key][1:]]
+    dets_c = model.test_forward(pts2)     # first attempt overflows, second attempt plans with the sync
+    for a, c in zip(dets_a, dets_c):
+        assert torch.equal(a["box3d_lidar"], c["box3d_lidar"]) and torch.equal(a["scores"], c["scores"])
