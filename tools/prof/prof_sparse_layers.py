@@ -12,6 +12,8 @@ from paddle3d_amd import synth  # noqa: E402
 from paddle3d_amd.ops import sparse_conv3d as _sp  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+# second argument "raster": rows in raster order (no tile order), the round-4 behaviour
+_sp.TILE_ORDER = not (len(sys.argv) > 2 and sys.argv[2] == "raster")
 model = cpm.centerpoint_voxels_nuscenes(max_num_voxels=(120000, 160000)).cuda().eval()
 pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(100 + i) for i in range(batch)])).cuda()
 rows = []
@@ -31,8 +33,12 @@ def traced(in_feats, idx, weight, *a, **kw):
     nbr = idx.nbr[: idx.n_out]
     present = nbr >= 0
     pairs = int(present.sum())
-    n16 = (idx.n_out + 15) // 16 * 16
-    pad = torch.zeros(n16 - idx.n_out, nbr.shape[1], dtype=torch.bool, device=nbr.device)
+    if idx.order is not None and _sp.TILE_ORDER:  # the blocks the kernel really forms: 16 consecutive slots of the order
+        slots = idx.order.long()
+        live = slots >= 0
+        present = torch.where(live.unsqueeze(1), present[slots.clamp(min=0)], torch.zeros_like(present[:1]))
+    n16 = (present.shape[0] + 15) // 16 * 16
+    pad = torch.zeros(n16 - present.shape[0], nbr.shape[1], dtype=torch.bool, device=nbr.device)
     blocks = int(torch.cat([present, pad]).view(-1, 16, nbr.shape[1]).any(1).sum()) * 16
     cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
     rows.append((idx.n_out, nbr.shape[1], cin, cout, pairs, blocks, ms))
@@ -46,8 +52,10 @@ with torch.no_grad():
     keep = coors.view(b * v, 4)[:, 0] >= 0
     cs = coors.view(b * v, 4)[keep].contiguous()
     feats = model.voxel_encoder(voxels.view(b * v, p, d)[keep], npv.view(b * v)[keep], cs)
+    model.middle_encoder.remember_capacities = False
     model.middle_encoder(feats, cs, b)
 tot = 0.0
+print("rows in", "tile order (windows of 8192 rows sorted by neighbour mask)" if _sp.TILE_ORDER else "raster order")
 print(f"{'rows':>8} {'K':>3} {'cin':>4} {'cout':>4} {'pairs/row':>9} {'exec/useful':>11} {'ms':>8} {'useful TF':>9} {'exec TF':>8}")
 for n, k, ci, co, pairs, blocks, ms in rows:
     tot += ms
