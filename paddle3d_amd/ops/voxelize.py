@@ -12,7 +12,53 @@ import torch
 
 from ._common import check, host_f32, lib, ptr, require_gpu, stream_ptr, workspace
 
-__all__ = ["dynamic_voxelize", "hard_voxelize", "hard_voxelize_batch"]
+__all__ = ["dynamic_voxelize", "hard_voxelize", "hard_voxelize_batch", "lds_atomic_order_ok"]
+
+_LDS_ORDER = {}  # device index -> bool, probed once per process
+
+
+def lds_atomic_order_ok(dev: torch.device) -> bool:
+    """The hardware property the wave / tiled forms of hard_voxelize rest on (csrc/selfcheck.hip: lanes of one
+    returning LDS add that hit one word are served in ascending lane order, a wave's LDS instructions in program
+    order), probed ONCE per process and device through the library itself: 65 k adds in four address patterns, each
+    must return the sequential count.  The automatic path choice falls back to the sort form (which does not depend
+    on it) when the probe fails -- a new part or driver must never silently reorder points inside a voxel."""
+    import numpy as np
+
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key in _LDS_ORDER:
+        return _LDS_ORDER[key]
+    blocks, waves, rounds, table = 32, 4, 8, 256
+    rng = np.random.default_rng(1)
+    n_w = blocks * waves
+    mode = (np.arange(n_w) % 4)[:, None, None]
+    a = np.where(mode == 0, rng.integers(0, table, (n_w, rounds, 64)),
+                 np.where(mode == 1, rng.integers(0, 4, (n_w, rounds, 64)),
+                          np.where(mode == 2, 7, (rng.integers(0, 37, (n_w, rounds, 64)) * 27) % table))).astype(np.uint32)
+    a[rng.random(a.shape) < 1 / 11] = 0xFFFFFFFF
+    da = torch.from_numpy(a.view(np.int32)).to(dev)
+    dold = torch.empty_like(da)
+    check(lib().pd3_selfcheck_lds_atomic_order(ptr(da), ptr(dold), blocks, waves, rounds, table, stream_ptr(dev)),
+          "selfcheck_lds_atomic_order")
+    old = dold.cpu().numpy().view(np.uint32).reshape(n_w, rounds * 64)
+    flat = a.reshape(n_w, rounds * 64)
+    want = np.full_like(flat, 0xFFFFFFFF)
+    cnt = np.zeros((n_w, table), np.uint32)
+    rows = np.arange(n_w)
+    for i in range(flat.shape[1]):  # sequential over the 512 adds of a wave, vectorised over the waves
+        ai = flat[:, i]
+        live = ai != 0xFFFFFFFF
+        idx = np.where(live, ai, 0)
+        want[:, i] = np.where(live, cnt[rows, idx], 0xFFFFFFFF)
+        cnt[rows[live], idx[live]] += 1
+    ok = bool((old == want).all())
+    if not ok:
+        import warnings
+
+        warnings.warn("paddle3d_amd: returning LDS atomics are NOT served in lane order on this device; "
+                      "hard_voxelize uses its sort form (slower, same results)", RuntimeWarning)
+    _LDS_ORDER[key] = ok
+    return ok
 
 
 def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max_num_points_in_voxel: int,
@@ -54,6 +100,8 @@ def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max
                                       ptr(coords), ptr(npv), ptr(nv), ptr(coors4), ptr(ws), ws.numel(),
                                       stream_ptr(dev)), "hard_voxelize")
     else:
+        if path == 0 and not lds_atomic_order_ok(dev):
+            path = 1  # the sort form does not depend on the order in which an LDS add serves its lanes
         check(L.pd3_hard_voxelize_path(ptr(pts), ptr(num_points), b, n, d, ptr(vs), ptr(pr), p, v, ptr(voxels),
                                        ptr(coords), ptr(npv), ptr(nv), ptr(coors4), ptr(ws), ws.numel(),
                                        stream_ptr(dev), int(path)),
