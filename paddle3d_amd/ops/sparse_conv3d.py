@@ -194,12 +194,12 @@ def plan(coords: torch.Tensor, batch: int, spatial_shape, specs, caps=None) -> S
             elif n_out > 0:
                 nbr.fill_(-1)
             sets[o]["coords"] = oc
-            order = None
+            tile_order = None
             if TILE_ORDER and n_out > 0 and kvol <= 32:
-                order = torch.empty((int(L.pd3_sparse_tile_order_entries(n_out)),), dtype=torch.int32, device=dev)
-                check(L.pd3_sparse_tile_order(ptr(nbr), ptr(sets[o]["n_dev"]), n_out, kvol, ptr(order),
+                tile_order = torch.empty((int(L.pd3_sparse_tile_order_entries(n_out)),), dtype=torch.int32, device=dev)
+                check(L.pd3_sparse_tile_order(ptr(nbr), ptr(sets[o]["n_dev"]), n_out, kvol, ptr(tile_order),
                                               stream_ptr(dev)), "sparse_tile_order")
-            books[tag] = SparseIndices(oc, nbr, n_out, sets[o]["shape"], kvol, order, sets[o]["n_dev"])
+            books[tag] = SparseIndices(oc, nbr, n_out, sets[o]["shape"], kvol, tile_order, sets[o]["n_dev"])
         out.append(books[tag])
     if sets[0]["coords"] is None:  # a chain that starts with a regular convolution: decode the first set here
         k = sets[0]["keys"][: sets[0]["n"]].long() & 0xFFFFFFFF
