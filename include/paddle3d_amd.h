@@ -84,6 +84,23 @@ int pd3_hard_voxelize_path(const float *points, const int32_t *num_points, int b
                            int32_t *num_points_per_voxel, int32_t *num_voxels, int32_t *coors_batched,
                            void *workspace, size_t workspace_bytes, void *stream, int path);
 
+/* hard_voxelize WITHOUT the padded [V, P, D] tensor (the model path; reference chain paddle3d/models/voxelizers/
+ * voxelize.py:39-58 -> voxel_encoders/pillar_encoder.py:156-210): the same voxel ids, coords, counts and batched
+ * coors as pd3_hard_voxelize, and in place of copies of the points an INDEX of them:
+ *   vox_span   [batch, max_voxels, 2] int32: (start, count) -- voxel v of frame b holds the points
+ *              point_list[b * max_points + start + 0 .. count - 1] (indices into frame b's rows of `points`,
+ *              ascending = the reference's order inside a voxel); count == num_points_per_voxel
+ *   point_list [pd3_hard_voxelize_index_list_entries(batch, max_points)] int32
+ * A consumer reads a voxel's points from `points` itself (pd3_pillar_feature_net_indexed): the 78 %-zeros tensor is
+ * neither written nor read.  Grids the wave forms do not serve (see pd3_hard_voxelize_path) return -3: run
+ * pd3_hard_voxelize there.  Workspace: pd3_hard_voxelize_workspace. */
+int64_t pd3_hard_voxelize_index_list_entries(int batch, int64_t max_points);
+int pd3_hard_voxelize_index(const float *points, const int32_t *num_points, int batch, int64_t max_points,
+                            int num_point_dim, const float *voxel_size, const float *point_cloud_range,
+                            int max_num_points_in_voxel, int max_voxels, int32_t *vox_span, int32_t *point_list,
+                            int32_t *coords, int32_t *num_points_per_voxel, int32_t *num_voxels,
+                            int32_t *coors_batched, void *workspace, size_t workspace_bytes, void *stream);
+
 /* hard_voxelize for double points: PD_DISPATCH_FLOATING_TYPES (voxelize_op.cc:128) instantiates the reference's CPU
  * kernel for float and double; with T = double the cell index is floor((p - (double)range_min) / (double)voxel_size)
  * (:37-45) and `voxels` is double.  Generic sort path (any grid below 2^31 cells); the workspace of
@@ -168,6 +185,19 @@ int pd3_pillar_feature_net_path(const float *voxels, const int32_t *num_points, 
                                 float y_offset, float z_offset, const float *w1, const float *scale1,
                                 const float *shift1, int c1, const float *w2, const float *scale2,
                                 const float *shift2, int c2, float *out, int path, void *stream);
+
+/* pd3_pillar_feature_net reading the pillars' points through pd3_hard_voxelize_index's (vox_span, point_list) from
+ * the point cloud itself: points [frames, points_per_frame, D], list_stride = rows of point_list per frame
+ * (= max_points of the voxelizer call), coors [num_pillars, 4], pillars_per_frame = max_voxels.  Bit-identical to
+ * pd3_hard_voxelize + pd3_pillar_feature_net.  Serves the two-layer 32 / 64 net with up to 32 points of 4 / 5
+ * floats per pillar and pillars_per_frame a multiple of 8; other shapes return -3 (run the pair). */
+int pd3_pillar_feature_net_indexed(const float *points, int64_t points_per_frame, const int32_t *vox_span,
+                                   const int32_t *point_list, int64_t list_stride, const int32_t *coors,
+                                   int64_t num_pillars, int pillars_per_frame, int max_points, int num_point_dim,
+                                   int voxel_center_dims, float vx, float vy, float vz, float x_offset,
+                                   float y_offset, float z_offset, const float *w1, const float *scale1,
+                                   const float *shift1, int c1, const float *w2, const float *scale2,
+                                   const float *shift2, int c2, float *out, void *stream);
 
 /* VoxelMean.forward, paddle3d/models/voxel_encoders/voxel_encoder.py:44-57: sum over P / count. */
 int pd3_voxel_mean(const float *voxels, const int32_t *num_points, int64_t num_voxels,

@@ -30,6 +30,15 @@ _SIGNATURES = {
     "pd3_hard_voxelize_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
+    "pd3_hard_voxelize_index_list_entries": (C.c_int64, [C.c_int, C.c_int64]),
+    "pd3_hard_voxelize_index": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pd3_pillar_feature_net_indexed": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                                 C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p]),
     "pd3_pointpillars_scatter_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "pd3_pointpillars_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

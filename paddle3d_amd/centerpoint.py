@@ -73,6 +73,20 @@ class HardVoxelizer(nn.Module):
                                                              with_batch_coors=True, path=self.path)
         return voxels, coors, npv, nv
 
+    def index(self, points: torch.Tensor, num_points: torch.Tensor | None = None):
+        """The same voxels as forward() as an INDEX of the points instead of padded copies of them: (vox_span
+        [B, V, 2], point_list, coors [B, V, 4], num_points [B, V], num_voxels [B]), or None where the voxelizer's
+        wave forms do not serve the grid (ops.voxelize.hard_voxelize_index_batch)."""
+        if self.path != 0:
+            return None  # a forced path is a measurement / test form of the full operator
+        v = self.max_num_voxels[0] if self.training else self.max_num_voxels[1]
+        res = _vox.hard_voxelize_index_batch(points, self.voxel_size, self.point_cloud_range,
+                                             self.max_num_points_in_voxel, v, num_points)
+        if res is None:
+            return None
+        span, plist, _, npv, nv, coors = res
+        return span, plist, coors, npv, nv
+
 
 class PFNLayer(nn.Module):
     """pillar_encoder.py:64-105; holds parameters only -- the arithmetic runs inside the fused HIP op."""
@@ -130,6 +144,17 @@ class PillarFeatureNet(nn.Module):
             self._folded = (sig, self._fold())
         return _ve.pillar_feature_net(features, num_points_per_voxel, coors, self.vx, self.vy, self.x_offset,
                                       self.y_offset, *self._folded[1])
+
+    def forward_indexed(self, points, vox_span, point_list, coors):
+        """forward() reading the pillars' points through the voxelizer's index (HardVoxelizer.index) from the point
+        cloud [B, N, D] itself; None for shapes the indexed kernel does not serve.  Same bytes as forward()."""
+        if len(self.pfn_layers) != 2:
+            return None
+        sig = _param_signature(self)
+        if self.training or self._folded is None or self._folded[0] != sig:
+            self._folded = (sig, self._fold())
+        return _ve.pillar_feature_net_indexed(points, vox_span, point_list, coors, self.max_num_points_in_voxel,
+                                              self.vx, self.vy, self.x_offset, self.y_offset, *self._folded[1])
 
 
 class HardVFE(nn.Module):
@@ -670,6 +695,9 @@ class CenterPoint(nn.Module):
         # the scatter is fused into the backbone's first convolution where it can be (a property of this model's
         # forward, not of the scatter module: `model.middle_encoder(...)` still returns the dense pseudo image)
         self.fuse_scatter = isinstance(middle_encoder, PointPillarsScatter) and isinstance(backbone, SecondBackbone)
+        # the row writer is fused away where the voxel encoder can read the points through the voxelizer's index
+        # (`model.voxelizer(...)` still returns the padded tensor: the operator's contract is unchanged)
+        self.fuse_rows = isinstance(voxel_encoder, PillarFeatureNet) and isinstance(middle_encoder, PointPillarsScatter)
 
     def scatter(self, feats, coors, batch_size):
         """The middle encoder as this model's forward runs it (a SparseCanvas when the scatter is fused)."""
@@ -708,6 +736,17 @@ class CenterPoint(nn.Module):
     def extract_pillars(self, points, num_points=None, dense=True):
         """voxelize -> voxel encoder -> middle encoder: the LiDAR front half (dense BEV features; dense=False leaves a
         PointPillarsScatter result as the SparseCanvas the backbone consumes without writing the pseudo image)."""
+        if self.fuse_rows and isinstance(points, torch.Tensor) and points.dim() == 3:
+            # voxelizer -> PFN through an index of the points: the padded [B, V, P, D] tensor (78 % zeros, written by
+            # the row writer and read back by the PFN) never exists.  Same bytes as the pair below.
+            idx = self.voxelizer.index(points, num_points)
+            if idx is not None:
+                span, plist, coors, npv, nv = idx
+                b, v = int(coors.shape[0]), int(coors.shape[1])
+                coors = coors.view(b * v, 4)
+                feats = self.voxel_encoder.forward_indexed(points, span, plist, coors)
+                if feats is not None:
+                    return self.middle_encoder(feats, coors, b) if dense else self.scatter(feats, coors, b)
         voxels, coors, npv, nv = self.voxelizer(points, num_points)
         b, v, p, d = voxels.shape
         voxels, coors, npv = voxels.view(b * v, p, d), coors.view(b * v, 4), npv.view(b * v)

@@ -51,6 +51,14 @@ struct PfnArgs {
   int c2;
   float* out;
   int in_dim, in_pad;
+  // indexed form (pd3_pillar_feature_net_indexed): the pillars' points are read from the point cloud itself through
+  // the voxelizer's index (pd3_hard_voxelize_index), no padded [M, P, D] tensor exists
+  const float* points = nullptr;     // [frames, n_pts, D]
+  int64_t n_pts = 0;
+  const uint2* span = nullptr;       // [M] (start in the frame's list, stored points)
+  const uint32_t* plist = nullptr;   // [frames, list_stride] point indices, a voxel's points consecutive
+  int64_t list_stride = 0;
+  int vper = 0;                      // pillars per frame (a multiple of the chunk: a chunk never straddles frames)
 };
 
 __global__ __launch_bounds__(kPfnMaxWaves * 64) void pfn_kernel(PfnArgs a) {
@@ -528,7 +536,13 @@ __device__ __forceinline__ float pk_max(float x, float y) {
 // (Tried with it and dropped: not loading the 64-float pieces behind a pillar's last stored point -- 22 of a HardVFE
 // pillar's 256 floats are stored on average -- with num_points travelling two chunks ahead; every form of the
 // conditional loads made the register allocator spill 32-219 registers at the 256 this kernel may use.)
-template <int D, int CD, int NV, int C1 = 32, int PC = kPkPillars, bool W2G = false>
+// IDX (pd3_pillar_feature_net_indexed, the model path of CenterPoint-Pillars): the chunk's stored points come straight
+// from the point cloud through the voxelizer's index -- lane = point slot (pillar, k) of the chunk: the pillars' (start,
+// count) words travel two chunks ahead, the index-list entries one chunk ahead, the points' D floats are requested
+// before a chunk's blocks are multiplied and parked in the same LDS layout the copy of a padded tensor would have
+// produced at the top of the next chunk.  The padded tensor (78 % zeros, 199 MB per 16 frames written by the row
+// writer and 180 MB read back here) never exists; everything after the staging is the same code: same bytes out.
+template <int D, int CD, int NV, int C1 = 32, int PC = kPkPillars, bool W2G = false, bool IDX = false, int NSL = 4>
 __global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_packed_kernel(PfnArgs a) {
   constexpr int IN = D + 3 + CD;
   static_assert(IN <= 12, "layer-1 K is padded to 12");
@@ -612,15 +626,63 @@ __global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_packed_kernel(PfnAr
   const int64_t stride = (int64_t)gridDim.x * 4;
   int64_t ch = (int64_t)blockIdx.x * 4 + wave;
   if (ch >= nchunks) return;
-  float vreg[NV];
+  float vreg[IDX ? 1 : NV];
   int npn = 0, c1 = 0, c2 = 0, c3 = 0;
+  // ---- indexed staging (IDX) --------------------------------------------------------------------
+  // NSL = point slots per lane: PC * p <= 64 NSL (3 for the 20-point pillars of the nuScenes models)
+  float pf[IDX ? NSL : 1][D];                // the D floats of this lane's slots, chunk `ch`
+  uint32_t sw1 = 0, yx1 = 0, sw2 = 0, yx2 = 0;  // (start | count << 24), (x | y << 16) of pillar `lane`: chunk + 1, + 2
+  int z1 = 0, z2 = 0;
+  const float inv_p = 1.0f / (float)a.p, inv_vper = IDX ? 1.0f / (float)a.vper : 0.f;
+  const int nslots = PC * a.p;
+  // frame of a chunk (a chunk never straddles frames; exact in fp32 for pillar ids below 2^22, the dispatcher's bound)
+  auto frame_of = [&](int64_t c) { return (int64_t)(int)(((float)(c * PC) + 0.5f) * inv_vper); };
+  auto slot_of = [&](int j, int& q, int& k) {  // slot lane + 64 j = (pillar q of the chunk, point k)
+    const int sl = lane + 64 * j;
+    q = (int)(((float)sl + 0.5f) * inv_p);
+    k = sl - q * a.p;
+  };
+  auto load_span = [&](int64_t c, uint32_t& w, uint32_t& yx, int& z) {
+    const int64_t q0 = c * PC;
+    const int cntp = (int)(a.m - q0 < PC ? a.m - q0 : PC);
+    const int ql = min(lane, cntp - 1);
+    const uint2 sp = a.span[q0 + ql];
+    const int32_t* co = a.coors + (q0 + ql) * 4;
+    z = co[1];
+    yx = (uint32_t)co[3] | ((uint32_t)co[2] << 16);
+    w = lane < cntp ? ((sp.x & 0xFFFFFFu) | (min(sp.y, (uint32_t)a.p) << 24)) : 0u;
+  };
+  uint32_t pidx[IDX ? NSL : 1];
+  auto issue_idx = [&](int64_t c, uint32_t w) {
+    const uint32_t* lst = a.plist + frame_of(c) * a.list_stride;
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+      int q, k;
+      slot_of(j, q, k);
+      const uint32_t wq = (uint32_t)__shfl((int)w, min(q, PC - 1), kWave);
+      const bool lv = lane + 64 * j < nslots && k < (int)(wq >> 24);
+      pidx[IDX ? j : 0] = lv ? lst[(wq & 0xFFFFFFu) + (uint32_t)k] : 0xFFFFFFFFu;
+    }
+  };
+  auto issue_pts = [&](int64_t c) {
+    const float* pb = a.points + frame_of(c) * a.n_pts * D;
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+      const uint32_t ix = pidx[IDX ? j : 0];
+      if (ix != 0xFFFFFFFFu) {
+        const float* src = pb + (int64_t)ix * D;
+#pragma unroll
+        for (int e = 0; e < D; ++e) pf[IDX ? j : 0][e] = src[e];
+      }
+    }
+  };
   auto fetch = [&](int64_t c) {
     const int64_t q0 = c * PC;
     const int cntp = (int)(a.m - q0 < PC ? a.m - q0 : PC);
     const int lim = cntp * pd;
     const float* src = a.voxels + q0 * pd;
 #pragma unroll
-    for (int q = 0; q < NV; ++q) vreg[q] = src[min(lane + 64 * q, lim - 1)];  // clamped, not predicated: no branches;
+    for (int q = 0; q < (IDX ? 1 : NV); ++q) vreg[q] = src[min(lane + 64 * q, lim - 1)];  // clamped, not predicated: no branches;
     const int ql = min(lane, cntp - 1);                                         // floats past `lim` belong to no pillar
     npn = a.num_points[q0 + ql];
     c1 = a.coors[(q0 + ql) * 4 + 1];
@@ -628,16 +690,51 @@ __global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_packed_kernel(PfnAr
     c3 = a.coors[(q0 + ql) * 4 + 3];
     npn = lane < cntp ? npn : 0;
   };
-  fetch(ch);
+  if (IDX) {
+    load_span(ch, sw1, yx1, z1);
+    issue_idx(ch, sw1);
+    issue_pts(ch);
+    if (ch + stride < nchunks) load_span(ch + stride, sw2, yx2, z2);
+  } else {
+    fetch(ch);
+  }
   for (; ch < nchunks; ch += stride) {
     const int64_t p0 = ch * PC;
+    if (IDX) {
+      // this chunk's words (sw1 ..) and points (pf) arrived during the previous chunk: park the stored points where
+      // the copy of a padded tensor would have put them ([pillar][k][D]; slots without a point keep stale floats that
+      // nothing reads: the means and the row layout stop at a pillar's count)
 #pragma unroll
-    for (int q = 0; q < NV; ++q) ln[64 * q + lane] = vreg[q];
+      for (int j = 0; j < NSL; ++j) {
+        int q, k;
+        slot_of(j, q, k);
+        const uint32_t wq = (uint32_t)__shfl((int)sw1, min(q, PC - 1), kWave);
+        if (lane + 64 * j < nslots && k < (int)(wq >> 24)) {
+#pragma unroll
+          for (int e = 0; e < D; ++e) ln[q * pd + k * D + e] = pf[IDX ? j : 0][e];
+        }
+      }
+      npn = (int)(sw1 >> 24);
+      c1 = z1;
+      c2 = (int)(yx1 >> 16);
+      c3 = (int)(yx1 & 0xFFFFu);
+      sw1 = sw2;
+      yx1 = yx2;
+      z1 = z2;
+    } else {
+#pragma unroll
+      for (int q = 0; q < (IDX ? 1 : NV); ++q) ln[64 * q + lane] = vreg[q];
+    }
     const int np_raw = npn;
     const float pcx = (float)c3 * a.vx + a.x_off, pcy = (float)c2 * a.vy + a.y_off;
     const float pcz = (float)c1 * a.vz + a.z_off;  // HardVFE-style centres only (CD == 3)
     wave_lds_order();
-    if (ch + stride < nchunks) fetch(ch + stride);  // the next chunk's loads fly while this one is evaluated
+    if (IDX) {
+      if (ch + stride < nchunks) issue_idx(ch + stride, sw1);           // (sw1 now holds the next chunk's words)
+      if (ch + 2 * stride < nchunks) load_span(ch + 2 * stride, sw2, yx2, z2);
+    } else if (ch + stride < nchunks) {
+      fetch(ch + stride);  // the next chunk's loads fly while this one is evaluated
+    }
     // ---- the chunk's row layout: lane q < PC is pillar p0 + q -------------------------------------
     const int np = np_raw > 0 ? min(np_raw, a.p) : 0;  // a padding row of a fixed-shape batch has no rows
     int end = np;
@@ -700,6 +797,7 @@ __global__ __launch_bounds__(256, C1 == 32 ? 3 : 2) void pfn_packed_kernel(PfnAr
     wave_lds_order();
     // running maxima of the pillar the walk is in (lane = channel); they start from the padded row's values
     // where the pillar has padded rows
+    if (IDX && ch + stride < nchunks) issue_pts(ch + stride);  // in flight while this chunk's blocks are multiplied
     unsigned live = live0;
     int cur = live ? __builtin_ctz(live) : 0;
     float m1 = (notfull >> cur) & 1u ? y1pad : -INFINITY;
@@ -985,6 +1083,97 @@ static int pfn_dispatch(const float* voxels, const int32_t* num_points, const in
   }
   const int64_t blocks = std::min<int64_t>(ceil_div(num_pillars, waves), 256 * 8);
   pfn_kernel<<<(unsigned)blocks, waves * 64, bytes, s>>>(a);
+  return launch_status();
+}
+
+extern "C" int pd3_pillar_feature_net_indexed(const float* points, int64_t points_per_frame, const int32_t* vox_span,
+                                              const int32_t* point_list, int64_t list_stride, const int32_t* coors,
+                                              int64_t num_pillars, int pillars_per_frame, int max_points,
+                                              int num_point_dim, int voxel_center_dims, float vx, float vy, float vz,
+                                              float x_offset, float y_offset, float z_offset, const float* w1,
+                                              const float* scale1, const float* shift1, int c1, const float* w2,
+                                              const float* scale2, const float* shift2, int c2, float* out,
+                                              void* stream) {
+  if (num_pillars < 0 || max_points <= 0 || num_point_dim < 3 || pillars_per_frame <= 0 || points_per_frame <= 0 ||
+      list_stride <= 0)
+    return PD3_EINVAL;
+  if (voxel_center_dims != 2 && voxel_center_dims != 3) return PD3_EINVAL;
+  if (num_pillars == 0) return 0;
+  if (!points || !vox_span || !point_list || !coors || !w1 || !scale1 || !shift1 || !w2 || !scale2 || !shift2 || !out)
+    return PD3_EINVAL;
+  const int in_dim = num_point_dim + 3 + voxel_center_dims;
+  // the shapes of the packed two-layer kernel (PillarFeatureNet of the pillar models), whole chunks per frame, grid
+  // coordinates that fit 16 bits, pillar ids the fp32 frame lookup is exact for
+  if (!(c1 == 32 && c2 == 64 && max_points <= 32 && (num_point_dim == 4 || num_point_dim == 5) && in_dim <= 12 &&
+        kPkPillars * max_points * num_point_dim <= 20 * 64 && pillars_per_frame % kPkPillars == 0 &&
+        num_pillars % pillars_per_frame == 0 && num_pillars < ((int64_t)1 << 22)))
+    return PD3_EUNSUPPORTED;
+  PfnArgs a{};
+  a.voxels = nullptr;
+  a.num_points = nullptr;
+  a.coors = coors;
+  a.m = num_pillars;
+  a.p = max_points;
+  a.d = num_point_dim;
+  a.vx = vx;
+  a.vy = vy;
+  a.vz = vz;
+  a.x_off = x_offset;
+  a.y_off = y_offset;
+  a.z_off = z_offset;
+  a.center_dims = voxel_center_dims;
+  a.w1 = w1;
+  a.scale1 = scale1;
+  a.shift1 = shift1;
+  a.c1 = c1;
+  a.w2 = w2;
+  a.scale2 = scale2;
+  a.shift2 = shift2;
+  a.c2 = c2;
+  a.out = out;
+  a.in_dim = in_dim;
+  a.in_pad = (in_dim + 3) / 4 * 4;
+  a.points = points;
+  a.n_pts = points_per_frame;
+  a.span = reinterpret_cast<const uint2*>(vox_span);
+  a.plist = reinterpret_cast<const uint32_t*>(point_list);
+  a.list_stride = list_stride;
+  a.vper = pillars_per_frame;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t nchunks = ceil_div(num_pillars, (int64_t)kPkPillars);
+  const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(nchunks, 4), 256 * 3);
+  const int nv = (kPkPillars * max_points * num_point_dim + 63) / 64 <= 13 ? 13 : 20;
+  const int rcap = (kPkPillars * max_points + 15) & ~15;
+  const size_t lds = ((size_t)4 * (nv * 64 + 16 * 34 + 16 * 68 + kPkPillars * 8 + rcap + 16 +
+                                   (max_points * num_point_dim >= 96 ? 0 : kPkPillars * 96)) + 32 * 64) * sizeof(float);
+#define PD3_PFN_INDEXED_N(DD, CDV, NVV, NS)                                                                           \
+  do {                                                                                                               \
+    if (lds > 48 * 1024) {                                                                                           \
+      hipError_t e_ = hipFuncSetAttribute(                                                                           \
+          reinterpret_cast<const void*>(pfn_packed_kernel<DD, CDV, NVV, 32, kPkPillars, false, true, NS>),           \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                                     \
+      if (e_ != hipSuccess) return (int)e_;                                                                          \
+    }                                                                                                                \
+    pfn_packed_kernel<DD, CDV, NVV, 32, kPkPillars, false, true, NS><<<blocks, 256, lds, s>>>(a);                    \
+  } while (0)
+#define PD3_PFN_INDEXED(DD, CDV, NVV)                                                                                 \
+  do {                                                                                                               \
+    if (kPkPillars * max_points <= 192) PD3_PFN_INDEXED_N(DD, CDV, NVV, 3);                                          \
+    else PD3_PFN_INDEXED_N(DD, CDV, NVV, 4);                                                                         \
+  } while (0)
+  if (nv == 13) {
+    if (num_point_dim == 4 && voxel_center_dims == 2) PD3_PFN_INDEXED(4, 2, 13);
+    else if (num_point_dim == 4) PD3_PFN_INDEXED(4, 3, 13);
+    else if (voxel_center_dims == 2) PD3_PFN_INDEXED(5, 2, 13);
+    else PD3_PFN_INDEXED(5, 3, 13);
+  } else {
+    if (num_point_dim == 4 && voxel_center_dims == 2) PD3_PFN_INDEXED(4, 2, 20);
+    else if (num_point_dim == 4) PD3_PFN_INDEXED(4, 3, 20);
+    else if (voxel_center_dims == 2) PD3_PFN_INDEXED(5, 2, 20);
+    else PD3_PFN_INDEXED(5, 3, 20);
+  }
+#undef PD3_PFN_INDEXED
+#undef PD3_PFN_INDEXED_N
   return launch_status();
 }
 

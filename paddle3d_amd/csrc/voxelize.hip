@@ -392,11 +392,36 @@ static bool wave_applicable(const VoxGrid& g, int64_t n, int dim, int max_pts, i
 
 // variant bit 0: heavy waves of the group kernel raise their issue priority; bit 1 (run_wave_split): two half batches
 // on two streams
+// index_span / index_list (pd3_hard_voxelize_index): the per-voxel (start, count) words and the index list are left in
+// the CALLER's arrays instead of the workspace, and the row writer does not run (voxels == nullptr): what remains of it
+// is vw_finish_index_kernel (num_voxels, the padding rows of coords / counts / coors_batched).
+__global__ __launch_bounds__(256) void vw_finish_index_kernel(const int* __restrict__ totals, int batch, int max_voxels,
+                                                              int32_t* __restrict__ coords, int32_t* __restrict__ num_pts,
+                                                              int32_t* __restrict__ num_voxels,
+                                                              int32_t* __restrict__ coors4) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)batch * max_voxels) return;
+  const int frame = (int)(t / max_voxels), v = (int)(t - (int64_t)frame * max_voxels);
+  const int nv = min(totals[frame], max_voxels);
+  if (v == 0) num_voxels[frame] = nv;
+  if (v >= nv) {
+    const VtInt3 z3{0, 0, 0};
+    __builtin_memcpy(coords + t * 3, &z3, sizeof(z3));
+    num_pts[t] = 0;
+    if (coors4) *reinterpret_cast<int4*>(coors4 + t * 4) = make_int4(-1, 0, 0, 0);
+  }
+}
+
 static int run_wave(const float* points, const int32_t* num_points, int batch, int64_t n, int dim, const VoxGrid& g,
                     int max_pts, int max_voxels, const VwPlan& plan, float* voxels, int32_t* coords,
                     int32_t* num_pts, int32_t* num_voxels, int32_t* coors4, void* workspace, hipStream_t s,
-                    int variant = 0, int frame0 = 0, bool three_d = false) {
+                    int variant = 0, int frame0 = 0, bool three_d = false, int32_t* index_span = nullptr,
+                    int32_t* index_list = nullptr) {
   VwWorkspace w = vw_carve(workspace, batch, n, max_voxels, plan, three_d);
+  if (index_span) {
+    w.vinfo = reinterpret_cast<uint2*>(index_span);
+    w.clist = reinterpret_cast<uint32_t*>(index_list);
+  }
   VtGrid vg{g.min_x, g.min_y, g.min_z, g.size_x, g.size_y, g.size_z,
             (float)(1.0 / (double)g.size_x), (float)(1.0 / (double)g.size_y), (float)(1.0 / (double)g.size_z),
             g.gx, g.gy, g.gz, g.ncells};
@@ -435,6 +460,11 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
   vw_assign_kernel<<<(unsigned)(plan.tiles * batch), kVwAssignThreads, lds_c, s>>>(
       w.flist, w.fcnt, plan.low, plan.gbits, plan.tiles, plan.tile, tp, batch, max_voxels, vg, w.vinfo, w.totals, coords,
       num_pts, coors4, frame0, three_d ? w.gregion : nullptr, w.cap);
+  if (index_span) {
+    vw_finish_index_kernel<<<(unsigned)ceil_div((int64_t)batch * max_voxels, 256), 256, 0, s>>>(
+        w.totals, batch, max_voxels, coords, num_pts, num_voxels, coors4);
+    return launch_status();
+  }
   const int64_t row = (int64_t)max_pts * dim;
   const bool vec4 = (row % 4 == 0) && (reinterpret_cast<uintptr_t>(voxels) % 16 == 0);
   const int rowq = (int)(vec4 ? row / 4 : row);
@@ -676,6 +706,40 @@ extern "C" int pd3_hard_voxelize_path(const float* points, const int32_t* num_po
   }
   return run_sort_path<float>(points, num_points, batch, max_points, num_point_dim, g, max_num_points_in_voxel,
                               max_voxels, voxels, coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s);
+}
+
+extern "C" int64_t pd3_hard_voxelize_index_list_entries(int batch, int64_t max_points) {
+  if (batch <= 0 || max_points <= 0) return 0;
+  return (int64_t)batch * max_points + 4;
+}
+
+extern "C" int pd3_hard_voxelize_index(const float* points, const int32_t* num_points, int batch, int64_t max_points,
+                                       int num_point_dim, const float* voxel_size, const float* point_cloud_range,
+                                       int max_num_points_in_voxel, int max_voxels, int32_t* vox_span,
+                                       int32_t* point_list, int32_t* coords, int32_t* num_points_per_voxel,
+                                       int32_t* num_voxels, int32_t* coors_batched, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  VoxGrid g;
+  if (!points || !vox_span || !point_list || !coords || !num_points_per_voxel || !num_voxels || !workspace)
+    return PD3_EINVAL;
+  if (batch <= 0 || max_points <= 0 || max_points >= ((int64_t)1 << 31) || num_point_dim < 3 ||
+      max_num_points_in_voxel <= 0 || max_voxels <= 0)
+    return PD3_EINVAL;
+  if (!make_grid(voxel_size, point_cloud_range, g)) return PD3_EINVAL;
+  if (workspace_bytes < pd3_hard_voxelize_workspace(batch, max_points, num_point_dim, voxel_size, point_cloud_range,
+                                                    max_num_points_in_voxel, max_voxels))
+    return PD3_EWORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  VwPlan wp;
+  if (wave_applicable(g, max_points, num_point_dim, max_num_points_in_voxel, max_voxels, batch, -1, wp))
+    return run_wave(points, num_points, batch, max_points, num_point_dim, g, max_num_points_in_voxel, max_voxels, wp,
+                    nullptr, coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s, 1, 0, false, vox_span,
+                    point_list);
+  if (wave3d_applicable(g, max_points, num_point_dim, max_num_points_in_voxel, max_voxels, batch, -1, wp))
+    return run_wave(points, num_points, batch, max_points, num_point_dim, g, max_num_points_in_voxel, max_voxels, wp,
+                    nullptr, coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s, 0, 0, true, vox_span,
+                    point_list);
+  return PD3_EUNSUPPORTED;  // (the tiled and sort forms keep no per-voxel index list: run pd3_hard_voxelize)
 }
 
 extern "C" int pd3_hard_voxelize(const float* points, const int32_t* num_points, int batch,

@@ -11,7 +11,7 @@ import torch
 
 from ._common import check, lib, ptr, require_gpu, stream_ptr
 
-__all__ = ["pillar_feature_net", "hard_vfe", "voxel_mean", "fold_batchnorm"]
+__all__ = ["pillar_feature_net", "pillar_feature_net_indexed", "hard_vfe", "voxel_mean", "fold_batchnorm"]
 
 
 def fold_batchnorm(gamma, beta, mean, var, eps):
@@ -48,6 +48,35 @@ def pillar_feature_net(voxels, num_points, coors, vx, vy, x_offset, y_offset, w1
                                             ptr(w2), ptr(scale2.contiguous() if two else None),
                                             ptr(shift2.contiguous() if two else None), c2, ptr(out), int(path),
                                             stream_ptr(v.device)), "pillar_feature_net")
+    return out
+
+
+def pillar_feature_net_indexed(points, vox_span, point_list, coors, max_points, vx, vy, x_offset, y_offset, w1, scale1,
+                               shift1, w2, scale2, shift2, vz=0.0, z_offset=0.0, voxel_center_dims=2):
+    """pillar_feature_net on the voxelizer's index instead of a padded [M, P, D] tensor (pd3_pillar_feature_net_indexed):
+    points [B, N, D], vox_span [B, V, 2] / point_list from ops.voxelize.hard_voxelize_index_batch, coors [B * V, 4].
+    Returns [B * V, C2] -- the same bytes as hard_voxelize_batch + pillar_feature_net -- or None for shapes the
+    indexed kernel does not serve (the caller then runs the pair)."""
+    pts = require_gpu(points, "pillar_feature_net_indexed")
+    sp = require_gpu(vox_span, "pillar_feature_net_indexed", torch.int32)
+    pl = require_gpu(point_list, "pillar_feature_net_indexed", torch.int32)
+    c = require_gpu(coors, "pillar_feature_net_indexed", torch.int32)
+    b, n, d = pts.shape
+    v = sp.shape[1]
+    w1 = require_gpu(w1, "pillar_feature_net_indexed")
+    w2 = require_gpu(w2, "pillar_feature_net_indexed")
+    c1, c2 = w1.shape[1], w2.shape[1]
+    if w1.shape[0] != d + 3 + voxel_center_dims or w2.shape[0] != 2 * c1:
+        raise RuntimeError("pillar_feature_net_indexed: weight shapes do not match the point width")
+    out = torch.empty((b * v, c2), dtype=torch.float32, device=pts.device)
+    rc = lib().pd3_pillar_feature_net_indexed(
+        ptr(pts), n, ptr(sp), ptr(pl), n, ptr(c), b * v, v, int(max_points), d, int(voxel_center_dims), C.c_float(vx),
+        C.c_float(vy), C.c_float(vz), C.c_float(x_offset), C.c_float(y_offset), C.c_float(z_offset), ptr(w1),
+        ptr(scale1.contiguous()), ptr(shift1.contiguous()), c1, ptr(w2), ptr(scale2.contiguous()),
+        ptr(shift2.contiguous()), c2, ptr(out), stream_ptr(pts.device))
+    if rc == -3:
+        return None
+    check(rc, "pillar_feature_net_indexed")
     return out
 
 

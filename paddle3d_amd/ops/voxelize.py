@@ -12,7 +12,8 @@ import torch
 
 from ._common import check, host_f32, lib, ptr, require_gpu, stream_ptr, workspace
 
-__all__ = ["dynamic_voxelize", "hard_voxelize", "hard_voxelize_batch", "lds_atomic_order_ok"]
+__all__ = ["dynamic_voxelize", "hard_voxelize", "hard_voxelize_batch", "hard_voxelize_index_batch",
+           "lds_atomic_order_ok"]
 
 _LDS_ORDER = {}  # device index -> bool, probed once per process
 
@@ -109,6 +110,43 @@ def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max
     if with_batch_coors:
         return voxels, coords, npv, nv, coors4
     return voxels, coords, npv, nv
+
+
+def hard_voxelize_index_batch(points: torch.Tensor, voxel_size, point_cloud_range, max_num_points_in_voxel: int,
+                              max_voxels: int, num_points: torch.Tensor | None = None):
+    """hard_voxelize_batch without the padded [B, V, P, D] tensor (pd3_hard_voxelize_index): returns
+    (vox_span [B, V, 2] int32 (start, count), point_list [B * N + 4] int32, coords [B, V, 3], num_points_per_voxel
+    [B, V], num_voxels [B], coors [B, V, 4]) -- voxel v of frame b holds the points
+    points[b, point_list[b * N + start + k]], k < count -- or None where the grid is not one the wave forms of the
+    voxelizer serve (the caller then runs hard_voxelize_batch)."""
+    pts = require_gpu(points, "hard_voxelize_index", torch.float32)
+    if pts.dim() != 3:
+        raise RuntimeError("hard_voxelize_index_batch expects points of shape [B, N, D]")
+    b, n, d = pts.shape
+    dev = pts.device
+    if not lds_atomic_order_ok(dev):
+        return None
+    vs, pr = host_f32(voxel_size, 3), host_f32(point_cloud_range, 6)
+    p, v = int(max_num_points_in_voxel), int(max_voxels)
+    L = lib()
+    ws_bytes = L.pd3_hard_voxelize_workspace(b, n, d, ptr(vs), ptr(pr), p, v)
+    if ws_bytes == 0:
+        raise RuntimeError("hard_voxelize: invalid voxel_size / point_cloud_range / sizes")
+    span = torch.empty((b, v, 2), dtype=torch.int32, device=dev)
+    plist = torch.empty((int(L.pd3_hard_voxelize_index_list_entries(b, n)),), dtype=torch.int32, device=dev)
+    coords = torch.empty((b, v, 3), dtype=torch.int32, device=dev)
+    npv = torch.empty((b, v), dtype=torch.int32, device=dev)
+    nv = torch.empty((b,), dtype=torch.int32, device=dev)
+    coors4 = torch.empty((b, v, 4), dtype=torch.int32, device=dev)
+    if num_points is not None:
+        num_points = require_gpu(num_points, "hard_voxelize_index", torch.int32)
+    ws = workspace(ws_bytes, dev)
+    rc = L.pd3_hard_voxelize_index(ptr(pts), ptr(num_points), b, n, d, ptr(vs), ptr(pr), p, v, ptr(span), ptr(plist),
+                                   ptr(coords), ptr(npv), ptr(nv), ptr(coors4), ptr(ws), ws.numel(), stream_ptr(dev))
+    if rc == -3:
+        return None
+    check(rc, "hard_voxelize_index")
+    return span, plist, coords, npv, nv, coors4
 
 
 def _stage_points(points, op):
