@@ -133,6 +133,68 @@ class GatherPipeline:
         return prev
 
 
+class H2DStage:
+    """Double-buffered host -> device staging of the input batches (the reference's deploy loop copies every frame from
+    the host before it runs it, deploy/centerpoint/cpp/main.cc:177-181; here the copy of batch k + 1 travels on its own
+    stream while batch k is computed).
+
+        stage = H2DStage(host_batch.shape, torch.float32, device)
+        stage.submit(host[0])
+        for k in range(K):
+            if k + 1 < K:
+                stage.submit(host[k + 1])     # copy stream; waits only for the buffer's previous consumer
+            x = stage.acquire()               # the compute stream waits for THIS batch's copy, not for the host
+            run(x)
+            stage.release()                   # the buffer may be overwritten once the kernels enqueued so far are done
+
+    `submit` takes pinned host memory for a truly asynchronous copy (pageable memory works, synchronously).  No host
+    synchronisation anywhere: ordering is by events between the two streams.  On a CPU device (the gloo tests) the
+    copies are plain synchronous copies."""
+
+    def __init__(self, shape, dtype, device, depth: int = 2):
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.buffers = [torch.empty(tuple(shape), dtype=dtype, device=self.device) for _ in range(depth)]
+        self.copy_stream = torch.cuda.Stream(self.device) if self.cuda else None
+        self.ready = [None] * depth      # copy finished (recorded on the copy stream)
+        self.consumed = [None] * depth   # consumer finished (recorded on the compute stream)
+        self._head = self._tail = self._inflight = 0
+
+    def submit(self, host: torch.Tensor):
+        if self._inflight == len(self.buffers):
+            raise RuntimeError("H2DStage: every buffer holds a batch that has not been released")
+        i = self._head
+        self._head = (i + 1) % len(self.buffers)
+        self._inflight += 1
+        if not self.cuda:
+            self.buffers[i].copy_(host)
+            return
+        with torch.cuda.stream(self.copy_stream):
+            if self.consumed[i] is not None:
+                self.copy_stream.wait_event(self.consumed[i])
+            self.buffers[i].copy_(host, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+            self.ready[i] = ev
+
+    def acquire(self) -> torch.Tensor:
+        if self._inflight == 0:
+            raise RuntimeError("H2DStage: acquire() without a submitted batch")
+        i = self._tail
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_event(self.ready[i])
+        return self.buffers[i]
+
+    def release(self):
+        i = self._tail
+        self._tail = (i + 1) % len(self.buffers)
+        self._inflight -= 1
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.consumed[i] = ev
+
+
 def _cpulist(text: str):
     out = []
     for part in text.strip().split(","):

@@ -47,6 +47,7 @@ def test_eight_ranks_over_gloo_with_extras():
     assert ss["scaling"] == "strong" and ss["frames"] == 32 and ss["frames_per_rank"] == 4
     assert ss["batches_per_rank_per_pass"] == 2 and ss["value"] > 0
     assert line["extras"]["h2d_inclusive"]["value"] > 0
+    assert line["extras"]["h2d_overlapped"]["value"] > 0  # the double-buffered stage (dist.H2DStage) on every rank
     assert "cpu_affinity_rank0" in line["config"]
 
 

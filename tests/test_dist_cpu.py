@@ -1,6 +1,8 @@
 """World-size-2 gloo test of the frame sharding + result all-gather (the N>1 path of bench.py)."""
 import os
 import socket
+
+import pytest
 import sys
 
 import torch
@@ -149,3 +151,28 @@ def test_gather_pipeline_inputs_may_be_reused_after_submit():
     rec.fill_(3.0)
     got = pipe.flush()
     assert (got[0] == 2.0).all() and (got[1] == 2).all()
+
+
+def test_h2d_stage_order_and_capacity():
+    """dist.H2DStage on a CPU device (plain copies): batches come out in submission order, the buffers alternate, a
+    third submit without a release is refused."""
+    from paddle3d_amd import dist as pdist
+
+    stage = pdist.H2DStage((2, 3), torch.float32, "cpu")
+    host = [torch.full((2, 3), float(k)) for k in range(5)]
+    stage.submit(host[0])
+    seen = []
+    for k in range(5):
+        if k + 1 < 5:
+            stage.submit(host[k + 1])
+        x = stage.acquire()
+        seen.append((float(x[0, 0]), x.data_ptr()))
+        stage.release()
+    assert [v for v, _ in seen] == [0.0, 1.0, 2.0, 3.0, 4.0]
+    assert seen[0][1] == seen[2][1] != seen[1][1]
+    stage.submit(host[0])
+    stage.submit(host[1])
+    with pytest.raises(RuntimeError):
+        stage.submit(host[2])
+    with pytest.raises(RuntimeError):
+        pdist.H2DStage((1,), torch.float32, "cpu").acquire()
