@@ -378,7 +378,7 @@ int pd3_sparse_conv3d_features(const float *in_feats, const int32_t *nbr, const 
  * kernel offsets (a block runs an offset if ANY of its rows has that neighbour: 1.3x - 7x more steps than pairs
  * exist with rows in raster order, 1.2x - 2x in tile order).
  *   order [pd3_sparse_tile_order_entries(n_out_cap)] int32: slot -> output row, -1 past the row count
- *   n_out may be NULL (= n_out_cap); kernel_volume <= 32
+ *   n_out may be NULL (= n_out_cap); kernel_volume <= 31
  * pd3_sparse_conv3d_features_ordered = pd3_sparse_conv3d_features taking `order` (NULL: raster order); same bytes
  * out for any order. */
 int64_t pd3_sparse_tile_order_entries(int n_out_cap);

@@ -633,48 +633,118 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_kernel(SpGemmArgs a) {
 // ---------------------------------------------------------------------------------------------------
 constexpr int kSpWindow = 8192;
 constexpr int kSpOrderThreads = 1024;
+constexpr int kSpOrderEpt = kSpWindow / kSpOrderThreads;  // 8 consecutive rows of the window per thread
+
+// One compare-exchange stage of the bitonic network over the window, element i = 8 * thread + r held in registers
+// (key = neighbour mask, val = row in window).  Partners 1 / 2 / 4 apart are registers of the same thread, partners 8 ..
+// 256 apart are the same register of another lane of the wave (ds_bpermute, no barrier), only partners 512 .. 4096 apart
+// live in another wave and travel through LDS: 10 of the 91 stages pay a workgroup barrier (the first version ran all
+// 91 through LDS: 160 us per rulebook, 1.3 ms per 8-scene step).  Equal keys stay where they are (both sides compare
+// strictly), so the network is deterministic without unique keys.
+template <int SIZE, int J>
+__device__ __forceinline__ void sp_order_stage(uint32_t (&key)[kSpOrderEpt], uint32_t (&val)[kSpOrderEpt],
+                                               uint32_t* lk, uint32_t* lv) {
+  const int t = threadIdx.x;
+  if constexpr (J < kSpOrderEpt) {
+#pragma unroll
+    for (int r = 0; r < kSpOrderEpt; ++r) {
+      if ((r & J) != 0) continue;
+      const bool up = ((t * kSpOrderEpt + r) & SIZE) == 0;
+      const bool sw = up ? key[r] > key[r | J] : key[r] < key[r | J];
+      const uint32_t k0 = key[r], v0 = val[r];
+      key[r] = sw ? key[r | J] : k0;
+      val[r] = sw ? val[r | J] : v0;
+      key[r | J] = sw ? k0 : key[r | J];
+      val[r | J] = sw ? v0 : val[r | J];
+    }
+  } else {
+    constexpr int TJ = J / kSpOrderEpt;  // partner thread = t ^ TJ, same register
+    const bool lower = (t & TJ) == 0;
+    if constexpr (TJ >= kWave) {
+#pragma unroll
+      for (int r = 0; r < kSpOrderEpt; ++r) {
+        lk[r * kSpOrderThreads + t] = key[r];
+        lv[r * kSpOrderThreads + t] = val[r];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < kSpOrderEpt; ++r) {
+      uint32_t pk, pv;
+      if constexpr (TJ >= kWave) {
+        pk = lk[r * kSpOrderThreads + (t ^ TJ)];
+        pv = lv[r * kSpOrderThreads + (t ^ TJ)];
+      } else {
+        pk = (uint32_t)__shfl_xor((int)key[r], TJ, kWave);
+        pv = (uint32_t)__shfl_xor((int)val[r], TJ, kWave);
+      }
+      const bool up = ((t * kSpOrderEpt + r) & SIZE) == 0;
+      const bool take = (lower == up) ? pk < key[r] : pk > key[r];  // this side keeps the smaller / the larger key
+      key[r] = take ? pk : key[r];
+      val[r] = take ? pv : val[r];
+    }
+    if constexpr (TJ >= kWave) __syncthreads();  // the next LDS stage overwrites the exchange area
+  }
+}
+template <int SIZE, int J>
+__device__ __forceinline__ void sp_order_merge(uint32_t (&key)[kSpOrderEpt], uint32_t (&val)[kSpOrderEpt],
+                                               uint32_t* lk, uint32_t* lv) {
+  sp_order_stage<SIZE, J>(key, val, lk, lv);
+  if constexpr (J > 1) sp_order_merge<SIZE, J / 2>(key, val, lk, lv);
+}
+template <int SIZE>
+__device__ __forceinline__ void sp_order_sort(uint32_t (&key)[kSpOrderEpt], uint32_t (&val)[kSpOrderEpt],
+                                              uint32_t* lk, uint32_t* lv) {
+  if constexpr (SIZE > 2) sp_order_sort<SIZE / 2>(key, val, lk, lv);
+  sp_order_merge<SIZE, SIZE / 2>(key, val, lk, lv);
+}
 
 __global__ __launch_bounds__(kSpOrderThreads) void sp_tile_order_kernel(
     const int32_t* __restrict__ nbr, const int* __restrict__ n_out_dev, int n_out_cap, int K,
     int32_t* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sp_order_smem[];
-  unsigned long long* key = reinterpret_cast<unsigned long long*>(sp_order_smem);  // [kSpWindow]
+  uint32_t* lk = reinterpret_cast<uint32_t*>(sp_order_smem);  // [8][1024] exchange area: keys
+  uint32_t* lv = lk + kSpWindow;                               // values
   const int n_out = n_out_dev ? min(*n_out_dev, n_out_cap) : n_out_cap;
   const int win0 = blockIdx.x * kSpWindow;
+  const int t = threadIdx.x;
   if (win0 >= n_out) {  // a window of padding only
-    for (int i = threadIdx.x; i < kSpWindow; i += kSpOrderThreads) order[win0 + i] = -1;
+#pragma unroll
+    for (int r = 0; r < kSpOrderEpt; ++r) order[win0 + r * kSpOrderThreads + t] = -1;
     return;
   }
-  for (int i = threadIdx.x; i < kSpWindow; i += kSpOrderThreads) {
-    const int row = win0 + i;
-    unsigned long long kv = ~0ull;
+  uint32_t key[kSpOrderEpt], val[kSpOrderEpt];
+#pragma unroll
+  for (int r = 0; r < kSpOrderEpt; ++r) {
+    const int i = t * kSpOrderEpt + r, row = win0 + i;
+    uint32_t m = 0xFFFFFFFFu;  // rows past the count sort last (a real mask has at most 31 bits)
     if (row < n_out) {
-      uint32_t m = 0;
+      m = 0;
       const int32_t* src = nbr + (int64_t)row * K;
-      for (int k = 0; k < K; ++k) m |= src[k] >= 0 ? 1u << (k & 31) : 0u;
-      kv = ((unsigned long long)m << 32) | (unsigned long long)i;
+      if (K == 27) {  // the encoder's kernels: the row's 108 bytes as 16-byte pieces (4-byte aligned loads)
+        struct Row27 { int32_t v[27]; } rw;
+        __builtin_memcpy(&rw, src, sizeof(rw));
+#pragma unroll
+        for (int k = 0; k < 27; ++k) m |= rw.v[k] >= 0 ? 1u << k : 0u;
+      } else {
+        for (int k = 0; k < K; ++k) m |= src[k] >= 0 ? 1u << k : 0u;
+      }
     }
-    key[i] = kv;
+    key[r] = m;
+    val[r] = (uint32_t)i;
+  }
+  sp_order_sort<kSpWindow>(key, val, lk, lv);
+  // element i of the sorted window leaves through LDS so that the stores are coalesced
+#pragma unroll
+  for (int r = 0; r < kSpOrderEpt; ++r) {
+    lk[t * kSpOrderEpt + r] = key[r];
+    lv[t * kSpOrderEpt + r] = val[r];
   }
   __syncthreads();
-  for (int size = 2; size <= kSpWindow; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = threadIdx.x; t < kSpWindow / 2; t += kSpOrderThreads) {
-        const int lo = ((t / stride) * stride * 2) + (t % stride);  // (stride is a power of two: shifts)
-        const int hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const unsigned long long a = key[lo], b = key[hi];
-        if ((a > b) == up) {
-          key[lo] = b;
-          key[hi] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = threadIdx.x; i < kSpWindow; i += kSpOrderThreads) {
-    const unsigned long long kv = key[i];
-    order[win0 + i] = kv == ~0ull ? -1 : win0 + (int)(kv & 0xFFFFFFFFull);
+#pragma unroll
+  for (int r = 0; r < kSpOrderEpt; ++r) {
+    const int i = r * kSpOrderThreads + t;
+    order[win0 + i] = lk[i] == 0xFFFFFFFFu ? -1 : win0 + (int)lv[i];
   }
 }
 
@@ -1286,9 +1356,9 @@ extern "C" int64_t pd3_sparse_tile_order_entries(int n_out_cap) {
 
 extern "C" int pd3_sparse_tile_order(const int32_t* nbr, const int32_t* n_out, int n_out_cap, int kernel_volume,
                                      int32_t* order, void* stream) {
-  if (!nbr || !order || n_out_cap <= 0 || kernel_volume <= 0 || kernel_volume > 32) return PD3_EINVAL;
+  if (!nbr || !order || n_out_cap <= 0 || kernel_volume <= 0 || kernel_volume > 31) return PD3_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t lds = (size_t)kSpWindow * sizeof(unsigned long long);
+  const size_t lds = (size_t)2 * kSpWindow * sizeof(uint32_t);
   static bool raised = false;  // (the attribute is per function, not per device state that could go stale)
   if (!raised) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_tile_order_kernel),

@@ -90,6 +90,7 @@ class ConvSpec:
     padding: tuple = (0, 0, 0)
     subm: bool = False
     key: object = None
+    order: bool = True   # build the tile order for this convolution's rulebook (it pays from 32 output channels on)
 
 
 @dataclass
@@ -195,7 +196,7 @@ def plan(coords: torch.Tensor, batch: int, spatial_shape, specs, caps=None) -> S
                 nbr.fill_(-1)
             sets[o]["coords"] = oc
             tile_order = None
-            if TILE_ORDER and n_out > 0 and kvol <= 32:
+            if TILE_ORDER and sp.order and n_out > 0 and 1 < kvol <= 31:
                 tile_order = torch.empty((int(L.pd3_sparse_tile_order_entries(n_out)),), dtype=torch.int32, device=dev)
                 check(L.pd3_sparse_tile_order(ptr(nbr), ptr(sets[o]["n_dev"]), n_out, kvol, ptr(tile_order),
                                               stream_ptr(dev)), "sparse_tile_order")

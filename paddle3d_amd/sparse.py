@@ -74,7 +74,10 @@ class _SparseConv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
 
     def spec(self):
-        return _sp.ConvSpec(self.ks, self.stride, self.padding, self.subm, self.key)
+        # the tile order of the rulebook (ops.sparse_conv3d) costs one sort per rulebook: it pays for the strided layers
+        # and from 32 output channels on (16 -> 16 over 1 M rows: 0.18 ms with it, 0.18 ms without)
+        worth = (not self.subm) or int(self.weight.shape[-1]) >= 32
+        return _sp.ConvSpec(self.ks, self.stride, self.padding, self.subm, self.key, worth)
 
     def _indices(self, x: SparseConvTensor):
         if x.plan is not None and id(self) in x.plan:

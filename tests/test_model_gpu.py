@@ -457,8 +457,16 @@ def test_amp_graph_close_to_fp32():
           f"mAP proxy {m:.4f} ({res['classes_scored']} classes, worst class {worst:.4f})")
     assert f16.dtype == torch.float32 and f16.shape == f32.shape
     assert 0 < rel_f < 2e-2 and rel_p < 5e-2
+    miss = nb.unmatched_detections(d16, d32, score_tol=2e-2)
+    miss_back = nb.unmatched_detections(d32, d16, score_tol=2e-2)
+    print("fp32 boxes without an AMP twin:", miss, "AMP boxes without an fp32 twin:", miss_back,
+          {c: round(v, 4) for c, v in res["per_class"].items()})
     assert res["classes_scored"] == 10, res
-    assert m >= 0.985, res
+    # the AP is quantised (one box of a class without a twin = 1 / 90 of that class's AP): the bar on the figure allows
+    # every class to lose one bin, the bar on the COUNT is what says how close the graphs are -- 99.5 % of the fp32
+    # graph's boxes have an AMP twin of the same class within 0.5 m and 0.02 of score, and the other way round
+    assert m >= 1.0 - 1.25 / 90, res
+    assert miss["unmatched"] <= 5e-3 * miss["total"] and miss_back["unmatched"] <= 5e-3 * miss_back["total"], (miss, miss_back)
 
 
 def test_pingpong_and_packed_winograd_graphs_are_identical():
