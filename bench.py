@@ -1059,6 +1059,7 @@ def other_workloads(args, rank, world, dev):
     out = {}
     todo = [("centerpoint_pillars_amp", bench_pillars, 16),
             ("pointpillars_kitti", bench_pointpillars_kitti, 16), ("centerpoint_voxel", bench_voxel, 8),
+            ("centerpoint_voxel_amp", bench_voxel, 8),
             ("bevfusion_lidar", bench_bevfusion_lidar, 16), ("bev_pool_v2", bench_bev_pool, 1)]
     for name, fn, batch in todo:
         a = copy.copy(args)
@@ -1101,6 +1102,8 @@ def bench_voxel(args, rank, world, dev):
     B = args.batch
     V = 160000  # the reference's test-time cap (max_num_voxels: [120000, 160000])
     model = cpm.centerpoint_voxels_nuscenes(max_num_voxels=(120000, V)).to(dev).eval()
+    amp = args.workload == "centerpoint_voxel_amp"
+    model.set_amp(amp)  # the sparse encoder from 16 -> 32 on (the 180-wide dense maps are not the fp16 kernel's shape)
     pts = make_batch(B, 100 + B * rank, dev)
     cfg = model.test_cfg
     names = ["start", "hard_voxelize", "voxel_mean_sparse_encoder", "dense", "postprocess", "gather"]
@@ -1148,10 +1151,13 @@ def bench_voxel(args, rank, world, dev):
         sp = _sparse.count_flops(model.middle_encoder, model.voxel_encoder(voxels.view(b * v, p, d)[keep],
                                                                           npv.view(b * v)[keep], cs), cs, b)
     line = {
-        "metric": "scenes/sec CenterPoint-Voxel nuScenes 300k-pt sweeps",
+        "metric": "scenes/sec CenterPoint-Voxel nuScenes 300k-pt sweeps" + (
+            " (AMP O2: the sparse encoder's convolutions on the fp16 matrix cores)" if amp else ""),
         "value": world * B * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": "f16 x f16 -> f32 (sparse convolutions from 16 -> 32 channels on), f32 elsewhere" if amp else "f32",
+        "data": "synthetic",
         "config": {"workload": "CenterPoint-Voxel nuScenes 10-sweep: 300000 pts x 5 per scene, 0.075 m voxels "
                                f"(1440x1440x40), P=10, max_voxels={V}, batch {B} distinct scenes/GPU/step, random-init "
                                "weights, voxelize->VoxelMean->SparseResNet3D->SECOND+FPN->CenterHead->postprocess",
@@ -1474,7 +1480,8 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default 16; 8 for centerpoint_voxel; 32 gives the headline workload +2 %% scenes/s)")
     ap.add_argument("--max-voxels", type=int, default=30000)
     ap.add_argument("--workload", default="centerpoint_pillars",
-                    choices=["centerpoint_pillars", "centerpoint_pillars_amp", "centerpoint_voxel", "bev_pool_v2",
+                    choices=["centerpoint_pillars", "centerpoint_pillars_amp", "centerpoint_voxel",
+                             "centerpoint_voxel_amp", "bev_pool_v2",
                              "bevfusion_lidar", "pointpillars_kitti"])
     ap.add_argument("--vox-path", type=int, default=0, help="pd3_hard_voxelize_path selector (0 = library default, "
                     "1 generic sort, 2 tiled with a compact payload array, 3 tiled with gathered rows, 5 wave form)")
@@ -1499,7 +1506,7 @@ def main(argv=None):
                     "(CPU, gloo); the line is marked stub")
     args = ap.parse_args(argv)
     if args.batch is None:
-        args.batch = {"centerpoint_voxel": 8}.get(args.workload, 16)
+        args.batch = {"centerpoint_voxel": 8, "centerpoint_voxel_amp": 8}.get(args.workload, 16)
     if args.repeats is None:
         args.repeats = 4 if args.gpus == 1 else 0
 
@@ -1531,7 +1538,7 @@ def main(argv=None):
         dev = torch.device("cuda", local)
         torch.manual_seed(0)
         fn = dict(centerpoint_pillars=bench_pillars, centerpoint_pillars_amp=bench_pillars,
-                  centerpoint_voxel=bench_voxel, bev_pool_v2=bench_bev_pool,
+                  centerpoint_voxel=bench_voxel, centerpoint_voxel_amp=bench_voxel, bev_pool_v2=bench_bev_pool,
                   bevfusion_lidar=bench_bevfusion_lidar, pointpillars_kitti=bench_pointpillars_kitti)[args.workload]
         line = fn(args, rank, world, dev)
     if rank == 0:

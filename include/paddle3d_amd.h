@@ -389,6 +389,19 @@ int pd3_sparse_conv3d_features_ordered(const float *in_feats, const int32_t *nbr
                                        const float *weight, const float *bias, const float *scale,
                                        const float *shift, const float *residual, int relu,
                                        const int32_t *order, float *out, void *stream);
+/* Mixed precision (the reference's amp_cfg level O2 for the CenterPoint-Voxel encoder): fp16 feature rows and weights
+ * on the fp16 matrix cores, fp32 accumulation; index sets, rulebooks and tile order are the fp32 path's.
+ *   pd3_sparse_pack_weight_f16   weight [K, Cin, Cout] fp32 (Paddle layout) -> packed fp16 (K * Cin * Cout halfs) in the
+ *                                operand order of the kernel; Cin % 16 == 0, Cout in {32, 64, 128}
+ *   pd3_sparse_conv3d_features_f16   as pd3_sparse_conv3d_features_ordered with in_feats / residual / out fp16
+ *                                (out fp32 when out_f32 != 0: the encoder's last layer feeds pd3_sparse_to_dense);
+ *                                bias / scale / shift stay fp32.  Other shapes return -3 (run the fp32 entry). */
+int pd3_sparse_pack_weight_f16(const float *weight, int kernel_volume, int cin, int cout, void *packed, void *stream);
+int pd3_sparse_conv3d_features_f16(const void *in_feats_f16, const int32_t *nbr, const int32_t *n_out, int n_out_cap,
+                                   int kernel_volume, int cin, int cout, const void *weight_packed_f16,
+                                   const float *bias, const float *scale, const float *shift,
+                                   const void *residual_f16, int relu, const int32_t *order, void *out, int out_f32,
+                                   void *stream);
 /* Plan path: the index sets of a whole encoder without a host round trip between the convolutions (the
  * reference's layers read nnz on the host after every sparse op).  An index set is a SORTED array of keys
  * ((b*D + z)*H + y)*W + x (raster order; 0xFFFFFFFF = padding, at the end) with its length in device memory.

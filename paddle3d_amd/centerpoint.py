@@ -717,7 +717,7 @@ class CenterPoint(nn.Module):
         accumulation (csrc/conv_f16.hip), fp16 NHWC activations between them; the stride-2 convolutions, the FPN, the
         final head convolutions, the front half and the post-processing stay fp32.  Off by default; layers the fp16
         kernel does not take (maps that are not a multiple of 32 wide) stay fp32."""
-        for m in (self.backbone, self.bbox_head):
+        for m in (self.backbone, self.bbox_head, self.middle_encoder):
             if hasattr(m, "amp"):
                 m.amp = bool(enabled)
         return self

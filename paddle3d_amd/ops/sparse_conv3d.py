@@ -18,8 +18,8 @@ import torch
 
 from ._common import check, host_i32, lib, ptr, require_gpu, stream_ptr, workspace
 
-__all__ = ["SparseIndices", "ConvSpec", "SparsePlan", "indices", "plan", "plan_caps", "features", "to_dense",
-           "out_spatial_shape"]
+__all__ = ["SparseIndices", "ConvSpec", "SparsePlan", "indices", "plan", "plan_caps", "features", "features_f16",
+           "pack_weight_f16", "f16_supported", "to_dense", "out_spatial_shape"]
 
 
 @dataclass
@@ -231,6 +231,42 @@ def features(in_feats: torch.Tensor, idx: SparseIndices, weight: torch.Tensor, b
         ptr(f), ptr(idx.nbr), ptr(idx.n_out_dev), idx.n_out, idx.kernel_volume, cin, cout, ptr(w), ptr(opt[0]),
         ptr(opt[1]), ptr(opt[2]), ptr(opt[3]), int(bool(relu)), ptr(idx.order) if TILE_ORDER else None, ptr(out),
         stream_ptr(f.device)), "sparse_conv3d_features")
+    return out
+
+
+def f16_supported(cin: int, cout: int, kernel_volume: int) -> bool:
+    """Shapes the fp16 gather-GEMM serves (the encoder's layers from 16 -> 32 on)."""
+    return cin % 16 == 0 and cout in (32, 64, 128) and kernel_volume <= 27
+
+
+def pack_weight_f16(weight: torch.Tensor) -> torch.Tensor:
+    """weight [kd, kh, kw, Cin, Cout] fp32 (Paddle layout) -> the fp16 operand order of features_f16."""
+    w = require_gpu(weight, "sparse_conv3d")
+    cin, cout = int(w.shape[-2]), int(w.shape[-1])
+    kvol = w.numel() // (cin * cout)
+    out = torch.empty((w.numel(),), dtype=torch.float16, device=w.device)
+    check(lib().pd3_sparse_pack_weight_f16(ptr(w), kvol, cin, cout, ptr(out), stream_ptr(w.device)),
+          "sparse_pack_weight_f16")
+    return out
+
+
+def features_f16(in_feats: torch.Tensor, idx: SparseIndices, packed_weight: torch.Tensor, cin: int, cout: int,
+                 bias=None, scale=None, shift=None, residual=None, relu: bool = False,
+                 out_f32: bool = False) -> torch.Tensor:
+    """features() on the fp16 matrix cores: in_feats / residual fp16 [n, C], packed_weight from pack_weight_f16, fp32
+    accumulation, bias / scale / shift fp32; fp16 rows out (fp32 with out_f32)."""
+    f = require_gpu(in_feats, "sparse_conv3d", torch.float16)
+    if f.shape[1] != cin or packed_weight.numel() != idx.kernel_volume * cin * cout:
+        raise RuntimeError("sparse_conv3d: weight / feature shapes do not match")
+    out = torch.empty((idx.n_out, cout), dtype=torch.float32 if out_f32 else torch.float16, device=f.device)
+    if idx.n_out == 0:
+        return out
+    opt = [None if t is None else require_gpu(t, "sparse_conv3d") for t in (bias, scale, shift)]
+    res = None if residual is None else require_gpu(residual, "sparse_conv3d", torch.float16)
+    check(lib().pd3_sparse_conv3d_features_f16(
+        ptr(f), ptr(idx.nbr), ptr(idx.n_out_dev), idx.n_out, idx.kernel_volume, cin, cout, ptr(packed_weight),
+        ptr(opt[0]), ptr(opt[1]), ptr(opt[2]), ptr(res), int(bool(relu)), ptr(idx.order) if TILE_ORDER else None,
+        ptr(out), int(bool(out_f32)), stream_ptr(f.device)), "sparse_conv3d_features_f16")
     return out
 
 

@@ -18,7 +18,8 @@ __all__ = ["SparseConvTensor", "SubmConv3D", "Conv3D", "SparseBasicBlock", "Spar
 class SparseConvTensor:
     """features [N, C] fp32 + indices [N, 4] int32 (b, z, y, x) + dense spatial shape (D, H, W)."""
 
-    def __init__(self, features, indices, spatial_shape, batch_size, cache=None, plan=None, n_dev=None):
+    def __init__(self, features, indices, spatial_shape, batch_size, cache=None, plan=None, n_dev=None, amp=False):
+        self.amp = bool(amp)  # mixed precision: convolutions the fp16 kernel serves take / leave fp16 rows
         self.features = features
         self.indices = indices
         self.spatial_shape = tuple(int(s) for s in spatial_shape)
@@ -31,10 +32,10 @@ class SparseConvTensor:
 
     def replace(self, features):
         return SparseConvTensor(features, self.indices, self.spatial_shape, self.batch_size, self.cache, self.plan,
-                                self.n_dev)
+                                self.n_dev, self.amp)
 
     def dense(self):
-        return _sp.to_dense(self.features, self.indices, self.batch_size, self.spatial_shape, self.n_dev)
+        return _sp.to_dense(self.features.float(), self.indices, self.batch_size, self.spatial_shape, self.n_dev)
 
 
 def _triple(v):
@@ -90,16 +91,37 @@ class _SparseConv(nn.Module):
             x.cache[self.key] = idx
         return idx
 
+    out_f32 = False  # mixed precision: this convolution writes fp32 rows (an encoder's last layer, in front of to_dense)
+
+    def _packed_f16(self):
+        """The weight in the fp16 kernel's operand order, repacked when the parameter changes."""
+        tag = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        hit = getattr(self, "_pd3_packed", None)
+        if hit is None or hit[0] != tag:
+            hit = (tag, _sp.pack_weight_f16(self.weight.detach()))
+            object.__setattr__(self, "_pd3_packed", hit)
+        return hit[1]
+
     def forward(self, x: SparseConvTensor, scale=None, shift=None, residual=None, relu=False):
         idx = self._indices(x)
+        cin, cout = int(self.weight.shape[-2]), int(self.weight.shape[-1])
         if _STATS is not None:  # measurement aid (bench.py): multiply-adds of the pairs that exist
-            cin, cout = int(self.weight.shape[-2]), int(self.weight.shape[-1])
             _STATS["pairs"] += 2 * cin * cout * int((idx.nbr >= 0).sum().item())
             _STATS["dense"] += 2 * cin * cout * idx.n_out * idx.kernel_volume
-        out = _sp.features(x.features, idx, self.weight, self.bias, scale, shift, residual, relu)
+        if x.amp and _sp.f16_supported(cin, cout, idx.kernel_volume):
+            # fp16 rows in (converted once where the chain leaves the narrow fp32 layers), fp16 rows out
+            feats = x.features if x.features.dtype == torch.float16 else x.features.half()
+            res = residual if residual is None or residual.dtype == torch.float16 else residual.half()
+            out = _sp.features_f16(feats, idx, self._packed_f16(), cin, cout, self.bias, scale, shift, res, relu,
+                                   out_f32=self.out_f32)
+        else:
+            feats = x.features if x.features.dtype == torch.float32 else x.features.float()
+            res = residual if residual is None or residual.dtype == torch.float32 else residual.float()
+            out = _sp.features(feats, idx, self.weight, self.bias, scale, shift, res, relu)
         if self.subm:
             return x.replace(out)
-        return SparseConvTensor(out, idx.out_coords, idx.out_shape, x.batch_size, plan=x.plan, n_dev=idx.n_out_dev)
+        return SparseConvTensor(out, idx.out_coords, idx.out_shape, x.batch_size, plan=x.plan, n_dev=idx.n_out_dev,
+                                amp=x.amp)
 
 
 class SubmConv3D(_SparseConv):
@@ -141,7 +163,8 @@ def _planned_input(encoder, voxel_features, coors, batch_size, caps=None):
     pl = _sp.plan(coors, batch_size, encoder.sparse_shape, [m.spec() for m in convs], caps=caps)
     feats = voxel_features.index_select(0, pl.order)
     return SparseConvTensor(feats, pl.coords, encoder.sparse_shape, batch_size,
-                            plan={id(m): idx for m, idx in zip(convs, pl.indices)}, n_dev=pl.n_in_dev), pl
+                            plan={id(m): idx for m, idx in zip(convs, pl.indices)}, n_dev=pl.n_in_dev,
+                            amp=getattr(encoder, "amp", False)), pl
 
 
 def _bn(channels):
@@ -222,10 +245,15 @@ class SparseResNet3D(nn.Module):
         self.conv4 = nn.Sequential(Conv3D(64, 128, 3, 2, padding=(0, 1, 1), bias=False), _bn(128), nn.ReLU(),
                                    SparseBasicBlock(128, 128, "res3"), SparseBasicBlock(128, 128, "res3"))
         self.extra_conv = nn.Sequential(Conv3D(128, 128, (3, 1, 1), (2, 1, 1), bias=False), _bn(128), nn.ReLU())
+        self.extra_conv[0].out_f32 = True  # (mixed precision: the densified map is fp32 like the fp32 path's)
         self.sparse_shape = _sparse_shape(voxel_size, point_cloud_range)
         self.in_channels = in_channels
 
     accepts_padding_rows = True  # rows with batch index < 0 are ignored (no boolean-mask sync in the caller)
+    # Mixed precision (CenterPoint.set_amp; the reference's amp_cfg level O2): the convolutions from 16 -> 32 on run on the
+    # fp16 matrix cores with fp16 feature rows between them (fp32 accumulation, fp32 BatchNorm fold); the 5 -> 16 and
+    # 16 -> 16 layers and the densified map stay fp32.  Never the default.
+    amp = False
 
     # remember_capacities: the first forward of a (batch size, input rows) shape plans with the ONE host sync and
     # remembers every index set's row count (x 1.25); later forwards of that shape plan without any host round trip

@@ -320,6 +320,29 @@ def test_sparse_encoder_full_c4_grid_vs_keyset_oracle(oracle):
     finally:
         sp.TILE_ORDER = True
         net.remember_capacities = True
+    # mixed precision (net.amp: the layers from 16 -> 32 on run on the fp16 matrix cores, fp16 rows between them): the
+    # same index sets, every layer and the map within fp16's resolution of the oracle (3 % of the layer's magnitude --
+    # twenty fp16 layers deep; the fp32 form above holds 1e-3)
+    got.clear()
+    net.amp = True
+    hooks = [m.register_forward_hook(lambda mod, inp, out: got.__setitem__(names[id(mod)], out))
+             for m in net.modules() if isinstance(m, S._SparseConv)]
+    try:
+        bev16 = net(feats, coors, b)
+    finally:
+        net.amp = False
+        for h in hooks:
+            h.remove()
+    assert bev16.dtype == torch.float32 and got["conv3.3.conv1"].features.dtype == torch.float16
+    assert got["conv1.1.conv2"].features.dtype == torch.float32  # the 16-channel layers stay fp32
+    for name, want in trace.items():
+        t = got[name]
+        np.testing.assert_array_equal(_keys_of(t.indices, t.spatial_shape), want["keys"], err_msg=name)
+        scale = max(1.0, float(np.abs(want["feats"]).max()))
+        err = float(np.abs(t.features.float().cpu().numpy() - want["feats"]).max())
+        assert err < 3e-2 * scale, ("amp", name, err, scale)
+    err16 = float(np.abs(bev16.cpu().numpy() - ref_bev).max())
+    assert 0 < err16 < 3e-2 * max(1.0, float(np.abs(ref_bev).max())), err16
     # the dense neighbourhoods the bench's tiles see are in this input: > 10 existing pairs per row on the 32+ layers
     assert trace["conv2.3.conv1"]["pairs"] > 10 * trace["conv2.3.conv1"]["keys"].shape[0]
 
@@ -427,3 +450,85 @@ def test_plan_without_host_sync_and_overflow(oracle):
     dets_c = model.test_forward(pts2)     # first attempt overflows, second attempt plans with the sync
     for a, c in zip(dets_a, dets_c):
         assert torch.equal(a["box3d_lidar"], c["box3d_lidar"]) and torch.equal(a["scores"], c["scores"])
+
+
+F16_CASES = [
+    # cin, cout, subm, kernel, stride, padding, epilogue (bias, bn, residual, relu), out_f32
+    (16, 32, False, (3, 3, 3), (2, 2, 2), (1, 1, 1), (False, True, False, True), False),
+    (32, 32, True, (3, 3, 3), (1, 1, 1), (1, 1, 1), (True, True, True, True), False),
+    (32, 64, False, (3, 3, 3), (2, 2, 2), (1, 1, 1), (False, True, False, True), False),
+    (64, 64, True, (3, 3, 3), (1, 1, 1), (1, 1, 1), (True, True, True, True), False),
+    (64, 128, False, (3, 3, 3), (2, 2, 2), (0, 1, 1), (False, False, False, False), False),
+    (128, 128, True, (3, 3, 3), (1, 1, 1), (1, 1, 1), (True, True, True, True), False),
+    (128, 128, False, (3, 1, 1), (2, 1, 1), (0, 0, 0), (False, True, False, True), True),
+    (48, 32, True, (3, 3, 3), (1, 1, 1), (1, 1, 1), (True, False, False, False), True),  # a 16-channel chunk, 3 chunks
+]
+
+
+@pytest.mark.parametrize("case", F16_CASES, ids=lambda c: f"{c[0]}to{c[1]}{'subm' if c[2] else 'down'}")
+@pytest.mark.parametrize("order", [True, False], ids=["tile_order", "raster"])
+def test_features_f16_matches_fp32_math_on_fp16_operands(case, order):
+    """pd3_sparse_conv3d_features_f16 against the fp32 kernel fed the SAME fp16-rounded rows and weights: what is left
+    is the accumulation order and the fp16 rounding of the result (fp32 out: 2e-4; fp16 out: one fp16 ulp of the
+    magnitude on top).  Every chunk width (16 / 32 / 64 channels), every output width, both epilogue forms, rows in
+    tile order and in raster order, a partial last tile."""
+    from paddle3d_amd.ops import sparse_conv3d as sp
+
+    cin, cout, subm, ks, stride, pad, (with_bias, with_bn, with_res, relu), out_f32 = case
+    rng = np.random.default_rng(cin * 7 + cout)
+    shape = (9, 60, 70)
+    coords, feats = _random_sparse(rng, 2, shape, 9000, cin)
+    slab = np.stack(np.meshgrid(np.arange(2), np.arange(3, 6), np.arange(20, 45), np.arange(30, 60), indexing="ij"),
+                    -1).reshape(-1, 4).astype(np.int32)
+    coords = np.unique(np.concatenate([coords, slab]), axis=0)
+    feats = rng.normal(size=(len(coords), cin)).astype(np.float32)
+    w = (rng.normal(size=(*ks, cin, cout)) / np.sqrt(np.prod(ks) * cin)).astype(np.float32)
+    sp.TILE_ORDER = order
+    try:
+        pl = sp.plan(torch.from_numpy(coords).cuda(), 2, shape, [sp.ConvSpec(ks, stride, pad, subm)])
+        idx = pl.indices[0]
+        f16 = torch.from_numpy(feats).cuda().index_select(0, pl.order).half()
+        w16 = torch.from_numpy(w).cuda().half()
+        bias = torch.from_numpy(rng.normal(size=cout).astype(np.float32)).cuda() if with_bias else None
+        sc = torch.from_numpy(rng.normal(size=cout).astype(np.float32)).cuda() if with_bn else None
+        sh = torch.from_numpy(rng.normal(size=cout).astype(np.float32)).cuda() if with_bn else None
+        res = torch.from_numpy(rng.normal(size=(idx.n_out, cout)).astype(np.float32)).cuda().half() if with_res else None
+        want = sp.features(f16.float(), idx, w16.float(), bias, sc, sh, None if res is None else res.float(), relu)
+        got = sp.features_f16(f16, idx, sp.pack_weight_f16(w16.float()), cin, cout, bias, sc, sh, res, relu,
+                              out_f32=out_f32)
+    finally:
+        sp.TILE_ORDER = True
+    assert got.dtype == (torch.float32 if out_f32 else torch.float16) and got.shape == want.shape
+    assert idx.n_out % 256 != 0 and idx.n_out > 2000
+    mag = float(want.abs().max())
+    tol = 2e-4 * max(1.0, mag) + (0.0 if out_f32 else 1e-3 * mag)
+    assert float((got.float() - want).abs().max()) < tol
+
+
+def test_sparse_encoder_amp_close_to_fp32_and_voxel_model(oracle):
+    """The whole CenterPoint-Voxel model with set_amp(True) on a quarter-range copy of config 4: the encoder's map within
+    2 % of the fp32 map's magnitude, detections of the two graphs agree (same count within 2 %, strong boxes have twins)."""
+    from paddle3d_amd import centerpoint as cpm
+    from paddle3d_amd import nuscenes_bridge as nb
+    from paddle3d_amd import synth
+
+    torch.manual_seed(9)
+    pcr = [-9.6, -9.6, -5.0, 9.6, 9.6, 3.0]
+    model = cpm.centerpoint_voxels_nuscenes(max_num_voxels=(40000, 40000), point_cloud_range=pcr).cuda().eval()
+    _randomise(model.middle_encoder)
+    with torch.no_grad():
+        for task in model.bbox_head.tasks:
+            task.hm[-1].bias.fill_(-1.0)
+    pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(93 + i, n_points=120_000) for i in range(2)])).cuda()
+    bev32 = model.extract_pillars(pts)
+    d32 = model.test_forward(pts)
+    model.set_amp(True)
+    assert model.middle_encoder.amp
+    bev16 = model.extract_pillars(pts)
+    d16 = model.test_forward(pts)
+    model.set_amp(False)
+    assert bev16.dtype == torch.float32 and bev16.shape == bev32.shape
+    rel = float((bev16 - bev32).abs().max() / bev32.abs().max())
+    assert 0 < rel < 2e-2, rel
+    miss = nb.unmatched_detections(d16, d32, score_tol=2e-2)
+    assert miss["total"] > 50 and miss["unmatched"] <= 0.05 * miss["total"], miss

@@ -14,6 +14,7 @@ from paddle3d_amd.ops import sparse_conv3d as _sp  # noqa: E402
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 # second argument "raster": rows in raster order (no tile order), the round-4 behaviour
 _sp.TILE_ORDER = not (len(sys.argv) > 2 and sys.argv[2] == "raster")
+AMP = len(sys.argv) > 2 and sys.argv[2] == "amp"  # third form: the fp16 kernel where it applies
 model = cpm.centerpoint_voxels_nuscenes(max_num_voxels=(120000, 160000)).cuda().eval()
 pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(100 + i) for i in range(batch)])).cuda()
 rows = []
@@ -46,6 +47,32 @@ def traced(in_feats, idx, weight, *a, **kw):
 
 
 _sp.features = traced
+_feat16 = _sp.features_f16
+
+
+def traced16(in_feats, idx, packed, cin, cout, *a, **kw):
+    for _ in range(2):
+        _feat16(in_feats, idx, packed, cin, cout, *a, **kw)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        out = _feat16(in_feats, idx, packed, cin, cout, *a, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    present = idx.nbr[: idx.n_out] >= 0
+    pairs = int(present.sum())
+    if idx.order is not None and _sp.TILE_ORDER:
+        slots = idx.order.long()
+        present = torch.where((slots >= 0).unsqueeze(1), present[slots.clamp(min=0)], torch.zeros_like(present[:1]))
+    n32 = (present.shape[0] + 31) // 32 * 32
+    pad = torch.zeros(n32 - present.shape[0], present.shape[1], dtype=torch.bool, device=present.device)
+    blocks = int(torch.cat([present, pad]).view(-1, 32, present.shape[1]).any(1).sum()) * 32  # 32-row blocks here
+    rows.append((idx.n_out, present.shape[1], cin, cout, pairs, blocks, ms))
+    return out
+
+
+_sp.features_f16 = traced16
 with torch.no_grad():
     voxels, coors, npv, nv = model.voxelizer(pts)
     b, v, p, d = voxels.shape
@@ -53,6 +80,7 @@ with torch.no_grad():
     cs = coors.view(b * v, 4)[keep].contiguous()
     feats = model.voxel_encoder(voxels.view(b * v, p, d)[keep], npv.view(b * v)[keep], cs)
     model.middle_encoder.remember_capacities = False
+    model.middle_encoder.amp = AMP
     model.middle_encoder(feats, cs, b)
 tot = 0.0
 print("rows in", "tile order (windows of 8192 rows sorted by neighbour mask)" if _sp.TILE_ORDER else "raster order")
