@@ -1174,6 +1174,22 @@ def bench_voxel(args, rank, world, dev):
     }
     if overflow:
         line["error"] = "sparse plan: an index set outgrew its remembered capacity during the timed steps"
+    if amp:
+        from paddle3d_amd import nuscenes_bridge as nb
+
+        with torch.no_grad():  # what the mode costs in accuracy on this batch (untimed)
+            bev16 = model.extract_pillars(pts)
+            d16 = model.test_forward(pts)
+            model.set_amp(False)
+            bev32 = model.extract_pillars(pts)
+            d32 = model.test_forward(pts)
+            model.set_amp(True)
+        line["amp_error"] = dict(
+            bev_map_max_abs=float((bev16 - bev32).abs().max()), bev_map_max_magnitude=float(bev32.abs().max()),
+            fp32_boxes_without_amp_twin=nb.unmatched_detections(d16, d32, score_tol=2e-2),
+            amp_boxes_without_fp32_twin=nb.unmatched_detections(d32, d16, score_tol=2e-2),
+            note="the encoder's [B, 256, 180, 180] map and the detections of the AMP graph against the fp32 graph's; fp16 "
+                 "feature rows and weights, fp32 accumulation, random-init weights")
     if sp:
         ms = per_op_ms["voxel_mean_sparse_encoder"]
         line["rooflines"] = {"sparse_encoder": dict(
@@ -1181,7 +1197,9 @@ def bench_voxel(args, rank, world, dev):
             frac=sp["pairs"] / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, traffic=None, ms_per_launch=ms,
             units_per_launch=B, flops_existing_pairs=sp["pairs"], flops_dense_equivalent=sp["dense"],
             note="flops of the (output row, kernel offset) pairs that exist, 2*Cin*Cout each, over the whole encoder "
-                 "stage time (index building included); dense-equivalent counts all 27 offsets")}
+                 "stage time (index building included); dense-equivalent counts all 27 offsets" +
+                 ("; AMP: priced against the fp32 matrix peak for comparison with the fp32 line, not a utilisation of "
+                  "the fp16 pipe (2.5 PFLOP/s) -- this mode is bound by the gather" if amp else ""))}
     return line
 
 
