@@ -18,8 +18,9 @@ for stage in "$@"; do
   echo "== $stage"
   case $name in
     tests)
-      if [ -n "$arg" ]; then timeout 1800 python -m pytest tests -m gpu -q -rf -k "$arg" 2>&1 | grep -v "^$" | tail -25 | tee gpurun_out/${tag}_tests.log
-      else timeout 1800 python -m pytest tests -m gpu -q -rf 2>&1 | grep -v "^$" | tail -25 | tee gpurun_out/${tag}_tests.log; fi ;;
+      if [ -n "$arg" ]; then timeout 1800 python -m pytest tests -m gpu -q -rf --tb=short -k "$arg" > gpurun_out/${tag}_tests_full.log 2>&1
+      else timeout 1800 python -m pytest tests -m gpu -q -rf --tb=short > gpurun_out/${tag}_tests_full.log 2>&1; fi
+      grep -v "^$" gpurun_out/${tag}_tests_full.log | grep -E "^E |^FAILED|^ERROR|passed|failed|Error" | tail -40 | tee gpurun_out/${tag}_tests.log ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/${tag}_smoke.log ;;
     bench)
