@@ -530,7 +530,8 @@ int pd3_stable_argsort(const void *keys, int64_t n, int mode, uint32_t max_key, 
  *   out          out_mode 0: [batch, h, w, cout] fp16 NHWC (the next fp16 layer's input);
  *                out_mode 1: [batch, cout, h, w] fp32 NCHW (what the fp32 kernels of the graph read)
  *   channels_per_tile 128 (workgroup = 128 channels x 16 rows x 32 columns) or 64 (64 channels x 32 rows x 32 columns)
- *   requires cin % 16 == 0, cout % T == 0, w % 32 == 0, h % (16 | 32) == 0; else PD3_EUNSUPPORTED (the caller runs fp32)
+ *   requires cin % 16 == 0, cout % T == 0; else PD3_EUNSUPPORTED (the caller runs fp32).  Maps that are not whole
+ *   tiles (config 4's 180 x 180) run with masked border tiles.
  */
 int pd3_conv3x3_f16_bias_relu(const void *x_f16_nhwc, const void *w_packed_f16, const float *bias, int batch, int cin,
                               int cout, int h, int w, int relu, void *out, int out_mode, int channels_per_tile,

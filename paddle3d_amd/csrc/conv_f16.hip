@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_f16_kernel(const _Float
   using S = CfShape<MB>;
   extern __shared__ __attribute__((aligned(16))) _Float16 cf_smem[];
   const int lane = lane_id(), wave = wave_id();
-  const int tiles_x = w / kCfCols, tiles_y = h / S::R;
+  const int tiles_x = (w + kCfCols - 1) / kCfCols, tiles_y = (h + S::R - 1) / S::R;  // partial border tiles are masked
   // XCD-aware order (as the fp32 kernels): pixel tile pt lives on XCD pt % 8 with all its channel tiles
   const int nct = cout / S::M;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_f16_kernel(const _Float
         v[r] = acc[i][j][r] + bv[r];
         if (relu) v[r] = fmaxf(v[r], 0.f);
       }
+      if (yg >= h || xg >= w) continue;  // a border tile's pixels outside the map (round 5: 180 x 180 maps of config 4)
       if (OUT_MODE == 0) {
         _Float16* o = reinterpret_cast<_Float16*>(out) + (((int64_t)n * h + yg) * w + xg) * cout + co0 + 32 * i + 4 * kh;
 #pragma unroll
@@ -218,7 +219,7 @@ static int launch_conv_f16(const void* x, const void* wp, const float* bias, int
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16_kernel<MB, OUT_MODE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS);
   if (e != hipSuccess) return (int)e;
-  const int64_t ptiles = (int64_t)batch * (h / S::R) * (w / kCfCols);
+  const int64_t ptiles = (int64_t)batch * ceil_div(h, S::R) * ceil_div(w, kCfCols);
   const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / S::M);
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
   conv3x3_f16_kernel<MB, OUT_MODE><<<(unsigned)nwg, kCfThreads, S::LDS, s>>>(
@@ -234,8 +235,7 @@ extern "C" int pd3_conv3x3_f16_bias_relu(const void* x_f16_nhwc, const void* w_p
   if (reinterpret_cast<uintptr_t>(x_f16_nhwc) % 16 != 0 || reinterpret_cast<uintptr_t>(w_packed_f16) % 16 != 0 ||
       reinterpret_cast<uintptr_t>(out) % 16 != 0)
     return PD3_EINVAL;
-  const int rows = channels_per_tile == 128 ? 16 : 32;
-  if (cin % kCfKc != 0 || cout % channels_per_tile != 0 || w % kCfCols != 0 || h % rows != 0) return PD3_EUNSUPPORTED;
+  if (cin % kCfKc != 0 || cout % channels_per_tile != 0) return PD3_EUNSUPPORTED;
   if ((int64_t)h * w * cin >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (channels_per_tile == 128)

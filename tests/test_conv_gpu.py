@@ -286,7 +286,7 @@ def test_scatter_fused_into_stride2_conv(ny, nx, batch):
 # ---- mixed precision: the fp16 matrix-core form of the stride-1 layers (csrc/conv_f16.hip) -----------------------------
 @pytest.mark.parametrize("out_f32", [False, True])
 @pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 32, 64), (32, 64, 64, 32), (128, 256, 16, 32), (16, 64, 32, 96),
-                                          (48, 384, 48, 32)])
+                                          (48, 384, 48, 32), (32, 128, 45, 52), (16, 64, 50, 20), (64, 128, 180, 180)])
 def test_conv3x3_f16_matches_fp32_math_on_fp16_operands(cin, cout, h, w, out_f32):
     """v_mfma_f32_32x32x16_f16 accumulates in fp32, so on operands that are already fp16 values the kernel must agree
     with an fp32 convolution of the same values to accumulation-order noise -- which pins the whole layout (A / B
@@ -321,10 +321,11 @@ def test_conv3x3_f16_refuses_shapes_it_does_not_take():
     from paddle3d_amd._lib import Paddle3DAmdError
     from paddle3d_amd.ops import conv
 
-    assert not conv.f16_supported(64, 64, 180, 180) and not conv.f16_supported(8, 64, 32, 32)
-    x = torch.zeros(1, 20, 32, 64, dtype=torch.float16, device="cuda")  # w % 32 != 0 as NHWC [1, 20, 32, 64]: h = 20
+    assert conv.f16_supported(64, 64, 180, 180)  # (round 5: border tiles are masked, any map size runs)
+    assert not conv.f16_supported(8, 64, 32, 32) and not conv.f16_supported(64, 96, 32, 32)
+    x = torch.zeros(1, 32, 32, 24, dtype=torch.float16, device="cuda")  # 24 input channels: not whole 16-channel chunks
     with pytest.raises(Paddle3DAmdError, match="status -3"):
-        conv.conv3x3_f16_bias_relu(x, torch.zeros(1, 4, 9, 64, 16, dtype=torch.float16, device="cuda"), None, 64)
+        conv.conv3x3_f16_bias_relu(x, torch.zeros(1, 1, 9, 64, 16, dtype=torch.float16, device="cuda"), None, 64)
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 64), (1, 128, 128, 16, 128), (1, 8, 64, 24, 68), (1, 64, 192, 12, 64),
