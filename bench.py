@@ -525,6 +525,30 @@ def _traffic(batch, v):
     return found
 
 
+def _vox_floor():
+    """The measured floor of hard_voxelize's MEMORY ACCESSES at C3 x 16 frames (tools/hwcheck/voxfloor: a program with
+    no ranking logic that only streams the points, gathers 2.16 M kept 20-byte records into the fixed-shape output and
+    performs the first-point stores / loads), from the newest profiles/r*_voxfloor.txt: what the access set costs on
+    this machine warm / after a cache flush, next to what the operator achieves."""
+    import glob
+    import re
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_voxfloor.txt")))
+    if not paths:
+        return None
+    try:
+        text = open(paths[-1]).read().split("# tools/hwcheck/voxfloor --random")[0]
+        warm = re.search(r"warm:.*?sum ([0-9.]+) us = ([0-9.]+) of", text)
+        cold = re.search(r"cold:.*?sum ([0-9.]+) us = ([0-9.]+) of", text)
+        return dict(warm_us=float(warm.group(1)), warm_frac=float(warm.group(2)), cold_us=float(cold.group(1)),
+                    cold_frac=float(cold.group(2)), source="profiles/" + os.path.basename(paths[-1]),
+                    note="tools/hwcheck/voxfloor: the operator's memory accesses alone (no ranking logic), 16 frames of "
+                         "config 3, index lists with a 10-sweep frame's locality; warm = points in the last-level "
+                         "cache, cold = after a 1 GiB flush (the in-step state lies between)")
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def bench_pillars(args, rank, world, dev):
     from paddle3d_amd import centerpoint as cpm
     from paddle3d_amd import dist as pdist
@@ -789,7 +813,8 @@ def bench_pillars(args, rank, world, dev):
                                        if pipe is not None else "all-gather inside the step")},
         "roofline": dict(rooflines["hard_voxelize"],
                          kernel="hard_voxelize launch sequence (vw_route + vw_group + vw_assign + vw_rows: the wave form, "
-                                "voxelize_wave.hpp; --vox-path picks another form)"),
+                                "voxelize_wave.hpp; --vox-path picks another form)",
+                         target=0.5, floor=_vox_floor()),
         "rooflines": rooflines,
         "front_half": dict(
             form=("fused: pd3_hard_voxelize_index (no padded [V, P, D] tensor) + pd3_pillar_feature_net_indexed"
