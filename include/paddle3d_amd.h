@@ -536,6 +536,14 @@ int pd3_stable_argsort(const void *keys, int64_t n, int mode, uint32_t max_key, 
 int pd3_conv3x3_f16_bias_relu(const void *x_f16_nhwc, const void *w_packed_f16, const float *bias, int batch, int cin,
                               int cout, int h, int w, int relu, void *out, int out_mode, int channels_per_tile,
                               void *stream);
+/* The final SeparateHead convolutions under AMP (center_head.py:99-118): grouped 3x3 / pad 1 convolution + bias reading
+ * the first stage's fp16 NHWC output.
+ *   x_f16_nhwc [batch, h, w, groups * 64] fp16; w_f16 [groups][9 taps][out_per_group][64] fp16; bias [groups *
+ *   out_per_group] fp32 or NULL; out [batch, out_groups * out_per_group, h, w] fp32 NCHW, the slice's maps at groups
+ *   [out_group0, out_group0 + groups); out_per_group 1 .. 4, 64 channels per group (else -3) */
+int pd3_grouped_conv3x3_small_f16(const void *x_f16_nhwc, const void *w_f16, const float *bias, int batch, int groups,
+                                  int channels_per_group, int out_per_group, int h, int w, float *out, int out_groups,
+                                  int out_group0, void *stream);
 /* x [batch, channels, h, w] fp32 NCHW -> out [batch, h, w, channels] fp16 NHWC (round to nearest even) */
 int pd3_f32_nchw_to_f16_nhwc(const float *x, int batch, int channels, int h, int w, void *out, void *stream);
 

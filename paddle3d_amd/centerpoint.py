@@ -568,7 +568,7 @@ class CenterHead(_InferenceCache, nn.Module):
                 bf[g * cmax:g * cmax + w.shape[0]] = b
             self._store_cache(dict(
                 shared=_Conv3x3(w0, b0, 1), first=_Conv3x3(torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous(), 1),
-                pf=_conv.pack_grouped_weight(wf, len(finals)), bf=bf, hc=int(hc), plan=plan, cmax=int(cmax),
+                pf=_conv.pack_grouped_weight(wf, len(finals)), bf=bf, hc=int(hc), plan=plan, cmax=int(cmax), wf=wf,
                 groups=len(finals), ncls=[int(f[0].shape[0]) for f in finals]))
         return self._cache
 
@@ -601,16 +601,22 @@ class CenterHead(_InferenceCache, nn.Module):
         full = n * f["hc"] * h * w * 4 * groups
         k = self.head_chunk if self.head_chunk else ((groups + 1) // 2 if full > self.head_chunk_bytes else groups)
         if amp:
+            # the first stage leaves fp16 NHWC (round 5; fp32 NCHW before: 2.4 GB written and fetched back per 16 frames),
+            # the grouped final convolutions read a group's 64 channels of a pixel as one 128-byte line
+            if "pf16" not in f:
+                f["pf16"] = _conv.pack_grouped_weight_f16(f["wf"], groups)
+            full = full // 2
+            k = self.head_chunk if self.head_chunk else ((groups + 1) // 2 if full > self.head_chunk_bytes else groups)
             k = k + (k & 1) if k < groups else groups  # slices of whole 128-channel tiles (two branches each)
             z = torch.empty((n, groups * f["cmax"], h, w), dtype=torch.float32, device=x.device)
-            buf = torch.empty((n * min(k, groups) * 64 * h * w,), dtype=torch.float32, device=x.device)
+            buf = torch.empty((n * min(k, groups) * 64 * h * w,), dtype=torch.float16, device=x.device)
             per = _conv.f16_tile(first.cout) // 64
             for c0 in range(0, groups, k):
                 c1 = min(c0 + k, groups)
-                y = buf[: n * (c1 - c0) * 64 * h * w].view(n, (c1 - c0) * 64, h, w)
-                first.f16(x, out_f32_nchw=True, out=y, tiles=(c0 // per, c1 // per))
-                _conv.grouped_conv3x3_small(y, f["pf"][c0:c1], f["bf"][c0 * f["cmax"]:c1 * f["cmax"]], c1 - c0, out=z,
-                                            out_groups=groups, out_group0=c0)
+                y = buf[: n * (c1 - c0) * 64 * h * w].view(n, h, w, (c1 - c0) * 64)
+                first.f16(x, out_f32_nchw=False, out=y, tiles=(c0 // per, c1 // per))
+                _conv.grouped_conv3x3_small_f16(y, f["pf16"][c0:c1], f["bf"][c0 * f["cmax"]:c1 * f["cmax"]], c1 - c0,
+                                                out=z, out_groups=groups, out_group0=c0)
             rets = [dict() for _ in self.tasks]
             for g, (t, head) in enumerate(f["plan"]):
                 rets[t][head] = z[:, g * f["cmax"]:g * f["cmax"] + f["ncls"][g]]

@@ -185,6 +185,67 @@ __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_f16_kernel(const _Float
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The final SeparateHead convolutions under AMP (center_head.py:99-118: per head a 3x3 convolution from the 64 channels
+// of its first stage to 1 .. 3 maps): a grouped 3x3 convolution reading the first stage's fp16 NHWC output -- group g
+// = channels 64 g .. 64 g + 63 of every pixel, 128 contiguous bytes -- and writing the fp32 NCHW maps the post-processing
+// reads.  The fp32 form of this pair wrote the 2304-channel first-stage map as fp32 NCHW (2.4 GB per 16 frames, 1.02 ms)
+// and fetched it back (0.53 ms); in fp16 NHWC it is half of that in each direction and every fetched line is used whole.
+// Workgroup = (8 x 32-pixel tile, group, frame): the tile's (10 x 34) x 64 halfs are staged once (pixel lines padded to
+// 68 halfs: conflict-free ds_read_b128), thread = pixel, v_dot2_f32_f16 accumulates in fp32; the group's 9 x CO x 64
+// weights are LDS broadcasts.  The op is bound by the 1.2 GB it streams, not by its 33 GFLOP.
+template <int CO>
+__global__ __launch_bounds__(256) void grouped_conv3x3_small_f16_kernel(
+    const _Float16* __restrict__ x, const _Float16* __restrict__ wg, const float* __restrict__ bias, int groups, int h,
+    int w, float* __restrict__ out, int out_groups, int out_group0) {
+  constexpr int TR = 8, TC = 32, PW = TC + 2, PS = 68;  // tile rows / columns, patch width, halfs per staged pixel
+  __shared__ __attribute__((aligned(16))) _Float16 patch[(TR + 2) * PW * PS];
+  __shared__ __attribute__((aligned(16))) _Float16 wl[9 * CO * 64];
+  const int tiles_x = (w + TC - 1) / TC;
+  const int tx0 = (blockIdx.x % tiles_x) * TC, ty0 = (blockIdx.x / tiles_x) * TR;
+  const int g = blockIdx.y, n = blockIdx.z;
+  const int c = groups * 64;
+  const _Float16* xin = x + (int64_t)n * h * w * c + g * 64;
+  for (int e = threadIdx.x; e < (TR + 2) * PW * 8; e += 256) {
+    const int pix = e >> 3, q = e & 7;
+    const int pr = pix / PW, pc = pix - pr * PW;
+    const int gy = ty0 - 1 + pr, gx = tx0 - 1 + pc;
+    cf_h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = *reinterpret_cast<const cf_h8*>(xin + ((int64_t)gy * w + gx) * c + q * 8);
+    *reinterpret_cast<cf_h8*>(patch + pix * PS + q * 8) = v;
+  }
+  for (int e = threadIdx.x; e < 9 * CO * 8; e += 256)
+    *reinterpret_cast<cf_h8*>(wl + e * 8) = *reinterpret_cast<const cf_h8*>(wg + (int64_t)g * 9 * CO * 64 + e * 8);
+  __syncthreads();
+  const int ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
+  float acc[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+  typedef _Float16 cf_h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const _Float16* p = patch + ((ty + t / 3) * PW + tx + t % 3) * PS;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const cf_h8 v = *reinterpret_cast<const cf_h8*>(p + q * 8);
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+        const cf_h8 wv = *reinterpret_cast<const cf_h8*>(wl + (t * CO + o) * 64 + q * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[o] = __builtin_amdgcn_fdot2(cf_h2{v[2 * e], v[2 * e + 1]}, cf_h2{wv[2 * e], wv[2 * e + 1]}, acc[o], false);
+      }
+    }
+  }
+  const int y = ty0 + ty, xg = tx0 + tx;
+  if (y >= h || xg >= w) return;
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    const int ch = (out_group0 + g) * CO + o;
+    out[(((int64_t)n * out_groups * CO + ch) * h + y) * w + xg] = acc[o] + (bias ? bias[g * CO + o] : 0.f);
+  }
+}
+
 // fp32 NCHW -> fp16 NHWC (the boundary in front of a chain of fp16 layers): one workgroup per (n, y, 64 columns),
 // channels in chunks of 64 through an LDS tile (reads coalesced along x, writes along c)
 __global__ __launch_bounds__(256) void f32_nchw_to_f16_nhwc_kernel(const float* __restrict__ x, int c, int h, int w,
@@ -243,6 +304,28 @@ extern "C" int pd3_conv3x3_f16_bias_relu(const void* x_f16_nhwc, const void* w_p
                          : launch_conv_f16<2, 1>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s);
   return out_mode == 0 ? launch_conv_f16<1, 0>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s)
                        : launch_conv_f16<1, 1>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s);
+}
+
+extern "C" int pd3_grouped_conv3x3_small_f16(const void* x_f16_nhwc, const void* w_f16, const float* bias, int batch,
+                                             int groups, int channels_per_group, int out_per_group, int h, int w,
+                                             float* out, int out_groups, int out_group0, void* stream) {
+  if (!x_f16_nhwc || !w_f16 || !out || batch <= 0 || groups <= 0 || h <= 0 || w <= 0 || out_groups < groups ||
+      out_group0 < 0 || out_group0 + groups > out_groups)
+    return PD3_EINVAL;
+  if (channels_per_group != 64 || out_per_group < 1 || out_per_group > 4 || groups > 65535 || batch > 65535)
+    return PD3_EUNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(x_f16_nhwc) % 16 != 0 || reinterpret_cast<uintptr_t>(w_f16) % 16 != 0) return PD3_EINVAL;
+  const dim3 grid((unsigned)(ceil_div(w, 32) * ceil_div(h, 8)), (unsigned)groups, (unsigned)batch);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const _Float16* x = static_cast<const _Float16*>(x_f16_nhwc);
+  const _Float16* wg = static_cast<const _Float16*>(w_f16);
+  switch (out_per_group) {
+    case 1: grouped_conv3x3_small_f16_kernel<1><<<grid, 256, 0, s>>>(x, wg, bias, groups, h, w, out, out_groups, out_group0); break;
+    case 2: grouped_conv3x3_small_f16_kernel<2><<<grid, 256, 0, s>>>(x, wg, bias, groups, h, w, out, out_groups, out_group0); break;
+    case 3: grouped_conv3x3_small_f16_kernel<3><<<grid, 256, 0, s>>>(x, wg, bias, groups, h, w, out, out_groups, out_group0); break;
+    default: grouped_conv3x3_small_f16_kernel<4><<<grid, 256, 0, s>>>(x, wg, bias, groups, h, w, out, out_groups, out_group0); break;
+  }
+  return launch_status();
 }
 
 extern "C" int pd3_f32_nchw_to_f16_nhwc(const float* x, int batch, int channels, int h, int w, void* out, void* stream) {

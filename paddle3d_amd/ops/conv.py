@@ -13,7 +13,8 @@ __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pitch4", "p
            "patch_mode", "patch_supported", "pack_patch_weight", "patch_conv_bias_relu",
            "winograd43_supported", "winograd43_tile", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu",
            "WINOGRAD43_PP_MIN_CIN", "winograd43_pp_supported", "pack_winograd43_lane_weight", "conv3x3_winograd43_pp_bias_relu",
-           "f16_supported", "f16_tile", "pack_conv3x3_f16_weight", "conv3x3_f16_bias_relu", "to_f16_nhwc"]
+           "f16_supported", "f16_tile", "pack_conv3x3_f16_weight", "conv3x3_f16_bias_relu", "to_f16_nhwc",
+           "pack_grouped_weight_f16", "grouped_conv3x3_small_f16"]
 
 
 def pitch4(w: int) -> int:
@@ -260,6 +261,35 @@ def conv3x3_f16_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: i
     check(lib().pd3_conv3x3_f16_bias_relu(ptr(x), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
                                           ptr(out), 1 if out_f32_nchw else 0, tile, stream_ptr(x.device)),
           "conv3x3_f16_bias_relu")
+    return out
+
+
+def pack_grouped_weight_f16(weight: torch.Tensor, groups: int) -> torch.Tensor:
+    """[groups * co, 64, 3, 3] fp32 -> fp16 [groups][9 taps (dy*3+dx)][co][64]: the operand order of
+    grouped_conv3x3_small_f16."""
+    gco, cg = weight.shape[:2]
+    co = gco // groups
+    assert weight.shape[2:] == (3, 3) and cg == 64 and gco == groups * co and 1 <= co <= 4
+    return weight.to(torch.float16).reshape(groups, co, cg, 9).permute(0, 3, 1, 2).contiguous()
+
+
+def grouped_conv3x3_small_f16(x_h: torch.Tensor, w_f16: torch.Tensor, bias, groups: int,
+                              out: torch.Tensor | None = None, out_groups: int | None = None,
+                              out_group0: int = 0) -> torch.Tensor:
+    """grouped_conv3x3_small on the first stage's fp16 NHWC output: x_h [n, h, w, groups * 64] fp16 -> fp32 NCHW maps
+    [n, out_groups * co, h, w] (this slice's groups at [out_group0, out_group0 + groups))."""
+    if x_h.dtype != torch.float16 or not x_h.is_cuda or not x_h.is_contiguous():
+        raise RuntimeError("grouped_conv3x3_small_f16: x must be a contiguous fp16 NHWC tensor on the GPU")
+    n, h, w, c = x_h.shape
+    co = int(w_f16.shape[2])
+    assert c == groups * 64 and tuple(w_f16.shape) == (groups, 9, co, 64)
+    total = groups if out_groups is None else int(out_groups)
+    if out is None:
+        out = torch.empty((n, total * co, h, w), dtype=torch.float32, device=x_h.device)
+    assert out.is_contiguous() and tuple(out.shape) == (n, total * co, h, w)
+    check(lib().pd3_grouped_conv3x3_small_f16(ptr(x_h), ptr(w_f16.contiguous()), ptr(bias), n, groups, 64, co, h, w,
+                                              ptr(out), total, int(out_group0), stream_ptr(x_h.device)),
+          "grouped_conv3x3_small_f16")
     return out
 
 

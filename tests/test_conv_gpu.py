@@ -355,3 +355,28 @@ def test_winograd43_pingpong_form(n, cin, cout, h, w, relu):
     assert (got[..., :wv].cpu() - ref).abs().max().item() < 1e-3
     assert (got[..., wv:] == 0).all()
     assert torch.equal(got, packed)  # the same U, the same order of accumulation: the same bytes
+
+
+@pytest.mark.parametrize("groups,co,h,w", [(6, 3, 32, 64), (4, 1, 20, 45), (36, 3, 16, 32), (2, 4, 9, 33), (3, 2, 128, 128)])
+def test_grouped_conv3x3_small_f16_matches_fp32_math_on_fp16_operands(groups, co, h, w):
+    """The AMP form of the final SeparateHead convolutions (fp16 NHWC in, fp32 NCHW out, v_dot2_f32_f16 with fp32
+    accumulation) against torch's grouped fp32 convolution of the same fp16-rounded values: accumulation-order noise only.
+    Partial tiles, every output width 1 .. 4, a slice of the groups written into a wider output."""
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator(device="cuda").manual_seed(groups * 100 + co + h)
+    x = torch.randn(2, groups * 64, h, w, device="cuda", generator=g)
+    wt = torch.randn(groups * co, 64, 3, 3, device="cuda", generator=g) / 24.0
+    b = torch.randn(groups * co, device="cuda", generator=g)
+    xh = conv.to_f16_nhwc(x)
+    ref = F.conv2d(x.half().float().cpu(), wt.half().float().cpu(), b.cpu(), padding=1, groups=groups).cuda()
+    wp = conv.pack_grouped_weight_f16(wt, groups)
+    got = conv.grouped_conv3x3_small_f16(xh, wp, b, groups)
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+    if groups >= 4:  # the head's slices: groups [2, 4) of the input land at groups [3, 5) of a 6-group output
+        out = torch.full((2, 6 * co, h, w), 7.0, device="cuda")
+        xs = xh[..., 2 * 64:4 * 64].contiguous()
+        conv.grouped_conv3x3_small_f16(xs, wp[2:4], b[2 * co:4 * co], 2, out=out, out_groups=6, out_group0=3)
+        assert torch.equal(out[:, 3 * co:5 * co], got[:, 2 * co:4 * co])
+        assert (out[:, :3 * co] == 7.0).all() and (out[:, 5 * co:] == 7.0).all()
