@@ -536,6 +536,16 @@ int pd3_stable_argsort(const void *keys, int64_t n, int mode, uint32_t max_key, 
 int pd3_conv3x3_f16_bias_relu(const void *x_f16_nhwc, const void *w_packed_f16, const float *bias, int batch, int cin,
                               int cout, int h, int w, int relu, void *out, int out_mode, int channels_per_tile,
                               void *stream);
+/* out_mode "both": a block's last stride-1 layer under AMP leaves fp16 NHWC (the next block's stride-2 convolution reads
+ * it) AND fp32 NCHW (the FPN level reads it) in one pass.  Arguments as pd3_conv3x3_f16_bias_relu. */
+int pd3_conv3x3_f16_bias_relu_dual(const void *x_f16_nhwc, const void *w_packed_f16, const float *bias, int batch,
+                                   int cin, int cout, int h, int w, int relu, void *out_f16_nhwc, float *out_f32_nchw,
+                                   int channels_per_tile, void *stream);
+/* The stride-2 3x3 / pad 1 convolutions that open SecondBackbone's blocks (second_backbone.py:84-113) under AMP:
+ * x [batch, h, w, cin] fp16 NHWC -> out [batch, (h - 1) / 2 + 1, (w - 1) / 2 + 1, cout] fp16 NHWC; weights packed as for
+ * pd3_conv3x3_f16_bias_relu with T = 128; cin % 16 == 0, cout % 128 == 0 (else -3: the caller runs the fp32 kernel). */
+int pd3_conv3x3_s2_f16_bias_relu(const void *x_f16_nhwc, const void *w_packed_f16, const float *bias, int batch, int cin,
+                                 int cout, int h, int w, int relu, void *out_f16_nhwc, void *stream);
 /* The final SeparateHead convolutions under AMP (center_head.py:99-118): grouped 3x3 / pad 1 convolution + bias reading
  * the first stage's fp16 NHWC output.
  *   x_f16_nhwc [batch, h, w, groups * 64] fp16; w_f16 [groups][9 taps][out_per_group][64] fp16; bias [groups *

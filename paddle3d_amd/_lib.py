@@ -121,6 +121,10 @@ _SIGNATURES = {
     "pd3_conv3x3_f16_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pd3_f32_nchw_to_f16_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_conv3x3_f16_bias_relu_dual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pd3_conv3x3_s2_f16_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pd3_grouped_conv3x3_small_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pd3_stable_argsort_workspace": (C.c_size_t, [C.c_int64, C.c_uint32]),

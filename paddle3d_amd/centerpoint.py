@@ -332,6 +332,21 @@ class _Conv3x3:
     def f16_ok(self, h, w):
         return self.stride == 1 and _conv.f16_supported(self.cin, self.cout, int(h), int(w))
 
+    def f16_s2_ok(self):
+        return self.stride == 2 and _conv.s2_f16_supported(self.cin, self.cout)
+
+    def f16_s2(self, x_h):
+        """The stride-2 layer in mixed precision: x_h [n, h, w, cin] fp16 NHWC -> fp16 NHWC at half the size."""
+        if "f16s2" not in self.packed:
+            self.packed["f16s2"] = _conv.pack_conv3x3_f16_weight(self.w, tile=128)
+        return _conv.conv3x3_s2_f16_bias_relu(x_h, self.packed["f16s2"], self.b, self.cout, relu=True)
+
+    def f16_dual(self, x_h):
+        """f16() leaving both forms of the result: (fp16 NHWC, fp32 NCHW)."""
+        if "f16" not in self.packed:
+            self.packed["f16"] = _conv.pack_conv3x3_f16_weight(self.w)
+        return _conv.conv3x3_f16_bias_relu_dual(x_h, self.packed["f16"], self.b, self.cout, relu=True)
+
     def f16(self, x_h, out_f32_nchw=False, out=None, tiles=None):
         """The same layer in mixed precision (AMP): x_h [n, h, w, cin] fp16 NHWC -> fp16 NHWC, or fp32 NCHW for the
         fp32 kernels behind a chain.  tiles = (first, last) channel tile of the packed weight (the head's slices)."""
@@ -408,6 +423,7 @@ class SecondBackbone(_InferenceCache, nn.Module):
             raise Paddle3DAmdError(f"SecondBackbone: unsupported configuration (input width {x.shape[3]} is not a "
                                    "multiple of 4) (status -3)")
         outs, wv = [], (0 if first is not None else int(x.shape[3]))
+        carry = None  # mixed precision: the previous block's result as fp16 NHWC, for this block's stride-2 convolution
         for bi, layers in enumerate(plan):
             li = 0
             while li < len(layers):
@@ -416,17 +432,36 @@ class SecondBackbone(_InferenceCache, nn.Module):
                     x, wv = first
                     li += 1
                     continue
+                xh = None
+                if self.amp and li == 0 and carry is not None and conv.f16_s2_ok() and wv == x.shape[3]:
+                    # (round 5) the block opens on the fp16 matrix cores too: no fp32 stride-2 kernel, no conversion
+                    xh = conv.f16_s2(carry)
+                    li, wv = 1, wv // 2
+                    x = None  # (the fp32 NCHW form of this layer's result is never needed)
+                carry = None
                 # mixed precision (set_amp): a run of stride-1 layers the fp16 kernel takes travels as fp16 NHWC --
-                # one conversion in front, the last layer of the run writes fp32 NCHW for the kernels behind it
+                # one conversion in front (none behind an fp16 stride-2 layer); the last layer of the run writes fp32
+                # NCHW for the kernels behind it, and fp16 NHWC as well where the next block can open on it
+                h_now = int(xh.shape[1]) if xh is not None else int(x.shape[2])
+                w_now = int(xh.shape[2]) if xh is not None else int(x.shape[3])
                 run = li
-                while (self.amp and run < len(layers) and wv == x.shape[3]
-                       and layers[run].f16_ok(x.shape[2], x.shape[3])):
+                while (self.amp and run < len(layers) and wv == w_now and layers[run].f16_ok(h_now, w_now)):
                     run += 1
                 if run > li:
-                    xh = _conv.to_f16_nhwc(x)
+                    if xh is None:
+                        xh = _conv.to_f16_nhwc(x)
+                    nxt = plan[bi + 1][0] if bi + 1 < len(plan) else None
+                    both = run == len(layers) and nxt is not None and nxt.f16_s2_ok()
                     for k in range(li, run):
-                        xh = layers[k].f16(xh, out_f32_nchw=(k == run - 1))
-                    x, li = xh, run
+                        if k == run - 1 and both:
+                            carry, x = layers[k].f16_dual(xh)
+                        else:
+                            xh = layers[k].f16(xh, out_f32_nchw=(k == run - 1))
+                            x = xh
+                    li = run
+                    continue
+                if xh is not None:  # an fp16 stride-2 layer with no fp16 run behind it: back to fp32 NCHW
+                    x = xh.permute(0, 3, 1, 2).float().contiguous()
                     continue
                 x, wv = conv(x, wv)
                 li += 1

@@ -49,13 +49,15 @@ struct CfShape {
   static constexpr size_t LDS = (size_t)2 * (PATCH + WTS) * sizeof(_Float16);
 };
 
-// out_mode 0: fp16 NHWC (the next stride-1 layer's input); 1: fp32 NCHW (what every fp32 kernel of the graph reads)
+// out_mode 0: fp16 NHWC (the next fp16 layer's input); 1: fp32 NCHW (what every fp32 kernel of the graph reads); 2: both
+// (a block's last layer: fp16 NHWC for the next block's stride-2 convolution, fp32 NCHW for the FPN level -- out2)
 template <int MB, int OUT_MODE>
 __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_f16_kernel(const _Float16* __restrict__ x,
                                                                     const _Float16* __restrict__ wp,
                                                                     const float* __restrict__ bias,
                                                                     void* __restrict__ out, int cin, int cout, int h,
-                                                                    int w, int relu, int ptiles) {
+                                                                    int w, int relu, int ptiles,
+                                                                    float* __restrict__ out2 = nullptr) {
   using S = CfShape<MB>;
   extern __shared__ __attribute__((aligned(16))) _Float16 cf_smem[];
   const int lane = lane_id(), wave = wave_id();
@@ -168,18 +170,163 @@ __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_f16_kernel(const _Float
         if (relu) v[r] = fmaxf(v[r], 0.f);
       }
       if (yg >= h || xg >= w) continue;  // a border tile's pixels outside the map (round 5: 180 x 180 maps of config 4)
-      if (OUT_MODE == 0) {
+      if (OUT_MODE == 0 || OUT_MODE == 2) {
         _Float16* o = reinterpret_cast<_Float16*>(out) + (((int64_t)n * h + yg) * w + xg) * cout + co0 + 32 * i + 4 * kh;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const cf_h4 pk = {(_Float16)v[4 * q], (_Float16)v[4 * q + 1], (_Float16)v[4 * q + 2], (_Float16)v[4 * q + 3]};
           *reinterpret_cast<cf_h4*>(o + 8 * q) = pk;
         }
-      } else {
-        float* o = reinterpret_cast<float*>(out) + (((int64_t)n * cout + co0 + 32 * i + 4 * kh) * h + yg) * w + xg;
+      }
+      if (OUT_MODE == 1 || OUT_MODE == 2) {
+        float* o = (OUT_MODE == 1 ? reinterpret_cast<float*>(out) : out2) +
+                   (((int64_t)n * cout + co0 + 32 * i + 4 * kh) * h + yg) * w + xg;
         const int64_t plane = (int64_t)h * w;
 #pragma unroll
         for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], o + ((r & 3) + 8 * (r >> 2)) * plane);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The stride-2 3x3 / pad 1 convolutions that open SecondBackbone's blocks 1 and 2 (second_backbone.py:84-113) under AMP:
+// the same direct implicit GEMM on fp16 NHWC, output pixel (y, x) reading input pixels (2 y - 1 + dy, 2 x - 1 + dx).
+// Workgroup = 8 waves = 128 output channels x 8 output rows x 32 output columns; wave (mw, nw) owns 64 channels x 2 rows =
+// 2 x 2 MFMA blocks.  The staged patch is 17 input rows x 65 input columns x 16 channels with the COLUMNS DE-INTERLEAVED
+// (even columns, then odd columns of a row): output column l reads input column 2 l + dx = entry l + (dx >> 1) of plane
+// dx & 1, so the 32 lanes of a B operand read 32 consecutive 32-byte pixels exactly as in the stride-1 kernel (with the
+// columns interleaved their stride would be 64 bytes: a four-way bank conflict on every ds_read_b128).
+// fp16 NHWC out (the block's stride-1 layers follow).  cin % 16 == 0, cout % 128 == 0.
+constexpr int kCs2R = 8;                         // output rows per workgroup
+constexpr int kCs2PR = 2 * kCs2R + 1;            // staged input rows
+constexpr int kCs2Half = kCfCols + 1;            // entries per parity plane of a staged row (33)
+constexpr int kCs2Patch = kCs2PR * 2 * kCs2Half * kCfKc;  // halfs
+constexpr int kCs2Wts = 9 * 128 * kCfKc;
+constexpr int kCs2PPieces = kCs2Patch / 8, kCs2WPieces = kCs2Wts / 8;
+constexpr int kCs2PPT = (kCs2PPieces + kCfThreads - 1) / kCfThreads, kCs2WPT = (kCs2WPieces + kCfThreads - 1) / kCfThreads;
+constexpr size_t kCs2Lds = (size_t)2 * (kCs2Patch + kCs2Wts) * sizeof(_Float16);
+
+__global__ __launch_bounds__(kCfThreads, 1) void conv3x3_s2_f16_kernel(const _Float16* __restrict__ x,
+                                                                       const _Float16* __restrict__ wp,
+                                                                       const float* __restrict__ bias,
+                                                                       _Float16* __restrict__ out, int cin, int cout,
+                                                                       int h, int w, int ho, int wo, int relu, int ptiles) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 cf_smem[];
+  const int lane = lane_id(), wave = wave_id();
+  const int tiles_x = (wo + kCfCols - 1) / kCfCols, tiles_y = (ho + kCs2R - 1) / kCs2R;
+  const int nct = cout / 128;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ct = slot % nct, pt = (slot / nct) * 8 + xcd;
+  if (pt >= ptiles) return;
+  const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
+  const int y0 = ty * kCs2R, x0 = tx * kCfCols;  // output coordinates of the tile
+  const int chunks = cin / kCfKc;
+  const _Float16* xin = x + (int64_t)n * h * w * cin;
+  const cf_h8* wsrc = reinterpret_cast<const cf_h8*>(wp) + (int64_t)ct * chunks * kCs2WPieces;
+
+  // staging pattern: piece e = (staged pixel, half of its 16 channels); staged pixel = (row pr, parity, entry)
+  int pofs[kCs2PPT];
+  unsigned plive = 0;
+#pragma unroll
+  for (int i = 0; i < kCs2PPT; ++i) {
+    const int e = min((int)threadIdx.x + i * kCfThreads, kCs2PPieces - 1);
+    const int pix = e >> 1, hf = e & 1;
+    const int pr = pix / (2 * kCs2Half), rem = pix - pr * (2 * kCs2Half);
+    const int par = rem / kCs2Half, ent = rem - par * kCs2Half;
+    const int pc = 2 * ent + par;  // input column of the patch, 0 .. 65 (65 = the odd plane's unused last entry)
+    const int gy = 2 * y0 - 1 + pr, gx = 2 * x0 - 1 + pc;
+    const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w && pc <= 2 * kCfCols;
+    pofs[i] = ok ? (gy * w + gx) * cin + 8 * hf : 0;
+    plive |= ok ? (1u << i) : 0u;
+  }
+  cf_h8 preg[kCs2PPT], wreg[kCs2WPT];
+  auto fetch = [&](int c) {
+    const _Float16* xc = xin + c * kCfKc;
+#pragma unroll
+    for (int i = 0; i < kCs2PPT; ++i) preg[i] = *reinterpret_cast<const cf_h8*>(xc + pofs[i]);
+    const cf_h8* wc = wsrc + (int64_t)c * kCs2WPieces;
+#pragma unroll
+    for (int i = 0; i < kCs2WPT; ++i) wreg[i] = wc[min((int)threadIdx.x + i * kCfThreads, kCs2WPieces - 1)];
+  };
+  auto stash = [&](int buf) {
+    _Float16* P = cf_smem + buf * (kCs2Patch + kCs2Wts);
+    _Float16* W = P + kCs2Patch;
+#pragma unroll
+    for (int i = 0; i < kCs2PPT; ++i) {
+      const int e = (int)threadIdx.x + i * kCfThreads;
+      const cf_h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (kCs2PPieces % kCfThreads == 0 || e < kCs2PPieces)
+        *reinterpret_cast<cf_h8*>(P + e * 8) = ((plive >> i) & 1u) ? preg[i] : z;
+    }
+#pragma unroll
+    for (int i = 0; i < kCs2WPT; ++i) {
+      const int e = (int)threadIdx.x + i * kCfThreads;
+      if (kCs2WPieces % kCfThreads == 0 || e < kCs2WPieces) *reinterpret_cast<cf_h8*>(W + e * 8) = wreg[i];
+    }
+  };
+
+  const int mw = wave & 1, nw = wave >> 1;  // the wave's 64-channel block and its pair of output rows
+  const int l31 = lane & 31, kh = lane >> 5;
+  cf_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int c = 0; c < chunks; ++c) {
+    const bool more = c + 1 < chunks;
+    if (more) fetch(c + 1);
+    const _Float16* P = cf_smem + (c & 1) * (kCs2Patch + kCs2Wts);
+    const _Float16* W = P + kCs2Patch;
+    const _Float16* wa = W + ((mw * 64 + l31) * kCfKc + 8 * kh);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3, dx = t - 3 * dy;
+      cf_h8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const cf_h8*>(wa + (t * 128 + i * 32) * kCfKc);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int pr = 2 * (nw * 2 + j) + dy;
+        b[j] = *reinterpret_cast<const cf_h8*>(P + (((pr * 2 + (dx & 1)) * kCs2Half + l31 + (dx >> 1)) * kCfKc + 8 * kh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) stash((c + 1) & 1);
+    __syncthreads();
+  }
+  const int co0 = ct * 128 + mw * 64;
+  const int xg = x0 + l31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = bias ? bias[co0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int yg = y0 + nw * 2 + j;
+      if (yg >= ho || xg >= wo) continue;
+      _Float16* o = out + (((int64_t)n * ho + yg) * wo + xg) * cout + co0 + 32 * i + 4 * kh;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[i][j][4 * q + e] + bv[4 * q + e];
+          if (relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        const cf_h4 pk = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        *reinterpret_cast<cf_h4*>(o + 8 * q) = pk;
       }
     }
   }
@@ -275,7 +422,7 @@ using namespace pd3;
 
 template <int MB, int OUT_MODE>
 static int launch_conv_f16(const void* x, const void* wp, const float* bias, int batch, int cin, int cout, int h, int w,
-                           int relu, void* out, hipStream_t s) {
+                           int relu, void* out, hipStream_t s, float* out2 = nullptr) {
   using S = CfShape<MB>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16_kernel<MB, OUT_MODE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS);
@@ -284,7 +431,8 @@ static int launch_conv_f16(const void* x, const void* wp, const float* bias, int
   const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / S::M);
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
   conv3x3_f16_kernel<MB, OUT_MODE><<<(unsigned)nwg, kCfThreads, S::LDS, s>>>(
-      static_cast<const _Float16*>(x), static_cast<const _Float16*>(wp), bias, out, cin, cout, h, w, relu, (int)ptiles);
+      static_cast<const _Float16*>(x), static_cast<const _Float16*>(wp), bias, out, cin, cout, h, w, relu, (int)ptiles,
+      out2);
   return launch_status();
 }
 
@@ -304,6 +452,46 @@ extern "C" int pd3_conv3x3_f16_bias_relu(const void* x_f16_nhwc, const void* w_p
                          : launch_conv_f16<2, 1>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s);
   return out_mode == 0 ? launch_conv_f16<1, 0>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s)
                        : launch_conv_f16<1, 1>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s);
+}
+
+extern "C" int pd3_conv3x3_f16_bias_relu_dual(const void* x_f16_nhwc, const void* w_packed_f16, const float* bias,
+                                              int batch, int cin, int cout, int h, int w, int relu, void* out_f16_nhwc,
+                                              float* out_f32_nchw, int channels_per_tile, void* stream) {
+  if (!x_f16_nhwc || !w_packed_f16 || !out_f16_nhwc || !out_f32_nchw || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 ||
+      w <= 0)
+    return PD3_EINVAL;
+  if (channels_per_tile != 64 && channels_per_tile != 128) return PD3_EINVAL;
+  if (reinterpret_cast<uintptr_t>(x_f16_nhwc) % 16 != 0 || reinterpret_cast<uintptr_t>(w_packed_f16) % 16 != 0 ||
+      reinterpret_cast<uintptr_t>(out_f16_nhwc) % 16 != 0 || reinterpret_cast<uintptr_t>(out_f32_nchw) % 16 != 0)
+    return PD3_EINVAL;
+  if (cin % kCfKc != 0 || cout % channels_per_tile != 0) return PD3_EUNSUPPORTED;
+  if ((int64_t)h * w * cin >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (channels_per_tile == 128)
+    return launch_conv_f16<2, 2>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out_f16_nhwc, s, out_f32_nchw);
+  return launch_conv_f16<1, 2>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out_f16_nhwc, s, out_f32_nchw);
+}
+
+extern "C" int pd3_conv3x3_s2_f16_bias_relu(const void* x_f16_nhwc, const void* w_packed_f16, const float* bias, int batch,
+                                            int cin, int cout, int h, int w, int relu, void* out_f16_nhwc, void* stream) {
+  if (!x_f16_nhwc || !w_packed_f16 || !out_f16_nhwc || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0)
+    return PD3_EINVAL;
+  if (reinterpret_cast<uintptr_t>(x_f16_nhwc) % 16 != 0 || reinterpret_cast<uintptr_t>(w_packed_f16) % 16 != 0 ||
+      reinterpret_cast<uintptr_t>(out_f16_nhwc) % 8 != 0)
+    return PD3_EINVAL;
+  if (cin % kCfKc != 0 || cout % 128 != 0) return PD3_EUNSUPPORTED;
+  if ((int64_t)h * w * cin >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_s2_f16_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCs2Lds);
+  if (e != hipSuccess) return (int)e;
+  const int64_t ptiles = (int64_t)batch * ceil_div(ho, kCs2R) * ceil_div(wo, kCfCols);
+  const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / 128);
+  if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
+  conv3x3_s2_f16_kernel<<<(unsigned)nwg, kCfThreads, kCs2Lds, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const _Float16*>(x_f16_nhwc), static_cast<const _Float16*>(w_packed_f16), bias,
+      static_cast<_Float16*>(out_f16_nhwc), cin, cout, h, w, ho, wo, relu, (int)ptiles);
+  return launch_status();
 }
 
 extern "C" int pd3_grouped_conv3x3_small_f16(const void* x_f16_nhwc, const void* w_f16, const float* bias, int batch,

@@ -14,7 +14,8 @@ __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pitch4", "p
            "winograd43_supported", "winograd43_tile", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu",
            "WINOGRAD43_PP_MIN_CIN", "winograd43_pp_supported", "pack_winograd43_lane_weight", "conv3x3_winograd43_pp_bias_relu",
            "f16_supported", "f16_tile", "pack_conv3x3_f16_weight", "conv3x3_f16_bias_relu", "to_f16_nhwc",
-           "pack_grouped_weight_f16", "grouped_conv3x3_small_f16"]
+           "pack_grouped_weight_f16", "grouped_conv3x3_small_f16", "conv3x3_f16_bias_relu_dual",
+           "s2_f16_supported", "conv3x3_s2_f16_bias_relu"]
 
 
 def pitch4(w: int) -> int:
@@ -261,6 +262,37 @@ def conv3x3_f16_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: i
     check(lib().pd3_conv3x3_f16_bias_relu(ptr(x), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
                                           ptr(out), 1 if out_f32_nchw else 0, tile, stream_ptr(x.device)),
           "conv3x3_f16_bias_relu")
+    return out
+
+
+def conv3x3_f16_bias_relu_dual(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, relu: bool = True):
+    """conv3x3_f16_bias_relu leaving BOTH forms of the result: ([n, h, w, cout] fp16 NHWC, [n, cout, h, w] fp32 NCHW)."""
+    if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous():
+        raise RuntimeError("conv3x3_f16_bias_relu: x must be a contiguous fp16 NHWC tensor on the GPU")
+    n, h, w, cin = x.shape
+    tile = int(w_packed.shape[3])
+    oh = torch.empty((n, h, w, cout), dtype=torch.float16, device=x.device)
+    of = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    check(lib().pd3_conv3x3_f16_bias_relu_dual(ptr(x), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
+                                               ptr(oh), ptr(of), tile, stream_ptr(x.device)),
+          "conv3x3_f16_bias_relu_dual")
+    return oh, of
+
+
+def s2_f16_supported(cin: int, cout: int) -> bool:
+    return cin % 16 == 0 and cout % 128 == 0
+
+
+def conv3x3_s2_f16_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, relu: bool = True) -> torch.Tensor:
+    """Stride-2 3x3 / pad 1 convolution on fp16 NHWC: x [n, h, w, cin] -> [n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, cout]
+    fp16 NHWC; w_packed = pack_conv3x3_f16_weight(weight, tile=128)."""
+    if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous():
+        raise RuntimeError("conv3x3_s2_f16_bias_relu: x must be a contiguous fp16 NHWC tensor on the GPU")
+    n, h, w, cin = x.shape
+    assert int(w_packed.shape[3]) == 128
+    out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, cout), dtype=torch.float16, device=x.device)
+    check(lib().pd3_conv3x3_s2_f16_bias_relu(ptr(x), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
+                                             ptr(out), stream_ptr(x.device)), "conv3x3_s2_f16_bias_relu")
     return out
 
 

@@ -380,3 +380,39 @@ def test_grouped_conv3x3_small_f16_matches_fp32_math_on_fp16_operands(groups, co
         conv.grouped_conv3x3_small_f16(xs, wp[2:4], b[2 * co:4 * co], 2, out=out, out_groups=6, out_group0=3)
         assert torch.equal(out[:, 3 * co:5 * co], got[:, 2 * co:4 * co])
         assert (out[:, :3 * co] == 7.0).all() and (out[:, 5 * co:] == 7.0).all()
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 128, 64, 64), (128, 256, 32, 96), (16, 128, 33, 45), (32, 384, 18, 70),
+                                          (64, 128, 256, 256)])
+def test_conv3x3_s2_f16_matches_fp32_math_on_fp16_operands(cin, cout, h, w):
+    """The stride-2 convolution that opens a backbone block under AMP (fp16 NHWC in and out, de-interleaved patch columns)
+    against torch's fp32 stride-2 convolution of the same fp16-rounded values; odd sizes, partial tiles, image borders."""
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator(device="cuda").manual_seed(cin + cout + h)
+    x = torch.randn(2, cin, h, w, device="cuda", generator=g)
+    wt = torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, device="cuda", generator=g)
+    assert conv.s2_f16_supported(cin, cout) and not conv.s2_f16_supported(cin, 64)
+    ref = F.relu(F.conv2d(x.half().float().cpu(), wt.half().float().cpu(), b.cpu(), stride=2, padding=1)).cuda()
+    got = conv.conv3x3_s2_f16_bias_relu(conv.to_f16_nhwc(x), conv.pack_conv3x3_f16_weight(wt, tile=128), b, cout)
+    assert got.dtype == torch.float16 and got.shape == (2, ref.shape[2], ref.shape[3], cout)
+    err = (got.float().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item())
+    got2 = conv.conv3x3_s2_f16_bias_relu(conv.to_f16_nhwc(x), conv.pack_conv3x3_f16_weight(wt, tile=128), None, cout,
+                                         relu=False)
+    ref2 = F.conv2d(x.half().float().cpu(), wt.half().float().cpu(), None, stride=2, padding=1).cuda()
+    assert (got2.float().permute(0, 3, 1, 2) - ref2).abs().max().item() < 2e-3 * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 40, 64), (128, 128, 16, 50)])
+def test_conv3x3_f16_dual_output_is_both_single_outputs(cin, cout, h, w):
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator(device="cuda").manual_seed(cin + h)
+    xh = conv.to_f16_nhwc(torch.randn(2, cin, h, w, device="cuda", generator=g))
+    wp = conv.pack_conv3x3_f16_weight(torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / (cin * 9) ** 0.5)
+    b = torch.randn(cout, device="cuda", generator=g)
+    oh, of = conv.conv3x3_f16_bias_relu_dual(xh, wp, b, cout)
+    assert torch.equal(oh, conv.conv3x3_f16_bias_relu(xh, wp, b, cout))
+    assert torch.equal(of, conv.conv3x3_f16_bias_relu(xh, wp, b, cout, out_f32_nchw=True))
