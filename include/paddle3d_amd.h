@@ -402,6 +402,14 @@ int pd3_sparse_conv3d_features_f16(const void *in_feats_f16, const int32_t *nbr,
                                    const float *bias, const float *scale, const float *shift,
                                    const void *residual_f16, int relu, const int32_t *order, void *out, int out_f32,
                                    void *stream);
+/* The same kernel as a general gather-GEMM: out[row, out_off + co] = epilogue(sum_k W[k] . in[nbr[row, k]]) into a
+ * channel slice of a wider row-major matrix (row stride out_ld).  Under AMP the FPN levels of SecondFPN
+ * (paddle3d/models/necks/second_fpn.py:99-157: kernel = stride convolutions / transposed convolutions) are this with a
+ * static neighbour table over the pixels of an fp16 NHWC map, each level writing its slice of the concatenated map. */
+int pd3_gather_gemm_f16(const void *in_feats_f16, const int32_t *nbr, const int32_t *n_out, int n_out_cap,
+                        int kernel_volume, int cin, int cout, const void *weight_packed_f16, const float *bias,
+                        const float *scale, const float *shift, const void *residual_f16, int relu,
+                        const int32_t *order, void *out, int out_f32, int out_ld, int out_off, void *stream);
 /* Plan path: the index sets of a whole encoder without a host round trip between the convolutions (the
  * reference's layers read nnz on the host after every sparse op).  An index set is a SORTED array of keys
  * ((b*D + z)*H + y)*W + x (raster order; 0xFFFFFFFF = padding, at the end) with its length in device memory.

@@ -101,6 +101,9 @@ _SIGNATURES = {
     "pd3_sparse_conv3d_features_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pd3_gather_gemm_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pd3_sparse_tile_order_entries": (C.c_int64, [C.c_int]),
     "pd3_sparse_tile_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pd3_sparse_plan_workspace": (C.c_size_t, [C.c_int]),

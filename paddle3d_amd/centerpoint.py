@@ -35,6 +35,7 @@ from ._lib import Paddle3DAmdError
 from .ops import centerpoint_postprocess as _cp
 from .ops import conv as _conv
 from .ops import pointpillars_scatter as _ps
+from .ops import sparse_conv3d as _sp3
 from .ops import voxel_encoder as _ve
 from .ops import voxelize as _vox
 
@@ -394,6 +395,8 @@ class SecondBackbone(_InferenceCache, nn.Module):
             blocks.append(nn.Sequential(*block))
         self.blocks = nn.ModuleList(blocks)
         self.amp = False  # True: the stride-1 layers run on the fp16 matrix cores (the reference's amp_cfg O2 configs)
+        self.amp_out_f16 = False  # under AMP the stage outputs leave as fp16 NHWC (set by CenterPoint.set_amp when the
+        #                           neck reads that form: no fp32 NCHW copy of a stage is written at all)
 
     def _plan(self):
         if not self._cache_valid():
@@ -433,7 +436,7 @@ class SecondBackbone(_InferenceCache, nn.Module):
                     li += 1
                     continue
                 xh = None
-                if self.amp and li == 0 and carry is not None and conv.f16_s2_ok() and wv == x.shape[3]:
+                if self.amp and li == 0 and carry is not None and conv.f16_s2_ok() and wv == carry.shape[2]:
                     # (round 5) the block opens on the fp16 matrix cores too: no fp32 stride-2 kernel, no conversion
                     xh = conv.f16_s2(carry)
                     li, wv = 1, wv // 2
@@ -442,6 +445,8 @@ class SecondBackbone(_InferenceCache, nn.Module):
                 # mixed precision (set_amp): a run of stride-1 layers the fp16 kernel takes travels as fp16 NHWC --
                 # one conversion in front (none behind an fp16 stride-2 layer); the last layer of the run writes fp32
                 # NCHW for the kernels behind it, and fp16 NHWC as well where the next block can open on it
+                if xh is None and x.dtype == torch.float16:  # (a stage left as fp16 NHWC whose successor stays fp32)
+                    x = x.permute(0, 3, 1, 2).float().contiguous()
                 h_now = int(xh.shape[1]) if xh is not None else int(x.shape[2])
                 w_now = int(xh.shape[2]) if xh is not None else int(x.shape[3])
                 run = li
@@ -451,9 +456,13 @@ class SecondBackbone(_InferenceCache, nn.Module):
                     if xh is None:
                         xh = _conv.to_f16_nhwc(x)
                     nxt = plan[bi + 1][0] if bi + 1 < len(plan) else None
-                    both = run == len(layers) and nxt is not None and nxt.f16_s2_ok()
+                    opens = run == len(layers) and nxt is not None and nxt.f16_s2_ok()
+                    stage_h = run == len(layers) and self.amp_out_f16  # the neck reads fp16 NHWC: no fp32 form at all
                     for k in range(li, run):
-                        if k == run - 1 and both:
+                        if k == run - 1 and stage_h:
+                            xh = layers[k].f16(xh)
+                            x, carry = xh, (xh if opens else None)
+                        elif k == run - 1 and opens:
                             carry, x = layers[k].f16_dual(xh)
                         else:
                             xh = layers[k].f16(xh, out_f32_nchw=(k == run - 1))
@@ -507,9 +516,75 @@ class SecondFPN(_InferenceCache, nn.Module):
             self._store_cache((plan, off))
         return self._cache
 
+    # ---- mixed precision (CenterPoint.set_amp): every level as one fp16 gather-GEMM over the pixels ------------------
+    def _amp_level(self, i, p, n, h, w, dev):
+        """Static pieces of level i on an [n, h, w, cin] fp16 NHWC input: the neighbour table over the output pixels
+        (a kernel = stride convolution reads s x s input pixels, a transposed one exactly one, at the tap its position
+        selects), its tile order, and the weight as [taps][cin][cout] in the fp16 kernel's operand order."""
+        key = (i, n, h, w)
+        cache = self.__dict__.setdefault("_amp_tables", {})
+        if key not in cache:
+            conv = self.deblocks[i][0]
+            s = int(conv.stride[0])
+            tr = isinstance(conv, nn.ConvTranspose2d)
+            ho, wo = (h * s, w * s) if tr else (h // s, w // s)
+            b = torch.arange(n, device=dev).view(n, 1, 1)
+            y = torch.arange(ho, device=dev).view(1, ho, 1)
+            x = torch.arange(wo, device=dev).view(1, 1, wo)
+            if tr:  # out (y, x) <- in (y // s, x // s) through tap (y % s, x % s)
+                src = ((b * h + y // s) * w + x // s).reshape(-1)
+                tap = ((y % s) * s + x % s).expand(n, ho, wo).reshape(-1)
+                nbr = torch.full((n * ho * wo, s * s), -1, dtype=torch.int32, device=dev)
+                nbr[torch.arange(n * ho * wo, device=dev), tap] = src.int()
+            else:   # out (y, x) <- in (s y + dy, s x + dx), tap dy s + dx
+                cols = [((b * h + y * s + dy) * w + x * s + dx).reshape(-1) for dy in range(s) for dx in range(s)]
+                nbr = torch.stack(cols, 1).int().contiguous()
+            order = _sp3.tile_order(nbr) if tr and s > 1 else None
+            cache[key] = (nbr, order, ho, wo)
+        wkey = ("w", i)
+        tag = _param_signature(self)
+        if wkey not in cache or cache[wkey][0] != tag:
+            conv, bn = self.deblocks[i][0], self.deblocks[i][1]
+            tr = isinstance(conv, nn.ConvTranspose2d)
+            wf, bf = _fold_conv_bn(conv, bn)
+            # [taps = ky * s + kx][cin][cout]
+            wk = wf.permute(2, 3, 0, 1) if tr else wf.permute(2, 3, 1, 0)
+            wk = wk.reshape(-1, wk.shape[2], wk.shape[3]).contiguous()
+            parts = []
+            step = 128 if wk.shape[2] % 128 == 0 else (64 if wk.shape[2] % 64 == 0 else 32)
+            for c0 in range(0, wk.shape[2], step):
+                parts.append((c0, step, _sp3.pack_weight_f16(wk[:, :, c0:c0 + step].contiguous()), bf[c0:c0 + step].contiguous()))
+            cache[wkey] = (tag, parts)
+        return cache[key], cache[wkey][1]
+
+    def amp_ok(self, xs):
+        plan, _ = self._plan()
+        return all(p["cin"] % 16 == 0 and p["cout"] % 32 == 0 and p["scale"] in (0.5, 1, 2, 4) for p in plan)
+
+    def forward_f16(self, xs):
+        """xs: the backbone's stage outputs as fp16 NHWC [n, h, w, c].  Returns the concatenated map as fp16 NHWC."""
+        self._require_eval()
+        plan, ctot = self._plan()
+        n = int(xs[0].shape[0])
+        out = None
+        for i, (p, x) in enumerate(zip(plan, xs)):
+            h, w = int(x.shape[1]), int(x.shape[2])
+            (nbr, order, ho, wo), parts = self._amp_level(i, p, n, h, w, x.device)
+            if out is None:
+                out = torch.empty((n, ho, wo, ctot), dtype=torch.float16, device=x.device)
+            elif tuple(out.shape[1:3]) != (ho, wo):
+                raise Paddle3DAmdError("SecondFPN: the levels do not meet at one resolution")
+            for c0, step, wp, bias in parts:
+                _sp3.gather_gemm_f16(x.view(n * h * w, p["cin"]), nbr, wp, p["cin"], step, out.view(n * ho * wo, ctot),
+                                     p["off"] + c0, bias=bias, relu=True, order=order)
+        return out
+
     def forward(self, xs):
         self._require_eval()
         plan, ctot = self._plan()
+        if all(x.dtype == torch.float16 for x in xs):
+            return self.forward_f16(xs)
+        xs = [x.permute(0, 3, 1, 2).float().contiguous() if x.dtype == torch.float16 else x for x in xs]
         sizes = {(int(x.shape[2] * p["scale"]), int(_valid_w(x) * p["scale"])) for p, x in zip(plan, xs)}
         if len(sizes) != 1 or len(plan) != len(xs):
             raise Paddle3DAmdError(f"SecondFPN: the levels do not meet at one resolution ({sorted(sizes)})")
@@ -611,15 +686,18 @@ class CenterHead(_InferenceCache, nn.Module):
         """x [B, C, H, W] -> (per task dict of head maps, shared feature map), center_head.py:212-220."""
         self._require_eval()
         f = self._plan()
-        if x.shape[3] % 4:
-            raise Paddle3DAmdError(f"CenterHead: unsupported configuration (map width {x.shape[3]} is not a multiple "
+        nhwc = x.dtype == torch.float16  # the neck's map as fp16 NHWC (the whole dense graph under AMP)
+        hh, ww = (int(x.shape[1]), int(x.shape[2])) if nhwc else (int(x.shape[2]), int(x.shape[3]))
+        if ww % 4:
+            raise Paddle3DAmdError(f"CenterHead: unsupported configuration (map width {ww} is not a multiple "
                                    "of 4) (status -3)")
-        amp = (self.amp and f["shared"].f16_ok(x.shape[2], x.shape[3])
-               and f["first"].f16_ok(x.shape[2], x.shape[3]) and f["hc"] == 64)
+        amp = self.amp and f["shared"].f16_ok(hh, ww) and f["first"].f16_ok(hh, ww) and f["hc"] == 64
+        if nhwc and not amp:
+            x, nhwc = x.permute(0, 3, 1, 2).float().contiguous(), False
         if amp:
             # mixed precision: shared convolution and the 36 first-stage convolutions on the fp16 matrix cores (fp16
-            # NHWC between them); the first stage writes fp32 NCHW for the grouped final convolutions, which stay fp32
-            x = f["shared"].f16(_conv.to_f16_nhwc(x))
+            # NHWC between them), the grouped final convolutions read the first stage's fp16 NHWC output
+            x = f["shared"].f16(x if nhwc else _conv.to_f16_nhwc(x))
             n, h, w, _ = (int(v) for v in x.shape)
         else:
             x, _ = f["shared"](x)
@@ -761,6 +839,10 @@ class CenterPoint(nn.Module):
         for m in (self.backbone, self.bbox_head, self.middle_encoder):
             if hasattr(m, "amp"):
                 m.amp = bool(enabled)
+        if hasattr(self.backbone, "amp_out_f16"):
+            # the whole dense graph in fp16 NHWC: backbone stages -> FPN levels (fp16 gather-GEMMs) -> head, no fp32 copy
+            # and no layout conversion between them
+            self.backbone.amp_out_f16 = bool(enabled) and hasattr(self.neck, "amp_ok") and self.neck.amp_ok(None)
         return self
 
     def _pack(self, points):

@@ -40,6 +40,7 @@ struct SpGemmF16Args {
   const int* n_out_dev;
   int n_out_cap, K, cin, cout, relu, out_f32;
   const int32_t* order;
+  int out_ld, out_off;       // row stride and first column of `out` (a channel slice of a wider row-major matrix)
 };
 
 template <int NC, int KC>
@@ -227,11 +228,11 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_f16_kernel(SpGemmF16Args 
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (a.out_f32) {
-          *reinterpret_cast<sf_f32x4*>(reinterpret_cast<float*>(a.out) + (int64_t)row * COUT + co) =
+          *reinterpret_cast<sf_f32x4*>(reinterpret_cast<float*>(a.out) + (int64_t)row * a.out_ld + a.out_off + co) =
               sf_f32x4{v[0], v[1], v[2], v[3]};
         } else {
           const sf_h4 pk = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-          *reinterpret_cast<sf_h4*>(reinterpret_cast<_Float16*>(a.out) + (int64_t)row * COUT + co) = pk;
+          *reinterpret_cast<sf_h4*>(reinterpret_cast<_Float16*>(a.out) + (int64_t)row * a.out_ld + a.out_off + co) = pk;
         }
       }
     }
@@ -275,14 +276,31 @@ extern "C" int pd3_sparse_pack_weight_f16(const float* weight, int kernel_volume
   return launch_status();
 }
 
+extern "C" int pd3_gather_gemm_f16(const void* in_feats_f16, const int32_t* nbr, const int32_t* n_out, int n_out_cap,
+                                   int kernel_volume, int cin, int cout, const void* weight_packed_f16,
+                                   const float* bias, const float* scale, const float* shift, const void* residual_f16,
+                                   int relu, const int32_t* order, void* out, int out_f32, int out_ld, int out_off,
+                                   void* stream);
+
 extern "C" int pd3_sparse_conv3d_features_f16(const void* in_feats_f16, const int32_t* nbr, const int32_t* n_out,
                                               int n_out_cap, int kernel_volume, int cin, int cout,
                                               const void* weight_packed_f16, const float* bias, const float* scale,
                                               const float* shift, const void* residual_f16, int relu,
                                               const int32_t* order, void* out, int out_f32, void* stream) {
+  return pd3_gather_gemm_f16(in_feats_f16, nbr, n_out, n_out_cap, kernel_volume, cin, cout, weight_packed_f16, bias,
+                             scale, shift, residual_f16, relu, order, out, out_f32, cout, 0, stream);
+}
+
+extern "C" int pd3_gather_gemm_f16(const void* in_feats_f16, const int32_t* nbr, const int32_t* n_out, int n_out_cap,
+                                   int kernel_volume, int cin, int cout, const void* weight_packed_f16,
+                                   const float* bias, const float* scale, const float* shift, const void* residual_f16,
+                                   int relu, const int32_t* order, void* out, int out_f32, int out_ld, int out_off,
+                                   void* stream) {
   if (!in_feats_f16 || !nbr || !weight_packed_f16 || !out || n_out_cap <= 0 || kernel_volume <= 0 || cin <= 0 ||
       cout <= 0)
     return PD3_EINVAL;
+  if (out_ld < cout || out_off < 0 || out_off + cout > out_ld || out_off % 4 != 0 || out_ld % 4 != 0) return PD3_EINVAL;
+  if (residual_f16 && (out_ld != cout || out_off != 0)) return PD3_EUNSUPPORTED;
   if ((scale == nullptr) != (shift == nullptr)) return PD3_EINVAL;
   if (cin % 16 != 0 || (cout != 32 && cout != 64 && cout != 128) || kernel_volume > kSfMaxK) return PD3_EUNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(in_feats_f16) % 16 != 0 || reinterpret_cast<uintptr_t>(weight_packed_f16) % 16 != 0 ||
@@ -292,7 +310,7 @@ extern "C" int pd3_sparse_conv3d_features_f16(const void* in_feats_f16, const in
     return PD3_EINVAL;
   SpGemmF16Args a{static_cast<const _Float16*>(in_feats_f16), nbr, static_cast<const _Float16*>(weight_packed_f16),
                   bias, scale, shift, static_cast<const _Float16*>(residual_f16), out, n_out, n_out_cap, kernel_volume,
-                  cin, cout, relu ? 1 : 0, out_f32 ? 1 : 0, order};
+                  cin, cout, relu ? 1 : 0, out_f32 ? 1 : 0, order, out_ld, out_off};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int kc = sf_chunk(cin), nc = cout / 32;
   const size_t lds = (size_t)2 * cout * (kc + 8) * sizeof(_Float16) +

@@ -19,7 +19,7 @@ import torch
 from ._common import check, host_i32, lib, ptr, require_gpu, stream_ptr, workspace
 
 __all__ = ["SparseIndices", "ConvSpec", "SparsePlan", "indices", "plan", "plan_caps", "features", "features_f16",
-           "pack_weight_f16", "f16_supported", "to_dense", "out_spatial_shape"]
+           "pack_weight_f16", "f16_supported", "gather_gemm_f16", "tile_order", "to_dense", "out_spatial_shape"]
 
 
 @dataclass
@@ -268,6 +268,29 @@ def features_f16(in_feats: torch.Tensor, idx: SparseIndices, packed_weight: torc
         ptr(opt[0]), ptr(opt[1]), ptr(opt[2]), ptr(res), int(bool(relu)), ptr(idx.order) if TILE_ORDER else None,
         ptr(out), int(bool(out_f32)), stream_ptr(f.device)), "sparse_conv3d_features_f16")
     return out
+
+
+def gather_gemm_f16(in_feats: torch.Tensor, nbr: torch.Tensor, packed_weight: torch.Tensor, cin: int, cout: int,
+                    out: torch.Tensor, out_off: int = 0, bias=None, relu: bool = False, order=None) -> torch.Tensor:
+    """The fp16 gather-GEMM as a general operator (pd3_gather_gemm_f16): out[row, out_off : out_off + cout] =
+    relu?(sum_k W[k] . in[nbr[row, k]] + bias) for a static neighbour table `nbr` [rows, K] (-1: no contribution); `out`
+    is a row-major fp16 matrix [rows, ld] of which this call writes one channel slice.  The FPN levels under AMP."""
+    f = require_gpu(in_feats, "gather_gemm_f16", torch.float16)
+    rows, k = int(nbr.shape[0]), int(nbr.shape[1])
+    if out.dtype != torch.float16 or not out.is_contiguous() or out.shape[0] != rows:
+        raise RuntimeError("gather_gemm_f16: out must be a contiguous fp16 [rows, ld] matrix")
+    check(lib().pd3_gather_gemm_f16(ptr(f), ptr(nbr), None, rows, k, cin, cout, ptr(packed_weight), ptr(bias), None, None,
+                                    None, int(bool(relu)), ptr(order), ptr(out), 0, int(out.shape[1]), int(out_off),
+                                    stream_ptr(f.device)), "gather_gemm_f16")
+    return out
+
+
+def tile_order(nbr: torch.Tensor) -> torch.Tensor:
+    """pd3_sparse_tile_order of a neighbour table with all of its rows real."""
+    rows, k = int(nbr.shape[0]), int(nbr.shape[1])
+    order = torch.empty((int(lib().pd3_sparse_tile_order_entries(rows)),), dtype=torch.int32, device=nbr.device)
+    check(lib().pd3_sparse_tile_order(ptr(nbr), None, rows, k, ptr(order), stream_ptr(nbr.device)), "sparse_tile_order")
+    return order
 
 
 def to_dense(feats: torch.Tensor, coords: torch.Tensor, batch: int, spatial_shape, n_dev=None) -> torch.Tensor:

@@ -416,3 +416,35 @@ def test_conv3x3_f16_dual_output_is_both_single_outputs(cin, cout, h, w):
     oh, of = conv.conv3x3_f16_bias_relu_dual(xh, wp, b, cout)
     assert torch.equal(oh, conv.conv3x3_f16_bias_relu(xh, wp, b, cout))
     assert torch.equal(of, conv.conv3x3_f16_bias_relu(xh, wp, b, cout, out_f32_nchw=True))
+
+
+@pytest.mark.parametrize("cfg", ["pillars", "voxels"])
+def test_second_fpn_f16_levels_match_fp32_levels(cfg):
+    """SecondFPN under AMP: every level (kernel = stride convolution, 1 x 1 convolution, transposed convolution) is one
+    fp16 gather-GEMM over a static pixel neighbour table writing its slice of the concatenated fp16 NHWC map; against
+    the fp32 patch-GEMM levels on the same fp16-rounded inputs and weights."""
+    from paddle3d_amd import centerpoint as cpm
+
+    torch.manual_seed(4)
+    if cfg == "pillars":  # second_fpn of CenterPoint-Pillars: strides (0.5, 1, 2), 128 channels each
+        neck = cpm.SecondFPN((64, 128, 256), (128, 128, 128), (0.5, 1, 2), use_conv_for_no_stride=True).cuda().eval()
+        shapes = [(64, 64, 96), (128, 32, 48), (256, 16, 24)]
+    else:                 # CenterPoint-Voxel: strides (1, 2), 256 channels each, a 180-wide map
+        neck = cpm.SecondFPN((128, 256), (256, 256), (1, 2), use_conv_for_no_stride=True).cuda().eval()
+        shapes = [(128, 20, 180), (256, 10, 90)]
+    with torch.no_grad():
+        for m in neck.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                m.weight.copy_(m.weight.half().float())
+    xs = [torch.randn(2, c, h, w, device="cuda").half().float() for c, h, w in shapes]
+    want = neck(xs)
+    assert neck.amp_ok(None)
+    got = neck([x.half().permute(0, 2, 3, 1).contiguous() for x in xs])
+    assert got.dtype == torch.float16 and got.shape == (2, want.shape[2], want.shape[3], want.shape[1])
+    err = (got.float().permute(0, 3, 1, 2) - want).abs().max().item()
+    assert err < 3e-3 * max(1.0, want.abs().max().item()), err  # (the folded weights are rounded to fp16 once more)

@@ -442,6 +442,8 @@ def test_amp_graph_close_to_fp32():
                 dets += [{k: d[k].cpu().numpy() for k in ("box3d_lidar", "scores", "label_preds")}
                          for d in model.bbox_head.predict_by_custom_op(preds, model.test_cfg)]
                 if b0 == 0:
+                    if feats.dtype == torch.float16:  # under AMP the FPN's map travels as fp16 NHWC
+                        feats = feats.permute(0, 3, 1, 2).float()
                     first = feats.clone(), [{k: v.clone() for k, v in p.items()} for p in preds]
         return first[0], first[1], dets
 
