@@ -369,19 +369,27 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_f16_kernel(
 #pragma unroll
   for (int o = 0; o < CO; ++o) acc[o] = 0.f;
   typedef _Float16 cf_h2 __attribute__((ext_vector_type(2)));
-#pragma unroll
+  // one tap at a time (the loop stays rolled: fully unrolled, the 288 LDS loads of a thread are hoisted in front of
+  // the arithmetic and 650 registers spill): the pixel's 64 channels of the tap in 32 registers, then CO dot products
+#pragma unroll 1
   for (int t = 0; t < 9; ++t) {
-    const _Float16* p = patch + ((ty + t / 3) * PW + tx + t % 3) * PS;
+    const int dy = t / 3, dx = t - 3 * dy;
+    const _Float16* p = patch + ((ty + dy) * PW + tx + dx) * PS;
+    cf_h8 v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const cf_h8 v = *reinterpret_cast<const cf_h8*>(p + q * 8);
+    for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const cf_h8*>(p + q * 8);
 #pragma unroll
-      for (int o = 0; o < CO; ++o) {
-        const cf_h8 wv = *reinterpret_cast<const cf_h8*>(wl + (t * CO + o) * 64 + q * 8);
+    for (int o = 0; o < CO; ++o) {
+      const _Float16* wrow = wl + (t * CO + o) * 64;
+      float a0 = acc[o];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const cf_h8 wv = *reinterpret_cast<const cf_h8*>(wrow + q * 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          acc[o] = __builtin_amdgcn_fdot2(cf_h2{v[2 * e], v[2 * e + 1]}, cf_h2{wv[2 * e], wv[2 * e + 1]}, acc[o], false);
+          a0 = __builtin_amdgcn_fdot2(cf_h2{v[q][2 * e], v[q][2 * e + 1]}, cf_h2{wv[2 * e], wv[2 * e + 1]}, a0, false);
       }
+      acc[o] = a0;
     }
   }
   const int y = ty0 + ty, xg = tx0 + tx;
