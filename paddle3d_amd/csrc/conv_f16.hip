@@ -340,14 +340,13 @@ __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_s2_f16_kernel(const _Fl
 // and fetched it back (0.53 ms); in fp16 NHWC it is half of that in each direction and every fetched line is used whole.
 // Workgroup = (8 x 32-pixel tile, group, frame): the tile's (10 x 34) x 64 halfs are staged once (pixel lines padded to
 // 68 halfs: conflict-free ds_read_b128), thread = pixel, v_dot2_f32_f16 accumulates in fp32; the group's 9 x CO x 64
-// weights are LDS broadcasts.  The op is bound by the 1.2 GB it streams, not by its 33 GFLOP.
+// weights arrive by scalar loads (wave-uniform addresses) as SGPR operands.
 template <int CO>
 __global__ __launch_bounds__(256) void grouped_conv3x3_small_f16_kernel(
     const _Float16* __restrict__ x, const _Float16* __restrict__ wg, const float* __restrict__ bias, int groups, int h,
     int w, float* __restrict__ out, int out_groups, int out_group0) {
   constexpr int TR = 8, TC = 32, PW = TC + 2, PS = 68;  // tile rows / columns, patch width, halfs per staged pixel
   __shared__ __attribute__((aligned(16))) _Float16 patch[(TR + 2) * PW * PS];
-  __shared__ __attribute__((aligned(16))) _Float16 wl[9 * CO * 64];
   const int tiles_x = (w + TC - 1) / TC;
   const int tx0 = (blockIdx.x % tiles_x) * TC, ty0 = (blockIdx.x / tiles_x) * TR;
   const int g = blockIdx.y, n = blockIdx.z;
@@ -361,9 +360,10 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_f16_kernel(
     if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = *reinterpret_cast<const cf_h8*>(xin + ((int64_t)gy * w + gx) * c + q * 8);
     *reinterpret_cast<cf_h8*>(patch + pix * PS + q * 8) = v;
   }
-  for (int e = threadIdx.x; e < 9 * CO * 8; e += 256)
-    *reinterpret_cast<cf_h8*>(wl + e * 8) = *reinterpret_cast<const cf_h8*>(wg + (int64_t)g * 9 * CO * 64 + e * 8);
   __syncthreads();
+  // the group's weights are read straight from memory with wave-uniform addresses: scalar loads into SGPRs, which
+  // v_dot2_f32_f16 takes as an operand -- through LDS they were 216 of a thread's 288 ds_read_b128 (0.69 ms per call)
+  const _Float16* wgrp = wg + (int64_t)g * 9 * CO * 64;
   const int ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
   float acc[CO];
 #pragma unroll
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_f16_kernel(
     for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const cf_h8*>(p + q * 8);
 #pragma unroll
     for (int o = 0; o < CO; ++o) {
-      const _Float16* wrow = wl + (t * CO + o) * 64;
+      const _Float16* wrow = wgrp + (t * CO + o) * 64;
       float a0 = acc[o];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
