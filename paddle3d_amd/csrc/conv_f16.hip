@@ -339,8 +339,7 @@ __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_s2_f16_kernel(const _Fl
 // reads.  The fp32 form of this pair wrote the 2304-channel first-stage map as fp32 NCHW (2.4 GB per 16 frames, 1.02 ms)
 // and fetched it back (0.53 ms); in fp16 NHWC it is half of that in each direction and every fetched line is used whole.
 // Workgroup = (8 x 32-pixel tile, group, frame): the tile's (10 x 34) x 64 halfs are staged once (pixel lines padded to
-// 68 halfs: conflict-free ds_read_b128), thread = pixel, v_dot2_f32_f16 accumulates in fp32; the group's 9 x CO x 64
-// weights arrive by scalar loads (wave-uniform addresses) as SGPR operands.
+// 68 halfs: conflict-free ds_read_b128); wave = two tile rows, v_mfma_f32_32x32x16_f16 with the weights as the A operand.
 template <int CO>
 __global__ __launch_bounds__(256) void grouped_conv3x3_small_f16_kernel(
     const _Float16* __restrict__ x, const _Float16* __restrict__ wg, const float* __restrict__ bias, int groups, int h,
@@ -352,6 +351,19 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_f16_kernel(
   const int g = blockIdx.y, n = blockIdx.z;
   const int c = groups * 64;
   const _Float16* xin = x + (int64_t)n * h * w * c + g * 64;
+  const int l31 = threadIdx.x & 31, kh = (threadIdx.x >> 5) & 1;
+  cf_h8 aw[36];  // A fragments: W[tap][m = l31][16 s + 8 kh ..] for m < CO, zero rows above
+  {
+    const _Float16* wgrp = wg + (int64_t)g * 9 * CO * 64 + (l31 < CO ? l31 : 0) * 64 + 8 * kh;
+    const cf_h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int sk = 0; sk < 4; ++sk) {
+        const cf_h8 v = *reinterpret_cast<const cf_h8*>(wgrp + t * CO * 64 + 16 * sk);
+        aw[t * 4 + sk] = l31 < CO ? v : z;
+      }
+  }
   {
     // all of a thread's pieces are requested before the first one is parked (one load per loop trip made the staging a
     // chain of eleven memory round trips: 0.59 ms per call, most of it here)
@@ -375,43 +387,41 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_f16_kernel(
     }
   }
   __syncthreads();
-  // the group's weights are read straight from memory with wave-uniform addresses: scalar loads into SGPRs, which
-  // v_dot2_f32_f16 takes as an operand -- through LDS they were 216 of a thread's 288 ds_read_b128 (0.69 ms per call)
-  const _Float16* wgrp = wg + (int64_t)g * 9 * CO * 64;
-  const int ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
-  float acc[CO];
+  // The products run on the matrix cores (v_mfma_f32_32x32x16_f16): A = the group's weights, output channel m = lane &
+  // 31 (rows CO .. 31 of the block are zero), B = the 32 pixels of a tile row, K = 16 channels per step -- 36 steps per
+  // tap-and-chunk, two tile rows per wave.  (v_dot2c_f32_f16 with one pixel per thread issued at ~22 cycles per
+  // instruction here: 864 of them per thread, 0.58 ms per call; the 32-wide M block wastes 29 of its 32 rows and is
+  // still four times faster.)  The 36 A fragments were requested before the staging loads, so they have landed.
+  const int ty = 2 * wave_id();
+  cf_f32x16 acc[2];
 #pragma unroll
-  for (int o = 0; o < CO; ++o) acc[o] = 0.f;
-  typedef _Float16 cf_h2 __attribute__((ext_vector_type(2)));
-  // one tap at a time (the loop stays rolled: fully unrolled, the 288 LDS loads of a thread are hoisted in front of
-  // the arithmetic and 650 registers spill): the pixel's 64 channels of the tap in 32 registers, then CO dot products
-#pragma unroll 1
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
   for (int t = 0; t < 9; ++t) {
     const int dy = t / 3, dx = t - 3 * dy;
-    const _Float16* p = patch + ((ty + dy) * PW + tx + dx) * PS;
-    cf_h8 v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const cf_h8*>(p + q * 8);
+    for (int sk = 0; sk < 4; ++sk) {
 #pragma unroll
-    for (int o = 0; o < CO; ++o) {
-      const _Float16* wrow = wgrp + (t * CO + o) * 64;
-      float a0 = acc[o];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const cf_h8 wv = *reinterpret_cast<const cf_h8*>(wrow + q * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          a0 = __builtin_amdgcn_fdot2(cf_h2{v[q][2 * e], v[q][2 * e + 1]}, cf_h2{wv[2 * e], wv[2 * e + 1]}, a0, false);
+      for (int j = 0; j < 2; ++j) {
+        const cf_h8 bv = *reinterpret_cast<const cf_h8*>(patch + ((ty + j + dy) * PW + l31 + dx) * PS + 16 * sk + 8 * kh);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw[t * 4 + sk], bv, acc[j], 0, 0, 0);
       }
-      acc[o] = a0;
     }
   }
-  const int y = ty0 + ty, xg = tx0 + tx;
-  if (y >= h || xg >= w) return;
+  // D[m = (reg & 3) + 8 (reg >> 2) + 4 kh][n = l31]: channels 0 .. CO - 1 are registers 0 .. CO - 1 of the kh = 0 lanes
+  const int xg = tx0 + l31;
+  if (kh != 0 || xg >= w) return;
 #pragma unroll
-  for (int o = 0; o < CO; ++o) {
-    const int ch = (out_group0 + g) * CO + o;
-    out[(((int64_t)n * out_groups * CO + ch) * h + y) * w + xg] = acc[o] + (bias ? bias[g * CO + o] : 0.f);
+  for (int j = 0; j < 2; ++j) {
+    const int y = ty0 + ty + j;
+    if (y >= h) continue;
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      const int ch = (out_group0 + g) * CO + o;
+      out[(((int64_t)n * out_groups * CO + ch) * h + y) * w + xg] = acc[j][o] + (bias ? bias[g * CO + o] : 0.f);
+    }
   }
 }
 
