@@ -76,7 +76,10 @@ int pd3_hard_voxelize(const float *points, const int32_t *num_points, int batch,
  * else 1), 1 = generic radix-sort path (any grid below 2^31 cells), 2 = tiled path, payload copied once into a
  * cell-ordered compact array, 3 = tiled path, rows gathered from the points through a cell-ordered index list (2 and
  * 3: BEV-sized grids up to 2^22 cells), 5 = wave form of the tiled path (one wave per group of 1024 cells, grids up to
- * 2^20 cells; 6 .. 10 = the same with the route kernel's tile shape forced: 4096 / 8192 / 10240 / 5120 / 5120 points).
+ * 2^20 cells; 6 .. 10 = the same with the route kernel's tile shape forced: 4096 / 8192 / 10240 / 5120 / 5120 points;
+ * 11 = 5 with heavy group waves at raised issue priority (the automatic choice), 12 / 13 = two half batches on two
+ * streams), 14 = the wave form for 3-D grids of 2^20 .. 2^28 cells (15 / 16: its route tile forced), 17 = a measurement
+ * form: path 6 with the points' payload carried through the route kernel's LDS slice.
  * PD3_EUNSUPPORTED when the shape does not qualify for a forced path.  Identical bytes out on every path. */
 int pd3_hard_voxelize_path(const float *points, const int32_t *num_points, int batch, int64_t max_points,
                            int num_point_dim, const float *voxel_size, const float *point_cloud_range,

@@ -427,7 +427,9 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
             g.gx, g.gy, g.gz, g.ncells};
   if (g.gz == 1 && !vt_single_cell_bounds(g.size_z, vg.z1_lo, vg.z1_hi)) vg.z1_lo = 0.f, vg.z1_hi = -1.f;
   const int waves = plan.threads / kWave;
-  const size_t lds_a = ((size_t)plan.tile + (size_t)waves * plan.groups + waves + 2) * 4;
+  const bool pay = (variant & 4) != 0 && voxels != nullptr;  // path 17: payload carried through the route kernel
+  const size_t lds_a = ((size_t)plan.tile + (size_t)waves * plan.groups + waves + 2) * 4 +
+                       (pay ? (size_t)plan.tile * dim * 4 : 0);
   const unsigned tile_grid = (unsigned)(plan.tiles * batch);
   // up to ~104 KB of dynamic LDS (1024 x 10 tile): above the 48 KB a kernel may use without asking, so the cap is
   // raised per instantiation like every other large-LDS kernel of the library (a host-side table write per launch)
@@ -440,6 +442,18 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
                                                       plan.tiles, batch, max_voxels, w.recs, w.dir, w.vinfo,       \
                                                       three_d ? 1 : 0);                                            \
   } while (0)
+  if (pay) {
+    // (measurement form) the carried payload goes to the head of the `voxels` buffer, which the row writer overwrites
+    if (plan.threads != 512 || plan.rounds != 8 || lds_a > 160 * 1024 ||
+        (int64_t)batch * plan.tiles * plan.tile * dim > (int64_t)batch * max_voxels * max_pts * dim)
+      return PD3_EUNSUPPORTED;
+    const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(vw_route_kernel<512, 8, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+    if (e_ != hipSuccess) return (int)e_;
+    vw_route_kernel<512, 8, true><<<tile_grid, 512, lds_a, s>>>(points, num_points, n, dim, vg, plan.low, plan.gbits,
+                                                                plan.tiles, batch, max_voxels, w.recs, w.dir, w.vinfo,
+                                                                three_d ? 1 : 0, voxels);
+  } else
   if (plan.threads == 512 && plan.rounds == 8) PD3_VW_ROUTE(512, 8);
   else if (plan.threads == 1024 && plan.rounds == 8) PD3_VW_ROUTE(1024, 8);
   else if (plan.threads == 1024 && plan.rounds == 10) PD3_VW_ROUTE(1024, 10);
@@ -651,14 +665,21 @@ extern "C" int pd3_hard_voxelize_path(const float* points, const int32_t* num_po
     return PD3_EINVAL;
   // paths: 0 the library's choice; 1 sort; 2 / 3 tiled forms; 5 wave form; 6 .. 5 + kVwShapes wave form with a forced
   // route-tile shape; 11 wave form + wave priorities; 12 wave form as two half batches on two streams; 13 both;
-  // 14 the wave form for 3-D grids (voxelize_wave3d.hpp; 15 / 16: its route tile forced to 8192 / 10240 points)
-  if (!make_grid(voxel_size, point_cloud_range, g) || path < 0 || path > 16) return PD3_EINVAL;
+  // 14 the wave form for 3-D grids (voxelize_wave3d.hpp; 15 / 16: its route tile forced to 8192 / 10240 points);
+  // 17 measurement: path 6 (4096-point route tiles) + the points' payload carried through the route kernel's LDS slice
+  if (!make_grid(voxel_size, point_cloud_range, g) || path < 0 || path > 17) return PD3_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t n = max_points;
   if (workspace_bytes < pd3_hard_voxelize_workspace(batch, max_points, num_point_dim, voxel_size,
                                                     point_cloud_range, max_num_points_in_voxel,
                                                     max_voxels))
     return PD3_EWORKSPACE;
+  if (path == 17) {  // measurement: the wave form (4096-point route tiles) with the payload carried through the route
+    VwPlan wp;
+    if (!wave_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, batch, 0, wp)) return PD3_EUNSUPPORTED;
+    return run_wave(points, num_points, batch, n, num_point_dim, g, max_num_points_in_voxel, max_voxels, wp, voxels,
+                    coords, num_points_per_voxel, num_voxels, coors_batched, workspace, s, 1 | 4);
+  }
   if (path >= 14) {
     VwPlan wp;
     if (!wave3d_applicable(g, n, num_point_dim, max_num_points_in_voxel, max_voxels, batch, path == 14 ? -1 : path - 14, wp))

@@ -76,11 +76,16 @@ static inline VwPlan vw_plan(uint32_t ncells, int64_t n, int max_pts, int batch,
 }
 
 // ------------------------------------------------------------------------------------------------ A
-template <int THREADS, int R>
+// PAY (path 17, a MEASUREMENT form: round 5's answer to "carry the payload through the route pass"): the point's D
+// floats travel with its record -- staged in the same LDS slice order (20 more bytes per point: the tile shrinks to
+// 4096 points, one 512-thread workgroup per CU) and written as one coalesced run per tile into `pay`.  Nothing reads
+// `pay` (the row writer still gathers): the path measures what the carried payload costs the route kernel, the other
+// half of the form -- a row writer that streams a compact payload -- is the tiled form's path 2 (vt_rows_kernel).
+template <int THREADS, int R, bool PAY = false>
 __global__ __launch_bounds__(THREADS, 8) void vw_route_kernel(
     const float* __restrict__ points, const int32_t* __restrict__ num_points, int64_t n, int dim, VtGrid g, int low,
     int gbits, int tiles, int batch, int max_voxels, uint32_t* __restrict__ recs, uint32_t* __restrict__ dir,
-    uint2* __restrict__ vinfo, int in_tile_index) {
+    uint2* __restrict__ vinfo, int in_tile_index, float* __restrict__ pay = nullptr) {
   // in_tile_index (the 3-D form, voxelize_wave3d.hpp): the record carries the point's index INSIDE its tile (< 2^14)
   // above `low` = 18 cell bits; the tile is what the group kernel's directory search finds anyway
   constexpr int kTile = THREADS * R;
@@ -90,6 +95,7 @@ __global__ __launch_bounds__(THREADS, 8) void vw_route_kernel(
   uint32_t* stage = reinterpret_cast<uint32_t*>(vt_smem);                      // [kTile]
   uint32_t* cnt_all = stage + kTile;                                           // [waves][groups]
   int* scan_tmp = reinterpret_cast<int*>(cnt_all + (size_t)kWaves * groups);   // [waves + 1]
+  float* pstage = reinterpret_cast<float*>(scan_tmp + kWaves + 2);             // PAY: [kTile][dim]
   int frame, tile;
   vt_unit(blockIdx.x, (uint32_t)tiles, (uint32_t)batch, frame, tile);
   const int lane = lane_id(), wave = wave_id();
@@ -162,12 +168,26 @@ __global__ __launch_bounds__(THREADS, 8) void vw_route_kernel(
     const uint32_t k = key[r];
     const int64_t i = wave_base + r * kWave + lane;
     const uint32_t iw = in_tile_index ? (uint32_t)(wave * (R * kWave) + r * kWave + lane) : (uint32_t)i;
-    if (k != 0xFFFFFFFFu) stage[cnt[k >> low] + ord[r]] = (iw << low) | (k & low_mask);
+    if (k != 0xFFFFFFFFu) {
+      const uint32_t at = cnt[k >> low] + ord[r];
+      stage[at] = (iw << low) | (k & low_mask);
+      if (PAY) {  // the point's floats behind its record (x, y, z are in registers, the rest is read again)
+        float* d = pstage + (size_t)at * dim;
+        d[0] = p[r].x;
+        d[1] = p[r].y;
+        d[2] = p[r].z;
+        for (int j = 3; j < dim; ++j) d[j] = pf[i * dim + j];
+      }
+    }
   }
   __syncthreads();
   // phase 4: the slice leaves as one coalesced run
   uint32_t* out = recs + ((int64_t)frame * tiles + tile) * kTile;
   for (int j = threadIdx.x; j < tile_total; j += THREADS) out[j] = stage[j];
+  if (PAY) {
+    float* po = pay + ((int64_t)frame * tiles + tile) * kTile * dim;
+    for (int j = threadIdx.x; j < tile_total * dim; j += THREADS) po[j] = pstage[j];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ B

@@ -72,7 +72,8 @@ def hard_voxelize_batch(points: torch.Tensor, voxel_size, point_cloud_range, max
     with_batch_coors=True additionally returns coors [B,V,4] = (batch, z, y, x), batch -1 on padding rows.
     path: 0 automatic, 1 generic sort path, 2 tiled path (compact payload array), 3 tiled path (gathered rows),
     5 wave form of the tiled path (6 .. 10: route tile shape forced; 11: heavy group waves at raised priority,
-    12: two half batches on two streams, 13: both) (pd3_hard_voxelize_path; the tests run them).
+    12: two half batches on two streams, 13: both; 14 .. 16 the 3-D wave form; 17 a measurement form: the points' payload
+    carried through the route kernel) (pd3_hard_voxelize_path; the tests run them).
     """
     f64 = isinstance(points, torch.Tensor) and points.dtype == torch.float64
     pts = require_gpu(points, "hard_voxelize", torch.float64 if f64 else torch.float32)

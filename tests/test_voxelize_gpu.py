@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 PATH = 0  # pd3_hard_voxelize_path selector of the running parametrisation (0 automatic, 1 generic sort path, ...)
 
 
-@pytest.fixture(params=["auto", "sort", "tiled", "gather", "wave", "wave_s1", "wave_s2", "wave_prio_split", "wave3d"], autouse=True)
+@pytest.fixture(params=["auto", "sort", "tiled", "gather", "wave", "wave_s1", "wave_s2", "wave_prio_split", "wave3d",
+                        "wave_payload"], autouse=True)
 def vox_path(request):
     """Every test runs on the automatic path choice, with the generic sort path forced, and with each form of the
     tiled path forced (2 = payload copied into a compact array, 3 = rows gathered through an index list, 5 = the
@@ -27,7 +28,8 @@ def vox_path(request):
     # 13 = the wave form with both round-4 measurement variants on: heavy waves of the group kernel at raised issue
     # priority, the batch as two half batches on two streams (the batch index of coors_batched continues across them)
     PATH = {"auto": 0, "sort": 1, "tiled": 2, "gather": 3, "wave": 5, "wave_s1": 7, "wave_s2": 8,
-            "wave_prio_split": 13, "wave3d": 14}[request.param]  # 14: the wave form for 3-D grids (hash tables per group)
+            "wave_prio_split": 13, "wave3d": 14,  # 14: the wave form for 3-D grids (hash tables per group)
+            "wave_payload": 17}[request.param]    # 17: the payload carried through the route kernel (measurement form)
     yield request.param
     PATH = 0
 
