@@ -313,16 +313,24 @@ static __global__ __launch_bounds__(kNmsSweepThreads) void nms_sweep_kernel(cons
     unsigned long long diag = 0ull;
     if (lane < rows)
       diag = in_lds ? mlds[(nb * 64 + lane) * cbs + nb] : m[(int64_t)(nb * 64 + lane) * cb_cap + nb];
-    unsigned long long cur = remv[nb];  // uniform
+    // The serial resolve of the diagonal word, on the SCALAR unit with constant lane indices (round 5): the rolled loop
+    // with a runtime trip count cost ~80 cycles per row (two v_readlane with an SGPR lane select, a 64-bit VALU chain);
+    // unrolled, the 128 readlanes are independent and what is left per row is a test and two conditional ORs on SGPRs.
+    // Rows past `rows` carry a zero word and are masked out of keepbits afterwards.
+    const unsigned long long cur0 = remv[nb];  // uniform
+    unsigned long long cur = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(cur0 >> 32)) << 32) |
+                             (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(cur0 & 0xffffffffull));
     unsigned long long keepbits = 0ull;
-    for (int t = 0; t < rows; ++t) {
-      const unsigned lo = __builtin_amdgcn_readlane((unsigned)(diag & 0xffffffffull), t);
-      const unsigned hi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), t);
-      if (!((cur >> t) & 1ull)) {
-        keepbits |= 1ull << t;
-        cur |= ((unsigned long long)hi << 32) | lo;
-      }
+    const unsigned dlo = (unsigned)(diag & 0xffffffffull), dhi = (unsigned)(diag >> 32);
+#pragma unroll
+    for (int t = 0; t < 64; ++t) {
+      const unsigned lo = __builtin_amdgcn_readlane(dlo, t);
+      const unsigned hi = __builtin_amdgcn_readlane(dhi, t);
+      const bool keep = !((cur >> t) & 1ull);
+      keepbits |= keep ? (1ull << t) : 0ull;
+      cur |= keep ? (((unsigned long long)hi << 32) | lo) : 0ull;
     }
+    keepbits &= rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
     // append kept rows in order
     if (lane < rows && ((keepbits >> lane) & 1ull))
       kp[kept_total + __popcll(keepbits & ((1ull << lane) - 1ull))] = nb * 64 + lane;
