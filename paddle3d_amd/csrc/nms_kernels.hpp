@@ -318,8 +318,10 @@ static __global__ __launch_bounds__(kNmsSweepThreads) void nms_sweep_kernel(cons
     // unrolled, the 128 readlanes are independent and what is left per row is a test and two conditional ORs on SGPRs.
     // Rows past `rows` carry a zero word and are masked out of keepbits afterwards.
     const unsigned long long cur0 = remv[nb];  // uniform
-    unsigned long long cur = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(cur0 >> 32)) << 32) |
-                             (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(cur0 & 0xffffffffull));
+    // (the builtin returns int: through `unsigned` first, or the low word's bit 31 sign-extends into the high word)
+    const unsigned cur_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(cur0 >> 32));
+    const unsigned cur_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(cur0 & 0xffffffffull));
+    unsigned long long cur = ((unsigned long long)cur_hi << 32) | (unsigned long long)cur_lo;
     unsigned long long keepbits = 0ull;
     const unsigned dlo = (unsigned)(diag & 0xffffffffull), dhi = (unsigned)(diag >> 32);
 #pragma unroll

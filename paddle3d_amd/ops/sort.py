@@ -28,7 +28,8 @@ def stable_argsort(keys: torch.Tensor, descending: bool = False, max_key: int | 
         mode, mk = 0, (0x7FFFFFFF if max_key is None else int(max_key))
         if not 0 <= mk <= 0x7FFFFFFF:
             raise RuntimeError("stable_argsort: max_key must lie in [0, 2^31)")
-        require_gpu(keys, "stable_argsort")
+        if not keys.is_cuda:
+            raise RuntimeError("Unsupported device type for stable_argsort operator.")
         # a key outside [0, max_key] would be narrowed / sorted on too few digits without any error: one read-back of
         # (min, max) -- this mode serves BevPoolV2.backward (training glue), not an inference step
         lo, hi = (int(v) for v in torch.stack([keys.amin(), keys.amax()]).tolist())
