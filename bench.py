@@ -637,8 +637,13 @@ def bench_pillars(args, rank, world, dev):
         t0 = time.perf_counter()
         run(pts, None)
         cpu_ms = (time.perf_counter() - t0) * 1e3  # host time to enqueue one eager step (no sync)
+        t1 = time.perf_counter()
         torch.cuda.synchronize()
-        if args.graph:
+        gpu_ms_est = cpu_ms + (time.perf_counter() - t1) * 1e3  # enqueue + drain of that one step
+        # --graph forces replay; otherwise it is turned on only where the host would hold the GPU up (dist.choose_launch:
+        # enqueue time above half of the step, measured under the node's real contention)
+        want_graph = pdist.choose_launch(cpu_ms, gpu_ms_est, "graph" if args.graph else "auto") == "graph"
+        if want_graph:
             fused_front = False  # (the captured segments are the pair form's)
             try:
                 st = {}
@@ -809,6 +814,8 @@ def bench_pillars(args, rank, world, dev):
                                + ("->RCCL all-gather" if world > 1 else ""),
                    "frames_per_gpu_per_step": B, "max_voxels": V, "parallelism": f"dp{world} (frames)",
                    "launch": launch, "host_ms_to_enqueue_one_eager_step": cpu_ms,
+                   "launch_policy": "graph replay is turned on when enqueueing a step takes the host more than half of "
+                                    "the step's GPU time (dist.choose_launch); --graph forces it",
                    "result_hand_off": ("all-gather of batch k overlapped with batch k + 1 (dist.GatherPipeline)"
                                        if pipe is not None else "all-gather inside the step")},
         "roofline": dict(rooflines["hard_voxelize"],

@@ -195,6 +195,20 @@ class H2DStage:
             self.consumed[i] = ev
 
 
+def choose_launch(host_ms_per_step: float, gpu_ms_per_step: float, requested: str = "auto") -> str:
+    """"eager" or "graph" for the step's launch path.  `requested` = "eager" / "graph" pins it; "auto" turns HIP-graph
+    replay on when the host needs more than half of the GPU's step time to enqueue a step -- measured on THIS rank while
+    the node's other ranks run their own warm-up, i.e. under the contention that will be there (ranks are pinned to
+    disjoint cores by set_cpu_affinity, so their enqueue times do not add up; what can happen on a loaded host is that
+    each rank's own enqueue time grows).  Below that ratio the GPU never waits for the host and replay changes nothing
+    (measured in rounds 2 and 4: 0.8-1.3 ms of enqueue for a 8.4-10 ms step)."""
+    if requested in ("eager", "graph"):
+        return requested
+    if gpu_ms_per_step <= 0:
+        return "eager"
+    return "graph" if host_ms_per_step > 0.5 * gpu_ms_per_step else "eager"
+
+
 def _cpulist(text: str):
     out = []
     for part in text.strip().split(","):

@@ -176,3 +176,13 @@ def test_h2d_stage_order_and_capacity():
         stage.submit(host[2])
     with pytest.raises(RuntimeError):
         pdist.H2DStage((1,), torch.float32, "cpu").acquire()
+
+
+def test_choose_launch_policy():
+    from paddle3d_amd import dist as pdist
+
+    assert pdist.choose_launch(1.3, 8.4) == "eager"        # the measured single-rank case
+    assert pdist.choose_launch(1.3, 4.3) == "eager"        # AMP step
+    assert pdist.choose_launch(5.0, 8.4) == "graph"        # a loaded host: enqueue above half a step
+    assert pdist.choose_launch(5.0, 8.4, "eager") == "eager" and pdist.choose_launch(0.1, 8.4, "graph") == "graph"
+    assert pdist.choose_launch(1.0, 0.0) == "eager"
