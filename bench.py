@@ -518,7 +518,7 @@ def _traffic(batch, v):
     try:
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
             t = json.load(open(path))
-            if t.get("batch") == batch and t.get("max_voxels") == v:
+            if t.get("batch") == batch and t.get("max_voxels") == v and t.get("front", "pair") == "pair":
                 found = t
     except Exception:  # noqa: BLE001
         found = {}

@@ -15,7 +15,7 @@ import sys
 from collections import defaultdict
 
 OPS = {
-    "hard_voxelize": ("vw_route", "vw_group", "vw_assign", "vw_rows",
+    "hard_voxelize": ("vw_route", "vw_group", "vw_assign", "vw_rows", "vw_finish_index",
                       "vt_route", "vt_group", "vt_assign", "vt_rows", "cell_key", "seg_head",
                       "gather_voxels", "voxel_meta", "EpiVoxelStart", "LoadNonNegative"),
     "pillar_feature_net": ("pfn_",),
@@ -43,8 +43,9 @@ def main():
     # steps of the profiled run = dispatches of a kernel that runs once per step (the route kernel of hard_voxelize);
     # the command-line count (steps + warmup) is only the fallback: bench.py also runs a few untimed set-up steps
     once = [n for k, n in nf.items() if "route_kernel" in k]
-    launches = once[0] if once else int(sys.argv[3])
+    launches = max(once) if once else int(sys.argv[3])  # (a one-frame probe may launch another tile shape once)
     out = {"batch": int(sys.argv[5]), "max_voxels": int(sys.argv[6]), "launches_profiled": launches,
+           "front": sys.argv[7] if len(sys.argv) > 7 else "pair",
            "note": "bytes per launch (= per bench step) ; fetch corrected x2 (gfx950 FETCH_SIZE), write uncorrected"}
     tiled = any("vt_route" in k or "vw_route" in k for k in fetch)
     ops = dict(OPS)

@@ -47,7 +47,8 @@ PY
       cp /tmp/prof_${tag}_step${sfx}/${tag}_step${sfx}_kernel_stats.csv gpurun_out/ 2>/dev/null
       head -16 gpurun_out/${tag}_step${sfx}_kernels.txt ;;
     traffic)
-      tools/gpu_traffic.sh ${tag}_b16 16 30000 > gpurun_out/${tag}_traffic.log 2>&1; tail -5 gpurun_out/${tag}_traffic.log ;;
+      tools/gpu_traffic.sh ${tag}_b16 16 30000 pair > gpurun_out/${tag}_traffic.log 2>&1; tail -5 gpurun_out/${tag}_traffic.log
+      tools/gpu_traffic.sh ${tag}_b16_fused 16 30000 fused >> gpurun_out/${tag}_traffic.log 2>&1 ;;
     vox)
       tools/gpu_vox.sh ${arg:-5,11} 0 > /dev/null 2>&1; cp gpurun_out/vox_paths.txt gpurun_out/${tag}_vox_paths.txt
       grep -v "^#" gpurun_out/${tag}_vox_paths.txt | head -30 ;;
