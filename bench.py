@@ -705,23 +705,19 @@ def bench_pillars(args, rank, world, dev):
                 print(f"bench: HIP-graph capture failed ({type(e).__name__}: {e}); running the eager step", file=sys.stderr)
                 step, launch = (lambda ev: run(pts, ev)), "eager (graph capture failed)"
     # The north star's roofline is that of the OPERATOR pd3_hard_voxelize (the padded [V, P, D] tensor written).  With
-    # the fused front the contract block's step no longer contains it, so it is timed in a block of its own: W warm-up +
-    # K steps of the pair form of the same graph (HIP events around the operator, the rest of the step between two
-    # launches: the points have left the caches, as in the step), BEFORE the contract block -- the state in which the
-    # earlier rounds' contract blocks measured it.  `value` / `ms_per_step` are the contract block's (fused front).
+    # the fused front the contract block's step no longer contains it, so it is timed in a block of its own, in the
+    # contract's own shape (the same _timed_loop: barrier, W warm-up steps, K timed steps of the PAIR form of the graph
+    # with the result hand-off, HIP events around the operator, the points evicted by the rest of the step) in front of
+    # the contract block.  `value` / `ms_per_step` are the contract block's (fused front).
     pair_ms = None
     if fused_front:
-        with torch.no_grad():
-            fused_front = False
-            for _ in range(max(args.warmup, 2)):
-                compute(pts, None)
-            ev = _events(names, args.steps, dev)
-            for k in range(args.steps):
-                compute(pts, ev[k])
-            torch.cuda.synchronize()
-            pair_ms = {names[i]: float(np.median([ev[k][i - 1].elapsed_time(ev[k][i]) for k in range(args.steps)]))
-                       for i in range(1, len(names) - 1)}
-            fused_front = True
+        import copy as _copy
+
+        a2 = _copy.copy(args)
+        a2.repeats = 0
+        fused_front = False  # (compute() reads the flag when it runs)
+        _dt2, pair_ms, _out2, _info2 = _timed_loop(step, a2, world, dev, names, finish=finish)
+        fused_front = True
     dt, per_op_ms, out, info = _timed_loop(step, args, world, dev, names, finish=finish)
     op_ms = per_op_ms if pair_ms is None else pair_ms
     multi = {}
