@@ -557,6 +557,13 @@ int pd3_conv3x3_f16_bias_relu_dual(const void *x_f16_nhwc, const void *w_packed_
  * pd3_conv3x3_f16_bias_relu with T = 128; cin % 16 == 0, cout % 128 == 0 (else -3: the caller runs the fp32 kernel). */
 int pd3_conv3x3_s2_f16_bias_relu(const void *x_f16_nhwc, const void *w_packed_f16, const float *bias, int batch, int cin,
                                  int cout, int h, int w, int relu, void *out_f16_nhwc, void *stream);
+/* PointPillarsScatter fused into that stride-2 convolution (the layer that opens SecondBackbone's block 0 under AMP, the
+ * fp16 sibling of pd3_scatter_conv3x3_bias_relu): features_f16 [M, cin] fp16 pillar features, inverse_map [batch, ny * nx]
+ * int32 (pd3_pointpillars_inverse_map: pillar row of a cell or -1) -> out [batch, ny / 2, nx / 2, cout] fp16 NHWC; the
+ * canvas is never written.  channels_per_tile 64 or 128 (weights packed with that T), cin % 16 == 0. */
+int pd3_scatter_conv3x3_s2_f16_bias_relu(const void *features_f16, const int32_t *inverse_map, const void *w_packed_f16,
+                                         const float *bias, int batch, int cin, int cout, int ny, int nx, int relu,
+                                         void *out_f16_nhwc, int channels_per_tile, void *stream);
 /* The final SeparateHead convolutions under AMP (center_head.py:99-118): grouped 3x3 / pad 1 convolution + bias reading
  * the first stage's fp16 NHWC output.
  *   x_f16_nhwc [batch, h, w, groups * 64] fp16; w_f16 [groups][9 taps][out_per_group][64] fp16; bias [groups *

@@ -128,6 +128,9 @@ _SIGNATURES = {
                                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pd3_conv3x3_s2_f16_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pd3_scatter_conv3x3_s2_f16_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                       C.c_void_p]),
     "pd3_grouped_conv3x3_small_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pd3_stable_argsort_workspace": (C.c_size_t, [C.c_int64, C.c_uint32]),

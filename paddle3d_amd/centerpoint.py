@@ -413,10 +413,20 @@ class SecondBackbone(_InferenceCache, nn.Module):
         self._require_eval()
         plan = self._plan()
         first = None
+        first_h = None  # mixed precision: the scatter-fused first layer's result as fp16 NHWC
         if isinstance(x, _ps.SparseCanvas):
             # PointPillarsScatter fused into the first convolution where the kernel takes it (stride 2), else written out
             c0 = plan[0][0]
-            if _conv.scatter_conv_supported(c0.cin, c0.cout, x.ny, x.nx, c0.stride) and x.shape[1] == c0.cin:
+            if (self.amp and c0.stride == 2 and x.shape[1] == c0.cin and len(plan[0]) > 1
+                    and _conv.scatter_conv_s2_f16_supported(c0.cin, c0.cout, x.ny, x.nx)
+                    and plan[0][1].f16_ok(x.ny // 2, x.nx // 2)):
+                # (round 5) on the fp16 matrix cores as well: the only fp32 layer of the AMP graph and its conversion go
+                key = "f16s2_64" if c0.cout % 128 else "f16s2"
+                if key not in c0.packed:
+                    c0.packed[key] = _conv.pack_conv3x3_f16_weight(c0.w, tile=64 if c0.cout % 128 else 128)
+                first_h = _conv.scatter_conv3x3_s2_f16_bias_relu(x, c0.packed[key], c0.b, c0.cout)
+                first = (None, x.nx // 2)
+            elif _conv.scatter_conv_supported(c0.cin, c0.cout, x.ny, x.nx, c0.stride) and x.shape[1] == c0.cin:
                 if "direct" not in c0.packed:
                     c0.packed["direct"] = _conv.pack_conv3x3_weight(c0.w)
                 first = (_conv.scatter_conv3x3_bias_relu(x, c0.packed["direct"], c0.b, c0.cout), x.nx // 2)
@@ -431,11 +441,14 @@ class SecondBackbone(_InferenceCache, nn.Module):
             li = 0
             while li < len(layers):
                 conv = layers[li]
+                xh = None
                 if first is not None and bi == 0 and li == 0:
                     x, wv = first
                     li += 1
-                    continue
-                xh = None
+                    if first_h is None:
+                        continue
+                    xh = first_h  # fp16 NHWC already: the run below starts without a conversion
+                    conv = layers[li]
                 if self.amp and li == 0 and carry is not None and conv.f16_s2_ok() and wv == carry.shape[2]:
                     # (round 5) the block opens on the fp16 matrix cores too: no fp32 stride-2 kernel, no conversion
                     xh = conv.f16_s2(carry)

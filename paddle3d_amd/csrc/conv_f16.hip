@@ -198,75 +198,96 @@ __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_f16_kernel(const _Float
 // dx & 1, so the 32 lanes of a B operand read 32 consecutive 32-byte pixels exactly as in the stride-1 kernel (with the
 // columns interleaved their stride would be 64 bytes: a four-way bank conflict on every ds_read_b128).
 // fp16 NHWC out (the block's stride-1 layers follow).  cin % 16 == 0, cout % 128 == 0.
+// Round 5, later: MW = 64-channel blocks per workgroup (2: 128 channels, 8 waves; 1: 64 channels, 4 waves -- the 64 -> 64
+// layer that opens block 0) and GATHER = PointPillarsScatter fused in: the "image" is the pillar features [M, cin] fp16
+// behind the inverse map (cell -> pillar row or -1, pd3_pointpillars_inverse_map), so the first layer of the backbone
+// runs on the fp16 matrix cores as well and the canvas is never written (as in the fp32 pd3_scatter_conv3x3_bias_relu).
 constexpr int kCs2R = 8;                         // output rows per workgroup
 constexpr int kCs2PR = 2 * kCs2R + 1;            // staged input rows
 constexpr int kCs2Half = kCfCols + 1;            // entries per parity plane of a staged row (33)
 constexpr int kCs2Patch = kCs2PR * 2 * kCs2Half * kCfKc;  // halfs
-constexpr int kCs2Wts = 9 * 128 * kCfKc;
-constexpr int kCs2PPieces = kCs2Patch / 8, kCs2WPieces = kCs2Wts / 8;
-constexpr int kCs2PPT = (kCs2PPieces + kCfThreads - 1) / kCfThreads, kCs2WPT = (kCs2WPieces + kCfThreads - 1) / kCfThreads;
-constexpr size_t kCs2Lds = (size_t)2 * (kCs2Patch + kCs2Wts) * sizeof(_Float16);
+constexpr int kCs2PPieces = kCs2Patch / 8;
+template <int MW>
+struct Cs2Shape {
+  static constexpr int THREADS = 256 * MW;
+  static constexpr int M = 64 * MW;
+  static constexpr int WTS = 9 * M * kCfKc;
+  static constexpr int WPIECES = WTS / 8;
+  static constexpr int PPT = (kCs2PPieces + THREADS - 1) / THREADS;
+  static constexpr int WPT = (WPIECES + THREADS - 1) / THREADS;
+  static constexpr size_t LDS = (size_t)2 * (kCs2Patch + WTS) * sizeof(_Float16);
+};
 
-__global__ __launch_bounds__(kCfThreads, 1) void conv3x3_s2_f16_kernel(const _Float16* __restrict__ x,
-                                                                       const _Float16* __restrict__ wp,
-                                                                       const float* __restrict__ bias,
-                                                                       _Float16* __restrict__ out, int cin, int cout,
-                                                                       int h, int w, int ho, int wo, int relu, int ptiles) {
+template <int MW, bool GATHER>
+__global__ __launch_bounds__(256 * MW, 1) void conv3x3_s2_f16_kernel(const _Float16* __restrict__ x,
+                                                                      const int32_t* __restrict__ inv,
+                                                                      const _Float16* __restrict__ wp,
+                                                                      const float* __restrict__ bias,
+                                                                      _Float16* __restrict__ out, int cin, int cout,
+                                                                      int h, int w, int ho, int wo, int relu,
+                                                                      int ptiles) {
+  using S = Cs2Shape<MW>;
   extern __shared__ __attribute__((aligned(16))) _Float16 cf_smem[];
   const int lane = lane_id(), wave = wave_id();
   const int tiles_x = (wo + kCfCols - 1) / kCfCols, tiles_y = (ho + kCs2R - 1) / kCs2R;
-  const int nct = cout / 128;
+  const int nct = cout / S::M;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int ct = slot % nct, pt = (slot / nct) * 8 + xcd;
   if (pt >= ptiles) return;
   const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
   const int y0 = ty * kCs2R, x0 = tx * kCfCols;  // output coordinates of the tile
   const int chunks = cin / kCfKc;
-  const _Float16* xin = x + (int64_t)n * h * w * cin;
-  const cf_h8* wsrc = reinterpret_cast<const cf_h8*>(wp) + (int64_t)ct * chunks * kCs2WPieces;
+  const _Float16* xin = GATHER ? x : x + (int64_t)n * h * w * cin;
+  const cf_h8* wsrc = reinterpret_cast<const cf_h8*>(wp) + (int64_t)ct * chunks * S::WPIECES;
 
   // staging pattern: piece e = (staged pixel, half of its 16 channels); staged pixel = (row pr, parity, entry)
-  int pofs[kCs2PPT];
+  int64_t pofs[S::PPT];
   unsigned plive = 0;
 #pragma unroll
-  for (int i = 0; i < kCs2PPT; ++i) {
-    const int e = min((int)threadIdx.x + i * kCfThreads, kCs2PPieces - 1);
+  for (int i = 0; i < S::PPT; ++i) {
+    const int e = min((int)threadIdx.x + i * S::THREADS, kCs2PPieces - 1);
     const int pix = e >> 1, hf = e & 1;
     const int pr = pix / (2 * kCs2Half), rem = pix - pr * (2 * kCs2Half);
     const int par = rem / kCs2Half, ent = rem - par * kCs2Half;
     const int pc = 2 * ent + par;  // input column of the patch, 0 .. 65 (65 = the odd plane's unused last entry)
     const int gy = 2 * y0 - 1 + pr, gx = 2 * x0 - 1 + pc;
-    const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w && pc <= 2 * kCfCols;
-    pofs[i] = ok ? (gy * w + gx) * cin + 8 * hf : 0;
+    bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w && pc <= 2 * kCfCols;
+    int64_t pixel = (int64_t)gy * w + gx;
+    if (GATHER) {  // the cell's pillar row (or none)
+      const int row = ok ? inv[(int64_t)n * h * w + pixel] : -1;
+      ok = row >= 0;
+      pixel = row;
+    }
+    pofs[i] = ok ? pixel * cin + 8 * hf : 0;
     plive |= ok ? (1u << i) : 0u;
   }
-  cf_h8 preg[kCs2PPT], wreg[kCs2WPT];
+  cf_h8 preg[S::PPT], wreg[S::WPT];
   auto fetch = [&](int c) {
     const _Float16* xc = xin + c * kCfKc;
 #pragma unroll
-    for (int i = 0; i < kCs2PPT; ++i) preg[i] = *reinterpret_cast<const cf_h8*>(xc + pofs[i]);
-    const cf_h8* wc = wsrc + (int64_t)c * kCs2WPieces;
+    for (int i = 0; i < S::PPT; ++i) preg[i] = *reinterpret_cast<const cf_h8*>(xc + pofs[i]);
+    const cf_h8* wc = wsrc + (int64_t)c * S::WPIECES;
 #pragma unroll
-    for (int i = 0; i < kCs2WPT; ++i) wreg[i] = wc[min((int)threadIdx.x + i * kCfThreads, kCs2WPieces - 1)];
+    for (int i = 0; i < S::WPT; ++i) wreg[i] = wc[min((int)threadIdx.x + i * S::THREADS, S::WPIECES - 1)];
   };
   auto stash = [&](int buf) {
-    _Float16* P = cf_smem + buf * (kCs2Patch + kCs2Wts);
+    _Float16* P = cf_smem + buf * (kCs2Patch + S::WTS);
     _Float16* W = P + kCs2Patch;
 #pragma unroll
-    for (int i = 0; i < kCs2PPT; ++i) {
-      const int e = (int)threadIdx.x + i * kCfThreads;
+    for (int i = 0; i < S::PPT; ++i) {
+      const int e = (int)threadIdx.x + i * S::THREADS;
       const cf_h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (kCs2PPieces % kCfThreads == 0 || e < kCs2PPieces)
+      if (kCs2PPieces % S::THREADS == 0 || e < kCs2PPieces)
         *reinterpret_cast<cf_h8*>(P + e * 8) = ((plive >> i) & 1u) ? preg[i] : z;
     }
 #pragma unroll
-    for (int i = 0; i < kCs2WPT; ++i) {
-      const int e = (int)threadIdx.x + i * kCfThreads;
-      if (kCs2WPieces % kCfThreads == 0 || e < kCs2WPieces) *reinterpret_cast<cf_h8*>(W + e * 8) = wreg[i];
+    for (int i = 0; i < S::WPT; ++i) {
+      const int e = (int)threadIdx.x + i * S::THREADS;
+      if (S::WPIECES % S::THREADS == 0 || e < S::WPIECES) *reinterpret_cast<cf_h8*>(W + e * 8) = wreg[i];
     }
   };
 
-  const int mw = wave & 1, nw = wave >> 1;  // the wave's 64-channel block and its pair of output rows
+  const int mw = wave % MW, nw = wave / MW;  // the wave's 64-channel block and its pair of output rows
   const int l31 = lane & 31, kh = lane >> 5;
   cf_f32x16 acc[2][2];
 #pragma unroll
@@ -282,7 +303,7 @@ __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_s2_f16_kernel(const _Fl
   for (int c = 0; c < chunks; ++c) {
     const bool more = c + 1 < chunks;
     if (more) fetch(c + 1);
-    const _Float16* P = cf_smem + (c & 1) * (kCs2Patch + kCs2Wts);
+    const _Float16* P = cf_smem + (c & 1) * (kCs2Patch + S::WTS);
     const _Float16* W = P + kCs2Patch;
     const _Float16* wa = W + ((mw * 64 + l31) * kCfKc + 8 * kh);
 #pragma unroll
@@ -290,7 +311,7 @@ __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_s2_f16_kernel(const _Fl
       const int dy = t / 3, dx = t - 3 * dy;
       cf_h8 a[2], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const cf_h8*>(wa + (t * 128 + i * 32) * kCfKc);
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const cf_h8*>(wa + (t * S::M + i * 32) * kCfKc);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int pr = 2 * (nw * 2 + j) + dy;
@@ -305,7 +326,7 @@ __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_s2_f16_kernel(const _Fl
     if (more) stash((c + 1) & 1);
     __syncthreads();
   }
-  const int co0 = ct * 128 + mw * 64;
+  const int co0 = ct * S::M + mw * 64;
   const int xg = x0 + l31;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -504,6 +525,23 @@ extern "C" int pd3_conv3x3_f16_bias_relu_dual(const void* x_f16_nhwc, const void
   return launch_conv_f16<1, 2>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out_f16_nhwc, s, out_f32_nchw);
 }
 
+template <int MW, bool GATHER>
+static int launch_conv_s2_f16(const void* x, const int32_t* inv, const void* wp, const float* bias, int batch, int cin,
+                              int cout, int h, int w, int relu, void* out, hipStream_t s) {
+  using S = Cs2Shape<MW>;
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_s2_f16_kernel<MW, GATHER>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS);
+  if (e != hipSuccess) return (int)e;
+  const int64_t ptiles = (int64_t)batch * ceil_div(ho, kCs2R) * ceil_div(wo, kCfCols);
+  const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / S::M);
+  if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
+  conv3x3_s2_f16_kernel<MW, GATHER><<<(unsigned)nwg, S::THREADS, S::LDS, s>>>(
+      static_cast<const _Float16*>(x), inv, static_cast<const _Float16*>(wp), bias, static_cast<_Float16*>(out), cin, cout,
+      h, w, ho, wo, relu, (int)ptiles);
+  return launch_status();
+}
+
 extern "C" int pd3_conv3x3_s2_f16_bias_relu(const void* x_f16_nhwc, const void* w_packed_f16, const float* bias, int batch,
                                             int cin, int cout, int h, int w, int relu, void* out_f16_nhwc, void* stream) {
   if (!x_f16_nhwc || !w_packed_f16 || !out_f16_nhwc || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0)
@@ -513,17 +551,28 @@ extern "C" int pd3_conv3x3_s2_f16_bias_relu(const void* x_f16_nhwc, const void* 
     return PD3_EINVAL;
   if (cin % kCfKc != 0 || cout % 128 != 0) return PD3_EUNSUPPORTED;
   if ((int64_t)h * w * cin >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
-  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_s2_f16_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCs2Lds);
-  if (e != hipSuccess) return (int)e;
-  const int64_t ptiles = (int64_t)batch * ceil_div(ho, kCs2R) * ceil_div(wo, kCfCols);
-  const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / 128);
-  if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
-  conv3x3_s2_f16_kernel<<<(unsigned)nwg, kCfThreads, kCs2Lds, static_cast<hipStream_t>(stream)>>>(
-      static_cast<const _Float16*>(x_f16_nhwc), static_cast<const _Float16*>(w_packed_f16), bias,
-      static_cast<_Float16*>(out_f16_nhwc), cin, cout, h, w, ho, wo, relu, (int)ptiles);
-  return launch_status();
+  return launch_conv_s2_f16<2, false>(x_f16_nhwc, nullptr, w_packed_f16, bias, batch, cin, cout, h, w, relu,
+                                      out_f16_nhwc, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int pd3_scatter_conv3x3_s2_f16_bias_relu(const void* features_f16, const int32_t* inverse_map,
+                                                    const void* w_packed_f16, const float* bias, int batch, int cin,
+                                                    int cout, int ny, int nx, int relu, void* out_f16_nhwc,
+                                                    int channels_per_tile, void* stream) {
+  if (!features_f16 || !inverse_map || !w_packed_f16 || !out_f16_nhwc || batch <= 0 || cin <= 0 || cout <= 0 || ny <= 0 ||
+      nx <= 0)
+    return PD3_EINVAL;
+  if (reinterpret_cast<uintptr_t>(features_f16) % 16 != 0 || reinterpret_cast<uintptr_t>(w_packed_f16) % 16 != 0 ||
+      reinterpret_cast<uintptr_t>(out_f16_nhwc) % 8 != 0)
+    return PD3_EINVAL;
+  if ((channels_per_tile != 64 && channels_per_tile != 128) || cin % kCfKc != 0 || cout % channels_per_tile != 0)
+    return PD3_EUNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (channels_per_tile == 128)
+    return launch_conv_s2_f16<2, true>(features_f16, inverse_map, w_packed_f16, bias, batch, cin, cout, ny, nx, relu,
+                                       out_f16_nhwc, s);
+  return launch_conv_s2_f16<1, true>(features_f16, inverse_map, w_packed_f16, bias, batch, cin, cout, ny, nx, relu,
+                                     out_f16_nhwc, s);
 }
 
 extern "C" int pd3_grouped_conv3x3_small_f16(const void* x_f16_nhwc, const void* w_f16, const float* bias, int batch,

@@ -15,7 +15,8 @@ __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pitch4", "p
            "WINOGRAD43_PP_MIN_CIN", "winograd43_pp_supported", "pack_winograd43_lane_weight", "conv3x3_winograd43_pp_bias_relu",
            "f16_supported", "f16_tile", "pack_conv3x3_f16_weight", "conv3x3_f16_bias_relu", "to_f16_nhwc",
            "pack_grouped_weight_f16", "grouped_conv3x3_small_f16", "conv3x3_f16_bias_relu_dual",
-           "s2_f16_supported", "conv3x3_s2_f16_bias_relu"]
+           "s2_f16_supported", "conv3x3_s2_f16_bias_relu", "scatter_conv_s2_f16_supported",
+           "scatter_conv3x3_s2_f16_bias_relu"]
 
 
 def pitch4(w: int) -> int:
@@ -293,6 +294,24 @@ def conv3x3_s2_f16_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout
     out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, cout), dtype=torch.float16, device=x.device)
     check(lib().pd3_conv3x3_s2_f16_bias_relu(ptr(x), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
                                              ptr(out), stream_ptr(x.device)), "conv3x3_s2_f16_bias_relu")
+    return out
+
+
+def scatter_conv_s2_f16_supported(cin: int, cout: int, ny: int, nx: int) -> bool:
+    return cin % 16 == 0 and cout % 64 == 0 and ny % 2 == 0 and nx % 2 == 0
+
+
+def scatter_conv3x3_s2_f16_bias_relu(canvas, w_packed: torch.Tensor, bias, cout: int, relu: bool = True) -> torch.Tensor:
+    """scatter_conv3x3_bias_relu on the fp16 matrix cores: a SparseCanvas (pillar features converted to fp16 once, the
+    inverse map) -> [B, ny / 2, nx / 2, cout] fp16 NHWC; w_packed = pack_conv3x3_f16_weight(weight, tile=64 | 128)."""
+    f, inv = canvas.features, canvas.inv
+    fh = f if f.dtype == torch.float16 else f.half()
+    n, cin, ny, nx = canvas.shape
+    tile = int(w_packed.shape[3])
+    out = torch.empty((n, ny // 2, nx // 2, cout), dtype=torch.float16, device=f.device)
+    check(lib().pd3_scatter_conv3x3_s2_f16_bias_relu(ptr(fh), ptr(inv), ptr(w_packed), ptr(bias), n, cin, cout, ny, nx,
+                                                     int(bool(relu)), ptr(out), tile, stream_ptr(f.device)),
+          "scatter_conv3x3_s2_f16_bias_relu")
     return out
 
 

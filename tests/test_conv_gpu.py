@@ -406,6 +406,38 @@ def test_conv3x3_s2_f16_matches_fp32_math_on_fp16_operands(cin, cout, h, w):
     assert (got2.float().permute(0, 3, 1, 2) - ref2).abs().max().item() < 2e-3 * max(1.0, ref2.abs().max().item())
 
 
+@pytest.mark.parametrize("ny,nx,batch,cout", [(512, 512, 2, 64), (496, 432, 2, 64), (64, 96, 3, 128), (40, 24, 1, 64)])
+def test_scatter_fused_into_stride2_f16_conv(ny, nx, batch, cout):
+    """PointPillarsScatter fused into the fp16 stride-2 convolution (pd3_scatter_conv3x3_s2_f16_bias_relu, channel tiles
+    of 64 and 128): against torch's fp32 stride-2 convolution of the fp16-rounded canvas, and -- for the 128 tile -- the
+    same bytes as the unfused fp16 kernel on the written-out canvas; duplicates, padding rows, partial tiles."""
+    from paddle3d_amd.ops import conv
+    from paddle3d_amd.ops import pointpillars_scatter as ps
+
+    torch.manual_seed(ny + nx)
+    cin = 64
+    m = min(6000, ny * nx // 3) * batch
+    coords = torch.stack([torch.randint(0, batch, (m,)), torch.zeros(m, dtype=torch.long),
+                          torch.randint(0, ny, (m,)), torch.randint(0, nx, (m,))], 1).int()
+    coords[::97, 0] = -1
+    coords[5] = coords[3]
+    feats, coords = torch.randn(m, cin).cuda(), coords.cuda()
+    w, b = (torch.randn(cout, cin, 3, 3) * 0.05).cuda(), torch.randn(cout).cuda()
+    assert conv.scatter_conv_s2_f16_supported(cin, cout, ny, nx)
+    canvas = ps.pointpillars_scatter(feats, coords, batch, ny, nx)
+    ref = F.relu(F.conv2d(canvas.half().float().cpu(), w.half().float().cpu(), b.cpu(), stride=2, padding=1)).cuda()
+    for tile in ([64, 128] if cout % 128 == 0 else [64]):
+        got = conv.scatter_conv3x3_s2_f16_bias_relu(ps.SparseCanvas(feats, coords, batch, ny, nx),
+                                                    conv.pack_conv3x3_f16_weight(w, tile=tile), b, cout)
+        assert got.dtype == torch.float16 and got.shape == (batch, ny // 2, nx // 2, cout)
+        err = (got.float().permute(0, 3, 1, 2) - ref).abs().max().item()
+        assert err < 2e-3 * max(1.0, ref.abs().max().item()), (tile, err)
+        if tile == 128:
+            dense = conv.conv3x3_s2_f16_bias_relu(conv.to_f16_nhwc(canvas), conv.pack_conv3x3_f16_weight(w, tile=128), b,
+                                                  cout)
+            assert torch.equal(got, dense)
+
+
 @pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 40, 64), (128, 128, 16, 50)])
 def test_conv3x3_f16_dual_output_is_both_single_outputs(cin, cout, h, w):
     from paddle3d_amd.ops import conv
