@@ -1202,6 +1202,23 @@ def bench_voxel(args, rank, world, dev):
     }
     if overflow:
         line["error"] = "sparse plan: an index set outgrew its remembered capacity during the timed steps"
+    if not amp:
+        from paddle3d_amd.ops import sparse_conv3d as _sp3
+
+        with torch.no_grad():  # (untimed) the encoder's map by the fp32 matrix-core kernel in every layer, for comparison
+            bev_x3 = model.extract_pillars(pts)
+            _sp3.SPLIT_BF16 = False
+            try:
+                bev_32 = model.extract_pillars(pts)
+            finally:
+                _sp3.SPLIT_BF16 = True
+        line["sparse_arithmetic"] = dict(
+            form="fp32; the layers with >= 64 output channels multiply on the bf16 matrix cores with every fp32 operand "
+                 "cut into three bf16 pieces (hi + mid + lo = the value to 2^-27) and six of the nine piece products "
+                 "accumulated in fp32 (csrc/sparse_conv_x3.hip): the error against exact arithmetic is that of the fp32 "
+                 "matrix-core kernel (tests/test_sparse_conv_gpu.py::test_features_bf16x3_is_fp32_arithmetic)",
+            encoder_map_max_abs_diff_vs_fp32_kernel=float((bev_x3 - bev_32).abs().max()),
+            encoder_map_max_abs=float(bev_32.abs().max()))
     if amp:
         from paddle3d_amd import nuscenes_bridge as nb
 

@@ -392,6 +392,19 @@ int pd3_sparse_conv3d_features_ordered(const float *in_feats, const int32_t *nbr
                                        const float *weight, const float *bias, const float *scale,
                                        const float *shift, const float *residual, int relu,
                                        const int32_t *order, float *out, void *stream);
+/* The fp32 gather-GEMM on the bf16 matrix cores (round 5; the default of the fp32 encoder from 16 -> 32 channels on): every
+ * fp32 operand is cut into three bf16 pieces (hi + mid + lo = the fp32 value to 2^-27) and six of the nine piece products
+ * are accumulated in fp32 -- the error against exact arithmetic is that of the fp32 matrix-core kernel
+ * (tests/test_sparse_conv_gpu.py::test_features_bf16x3_is_fp32_arithmetic), the rate 2.7 x the fp32 pipe's.
+ *   pd3_sparse_pack_weight_bf16x3       weight [K, Cin, Cout] fp32 (Paddle layout) -> 3 * K * Cin * Cout bf16 in the
+ *                                       kernel's operand order; Cin % 16 == 0, Cout in {32, 64, 128}
+ *   pd3_sparse_conv3d_features_bf16x3   as pd3_sparse_conv3d_features_ordered (all fp32 rows in and out) with that
+ *                                       packed weight.  Other shapes return -3 (run the fp32 entry). */
+int pd3_sparse_pack_weight_bf16x3(const float *weight, int kernel_volume, int cin, int cout, void *packed, void *stream);
+int pd3_sparse_conv3d_features_bf16x3(const float *in_feats, const int32_t *nbr, const int32_t *n_out, int n_out_cap,
+                                      int kernel_volume, int cin, int cout, const void *weight_packed,
+                                      const float *bias, const float *scale, const float *shift, const float *residual,
+                                      int relu, const int32_t *order, float *out, void *stream);
 /* Mixed precision (the reference's amp_cfg level O2 for the CenterPoint-Voxel encoder): fp16 feature rows and weights
  * on the fp16 matrix cores, fp32 accumulation; index sets, rulebooks and tile order are the fp32 path's.
  *   pd3_sparse_pack_weight_f16   weight [K, Cin, Cout] fp32 (Paddle layout) -> packed fp16 (K * Cin * Cout halfs) in the

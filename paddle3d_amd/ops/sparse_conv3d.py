@@ -19,7 +19,8 @@ import torch
 from ._common import check, host_i32, lib, ptr, require_gpu, stream_ptr, workspace
 
 __all__ = ["SparseIndices", "ConvSpec", "SparsePlan", "indices", "plan", "plan_caps", "features", "features_f16",
-           "pack_weight_f16", "f16_supported", "gather_gemm_f16", "tile_order", "to_dense", "out_spatial_shape"]
+           "pack_weight_f16", "f16_supported", "SPLIT_BF16", "bf16x3_supported", "bf16x3_pays", "pack_weight_bf16x3",
+           "features_bf16x3", "gather_gemm_f16", "tile_order", "to_dense", "out_spatial_shape"]
 
 
 @dataclass
@@ -231,6 +232,53 @@ def features(in_feats: torch.Tensor, idx: SparseIndices, weight: torch.Tensor, b
         ptr(f), ptr(idx.nbr), ptr(idx.n_out_dev), idx.n_out, idx.kernel_volume, cin, cout, ptr(w), ptr(opt[0]),
         ptr(opt[1]), ptr(opt[2]), ptr(opt[3]), int(bool(relu)), ptr(idx.order) if TILE_ORDER else None, ptr(out),
         stream_ptr(f.device)), "sparse_conv3d_features")
+    return out
+
+
+# The fp32 layers from 16 -> 32 channels on run on the bf16 matrix cores with every operand cut into three bf16 pieces
+# (csrc/sparse_conv_x3.hip: fp32 arithmetic -- six piece products accumulated in fp32 -- at 2.7 x the fp32 pipe's rate).
+# False = the fp32 matrix-core kernel everywhere (pd3_sparse_conv3d_features_ordered), kept as the comparison.
+SPLIT_BF16 = True
+
+
+def bf16x3_supported(cin: int, cout: int, kernel_volume: int) -> bool:
+    """Shapes pd3_sparse_conv3d_features_bf16x3 serves."""
+    return cin % 16 == 0 and cout in (32, 64, 128) and kernel_volume <= 27
+
+
+def bf16x3_pays(cin: int, cout: int, kernel_volume: int) -> bool:
+    """... and where it is faster than the fp32 matrix-core kernel: from 64 output channels on (measured, 8 scenes:
+    32 -> 32 1.00 ms against 0.89-0.94, 32 -> 64 0.79 against 0.94, 64 -> 64 1.6 against 2.4-2.5, 128 -> 128 2.3 against
+    3.9-4.0; profiles/r05_sparse_layers.txt, r05_sparse_layers_fp32.txt)."""
+    return bf16x3_supported(cin, cout, kernel_volume) and cout >= 64
+
+
+def pack_weight_bf16x3(weight: torch.Tensor) -> torch.Tensor:
+    """weight [kd, kh, kw, Cin, Cout] fp32 (Paddle layout) -> its three bf16 pieces in the operand order of
+    features_bf16x3."""
+    w = require_gpu(weight, "sparse_conv3d")
+    cin, cout = int(w.shape[-2]), int(w.shape[-1])
+    kvol = w.numel() // (cin * cout)
+    out = torch.empty((3 * w.numel(),), dtype=torch.bfloat16, device=w.device)
+    check(lib().pd3_sparse_pack_weight_bf16x3(ptr(w), kvol, cin, cout, ptr(out), stream_ptr(w.device)),
+          "sparse_pack_weight_bf16x3")
+    return out
+
+
+def features_bf16x3(in_feats: torch.Tensor, idx: SparseIndices, packed_weight: torch.Tensor, cin: int, cout: int,
+                    bias=None, scale=None, shift=None, residual=None, relu: bool = False) -> torch.Tensor:
+    """features() on the bf16 matrix cores, fp32 rows in and out (pd3_sparse_conv3d_features_bf16x3)."""
+    f = require_gpu(in_feats, "sparse_conv3d")
+    if f.shape[1] != cin or packed_weight.numel() != 3 * idx.kernel_volume * cin * cout:
+        raise RuntimeError("sparse_conv3d: weight / feature shapes do not match")
+    out = torch.empty((idx.n_out, cout), dtype=torch.float32, device=f.device)
+    if idx.n_out == 0:
+        return out
+    opt = [None if t is None else require_gpu(t, "sparse_conv3d") for t in (bias, scale, shift, residual)]
+    check(lib().pd3_sparse_conv3d_features_bf16x3(
+        ptr(f), ptr(idx.nbr), ptr(idx.n_out_dev), idx.n_out, idx.kernel_volume, cin, cout, ptr(packed_weight),
+        ptr(opt[0]), ptr(opt[1]), ptr(opt[2]), ptr(opt[3]), int(bool(relu)), ptr(idx.order) if TILE_ORDER else None,
+        ptr(out), stream_ptr(f.device)), "sparse_conv3d_features_bf16x3")
     return out
 
 

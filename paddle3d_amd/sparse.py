@@ -102,6 +102,15 @@ class _SparseConv(nn.Module):
             object.__setattr__(self, "_pd3_packed", hit)
         return hit[1]
 
+    def _packed_bf16x3(self):
+        """The weight's three bf16 pieces in the bf16x3 kernel's operand order, repacked when the parameter changes."""
+        tag = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        hit = getattr(self, "_pd3_packed_x3", None)
+        if hit is None or hit[0] != tag:
+            hit = (tag, _sp.pack_weight_bf16x3(self.weight.detach()))
+            object.__setattr__(self, "_pd3_packed_x3", hit)
+        return hit[1]
+
     def forward(self, x: SparseConvTensor, scale=None, shift=None, residual=None, relu=False):
         idx = self._indices(x)
         cin, cout = int(self.weight.shape[-2]), int(self.weight.shape[-1])
@@ -117,7 +126,12 @@ class _SparseConv(nn.Module):
         else:
             feats = x.features if x.features.dtype == torch.float32 else x.features.float()
             res = residual if residual is None or residual.dtype == torch.float32 else residual.float()
-            out = _sp.features(feats, idx, self.weight, self.bias, scale, shift, res, relu)
+            if _sp.SPLIT_BF16 and _sp.bf16x3_pays(cin, cout, idx.kernel_volume):
+                # fp32 arithmetic on the bf16 matrix cores (three bf16 pieces per operand, six products)
+                out = _sp.features_bf16x3(feats, idx, self._packed_bf16x3(), cin, cout, self.bias, scale, shift, res,
+                                          relu)
+            else:
+                out = _sp.features(feats, idx, self.weight, self.bias, scale, shift, res, relu)
         if self.subm:
             return x.replace(out)
         return SparseConvTensor(out, idx.out_coords, idx.out_shape, x.batch_size, plan=x.plan, n_dev=idx.n_out_dev,

@@ -508,6 +508,67 @@ def test_features_f16_matches_fp32_math_on_fp16_operands(case, order):
     assert float((got.float() - want).abs().max()) < tol
 
 
+@pytest.mark.parametrize("case", F16_CASES, ids=lambda c: f"{c[0]}to{c[1]}{'subm' if c[2] else 'down'}")
+@pytest.mark.parametrize("order", [True, False], ids=["tile_order", "raster"])
+def test_features_bf16x3_is_fp32_arithmetic(case, order):
+    """pd3_sparse_conv3d_features_bf16x3 (fp32 operands as three bf16 pieces, six piece products, fp32 accumulation)
+    against an fp64 gather-GEMM of the same fp32 rows and weights: its error is that of the fp32 matrix-core kernel
+    (pd3_sparse_conv3d_features_ordered) -- both a few 1e-7 of the magnitude -- and 1000 times below what a 16-bit
+    operand format leaves (the fp16 form's test: 2e-4).  Values with a wide spread of magnitudes, every chunk width,
+    every output width, all epilogue forms, tile order and raster order, a partial last tile."""
+    from paddle3d_amd.ops import sparse_conv3d as sp
+
+    cin, cout, subm, ks, stride, pad, (with_bias, with_bn, with_res, relu), _ = case
+    rng = np.random.default_rng(cin * 11 + cout)
+    shape = (9, 60, 70)
+    coords, feats = _random_sparse(rng, 2, shape, 9000, cin)
+    slab = np.stack(np.meshgrid(np.arange(2), np.arange(3, 6), np.arange(20, 45), np.arange(30, 60), indexing="ij"),
+                    -1).reshape(-1, 4).astype(np.int32)
+    coords = np.unique(np.concatenate([coords, slab]), axis=0)
+    feats = (rng.normal(size=(len(coords), cin)) * np.exp(rng.normal(size=(len(coords), cin)))).astype(np.float32)
+    w = (rng.normal(size=(*ks, cin, cout)) * np.exp(rng.normal(size=(*ks, cin, cout))) /
+         np.sqrt(np.prod(ks) * cin)).astype(np.float32)
+    sp.TILE_ORDER = order
+    try:
+        pl = sp.plan(torch.from_numpy(coords).cuda(), 2, shape, [sp.ConvSpec(ks, stride, pad, subm)])
+        idx = pl.indices[0]
+        f = torch.from_numpy(feats).cuda().index_select(0, pl.order)
+        wt = torch.from_numpy(w).cuda()
+        bias = torch.from_numpy(rng.normal(size=cout).astype(np.float32)).cuda() if with_bias else None
+        sc = torch.from_numpy(rng.normal(size=cout).astype(np.float32)).cuda() if with_bn else None
+        sh = torch.from_numpy(rng.normal(size=cout).astype(np.float32)).cuda() if with_bn else None
+        res = torch.from_numpy(rng.normal(size=(idx.n_out, cout)).astype(np.float32)).cuda() if with_res else None
+        assert sp.bf16x3_supported(cin, cout, idx.kernel_volume)
+        fp32 = sp.features(f, idx, wt, bias, sc, sh, res, relu)
+        got = sp.features_bf16x3(f, idx, sp.pack_weight_bf16x3(wt), cin, cout, bias, sc, sh, res, relu)
+        again = sp.features_bf16x3(f, idx, sp.pack_weight_bf16x3(wt), cin, cout, bias, sc, sh, res, relu)
+    finally:
+        sp.TILE_ORDER = True
+    # the fp64 reference: gathered rows (a zero row for a missing neighbour) times the offset's matrix
+    f64 = torch.cat([f.double(), torch.zeros(1, cin, dtype=torch.float64, device="cuda")])
+    w64 = wt.double().reshape(-1, cin, cout)
+    nbr = idx.nbr[: idx.n_out].long()
+    nbr = torch.where(nbr < 0, torch.full_like(nbr, f.shape[0]), nbr)
+    want = torch.zeros(idx.n_out, cout, dtype=torch.float64, device="cuda")
+    for k in range(idx.kernel_volume):
+        want += f64.index_select(0, nbr[:, k]) @ w64[k]
+    if bias is not None:
+        want += bias.double()
+    if sc is not None:
+        want = want * sc.double() + sh.double()
+    if res is not None:
+        want += res.double()
+    if relu:
+        want = want.clamp_min(0)
+    assert got.dtype == torch.float32 and got.shape == want.shape and torch.equal(got, again)
+    assert idx.n_out % 256 != 0 and idx.n_out > 2000
+    mag = float(want.abs().max())
+    e_x3, e_32 = float((got.double() - want).abs().max()), float((fp32.double() - want).abs().max())
+    print(f"bf16x3 error {e_x3:.3g}, fp32 kernel error {e_32:.3g}, magnitude {mag:.3g}")
+    assert e_x3 <= max(2.0 * e_32, 2e-7 * mag), (e_x3, e_32, mag)
+    assert e_x3 < 2e-6 * mag
+
+
 def test_sparse_encoder_amp_close_to_fp32_and_voxel_model(oracle):
     """The whole CenterPoint-Voxel model with set_amp(True) on a quarter-range copy of config 4: the encoder's map within
     2 % of the fp32 map's magnitude, detections of the two graphs agree (same count within 2 %, strong boxes have twins)."""

@@ -15,6 +15,8 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 # second argument "raster": rows in raster order (no tile order), the round-4 behaviour
 _sp.TILE_ORDER = not (len(sys.argv) > 2 and sys.argv[2] == "raster")
 AMP = len(sys.argv) > 2 and sys.argv[2] == "amp"  # third form: the fp16 kernel where it applies
+# fourth form "fp32": the fp32 matrix-core kernel in every layer (round 4 / early round 5); the default runs the bf16x3 form
+_sp.SPLIT_BF16 = not (len(sys.argv) > 2 and sys.argv[2] in ("fp32", "raster"))
 model = cpm.centerpoint_voxels_nuscenes(max_num_voxels=(120000, 160000)).cuda().eval()
 pts = torch.from_numpy(np.stack([synth.nuscenes_sweep(100 + i) for i in range(batch)])).cuda()
 rows = []
@@ -73,6 +75,19 @@ def traced16(in_feats, idx, packed, cin, cout, *a, **kw):
 
 
 _sp.features_f16 = traced16
+_featx3 = _sp.features_bf16x3
+
+
+def tracedx3(in_feats, idx, packed, cin, cout, *a, **kw):  # (same 32-row blocks as the fp16 form)
+    global _feat16
+    keep, _feat16 = _feat16, _featx3
+    try:
+        return traced16(in_feats, idx, packed, cin, cout, *a, **kw)
+    finally:
+        _feat16 = keep
+
+
+_sp.features_bf16x3 = tracedx3
 with torch.no_grad():
     voxels, coors, npv, nv = model.voxelizer(pts)
     b, v, p, d = voxels.shape
@@ -83,6 +98,8 @@ with torch.no_grad():
     model.middle_encoder.amp = AMP
     model.middle_encoder(feats, cs, b)
 tot = 0.0
+print("fp32 layers:", "bf16x3 form where it applies (three bf16 pieces per fp32 operand, six products)" if _sp.SPLIT_BF16
+      else "fp32 matrix-core kernel", "| amp" if AMP else "")
 print("rows in", "tile order (windows of 8192 rows sorted by neighbour mask)" if _sp.TILE_ORDER else "raster order")
 print(f"{'rows':>8} {'K':>3} {'cin':>4} {'cout':>4} {'pairs/row':>9} {'exec/useful':>11} {'ms':>8} {'useful TF':>9} {'exec TF':>8}")
 for n, k, ci, co, pairs, blocks, ms in rows:
