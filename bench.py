@@ -1092,6 +1092,8 @@ def other_workloads(args, rank, world, dev):
     for name, fn, batch in todo:
         a = copy.copy(args)
         a.batch, a.steps, a.warmup, a.repeats = batch, 5, 2, 0
+        if fn is bench_voxel:  # (a 35-45 ms step whose first few runs still grow the allocator's pools)
+            a.steps, a.warmup = 10, 4
         a.no_extras = a.no_cpu_baseline = True
         a.workload = name
         try:
