@@ -9,7 +9,7 @@
 // Why: v_mfma_f32_16x16x4_f32 runs at 64 flop per cycle and SIMD, v_mfma_f32_32x32x16_bf16 at 1024; six of the latter per
 // fp32 product are 2.7 times the fp32 pipe's rate, and a sparse convolution has no Winograd form to shrink its products
 // by -- the big layers of the CenterPoint-Voxel encoder (sparse_resnet.py:115-206: 64 -> 64 and 128 -> 128 over 27
-// offsets) ran at 85-105 executed TFLOP/s of the fp32 pipe's 157 (profiles/r05_sparse_layers.txt).
+// offsets) ran at 85-105 executed TFLOP/s of the fp32 pipe's 157 (profiles/r05_sparse_layers_fp32.txt).
 // NaN / Inf inputs: x - bf16(x) is NaN for an infinite x, so an Inf in the input becomes a NaN in the output (the fp32
 // kernel would carry the Inf); activations of a network are finite.
 //
@@ -17,11 +17,16 @@
 // MFMA's A operand (M = 32 output channels) read from padded LDS lines, the gathered rows its B operand (N = 32 output
 // rows) loaded straight into registers -- here as fp32 (lane (row n, kh) reads KC / 2 consecutive floats of input row
 // nbr[n][k]: 64 contiguous bytes with KC = 32) and cut into pieces by the lane (5.5 VALU instructions per value:
-// v_cvt_pk_bf16_f32, shifts, subtractions; the value then feeds 6 Cout / 32 MFMAs).  The weights are cut on the host side
-// of the launch once (pd3_sparse_pack_weight_bf16x3: [offset][chunk][piece][co][KC / 16][2][8]).  A wave owns RB
-// 32-row blocks for all Cout: RB = 1 with eight waves for Cout = 128 (64 accumulator registers, two waves per SIMD with
-// one 90 KB workgroup per CU), RB = 2 with four waves below.  Block-uniform offset skip and tile order as in the other
-// forms; summation order fixed (offsets ascending, chunks, K-steps, pieces): run-to-run identical.
+// v_cvt_pk_bf16_f32, shifts, subtractions; the value then feeds 6 Cout / 32 MFMAs).  The weights are cut once per
+// parameter version (pd3_sparse_pack_weight_bf16x3: [offset][chunk][piece][co][KC / 16][2][8]).  A wave owns RB 32-row
+// blocks for all Cout: RB = 1 with eight waves for Cout = 128 (64 accumulator registers, two waves per SIMD, one 90 KB
+// workgroup per CU), RB = 2 with four waves below.  Block-uniform offset skip and tile order as in the other forms;
+// summation order fixed (offsets ascending, chunks, K-steps, pieces): run-to-run identical.
+// Measured on the way (profiles/r05_sparse_x3_forms.txt): rows cut by the layer that computes them and
+// gathered as pieces (6 B per value, no VALU in the loop) are slower than this form -- the gather bounds the kernel;
+// an XCD-contiguous tile range is slower than round-robin tiles; gathers two steps ahead pay, but only with a constant
+// number of loads in flight (see fetch_b).  Used from 64 output channels on (ops.sparse_conv3d.bf16x3_pays): 32 -> 32
+// spends 7 VALU instructions per MFMA here and is faster on the fp32 kernel.
 #include "../../include/paddle3d_amd.h"
 #include "common.hpp"
 
