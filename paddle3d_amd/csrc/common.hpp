@@ -37,6 +37,24 @@ struct Carver {
   }
 };
 
+// Tile of a sparse gather-GEMM block.  Blocks go to the 8 XCDs round-robin (block b runs on XCD b % 8, each XCD with its own
+// 4 MB L2): the `per_win` tiles of one 8192-row window (the unit of the tile order: a few neighbouring lines of the sorted
+// rows, whose tiles gather from the same three z-slabs) all run on ONE XCD, consecutive windows on consecutive XCDs -- the
+// window's input rows are fetched into one L2 instead of into eight, and the eight XCDs still walk neighbouring windows at
+// the same time (shared through the Infinity Cache).  Measured (profiles/r05_sparse_tilemap.txt): feature kernels of the
+// CenterPoint-Voxel encoder 22.8 -> 22.1 ms (fp32 / bf16x3), 9.73 -> 9.06 ms (fp16); groups of 16, 64 or 128 tiles, and
+// one contiguous eighth of all tiles per XCD, are slower than block order.
+// Launch with sp_window_grid(tiles, per_win) blocks; -1 = nothing to do for this block.
+__device__ __forceinline__ int sp_window_tile(int block, int tiles, int per_win) {
+  const int xcd = block & 7, slot = block >> 3;
+  const int t = ((slot / per_win) * 8 + xcd) * per_win + slot % per_win;
+  return t < tiles ? t : -1;
+}
+static inline unsigned sp_window_grid(long long tiles, int per_win) {
+  const long long group = 8LL * per_win;
+  return (unsigned)((tiles + group - 1) / group * group);
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

@@ -441,8 +441,9 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_kernel(SpGemmArgs a) {
   const int lane = lane_id(), wave = wave_id();
   const int K = a.K, cin = a.cin;
   const int n_out = a.n_out_dev ? min(*a.n_out_dev, a.n_out_cap) : a.n_out_cap;
-  const int row0 = blockIdx.x * kSg2Rows;
-  if (row0 >= n_out) return;  // (ordered: rows past n_out sort last in the last window, so this still holds)
+  const int tile = sp_window_tile(blockIdx.x, (n_out + kSg2Rows - 1) / kSg2Rows, 8192 / kSg2Rows);  // (a window per XCD)
+  if (tile < 0) return;  // (ordered: rows past n_out sort last in the last window, so whole tiles past it hold nothing)
+  const int row0 = tile * kSg2Rows;
   if (a.order) {
     // the tile's rows come from the tile order: rows of one window with similar neighbour masks share a 16-row
     // block, so fewer (block, offset) steps run on rows that lack the neighbour
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_kernel(SpGemmArgs a) {
 // Measured on config 4 (two frames): steps / pairs 1.73 -> 1.31 (64 -> 64), 2.15 -> 1.41 (32 -> 32), 1.29 -> 1.17
 // (128 -> 128), 4.8 - 7.0 -> 1.9 - 2.0 on the strided layers.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kSpWindow = 8192;
+constexpr int kSpWindow = 8192;  // (= the window of sp_window_tile in the gather-GEMMs)
 constexpr int kSpOrderThreads = 1024;
 constexpr int kSpOrderEpt = kSpWindow / kSpOrderThreads;  // 8 consecutive rows of the window per thread
 
@@ -1274,7 +1275,7 @@ extern "C" int pd3_sparse_conv3d_features_ordered(const float* in_feats, const i
     const int t = cin % 32 == 0 ? 8 : 4, nb = cout / 16;
     const size_t lds = (size_t)2 * 64 * (nb * t + 4) * sizeof(float) +
                        ((size_t)kSg2Rows * kernel_volume + 16 + kSg2Rows) * sizeof(int);
-    const unsigned grid = (unsigned)ceil_div(n_out_cap, kSg2Rows);
+    const unsigned grid = sp_window_grid(ceil_div(n_out_cap, kSg2Rows), 8192 / kSg2Rows);
 #define PD3_SP_ROWS(NBV, TV)                                                                      \
   do {                                                                                            \
     if (lds > 48 * 1024) {                                                                        \

@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_f16_kernel(SpGemmF16Args 
   const int l31 = lane & 31, kh = lane >> 5;
   const int K = a.K, cin = a.cin;
   const int n_out = a.n_out_dev ? min(*a.n_out_dev, a.n_out_cap) : a.n_out_cap;
-  const int row0 = blockIdx.x * kSfRows;
-  if (row0 >= n_out) return;
+  const int tile = sp_window_tile(blockIdx.x, (n_out + kSfRows - 1) / kSfRows, 8192 / kSfRows);  // (a window per XCD)
+  if (tile < 0) return;
+  const int row0 = tile * kSfRows;
   {
     int r = row0 + (int)threadIdx.x;
     if (a.order) r = a.order[row0 + threadIdx.x];
@@ -315,7 +316,7 @@ extern "C" int pd3_gather_gemm_f16(const void* in_feats_f16, const int32_t* nbr,
   const int kc = sf_chunk(cin), nc = cout / 32;
   const size_t lds = (size_t)2 * cout * (kc + 8) * sizeof(_Float16) +
                      ((size_t)kSfRows * kernel_volume + 16 + kSfRows) * sizeof(int);
-  const unsigned grid = (unsigned)ceil_div(n_out_cap, kSfRows);
+  const unsigned grid = sp_window_grid(ceil_div(n_out_cap, kSfRows), 8192 / kSfRows);
   hipError_t e;
 #define PD3_SF(NCV, KCV)                                                                           \
   do {                                                                                             \

@@ -84,8 +84,9 @@ __global__ __launch_bounds__(64 * (8 / RB), RB == 1 ? 1 : 2) void sp_gemm_rows_x
   const int l31 = lane & 31, kh = lane >> 5;
   const int K = a.K, cin = a.cin;
   const int n_out = a.n_out_dev ? min(*a.n_out_dev, a.n_out_cap) : a.n_out_cap;
-  const int row0 = blockIdx.x * kSxRows;
-  if (row0 >= n_out) return;
+  const int tile = sp_window_tile(blockIdx.x, (n_out + kSxRows - 1) / kSxRows, 8192 / kSxRows);  // (a window per XCD)
+  if (tile < 0) return;
+  const int row0 = tile * kSxRows;
   if (threadIdx.x < kSxRows) {
     int r = row0 + (int)threadIdx.x;
     if (a.order) r = a.order[row0 + threadIdx.x];
@@ -365,7 +366,7 @@ extern "C" int pd3_sparse_conv3d_features_bf16x3(const float* in_feats, const in
   const int kc = sx_chunk(cin), nc = cout / 32;
   const size_t lds = (size_t)2 * 3 * cout * (kc + 8) * sizeof(__bf16) +
                      ((size_t)kSxRows * kernel_volume + 16 + kSxRows) * sizeof(int);
-  const unsigned grid = (unsigned)ceil_div(n_out_cap, kSxRows);
+  const unsigned grid = sp_window_grid(ceil_div(n_out_cap, kSxRows), 8192 / kSxRows);
   hipError_t e;
 #define PD3_SX(NCV, KCV, RBV)                                                                        \
   do {                                                                                               \
