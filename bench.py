@@ -1216,7 +1216,7 @@ def bench_voxel(args, rank, world, dev):
                 _sp3.SPLIT_BF16 = True
         line["sparse_arithmetic"] = dict(
             form="fp32; the layers with >= 64 output channels multiply on the bf16 matrix cores with every fp32 operand "
-                 "cut into three bf16 pieces (hi + mid + lo = the value to 2^-27) and six of the nine piece products "
+                 "cut into three bf16 pieces (hi + mid + lo = the value exactly) and six of the nine piece products "
                  "accumulated in fp32 (csrc/sparse_conv_x3.hip): the error against exact arithmetic is that of the fp32 "
                  "matrix-core kernel (tests/test_sparse_conv_gpu.py::test_features_bf16x3_is_fp32_arithmetic)",
             encoder_map_max_abs_diff_vs_fp32_kernel=float((bev_x3 - bev_32).abs().max()),

@@ -393,8 +393,8 @@ int pd3_sparse_conv3d_features_ordered(const float *in_feats, const int32_t *nbr
                                        const float *shift, const float *residual, int relu,
                                        const int32_t *order, float *out, void *stream);
 /* The fp32 gather-GEMM on the bf16 matrix cores (round 5; the default of the fp32 encoder from 16 -> 32 channels on): every
- * fp32 operand is cut into three bf16 pieces (hi + mid + lo = the fp32 value to 2^-27) and six of the nine piece products
- * are accumulated in fp32 -- the error against exact arithmetic is that of the fp32 matrix-core kernel
+ * fp32 operand is cut into three bf16 pieces (hi + mid + lo = the fp32 value exactly: 3 x 8 significand bits) and six of
+ * the nine piece products are accumulated in fp32 (the three dropped ones: <= 2^-23 of a product, 2^-28 on average) -- the error against exact arithmetic is that of the fp32 matrix-core kernel
  * (tests/test_sparse_conv_gpu.py::test_features_bf16x3_is_fp32_arithmetic), the rate 2.7 x the fp32 pipe's.
  *   pd3_sparse_pack_weight_bf16x3       weight [K, Cin, Cout] fp32 (Paddle layout) -> 3 * K * Cin * Cout bf16 in the
  *                                       kernel's operand order; Cin % 16 == 0, Cout in {32, 64, 128}

@@ -1,11 +1,13 @@
 // The fp32 sparse gather-GEMM on the bf16 matrix cores (round 5): every fp32 operand travels as THREE bf16 pieces whose
-// sum is the fp32 value, and six of the nine piece products are accumulated in fp32 -- fp32 arithmetic, not a reduced
-// precision: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (both differences are exact in fp32, each piece
-// rounds to nearest: |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|, what is left <= 2^-27 |x|); a piece product has 16 significant
-// bits and is exact in the fp32 accumulator; kept are hi hi, hi mid, mid hi, hi lo, mid mid, lo hi -- the three dropped
-// products and the representation remainder are each <= 2^-27 of the product, together below the 2^-24 an fp32
-// multiplication rounds by itself.  tests/test_sparse_conv_gpu.py measures it: against an fp64 gather-GEMM this kernel's
-// error is that of the fp32 matrix-core kernel (sparse_conv.hip), not that of a 16-bit format.
+// sum IS the fp32 value, and six of the nine piece products are accumulated in fp32 -- fp32 arithmetic, not a reduced
+// precision: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); both differences are exact in fp32, each piece
+// rounds to nearest and carries 8 significand bits, and 3 x 8 = the 24 bits of an fp32 significand: x = hi + mid + lo
+// EXACTLY, with |mid| <= 2^-8 |x| and |lo| <= 2^-16 |x|.  A piece product (8 x 8 bits) is exact in the MFMA's fp32
+// accumulator; kept are hi hi, hi mid, mid hi, hi lo, mid mid, lo hi; dropped are mid lo, lo mid, lo lo: at most 2^-23 of
+// the product in the worst case, 2^-24.3 at most and 2^-28 on average over millions of random pairs (tests/
+// test_bf16x3_arith.py restates the scheme on the CPU) -- the size of the rounding an fp32 multiplication does by itself
+// (2^-24).  tests/test_sparse_conv_gpu.py measures the kernel: against an fp64 gather-GEMM its error is that of the fp32
+// matrix-core kernel (sparse_conv.hip), not that of a 16-bit format.
 // Why: v_mfma_f32_16x16x4_f32 runs at 64 flop per cycle and SIMD, v_mfma_f32_32x32x16_bf16 at 1024; six of the latter per
 // fp32 product are 2.7 times the fp32 pipe's rate, and a sparse convolution has no Winograd form to shrink its products
 // by -- the big layers of the CenterPoint-Voxel encoder (sparse_resnet.py:115-206: 64 -> 64 and 128 -> 128 over 27
@@ -51,7 +53,7 @@ struct SpGemmX3Args {
   const int32_t* order;
 };
 
-// x = hi + mid + lo (+ at most 2^-27 |x|), every piece a bf16 (round to nearest even)
+// x = hi + mid + lo exactly, every piece a bf16 (round to nearest even)
 __device__ __forceinline__ void sx_split(const sx_f32x4 lo4, const sx_f32x4 hi4, sx_b8& h, sx_b8& m, sx_b8& l) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
