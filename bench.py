@@ -770,7 +770,12 @@ def bench_pillars(args, rank, world, dev):
                            measured_in=("W + K steps of the pair form of the graph (pd3_hard_voxelize + pd3_pillar_feature_net), "
                                         "run in front of the contract block: the contract block's step holds "
                                         "pd3_hard_voxelize_index instead, see front_half") if fused_front
-                           else "the contract block's steps"),
+                           else "the contract block's steps",
+                           input_state=("every step reads the same 16-frame batch (96 MB: it would fit the 256 MB Infinity "
+                                        "Cache), but the 8 ms of convolutions between two voxelizer runs evict it -- the "
+                                        "route kernel takes ~30 us inside the step against ~24 us when the operator is "
+                                        "looped alone (profiles/r05_vox_paths.txt), so the in-step figure is the cold-input "
+                                        "one; roofline.floor gives both states of the bare memory accesses")),
         pointpillars_scatter=(dict(bound="hbm", fused_into="dense_backbone_fpn_head", achieved=None,
                                    peak=HBM_PEAK_GBPS, unit="GB/s", frac=None,
                                    traffic=traffic.get("pointpillars_scatter", {}).get("bytes_per_launch"),
