@@ -1,0 +1,686 @@
+"""The headline workload: CenterPoint-Pillars nuScenes (BASELINE.json configs[2]) and its AMP variant."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from .common import *  # noqa: F401,F403
+from .common import _LAST_LOOP, _timed_loop, _timed_region  # noqa: F401
+
+def dense_flops():
+    """(direct-form, executed) flops per scene of backbone + FPN + CenterHead at 512x512 input:
+    direct = 2*Cin*Cout*k*k*Hout*Wout per conv; executed = what the kernels issue: the stride-1 3x3 layers run
+    Winograd F(4x4,3x3) = 36 multiplies per 4x4 outputs x 9 taps -> a quarter of the direct flops."""
+    def conv(cin, cout, k, h):
+        return 2 * cin * cout * k * k * h * h
+
+    s1 = 3 * conv(64, 64, 3, 256) + 5 * conv(128, 128, 3, 128) + 5 * conv(256, 256, 3, 64)   # backbone, stride 1
+    s1 += conv(384, 64, 3, 128) + 36 * conv(64, 64, 3, 128)                                   # head, Winograd
+    s2 = conv(64, 64, 3, 256) + conv(64, 128, 3, 128) + conv(128, 256, 3, 64)                 # stride 2, direct
+    other = conv(64, 128, 2, 128) + conv(128, 128, 1, 128) + 2 * 256 * 128 * 128 * 128        # FPN patch GEMMs
+    other += conv(64, 70, 3, 128)                                                             # final grouped (VALU)
+    return s1 + s2 + other, s1 / 4 + s2 + other
+
+
+def dense_flops_by_pipe(model=None):
+    """Executed flops per scene of the fp32 dense graph, split by the matrix pipe each layer's kernel issues on: the
+    Winograd layers on the fp32 pipe; the direct layers (stride-2 openers, FPN levels) on the fp32 pipe, or -- when the
+    model runs them as bf16x3 (`model.backbone.split_bf16`, csrc/conv_x3.hip) -- as fp32-equivalent flops on the bf16
+    pipe; the final grouped 3x3 convolutions (70 channels) on the fp32 pipe."""
+    def conv(cin, cout, k, h):
+        return 2 * cin * cout * k * k * h * h
+
+    wino = (3 * conv(64, 64, 3, 256) + 5 * conv(128, 128, 3, 128) + 5 * conv(256, 256, 3, 64) + conv(384, 64, 3, 128) +
+            36 * conv(64, 64, 3, 128)) / 4
+    direct = (conv(64, 64, 3, 256) + conv(64, 128, 3, 128) + conv(128, 256, 3, 64) + conv(64, 128, 2, 128) +
+              conv(128, 128, 1, 128) + 2 * 256 * 128 * 128 * 128)
+    final = conv(64, 70, 3, 128)
+    x3 = bool(model is not None and getattr(getattr(model, "backbone", None), "split_bf16", False))
+    out = {"f32": wino + final + (0 if x3 else direct)}
+    if x3:
+        out["bf16x3"] = direct
+    return out
+
+
+def pfn_flops(v, mfma_per_scene=None):
+    """(direct-form, executed) flops per scene of the two-layer PFN: direct = per real-or-padded point
+    2*(10*32 + 64*64); executed = the v_mfma_f32_16x16x4_f32 (2048 flops each) the kernel issues.
+    The packed form (round 3) packs the stored points of 8 consecutive pillars into 16-row blocks, so the count depends
+    on the fill levels and is taken from the batch (`pfn_packed_mfma`); without it, the per-pillar
+    form's 38 per pillar slot are assumed."""
+    mf = mfma_per_scene if mfma_per_scene is not None else v * 38
+    return v * P * 2 * (10 * 32 + 64 * 64), mf * 2048
+
+
+def pfn_packed_mfma(npv, p, chunk=8):
+    """MFMA instructions the packed PFN kernel issues for num_points_per_voxel `npv` [B, V] (csrc/pfn.hip): 38 per
+    16-row block of a chunk's stored points (6 layer 1 + 32 layer 2) and 32 per chunk that holds a pillar (the
+    row-independent half of layer 2 for the chunk's 8 pillars)."""
+    n = npv.reshape(-1).to(torch.int64).clamp(min=0, max=p)
+    pad = (-n.numel()) % chunk
+    if pad:
+        n = torch.cat([n, n.new_zeros(pad)])
+    rows = n.reshape(-1, chunk).sum(1)
+    return int((((rows + 15) // 16) * 38 + (rows > 0).to(torch.int64) * 32).sum().item())
+
+
+def _oracle_scene(model_cpu, max_voxels, seed):
+    """One scene through the oracle pipeline (the CPU statement of the whole path)."""
+    from oracle import pyoracle as O
+    from paddle3d_amd import synth
+
+    kind = "ref" if O.have_ref() else "port"
+    O.centerpoint_pillars_pipeline(model_cpu, [synth.nuscenes_sweep(seed)], P, max_voxels, kind, dense_batch=1)
+    return kind
+
+
+def map_proxy(model, model_cpu, max_voxels, frames, dev):
+    """mAP-shaped evidence without a dataset: `frames` synthetic scenes through the oracle pipeline (CPU) and through
+    the device pipeline with the same weights; nuScenes-style AP (centre distance 0.5 / 1 / 2 / 4 m,
+    paddle3d_amd.nuscenes_bridge) of the device's detections scored against the oracle's, and the other way round.
+    The heads' last heat-map convolutions are scaled by 30 (bias per class: synth.trained_like_heads) on BOTH sides: plain
+    random-init heads put all scores of a class into a band 0.003 wide, where the top-K cut and the NMS order are
+    thousands of near-ties and the figure measures tie-breaking of 1e-6 noise (0.996 CPU against CPU), not the
+    pipelines; spread like a trained head's (0.10 .. 0.77) it is insensitive to such noise (1.0 CPU against CPU)."""
+    import copy
+
+    from oracle import pyoracle as O
+    from paddle3d_amd import nuscenes_bridge as nb
+    from paddle3d_amd import synth
+
+    model, model_cpu = copy.deepcopy(model), copy.deepcopy(model_cpu)
+    with torch.no_grad():
+        for m in (model, model_cpu):
+            # BatchNorm statistics like a trained net's (with the constructor's identity statistics the activations
+            # shrink layer by layer and no cell reaches the score threshold at all), the same values on both sides
+            g = torch.Generator().manual_seed(0)
+            for mod in m.modules():
+                if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                    mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+                    mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+                    mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) + 0.5)
+                    mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
+    pts = np.stack([synth.nuscenes_sweep(700 + i) for i in range(frames)])
+    # heads like a trained net's: gain 30, the bias per class from the heat maps of two frames (every class of every
+    # task crosses the score threshold in 1 % of the cells); the CPU twin takes the device model's parameters
+    synth.trained_like_heads(model, torch.from_numpy(pts[:2]).to(dev))
+    model_cpu.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    if hasattr(model_cpu, "invalidate"):
+        model_cpu.invalidate()
+    t0 = time.perf_counter()
+    ref = O.centerpoint_pillars_pipeline(model_cpu, pts, P, max_voxels)
+    t_cpu = time.perf_counter() - t0
+    got = []
+    with torch.no_grad():
+        for b0 in range(0, frames, 16):
+            for d in model.test_forward(torch.from_numpy(pts[b0:b0 + 16]).to(dev)):
+                got.append({k: d[k].cpu().numpy() for k in ("box3d_lidar", "scores", "label_preds")})
+    fwd, back = nb.nuscenes_style_map(got, ref), nb.nuscenes_style_map(ref, got)
+    return dict(value=fwd["mAP"], reverse=back["mAP"], frames=frames, classes_scored=fwd["classes_scored"],
+                oracle_boxes_without_device_twin=nb.unmatched_detections(got, ref),
+                device_boxes_without_oracle_twin=nb.unmatched_detections(ref, got),
+                per_class={str(c): round(v, 5) for c, v in fwd["per_class"].items()},
+                oracle_detections=int(sum(len(r["scores"]) for r in ref)),
+                device_detections=int(sum(int((g["scores"] >= 0).sum()) for g in got)), cpu_seconds=t_cpu,
+                note="AP of the HIP pipeline's detections against the oracle pipeline's (as if those were the "
+                     "annotations), mean over classes and the four centre-distance thresholds; random-init weights "
+                     "(heat-map heads scaled so that scores spread like a trained head's), "
+                     "so the absolute detections mean nothing -- the figure says how far the two pipelines' outputs "
+                     "are apart on the mAP scale (1.0 = identical detection sets; the north star's 0.1 mAP = 0.001 "
+                     "here, and the AP is quantised: one box without a twin costs its class one of 90 recall bins at every "
+                     "threshold = 1/900 of the mean, see *_without_*_twin for the counts); "
+                     "tests/test_model_gpu.py::test_map_proxy_64_frames runs 64 frames")
+
+
+def _oracle_worker(args):
+    """Process-pool worker of the P x 1-thread leg: builds its own model, times one scene with one thread."""
+    state_path, max_voxels, seed = args
+    torch.set_num_threads(1)
+    from paddle3d_amd import centerpoint as cpm
+
+    m = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(max_voxels, max_voxels)).eval()
+    m.load_state_dict(torch.load(state_path))
+    t0 = time.perf_counter()
+    _oracle_scene(m, max_voxels, seed)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(model_cpu, max_voxels, frames=6):
+    """Oracle pipeline on the host cores (bounded samples, ~25 s in all)."""
+    import multiprocessing as mp
+    import tempfile
+
+    threads = torch.get_num_threads()
+    t0 = time.perf_counter()
+    for i in range(frames):
+        kind = _oracle_scene(model_cpu, max_voxels, 100 + i)
+    dt_all = time.perf_counter() - t0
+    src = ("reference voxelize_op.cc:19-82 compiled from /root/reference" if kind == "ref" else "C port")
+    out = dict(value=frames / dt_all, unit="scenes/s", cores=threads, kind="reference" if kind == "ref" else "port",
+               sample=f"{frames} frames of the same workload: hard_voxelize = {src} (1 thread), PFN / dense graph = "
+                      f"torch CPU fp32 ({threads} threads), scatter / postprocess = C port")
+    # (i) one thread, one frame at a time -- how the reference's CPU path runs a frame (voxelize_op.cc:36)
+    torch.set_num_threads(1)
+    try:
+        t0 = time.perf_counter()
+        _oracle_scene(model_cpu, max_voxels, 100)
+        dt1 = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(threads)
+    out["one_thread"] = dict(value=1.0 / dt1, unit="scenes/s", cores=1, sample="1 frame, every stage on 1 thread")
+    # (ii) P processes x 1 thread, one frame each
+    procs = max(1, min(os.cpu_count() or 1, 32))
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "state.pt")
+            torch.save(model_cpu.state_dict(), path)
+            ctx = mp.get_context("spawn")
+            t0 = time.perf_counter()
+            with ctx.Pool(procs) as pool:
+                pool.map(_oracle_worker, [(path, max_voxels, 100 + i) for i in range(procs)])
+            dtp = time.perf_counter() - t0
+        out["procs_x_1thread"] = dict(value=procs / dtp, unit="scenes/s", cores=procs,
+                                      sample=f"{procs} processes x 1 thread, one frame each (wall time incl. process "
+                                             "start and model construction)")
+    except Exception as e:  # noqa: BLE001 -- a reported extra, never required
+        out["procs_x_1thread"] = dict(value=None, unit="scenes/s", cores=procs, sample=f"failed: {e}")
+    return out
+
+
+def _traffic(batch, v):
+    """HBM traffic per launch from the PMC passes (tools/gpu_traffic.sh -> profiles/*_traffic.json), when a profile
+    of this exact configuration is committed; collected offline because rocprofv3 --pmc cannot wrap the timed run."""
+    import glob
+
+    found = {}
+    try:
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+            t = json.load(open(path))
+            if t.get("batch") == batch and t.get("max_voxels") == v and t.get("front", "pair") == "pair":
+                found = dict(t, _source="profiles/" + os.path.basename(path))
+    except Exception:  # noqa: BLE001
+        found = {}
+    return found
+
+
+def _vox_floor():
+    """The measured floor of hard_voxelize's MEMORY ACCESSES at C3 x 16 frames (tools/hwcheck/voxfloor: a program with
+    no ranking logic that only streams the points, gathers 2.16 M kept 20-byte records into the fixed-shape output and
+    performs the first-point stores / loads), from the newest profiles/r*_voxfloor.txt: what the access set costs on
+    this machine warm / after a cache flush, next to what the operator achieves."""
+    import glob
+    import re
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_voxfloor.txt")))
+    if not paths:
+        return None
+    try:
+        text = open(paths[-1]).read().split("# tools/hwcheck/voxfloor --random")[0]
+        warm = re.search(r"warm:.*?sum ([0-9.]+) us = ([0-9.]+) of", text)
+        cold = re.search(r"cold:.*?sum ([0-9.]+) us = ([0-9.]+) of", text)
+        return dict(warm_us=float(warm.group(1)), warm_frac=float(warm.group(2)), cold_us=float(cold.group(1)),
+                    cold_frac=float(cold.group(2)), source="profiles/" + os.path.basename(paths[-1]),
+                    note="tools/hwcheck/voxfloor: the operator's memory accesses alone (no ranking logic), 16 frames of "
+                         "config 3, index lists with a 10-sweep frame's locality; warm = points in the last-level "
+                         "cache, cold = after a 1 GiB flush (the in-step state lies between)")
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def bench_pillars(args, rank, world, dev):
+    from paddle3d_amd import centerpoint as cpm
+    from paddle3d_amd import dist as pdist
+
+    V, B = args.max_voxels, args.batch
+    model = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(V, V)).to(dev).eval()
+    model.voxelizer.path = args.vox_path
+    amp = args.workload == "centerpoint_pillars_amp"
+    model.set_amp(amp)
+    pts = make_batch(B, 100 + B * rank, dev)
+    cfg = model.test_cfg
+    max_per_img = cfg["max_per_img"]
+    names = ["start", "hard_voxelize", "pillar_feature_net", "pointpillars_scatter", "dense", "postprocess", "gather"]
+    # the result hand-off: batch k's all-gather travels on RCCL's stream while batch k + 1 is computed (--gather sync:
+    # the collective inside the step, on the compute stream's critical path)
+    pipe = pdist.GatherPipeline() if args.gather == "overlap" else None
+    # --front fused (default): voxelizer -> PFN through the index of the points, as CenterPoint.test_forward runs it;
+    # --front pair: pd3_hard_voxelize (the full operator, padded tensor written) + pd3_pillar_feature_net
+    fused_front = args.front == "fused" and args.vox_path == 0 and getattr(model, "fuse_rows", False)
+    if fused_front:
+        with torch.no_grad():
+            probe = model.voxelizer.index(pts[:1])
+            fused_front = probe is not None and model.voxel_encoder.forward_indexed(
+                pts[:1], probe[0], probe[1], probe[2].view(-1, 4)) is not None
+
+    def hand_off(rec, cnt):
+        if pipe is None:
+            return pdist.gather_detections(rec, cnt)
+        prev = pipe.submit(rec, cnt)
+        return prev if prev is not None else (rec, cnt)
+
+    def finish(out):
+        return pipe.flush() if pipe is not None else out
+
+    def compute(points, events):
+        """One step up to the operator's own record: (rec [B, max_per_img, 11], cnt [B]) of THIS batch."""
+        def mark(i):
+            if events is not None:
+                events[i].record()
+
+        mark(0)
+        feats = None
+        if fused_front:
+            # the model path: the voxelizer leaves an INDEX of the points (no padded [V, P, D] tensor), the PFN reads
+            # the points through it (pd3_hard_voxelize_index + pd3_pillar_feature_net_indexed)
+            idx = model.voxelizer.index(points)
+            if idx is not None:
+                span, plist, coors, npv, nv = idx
+                mark(1)
+                b, v = int(coors.shape[0]), int(coors.shape[1])
+                feats = model.voxel_encoder.forward_indexed(points, span, plist, coors.view(b * v, 4))
+        if feats is None:
+            voxels, coors, npv, nv = model.voxelizer(points)
+            mark(1)
+            b, v, p, d = voxels.shape
+            feats = model.voxel_encoder(voxels.view(b * v, p, d), npv.view(b * v), coors.view(b * v, 4))
+        mark(2)
+        canvas = model.scatter(feats, coors.view(b * v, 4), b)
+        mark(3)
+        x = model.dense_forward(canvas)
+        preds, _ = model.bbox_head(x)
+        mark(4)
+        _bx, _sc, _lb, cnt, rec = model.bbox_head.predict_by_custom_op(preds, cfg, device_only=True,
+                                                                      records=max_per_img)
+        mark(5)
+        return rec, cnt
+
+    def run(points, events):
+        rec, cnt = compute(points, events)
+        all_rec, all_cnt = hand_off(rec, cnt)  # the record comes out of the operator itself
+        if events is not None:
+            events[6].record()
+        return all_rec, all_cnt
+
+    # --graph: the step as five HIP graphs (one per op, so that the per-op HIP events stay between them): ~60 kernel
+    # launches and their Python / allocator work become five graph launches.  Same kernels, same order, same buffers
+    # every replay; the collective stays outside.  Measured: no difference on this path (the host needs 0.8-1.0 ms to
+    # enqueue a 10 ms step, the GPU never waits for it), so the default stays the eager step.
+    launch = "eager"
+    step = lambda ev: run(pts, ev)  # noqa: E731
+    cpu_ms = None
+    with torch.no_grad():
+        for _ in range(2):  # packs weights, sizes workspaces: nothing of that may happen inside a capture
+            run(pts, None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(pts, None)
+        cpu_ms = (time.perf_counter() - t0) * 1e3  # host time to enqueue one eager step (no sync)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        gpu_ms_est = cpu_ms + (time.perf_counter() - t1) * 1e3  # enqueue + drain of that one step
+        # --graph forces replay; otherwise it is turned on only where the host would hold the GPU up (dist.choose_launch:
+        # enqueue time above half of the step, measured under the node's real contention)
+        want_graph = pdist.choose_launch(cpu_ms, gpu_ms_est, "graph" if args.graph else "auto") == "graph"
+        if want_graph:
+            fused_front = False  # (the captured segments are the pair form's)
+            try:
+                st = {}
+
+                def seg_vox():
+                    st["vox"] = model.voxelizer(pts)
+
+                def seg_pfn():
+                    voxels, coors, npv, _nv = st["vox"]
+                    b, v, p, d = voxels.shape
+                    st["b"], st["c4"] = b, coors.view(b * v, 4)
+                    st["feats"] = model.voxel_encoder(voxels.view(b * v, p, d), npv.view(b * v), st["c4"])
+
+                def seg_scatter():
+                    st["canvas"] = model.scatter(st["feats"], st["c4"], st["b"])
+
+                def seg_dense():
+                    st["preds"] = model.bbox_head(model.dense_forward(st["canvas"]))[0]
+
+                def seg_post():
+                    st["post"] = model.bbox_head.predict_by_custom_op(st["preds"], cfg, device_only=True,
+                                                                      records=max_per_img)
+
+                segs = [seg_vox, seg_pfn, seg_scatter, seg_dense, seg_post]
+                pool = torch.cuda.graph_pool_handle()
+                graphs = []
+                for f in segs:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool):
+                        f()
+                    graphs.append(g)
+                torch.cuda.synchronize()
+
+                def run_graphs(events):
+                    if events is not None:
+                        events[0].record()
+                    for i, g in enumerate(graphs):
+                        g.replay()
+                        if events is not None:
+                            events[i + 1].record()
+                    _bx, _sc, _lb, cnt, rec = st["post"]
+                    res = hand_off(rec, cnt)
+                    if events is not None:
+                        events[6].record()
+                    return res
+
+                # the guard compares THIS batch's records of the two launch paths (not what hand_off returns: with
+                # --gather overlap that is the previous batch's result, which would compare eager with eager)
+                ref = [t.clone() for t in compute(pts, None)]
+                for g in graphs:
+                    g.replay()
+                torch.cuda.synchronize()
+                got = (st["post"][4], st["post"][3])
+                if not (torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])):
+                    raise RuntimeError("graph replay and eager step disagree")
+                step, launch = run_graphs, f"hip graphs ({len(graphs)} per step, one per op) + eager result hand-off"
+            except Exception as e:  # noqa: BLE001  (capture is an optimisation of the launch path, never a requirement)
+                torch.cuda.synchronize()
+                print(f"bench: HIP-graph capture failed ({type(e).__name__}: {e}); running the eager step", file=sys.stderr)
+                step, launch = (lambda ev: run(pts, ev)), "eager (graph capture failed)"
+    # The north star's roofline is that of the OPERATOR pd3_hard_voxelize (the padded [V, P, D] tensor written).  With
+    # the fused front the contract block's step no longer contains it, so it is timed in a block of its own, in the
+    # contract's own shape (the same _timed_loop: barrier, W warm-up steps, K timed steps of the PAIR form of the graph
+    # with the result hand-off, HIP events around the operator, the points evicted by the rest of the step) in front of
+    # the contract block.  `value` / `ms_per_step` are the contract block's (fused front).
+    pair_ms = None
+    if fused_front:
+        import copy as _copy
+
+        a2 = _copy.copy(args)
+        a2.repeats = 0
+        fused_front = False  # (compute() reads the flag when it runs)
+        _dt2, pair_ms, _out2, _info2 = _timed_loop(step, a2, world, dev, names, finish=finish)
+        fused_front = True
+    dt, per_op_ms, out, info = _timed_loop(step, args, world, dev, names, finish=finish)
+    op_ms = per_op_ms if pair_ms is None else pair_ms
+    multi = {}
+    if args.strong_frames > 0 and not args.no_extras:
+        # every rank takes part (collectives inside); the line is rank 0's
+        loop = dict(_LAST_LOOP)
+        with torch.no_grad():
+            from paddle3d_amd import synth
+
+            def shard(ids):
+                return torch.from_numpy(np.stack([synth.nuscenes_sweep(1000 + i) for i in ids])).to(dev)
+
+            flush = (lambda: pipe.flush()) if pipe is not None else None
+            multi["strong_scaling"] = strong_scaling(lambda b: run(b, None), flush, shard, args.strong_frames, B, rank,
+                                                     world, dev)
+            if world > 1:
+                host = make_batch(B, 100 + B * rank, pin=True)
+                multi["h2d_inclusive"] = h2d_inclusive(lambda b: run(b, None), flush, host, torch.empty_like(pts),
+                                                       args.steps, world, dev)
+                multi["h2d_overlapped"] = h2d_overlapped(lambda b: run(b, None), flush,
+                                                         [host, make_batch(B, 900 + B * rank, pin=True)], args.steps,
+                                                         world, dev)
+        _LAST_LOOP.clear()
+        _LAST_LOOP.update(loop)
+    if rank != 0:
+        return None
+    alg = algorithmic_bytes(V)
+    traffic = _traffic(B, V)
+
+    traffic_src = traffic.get("_source")
+
+    def hbm(name, key, src=None):
+        src = per_op_ms if src is None else src
+        return hbm_roofline(alg[key] * B, src[name], B, traffic.get(key, {}).get("bytes_per_launch"),
+                            traffic_src if key in traffic else None)
+
+    def mfma(ms, direct, by_pipe, note):
+        return mfma_roofline({k: v * B for k, v in by_pipe.items()}, ms, B,
+                             executed_flops_per_unit=sum(by_pipe.values()), direct_form_flops_per_unit=direct,
+                             direct_form_tflops=direct * B / (ms * 1e-3) / 1e12, note=note)
+
+    d_direct, d_exec = dense_flops()
+    with torch.no_grad():
+        pfn_mfma = pfn_packed_mfma(model.voxelizer(pts)[2], P) / B
+    p_direct, p_exec = pfn_flops(V, pfn_mfma)
+    rooflines = dict(
+        hard_voxelize=dict(hbm("hard_voxelize", "hard_voxelize", op_ms),
+                           measured_in=("W + K steps of the pair form of the graph (pd3_hard_voxelize + pd3_pillar_feature_net), "
+                                        "run in front of the contract block: the contract block's step holds "
+                                        "pd3_hard_voxelize_index instead, see front_half") if fused_front
+                           else "the contract block's steps",
+                           input_state=("every step reads the same 16-frame batch (96 MB: it would fit the 256 MB Infinity "
+                                        "Cache), but the 8 ms of convolutions between two voxelizer runs evict it -- the "
+                                        "route kernel takes ~30 us inside the step against ~24 us when the operator is "
+                                        "looped alone (profiles/r05_vox_paths.txt), so the in-step figure is the cold-input "
+                                        "one; roofline.floor gives both states of the bare memory accesses")),
+        pointpillars_scatter=(dict(bound="hbm", fused_into="dense_backbone_fpn_head", achieved=None,
+                                   peak=HBM_PEAK_GBPS, unit="GB/s", frac=None,
+                                   traffic=traffic.get("pointpillars_scatter", {}).get("bytes_per_launch"),
+                                   ms_per_launch=per_op_ms["pointpillars_scatter"], units_per_launch=B,
+                                   note="PointPillarsScatter is fused into the first backbone convolution (round 3): "
+                                        "this interval holds the inverse-map kernels only, the canvas is never "
+                                        "written; `pd3_pointpillars_scatter` alone runs at 0.49-0.51 of the HBM "
+                                        "roofline (DESIGN 4.2)")
+                              if getattr(model, "fuse_scatter", False)
+                              else hbm("pointpillars_scatter", "pointpillars_scatter")),
+        centerpoint_postprocess=dict(hbm("postprocess", "centerpoint_postprocess"),
+                                     us_per_frame=per_op_ms["postprocess"] * 1e3 / B,
+                                     note="latency bound (SURVEY 8(d)): us_per_frame is the figure, the HBM "
+                                          "fraction is for completeness (6 tasks x up to 1000 candidates per "
+                                          "frame: random-init heads fill the NMS cap)"),
+        pillar_feature_net=mfma(per_op_ms["pillar_feature_net"], p_direct, {"f32": p_exec},
+                                "achieved / frac = executed MFMA flops: the packed form issues 38 "
+                                "v_mfma_f32_16x16x4_f32 per 16-row block of stored points (packed per 8 pillars) + 32 "
+                                f"per chunk, {pfn_mfma:.0f} per scene counted on this batch; the kernel is bound by "
+                                "VALU / LDS instruction issue next to the MFMAs, not by the matrix pipe (DESIGN 4.3); "
+                                "direct_form_tflops = the layer's own multiply-adds over all P slots / time"),
+        dense_backbone_fpn_head=(
+            mfma(per_op_ms["dense"], d_direct, {"f16": d_direct},
+                 "AMP: the whole dense graph is direct-form implicit GEMM on the fp16 matrix cores (csrc/conv_f16.hip: "
+                 "no Winograd), so executed = direct-form flops, priced against the fp16 pipe's 2.5 PFLOP/s")
+            if amp else
+            mfma(per_op_ms["dense"], d_direct, dense_flops_by_pipe(model),
+                 "achieved / frac = executed flops: the 52 stride-1 3x3 layers run Winograd F(4x4,3x3) on the fp32 "
+                 "matrix cores (a quarter of the direct multiplies); the 3 stride-2 layers and the FPN levels run direct "
+                 "GEMMs (fp32 pipe, or fp32 arithmetic as bf16x3 where `pipes` says so); peak = the mix's own ceiling; "
+                 "direct_form_tflops = 127.2 GFLOP/scene / time (may exceed the peak: fewer multiplies are issued than "
+                 "counted)")))
+    line = {
+        "metric": ("scenes/sec CenterPoint-Pillars nuScenes 300k-pt sweeps" +
+                   (" (AMP O2: fp16 matrix cores in the stride-1 convolutions)" if amp else "")),
+        "value": world * B * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16 x f16 -> f32 (dense 3x3 stride 1), f32 elsewhere" if amp else "f32",
+        "data": "synthetic",
+        "config": {"workload": "CenterPoint-Pillars nuScenes 10-sweep: 300000 pts x 5 per scene, 0.2 m pillars "
+                               f"(512x512), P=20, max_voxels={V}, batch {B} distinct scenes/GPU/step, random-init "
+                               "weights, full graph voxelize->PFN->scatter->SECOND+FPN->CenterHead->postprocess"
+                               + ("->RCCL all-gather" if world > 1 else ""),
+                   "frames_per_gpu_per_step": B, "max_voxels": V, "parallelism": f"dp{world} (frames)",
+                   "launch": launch, "host_ms_to_enqueue_one_eager_step": cpu_ms,
+                   "launch_policy": "graph replay is turned on when enqueueing a step takes the host more than half of "
+                                    "the step's GPU time (dist.choose_launch); --graph forces it",
+                   "result_hand_off": ("all-gather of batch k overlapped with batch k + 1 (dist.GatherPipeline)"
+                                       if pipe is not None else "all-gather inside the step")},
+        "roofline": dict(rooflines["hard_voxelize"],
+                         kernel="hard_voxelize launch sequence (vw_route + vw_group + vw_assign + vw_rows: the wave form, "
+                                "voxelize_wave.hpp; --vox-path picks another form)",
+                         target=0.5, floor=_vox_floor()),
+        "rooflines": rooflines,
+        "front_half": dict(
+            form=("fused: pd3_hard_voxelize_index (no padded [V, P, D] tensor) + pd3_pillar_feature_net_indexed"
+                  if fused_front else "pair: pd3_hard_voxelize + pd3_pillar_feature_net"),
+            ms_in_step=per_op_ms["hard_voxelize"] + per_op_ms["pillar_feature_net"],
+            pair_ms=dict(hard_voxelize=op_ms["hard_voxelize"], pillar_feature_net=op_ms["pillar_feature_net"]),
+            note="per_op_ms.hard_voxelize / .pillar_feature_net are the intervals of the form the step runs; pair_ms are "
+                 "the two full operators inside K steps of the pair form"),
+        # `roofline` is the kernel the north star puts the HBM target on; by time the step is dominated by
+        # the dense graph (rooflines["dense_backbone_fpn_head"], MFMA bound)
+        "dominant_by_time": "dense_backbone_fpn_head",
+        "per_op_ms": per_op_ms,
+        "detections_first_frame": int(out[1][0].item()),
+    }
+    if amp:
+        # what the mixed-precision graph costs in accuracy on this batch: head maps against the fp32 graph's, and the
+        # detections of the two graphs scored against each other on the mAP scale (the fp32 graph as the annotations)
+        from paddle3d_amd import nuscenes_bridge as nb
+
+        import copy
+
+        from paddle3d_amd import synth
+
+        with torch.no_grad():
+            # a copy with heads like a trained net's (synth.trained_like_heads: every class of every task fires), so
+            # that the detections compared are not thousands of near-ties of one score band
+            m2 = copy.deepcopy(model)
+            m2.set_amp(False)
+            synth.trained_like_heads(m2, pts[:2])
+
+            def maps_and_dets(flag):
+                m2.set_amp(flag)
+                canvas = m2.extract_pillars(pts, dense=False)
+                preds, _ = m2.bbox_head(m2.dense_forward(canvas))
+                dets = m2.bbox_head.predict_by_custom_op(preds, cfg)
+                return preds, [{k: d[k].cpu().numpy() for k in ("box3d_lidar", "scores", "label_preds")} for d in dets]
+
+            p16, d16 = maps_and_dets(True)
+            p32, d32 = maps_and_dets(False)
+            err = max(float((a[k].float() - b[k].float()).abs().max()) for a, b in zip(p16, p32) for k in a)
+            mag = max(float(b[k].float().abs().max()) for b in p32 for k in b)
+            del m2
+        res = nb.nuscenes_style_map(d16, d32)
+        line["amp_error"] = dict(head_maps_max_abs=err, head_maps_max_magnitude=mag,
+                                 map_proxy_vs_fp32=res["mAP"], classes_scored=res["classes_scored"],
+                                 per_class_ap_vs_fp32={str(c): round(v, 5) for c, v in res["per_class"].items()},
+                                 fp32_boxes_without_amp_twin=nb.unmatched_detections(d16, d32, score_tol=2e-2),
+                                 amp_boxes_without_fp32_twin=nb.unmatched_detections(d32, d16, score_tol=2e-2),
+                                 frames=int(pts.shape[0]),
+                                 note="fp16 activations and weights, fp32 accumulation; random-init weights with "
+                                      "heads calibrated like a trained net's (synth.trained_like_heads); the AP is "
+                                      "quantised (one box of a class without a twin = one of 90 recall bins = 0.011 of "
+                                      "that class's AP, whatever the number of boxes): the *_without_*_twin counts "
+                                      "(same frame and class, centre within 0.5 m, score within 0.02) say how many "
+                                      "boxes that is; "
+                                      "tests/test_model_gpu.py::test_amp_graph_close_to_fp32 runs 64 frames")
+    if multi:
+        line["extras"] = dict(multi)
+    if world == 1 and not args.no_extras:
+        extras = line.setdefault("extras", {})
+        with torch.no_grad():
+            # (a) the same steps with the batch copied from pinned host memory inside every step (not overlapped)
+            host = make_batch(B, 100, pin=True)
+            stage = torch.empty_like(pts)
+
+            def h2d_step():
+                stage.copy_(host, non_blocking=True)
+                return run(stage, None)
+
+            for _ in range(2):
+                h2d_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                h2d_step()
+            torch.cuda.synchronize()
+            dth = time.perf_counter() - t0
+            extras["h2d_inclusive"] = dict(value=B * args.steps / dth, unit="scenes/s",
+                                           note=f"{host.numel() * 4 / B / 1e6:.1f} MB per scene over PCIe from pinned "
+                                                "memory inside every step, not overlapped with compute")
+            ov = h2d_overlapped(lambda b: run(b, None), (lambda: pipe.flush()) if pipe is not None else None,
+                                [host, make_batch(B, 900, pin=True)], args.steps, 1, dev)
+            ov["fraction_of_resident"] = ov["value"] / (world * B * args.steps / dt)
+            extras["h2d_overlapped"] = ov
+            # (b) per-frame latency: batch 1, one frame in flight
+            one = pts[:1].contiguous()
+            for _ in range(3):
+                run(one, None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                run(one, None)
+            torch.cuda.synchronize()
+            extras["latency_batch1_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+            # (c) two batches in flight: batch k + 1's front half (voxelize -> PFN -> scatter: instruction / latency
+            # bound) on a second stream beside batch k's dense graph + postprocess (matrix-core bound).  Same kernels,
+            # same work per batch; a different schedule, so it is reported under its own name, never as `value`.
+            try:
+                main_s, side_s = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+
+                def front():
+                    voxels, coors, npv, _nv = model.voxelizer(pts)
+                    b, v, p, d = voxels.shape
+                    feats = model.voxel_encoder(voxels.view(b * v, p, d), npv.view(b * v), coors.view(b * v, 4))
+                    return model.scatter(feats, coors.view(b * v, 4), b)
+
+                def back(canvas):
+                    preds, _ = model.bbox_head(model.dense_forward(canvas))
+                    out = model.bbox_head.predict_by_custom_op(preds, cfg, device_only=True, records=max_per_img)
+                    return pdist.gather_detections(out[4], out[3])
+
+                def pipelined(steps):
+                    done = [None] * (steps + 1)
+                    canvas = None
+                    for k in range(steps + 1):
+                        nxt = None
+                        if k < steps:
+                            if k >= 2 and done[k - 2] is not None:
+                                side_s.wait_event(done[k - 2])  # at most two batches in flight
+                            with torch.cuda.stream(side_s):
+                                nxt = front()
+                                ready = torch.cuda.Event()
+                                ready.record(side_s)
+                        if canvas is not None:
+                            main_s.wait_event(canvas[1])
+                            cv = canvas[0]
+                            for t in ([cv.features, cv.coords, cv.inv] if hasattr(cv, "inv") else [cv]):
+                                t.record_stream(main_s)
+                            res = back(canvas[0])
+                            done[k - 1] = torch.cuda.Event()
+                            done[k - 1].record(main_s)
+                        canvas = (nxt, ready) if nxt is not None else None
+                    return res
+
+                side_s.wait_stream(main_s)
+                pipelined(3)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = pipelined(args.steps)
+                torch.cuda.synchronize()
+                dtp = time.perf_counter() - t0
+                same = bool(torch.equal(res[0], out[0]) and torch.equal(res[1], out[1]))
+                extras["pipelined_two_streams"] = dict(
+                    value=B * args.steps / dtp, unit="scenes/s", identical_results=same,
+                    note="batch k+1's voxelize + PFN + scatter on a second HIP stream beside batch k's dense graph + "
+                         "postprocess; same kernels and work per batch, two batches in flight; not the headline")
+            except Exception as e:  # noqa: BLE001 -- an extra
+                torch.cuda.synchronize()
+                extras["pipelined_two_streams"] = dict(value=None, note=f"failed: {type(e).__name__}: {e}")
+        extras["measured_ceilings"] = measured_ceilings(dev)
+    if world == 1:
+        if not args.no_cpu_baseline:
+            try:
+                model_cpu = cpm.centerpoint_pillars_nuscenes(max_num_voxels=(V, V)).eval()
+                model_cpu.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+                line["cpu_baseline"] = cpu_baseline(model_cpu, V)
+            except Exception as e:  # the baseline is reported, never required
+                line["cpu_baseline"] = dict(value=None, unit="scenes/s", cores=0, kind="port", sample=f"failed: {e}")
+                model_cpu = None
+            if model_cpu is not None and args.map_frames > 0 and "extras" in line:
+                try:
+                    line["extras"]["map_proxy"] = map_proxy(model, model_cpu, V, args.map_frames, dev)
+                except Exception as e:  # noqa: BLE001 -- an extra
+                    line["extras"]["map_proxy"] = dict(value=None, note=f"failed: {type(e).__name__}: {e}")
+    if world == 1 and not args.no_extras:
+        del model
+        torch.cuda.empty_cache()
+        loop = dict(_LAST_LOOP)  # the headline's launch facts, not the last extra workload's
+        from .registry import other_workloads  # (the registry imports this module)
+
+        line["extras"]["other_workloads"] = other_workloads(args, rank, world, dev)
+        _LAST_LOOP.clear()
+        _LAST_LOOP.update(loop)
+    return line

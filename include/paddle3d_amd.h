@@ -337,6 +337,9 @@ int pd3_frustum_to_lidar(const float *frustum, int64_t points_per_camera, int ba
  *   mode 0 (BEVDet)  rank = b * (Z*Y*X) + z * (Y*X) + y * X + x;  ranks_feat = camera-pixel index
  *   mode 1 (LSS)     rank = ((b * Z + z) * X + x) * Y + y  (the cell of the reference's [B, Z, X, Y] output);
  *                    ranks_feat = point index
+ *   mode 2 (LSS, split operands)  rank as mode 1, ranks_depth = point index, ranks_feat = camera-pixel index as
+ *                    mode 0: pools depth [B*N, D, H, W] and feat [B*N, H, W, C] directly -- the lifted
+ *                    depth (x) feat tensor of CamEncode.get_depth_feat (cam_stream_lss.py:166) is never formed
  *   ranks_bev / ranks_depth / ranks_feat [num_points] int32 (first counts[0] valid, sorted by rank, points of
  *   a cell in index order = a stable argsort), interval_starts / interval_lengths [num_points] int32 (first
  *   counts[1] valid), counts [2] int32 (device): kept points, intervals.

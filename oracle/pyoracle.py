@@ -266,6 +266,32 @@ def lss_voxel_pooling_numpy(geom, x, dx, bx, nx):
     return final.reshape(B, nx[2], nx[0], nx[1], C).transpose(0, 4, 1, 2, 3)
 
 
+def lss_voxel_pooling_exact(geom, x, dx, bx, nx, chunk=16):
+    """The map `LiftSplatShoot.voxel_pooling` DEFINES (cam_stream_lss.py:318-373: the sum of the lifted features of
+    the frustum points of every cell), with every per-cell sum taken in float64 -- the yardstick both the reference's
+    cumsum trick (fp32 running totals over millions of rows, then differences) and the device's per-cell fp32 sums are
+    measured against.  Same quantisation and filter as `lss_voxel_pooling_numpy`; channels in chunks to bound memory.
+    Returns float64 [B, C, Z, X, Y]."""
+    B, C = x.shape[0], x.shape[-1]
+    nprime = int(np.prod(x.shape[:-1]))
+    xf = x.reshape(nprime, C)
+    g = ((geom - (bx - dx / 2.0)) / dx).astype(np.int64).reshape(nprime, 3)
+    kept = (g[:, 0] >= 0) & (g[:, 0] < nx[0]) & (g[:, 1] >= 0) & (g[:, 1] < nx[1]) & (g[:, 2] >= 0) & (g[:, 2] < nx[2])
+    idx = np.nonzero(kept)[0]
+    g = g[idx]
+    cell = ((idx // (nprime // B)) * nx[2] + g[:, 2]) * (nx[0] * nx[1]) + g[:, 0] * nx[1] + g[:, 1]
+    order = np.argsort(cell, kind="stable")
+    idx, cell = idx[order], cell[order]
+    head = np.ones(len(cell), bool)
+    head[1:] = cell[1:] != cell[:-1]
+    starts = np.nonzero(head)[0]
+    final = np.zeros((B * nx[2] * nx[0] * nx[1], C), np.float64)
+    for c0 in range(0, C, chunk):
+        rows = xf[idx, c0:c0 + chunk].astype(np.float64)
+        final[cell[starts], c0:c0 + chunk] = np.add.reduceat(rows, starts, axis=0) if len(starts) else 0.0
+    return final.reshape(B, nx[2], nx[0], nx[1], C).transpose(0, 4, 1, 2, 3)
+
+
 # ------------------------------------------------------------------------------------------------
 # centerpoint_postprocess
 # ------------------------------------------------------------------------------------------------

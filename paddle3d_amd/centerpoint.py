@@ -904,16 +904,22 @@ class CenterPoint(nn.Module):
 
     @torch.no_grad()
     def test_forward(self, points, device_only=False):
+        """points -> detections.  device_only=False reads the detections to the host; a sparse middle encoder may then
+        plan from remembered capacities (no host sync inside the graph) because the overflow word is checked HERE and
+        the frame recomputed with exact sizes when a set outgrew its capacity.  device_only=True never synchronises,
+        so the encoder plans with its one host sync (exact, like the reference) unless the caller set
+        `middle_encoder.remember_capacities = True` and reads `middle_encoder.take_overflow()` itself."""
+        import contextlib
+
         pts, lens = self._pack(points)
+        checked = getattr(self.middle_encoder, "overflow_checked", None)
+        take = getattr(self.middle_encoder, "take_overflow", None)
         for _attempt in range(2):
-            x = self.extract_pillars(pts, lens, dense=False)
+            with (checked() if (checked is not None and not device_only) else contextlib.nullcontext()):
+                x = self.extract_pillars(pts, lens, dense=False)
             x = self.dense_forward(x)
             preds, _ = self.bbox_head(x)
             out = self.bbox_head.predict_by_custom_op(preds, self.test_cfg, device_only=device_only)
-            # A sparse middle encoder that planned from remembered capacities (no host sync) reports here, after the
-            # host has read the detections anyway, whether an index set outgrew its capacity; then the frame is run
-            # again with exact sizes.  device_only callers ask `middle_encoder.take_overflow()` where they synchronise.
-            take = getattr(self.middle_encoder, "take_overflow", None)
             if device_only or take is None or not take():
                 break
         return out

@@ -119,6 +119,8 @@ struct VppGrid {
 
 // mode 0: BEVDet  rank = b * (gz*gy*gx) + z * (gy*gx) + y * gx + x        (bevdet_transformer.py:256-259)
 // mode 1: LSS     cell = ((b * gz + z) * gx + x) * gy + y                  (cam_stream_lss.py:358-361)
+// mode 2: LSS cell order with BEVDet's split operands (ranks_depth = point, ranks_feat = camera pixel): the form
+//         that pools depth [B*N, D, H, W] and feat [B*N, H, W, C] without the lifted depth (x) feat tensor
 __global__ __launch_bounds__(256) void vpp_key_kernel(const float* __restrict__ coor, int64_t n, int64_t per_batch,
                                                       VppGrid g, int mode, uint32_t outside,
                                                       uint32_t* __restrict__ keys) {
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void vpp_finish_kernel(const uint32_t* __restr
   ranks_depth[j] = (int32_t)idx;
   // ranks_feat = arange(num_points // D).reshape(B, N, 1, H, W).expand(B, N, D, H, W) (:236-239)
   const uint32_t dhw = (uint32_t)depth_bins * (uint32_t)feat_hw;
-  ranks_feat[j] = mode == 0 ? (int32_t)((idx / dhw) * (uint32_t)feat_hw + idx % (uint32_t)feat_hw) : (int32_t)idx;
+  ranks_feat[j] = mode != 1 ? (int32_t)((idx / dhw) * (uint32_t)feat_hw + idx % (uint32_t)feat_hw) : (int32_t)idx;
 }
 
 // frustum template -> ego-frame coordinates of every frustum point (LSSViewTransformer.get_lidar_coor,
@@ -297,7 +299,7 @@ extern "C" int pd3_voxel_pooling_prepare(const float* coor, int64_t num_points, 
       !interval_starts || !interval_lengths || !counts || !workspace)
     return PD3_EINVAL;
   if (num_points <= 0 || num_points >= ((int64_t)1 << 31) || batch <= 0 || num_points % batch != 0 ||
-      depth_bins <= 0 || feat_hw <= 0 || mode < 0 || mode > 1)
+      depth_bins <= 0 || feat_hw <= 0 || mode < 0 || mode > 2)
     return PD3_EINVAL;
   VppGrid g;
   for (int a = 0; a < 3; ++a) {

@@ -13,7 +13,8 @@ import torch
 
 from ._common import check, lib, ptr, require_gpu, stream_ptr
 
-__all__ = ["bev_pool_v2", "bev_pool_v2_bkwd", "BevPoolV2", "lss_voxel_pooling", "voxel_pooling_prepare_v2"]
+__all__ = ["bev_pool_v2", "bev_pool_v2_bkwd", "BevPoolV2", "lss_voxel_pooling", "lss_voxel_pooling_fused",
+           "lss_pooling_prepare", "voxel_pooling_prepare_v2"]
 
 
 def _i32(t, op):
@@ -110,6 +111,45 @@ def voxel_pooling_prepare_v2(coor: torch.Tensor, grid_lower_bound, grid_interval
     return out
 
 
+def _lss_lower(dx, bx):
+    dxn = np.asarray(dx, dtype=np.float32).reshape(3)
+    bxn = np.asarray(bx, dtype=np.float32).reshape(3)
+    return bxn - dxn / np.float32(2.0), dxn  # (bx - dx / 2.) in fp32, as the reference's tensors evaluate it (:328-329)
+
+
+def lss_pooling_prepare(geom_feats: torch.Tensor, dx, bx, nx, split: bool = True):
+    """The index build of `LiftSplatShoot.voxel_pooling` (cam_stream_lss.py:325-346: quantise, filter, sort by cell)
+    on the device, for reuse across forwards with a fixed calibration.  geom_feats [B, N, D, H, W, 3] ->
+    (cell, ranks_depth, ranks_feat, interval_starts, interval_lengths) int32; `split` = ranks_feat addresses
+    feat [B*N, H, W, C] (the fused form), otherwise the lifted [B*N*D*H*W, C] tensor."""
+    gg = require_gpu(geom_feats, "lss_pooling_prepare")
+    B, N, D, H, W, _ = gg.shape
+    lower, dxn = _lss_lower(dx, bx)
+    return _prepare(gg, B, D if split else 1, H * W if split else 1, lower, dxn, np.asarray(nx, dtype=np.float32),
+                    2 if split else 1)
+
+
+def lss_voxel_pooling_fused(geom_feats: torch.Tensor, depth: torch.Tensor, feat: torch.Tensor, dx, bx, nx,
+                            prepared=None) -> torch.Tensor:
+    """BEVFusion's camera->BEV pooling WITHOUT the lifted tensor.  The reference forms x = depth (x) feat
+    [B, N, D, H, W, C] in `CamEncode.get_depth_feat` (cam_stream_lss.py:166: 1.41 GB per scene at config 5) and
+    pools it (`voxel_pooling`, :318-373); here the two factors go to the pooling kernel as they are:
+
+        geom_feats [B, N, D, H, W, 3], depth [B*N, D, H, W] (softmax over D), feat [B*N, H, W, C]  ->  [B, C, Z, X, Y]
+
+    through pd3_bev_pool_v2 with ranks_depth = frustum point, ranks_feat = camera pixel (prepare mode 2).  Every
+    product depth * feat is the fp32 product the reference stores in x, summed per cell in point order: the result is
+    bit-identical to `lss_voxel_pooling` on the materialised x (tests/test_lss_c5_gpu.py).  `prepared`: the index
+    sets of `lss_pooling_prepare(geom_feats, dx, bx, nx)` when the calibration is fixed."""
+    op = "lss_voxel_pooling_fused"
+    d, f = require_gpu(depth, op), require_gpu(feat, op)
+    B = int(geom_feats.shape[0])
+    C = int(f.shape[-1])
+    cell, rd, rf, starts, lengths = prepared if prepared is not None else lss_pooling_prepare(geom_feats, dx, bx, nx)
+    out = bev_pool_v2(d, f.reshape(-1, C), rd, rf, cell, lengths, starts, (B, nx[2], nx[0] * nx[1], C))
+    return out.reshape(B, nx[2], nx[0], nx[1], C).permute(0, 4, 1, 2, 3)
+
+
 def lss_voxel_pooling(geom_feats: torch.Tensor, x: torch.Tensor, dx, bx, nx) -> torch.Tensor:
     """BEVFusion's camera->BEV pooling, `LiftSplatShoot.voxel_pooling`
     (paddle3d/models/detection/bevfusion/cam_stream_lss.py:318-373), expressed through the bev_pool kernel.
@@ -127,9 +167,7 @@ def lss_voxel_pooling(geom_feats: torch.Tensor, x: torch.Tensor, dx, bx, nx) -> 
     B, C = int(xg.shape[0]), int(xg.shape[-1])
     nprime = xg.numel() // C
     dev = xg.device
-    dxn = np.asarray(dx, dtype=np.float32).reshape(3)
-    bxn = np.asarray(bx, dtype=np.float32).reshape(3)
-    lower = bxn - dxn / np.float32(2.0)  # (bx - dx / 2.) in fp32, as the reference's tensors evaluate it (:328-329)
+    lower, dxn = _lss_lower(dx, bx)
     cell, _, src, starts, lengths = _prepare(gg, B, 1, 1, lower, dxn, np.asarray(nx, dtype=np.float32), 1)
     ones = torch.ones(1, dtype=torch.float32, device=dev)
     zeros = torch.zeros(cell.shape[0], dtype=torch.int32, device=dev)

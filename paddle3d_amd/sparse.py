@@ -47,9 +47,11 @@ _STATS = None  # dict(pairs=..., dense=...) while count_flops() runs
 
 def count_flops(encoder, voxel_features, coors, batch_size) -> dict:
     """Flops of one forward of a sparse encoder: `pairs` = 2 * Cin * Cout per existing (output row, kernel offset)
-    pair, `dense` = the same with all kernel offsets counted.  Host syncs per convolution: not for timed code."""
+    pair, `dense` = the same with all kernel offsets counted, `pairs_by_pipe` = `pairs` split by the matrix pipe the
+    layer's kernel runs on ("f32", "bf16x3" = fp32 arithmetic as six bf16 products, "f16").  Host syncs per
+    convolution: not for timed code."""
     global _STATS
-    _STATS = dict(pairs=0, dense=0)
+    _STATS = dict(pairs=0, dense=0, pairs_by_pipe={})
     keep = getattr(encoder, "remember_capacities", None)
     if keep is not None:
         encoder.remember_capacities = False  # exact-size rulebooks: every row of `nbr` is a real row
@@ -115,7 +117,11 @@ class _SparseConv(nn.Module):
         idx = self._indices(x)
         cin, cout = int(self.weight.shape[-2]), int(self.weight.shape[-1])
         if _STATS is not None:  # measurement aid (bench.py): multiply-adds of the pairs that exist
-            _STATS["pairs"] += 2 * cin * cout * int((idx.nbr >= 0).sum().item())
+            fl = 2 * cin * cout * int((idx.nbr >= 0).sum().item())
+            pipe = ("f16" if x.amp and _sp.f16_supported(cin, cout, idx.kernel_volume) else
+                    "bf16x3" if _sp.SPLIT_BF16 and _sp.bf16x3_pays(cin, cout, idx.kernel_volume) else "f32")
+            _STATS["pairs"] += fl
+            _STATS["pairs_by_pipe"][pipe] = _STATS["pairs_by_pipe"].get(pipe, 0) + fl
             _STATS["dense"] += 2 * cin * cout * idx.n_out * idx.kernel_volume
         if x.amp and _sp.f16_supported(cin, cout, idx.kernel_volume):
             # fp16 rows in (converted once where the chain leaves the narrow fp32 layers), fp16 rows out
@@ -271,18 +277,44 @@ class SparseResNet3D(nn.Module):
 
     # remember_capacities: the first forward of a (batch size, input rows) shape plans with the ONE host sync and
     # remembers every index set's row count (x 1.25); later forwards of that shape plan without any host round trip
-    # (sparse_conv3d.plan(caps=...)), and `take_overflow()` -- read where the caller synchronises anyway, e.g. where
-    # detections reach the host -- says whether a set outgrew its capacity (then the result is to be recomputed: the
-    # capacities are dropped and the next forward plans with the sync again).  The reference's layers read nnz on the
-    # host after every sparse op.
-    remember_capacities = True
+    # (sparse_conv3d.plan(caps=...)).  A denser later scene can make a set reach its capacity: the map is then
+    # TRUNCATED, and only `take_overflow()` says so.  The reference never truncates (its layers read nnz on the host
+    # after every sparse op), so the unsynced plan is OPT-IN:
+    #   None (default)  used only inside `with encoder.overflow_checked():`, i.e. by callers that read take_overflow()
+    #                   where they synchronise anyway and recompute (CenterPoint.test_forward does);
+    #   True            always -- the caller promises to read take_overflow() itself (bench.py, tools/prof);
+    #   False           never.
+    # Direct calls (`encoder(...)`, `CenterPoint.extract_pillars`, `test_forward(device_only=True)`) therefore plan
+    # with the sync and return exact maps unless the flag was set.
+    remember_capacities = None
+    _overflow_checked = False
+
+    def overflow_checked(self):
+        """Context: forwards inside it may plan from remembered capacities; the caller MUST read `take_overflow()`
+        after it has synchronised and recompute the frame if it returns True."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev = self._overflow_checked
+            object.__setattr__(self, "_overflow_checked", True)
+            try:
+                yield self
+            finally:
+                object.__setattr__(self, "_overflow_checked", prev)
+
+        return ctx()
+
+    def _unsynced(self) -> bool:
+        return self.remember_capacities is True or (self.remember_capacities is None and self._overflow_checked)
 
     def _plan_input(self, voxel_features, coors, batch_size):
         shape_key = (int(batch_size), int(coors.shape[0]))
-        caps = getattr(self, "_caps", {}).get(shape_key) if self.remember_capacities else None
+        remember = self._unsynced()
+        caps = getattr(self, "_caps", {}).get(shape_key) if remember else None
         x, pl = _planned_input(self, voxel_features, coors, batch_size, caps)
         if caps is None:
-            if self.remember_capacities:
+            if remember:
                 if not hasattr(self, "_caps"):
                     object.__setattr__(self, "_caps", {})
                 self._caps[shape_key] = _sp.plan_caps(pl)

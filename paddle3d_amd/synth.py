@@ -201,6 +201,50 @@ def camera_rig(seed: int, n_cam: int = 6, input_size=(256, 704), batch: int = 1)
                 post_trans=np.asarray(ptran, f32).reshape(*sh, 3), bda=np.tile(np.eye(3, dtype=f32), (batch, 1, 1)))
 
 
+def lss_camera_rig(seed: int, n_cam: int = 6, batch: int = 1):
+    """Calibration in the form BEVFusion's camera stream consumes (reference bevf_faster_rcnn.py:171-185): per view
+    rots = inverse(lidar2img)[:3, :3] and trans = inverse(lidar2img)[:3, 3] of the full-size 900 x 1600 image, i.e.
+    R_cam->lidar @ K^-1 and t_cam->lidar of the same nuScenes-like ring as `camera_rig`."""
+    rig = camera_rig(seed, n_cam, (900, 1600), batch)
+    kinv = np.linalg.inv(rig["cam2imgs"].astype(np.float64))
+    rots = (rig["rots"].astype(np.float64) @ kinv).astype(np.float32)
+    return dict(rots=rots, trans=rig["trans"].copy())
+
+
+def lss_camera_features(seed: int, n_views: int, depth_bins: int, fh: int, fw: int, channels: int):
+    """Outputs of `CamEncode.get_depth_feat` (cam_stream_lss.py:160-167) before the lift: depth [views, D, fH, fW] (a
+    softmax over D) and feat [views, fH, fW, C] channels-last, float32."""
+    rng = np.random.default_rng(seed)
+    logit = rng.normal(0, 1.5, (n_views, depth_bins, fh, fw)).astype(np.float32)
+    logit -= logit.max(1, keepdims=True)
+    e = np.exp(logit)
+    depth = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    feat = rng.normal(0, 1, (n_views, fh, fw, channels)).astype(np.float32)
+    return depth, feat
+
+
+def trained_like_batchnorm(model, seed: int = 0):
+    """Measurement aid for RANDOM-INIT weights: BatchNorm statistics and affine parameters like a trained net's (with
+    the constructor's identity statistics the activations shrink layer by layer, every head logit lands in a band 0.01
+    wide, and a calibrated gain then amplifies rounding noise into score differences).  Seeded, in place; also the
+    biases of sparse convolutions that have one."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+            elif getattr(m, "bias", None) is not None and hasattr(m, "subm"):
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    if hasattr(model, "invalidate"):
+        model.invalidate()
+    return model
+
+
 def trained_like_heads(model, points, fraction: float = 0.01, top_fraction: float = 0.001, top_score: float = 0.35):
     """Measurement aid for RANDOM-INIT weights (bench.py's mAP proxy, tests/test_model_gpu.py): gives every class of
     every task of a CenterPoint head a heat map that behaves like a trained one's, so that all tasks emit detections

@@ -71,6 +71,24 @@ def test_lss_voxel_pooling_restatement(oracle, pg):
     np.testing.assert_array_equal(out != 0, pg["lss_out"] != 0)
 
 
+def test_lss_exact_sums_against_the_reference_output(oracle, pg):
+    """The float64 per-cell sums (the yardstick of tests/test_lss_c5_gpu.py) against the output of the reference's own
+    voxel_pooling executed through the shim: same cells written, values within the cumsum trick's fp32 noise."""
+    dx, bx = np.array([0.5, 0.5, 20.0], np.float32), np.array([-9.75, -9.75, 0.0], np.float32)
+    exact = oracle.lss_voxel_pooling_exact(pg["lss_geom"], pg["lss_x"], dx, bx, [40, 40, 1])
+    assert exact.dtype == np.float64 and exact.shape == pg["lss_out"].shape
+    np.testing.assert_allclose(exact, pg["lss_out"], rtol=0, atol=2e-4)
+    np.testing.assert_array_equal(exact != 0, pg["lss_out"] != 0)
+    # and brute force on a sub-sample of cells: the reduceat grouping is the per-cell sum
+    B, C = pg["lss_x"].shape[0], pg["lss_x"].shape[-1]
+    g = ((pg["lss_geom"] - (bx - dx / 2.0)) / dx).astype(np.int64)
+    for b in range(B):
+        gb, xb = g[b].reshape(-1, 3), pg["lss_x"][b].reshape(-1, C).astype(np.float64)
+        for (cx, cy) in [(3, 7), (20, 20), (39, 0)]:
+            m = (gb[:, 0] == cx) & (gb[:, 1] == cy) & (gb[:, 2] == 0)
+            np.testing.assert_allclose(exact[b, :, 0, cx, cy], xb[m].sum(0), rtol=1e-12, atol=1e-12)
+
+
 @pytest.mark.parametrize("tag,pre,post", [("a", 300, 80), ("b", None, None), ("c", 50, 500)])
 def test_rotate_nms_pcdet_restatement(oracle, pg, tag, pre, post):
     for kind in (["port", "ref"] if oracle.have_ref() else ["port"]):
