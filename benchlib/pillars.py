@@ -311,6 +311,7 @@ def bench_pillars(args, rank, world, dev):
     # every replay; the collective stays outside.  Measured: no difference on this path (the host needs 0.8-1.0 ms to
     # enqueue a 10 ms step, the GPU never waits for it), so the default stays the eager step.
     launch = "eager"
+    launch_reason = None
     step = lambda ev: run(pts, ev)  # noqa: E731
     cpu_ms = None
     with torch.no_grad():
@@ -326,19 +327,33 @@ def bench_pillars(args, rank, world, dev):
         # --graph forces replay; otherwise it is turned on only where the host would hold the GPU up (dist.choose_launch:
         # enqueue time above half of the step, measured under the node's real contention)
         want_graph = pdist.choose_launch(cpu_ms, gpu_ms_est, "graph" if args.graph else "auto") == "graph"
+        launch_reason = ("--graph" if args.graph else
+                         f"auto: enqueueing one eager step takes the host {cpu_ms:.2f} ms of a {gpu_ms_est:.2f} ms step "
+                         f"(ratio {cpu_ms / max(gpu_ms_est, 1e-9):.2f}, graph replay from 0.50)")
         if want_graph:
-            fused_front = False  # (the captured segments are the pair form's)
             try:
                 st = {}
 
+                # the captured segments are the form the eager step runs: with the fused front the voxelizer leaves its
+                # INDEX of the points and the PFN reads the points through it (round 6; round 5 captured the pair form
+                # only and silently lost the fused front's 0.05 ms per step under --graph)
                 def seg_vox():
-                    st["vox"] = model.voxelizer(pts)
+                    if fused_front:
+                        st["idx"] = model.voxelizer.index(pts)
+                    else:
+                        st["vox"] = model.voxelizer(pts)
 
                 def seg_pfn():
-                    voxels, coors, npv, _nv = st["vox"]
-                    b, v, p, d = voxels.shape
-                    st["b"], st["c4"] = b, coors.view(b * v, 4)
-                    st["feats"] = model.voxel_encoder(voxels.view(b * v, p, d), npv.view(b * v), st["c4"])
+                    if fused_front:
+                        span, plist, coors, _npv, _nv = st["idx"]
+                        b, v = int(coors.shape[0]), int(coors.shape[1])
+                        st["b"], st["c4"] = b, coors.view(b * v, 4)
+                        st["feats"] = model.voxel_encoder.forward_indexed(pts, span, plist, st["c4"])
+                    else:
+                        voxels, coors, npv, _nv = st["vox"]
+                        b, v, p, d = voxels.shape
+                        st["b"], st["c4"] = b, coors.view(b * v, 4)
+                        st["feats"] = model.voxel_encoder(voxels.view(b * v, p, d), npv.view(b * v), st["c4"])
 
                 def seg_scatter():
                     st["canvas"] = model.scatter(st["feats"], st["c4"], st["b"])
@@ -382,7 +397,9 @@ def bench_pillars(args, rank, world, dev):
                 got = (st["post"][4], st["post"][3])
                 if not (torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])):
                     raise RuntimeError("graph replay and eager step disagree")
-                step, launch = run_graphs, f"hip graphs ({len(graphs)} per step, one per op) + eager result hand-off"
+                step = run_graphs
+                launch = (f"hip graphs ({len(graphs)} per step, one per op; front half "
+                          f"{'fused (index + indexed PFN)' if fused_front else 'pair'}) + eager result hand-off")
             except Exception as e:  # noqa: BLE001  (capture is an optimisation of the launch path, never a requirement)
                 torch.cuda.synchronize()
                 print(f"bench: HIP-graph capture failed ({type(e).__name__}: {e}); running the eager step", file=sys.stderr)
@@ -399,7 +416,8 @@ def bench_pillars(args, rank, world, dev):
         a2 = _copy.copy(args)
         a2.repeats = 0
         fused_front = False  # (compute() reads the flag when it runs)
-        _dt2, pair_ms, _out2, _info2 = _timed_loop(step, a2, world, dev, names, finish=finish)
+        # always the EAGER pair step: under graph replay `step` is the captured fused form
+        _dt2, pair_ms, _out2, _info2 = _timed_loop(lambda ev: run(pts, ev), a2, world, dev, names, finish=finish)
         fused_front = True
     dt, per_op_ms, out, info = _timed_loop(step, args, world, dev, names, finish=finish)
     op_ms = per_op_ms if pair_ms is None else pair_ms
@@ -501,7 +519,7 @@ def bench_pillars(args, rank, world, dev):
                                "weights, full graph voxelize->PFN->scatter->SECOND+FPN->CenterHead->postprocess"
                                + ("->RCCL all-gather" if world > 1 else ""),
                    "frames_per_gpu_per_step": B, "max_voxels": V, "parallelism": f"dp{world} (frames)",
-                   "launch": launch, "host_ms_to_enqueue_one_eager_step": cpu_ms,
+                   "launch": launch, "launch_reason": launch_reason, "host_ms_to_enqueue_one_eager_step": cpu_ms,
                    "launch_policy": "graph replay is turned on when enqueueing a step takes the host more than half of "
                                     "the step's GPU time (dist.choose_launch); --graph forces it",
                    "result_hand_off": ("all-gather of batch k overlapped with batch k + 1 (dist.GatherPipeline)"

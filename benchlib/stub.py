@@ -78,6 +78,11 @@ def bench_stub(args, rank, world, dev):
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "STUB: no device ops; launch / collective path only", "frames_per_gpu_per_step": B,
-                       "parallelism": f"dp{world} (frames)"},
+                       "parallelism": f"dp{world} (frames)", "launch": "eager (stub: no device to capture on)",
+                       "launch_reason": "stub"},
+            # the line's shape as the real workloads print it: a roofline object built by the same helpers (the stub's
+            # "kernel" is a 2 ms sleep that moves the records once)
+            "roofline": hbm_roofline(float(out[0].numel() * 4), per_op_ms["ops_stub"], B, kernel="stub"),
+            "rooflines": {"stub_mfma": mfma_roofline({"f32": 1e9, "f16": 4e9, "bf16x3": 2e9}, per_op_ms["ops_stub"], B)},
             "per_op_ms": per_op_ms, "frames_gathered": int(out[1].shape[0]), "extras": multi,
             "result_hand_off": "overlap" if pipe is not None else "sync"}

@@ -287,7 +287,8 @@ extern "C" int pd3_bev_pool_v2_bkwd(const float* out_grad, const float* depth, c
 
 extern "C" size_t pd3_voxel_pooling_prepare_workspace(int64_t num_points) {
   if (num_points <= 0) return 0;
-  return vpp_carve(nullptr, num_points, radix_plan(0xFFFFFFFFu, num_points)).bytes;
+  // the widest [digit][tile] table a plan can ask for: 10-bit digits (a 20-bit key; wider keys take narrower digits)
+  return vpp_carve(nullptr, num_points, radix_plan(0xFFFFFu, num_points)).bytes;
 }
 
 extern "C" int pd3_voxel_pooling_prepare(const float* coor, int64_t num_points, int batch, int depth_bins,

@@ -245,7 +245,8 @@ def trained_like_batchnorm(model, seed: int = 0):
     return model
 
 
-def trained_like_heads(model, points, fraction: float = 0.01, top_fraction: float = 0.001, top_score: float = 0.35):
+def trained_like_heads(model, points, fraction: float = 0.01, top_fraction: float = 0.001, top_score: float = 0.35,
+                       remove_dc: bool = False):
     """Measurement aid for RANDOM-INIT weights (bench.py's mAP proxy, tests/test_model_gpu.py): gives every class of
     every task of a CenterPoint head a heat map that behaves like a trained one's, so that all tasks emit detections
     and every class is scored.  Plain random-init heads put all scores of a class into a band 0.003 wide, where the
@@ -254,7 +255,15 @@ def trained_like_heads(model, points, fraction: float = 0.01, top_fraction: floa
     still took all 83 post-NMS places of its task.  So the last heat-map convolution of each task gets a gain AND a
     bias PER CLASS that put two quantiles of the class's map over the cells of `points` (a [B, N, D] device tensor,
     two frames are enough) at fixed scores: `fraction` of the cells score above the model's score threshold and
-    `top_fraction` of them above `top_score`.  In place; the caller copies the state dict to a CPU twin afterwards."""
+    `top_fraction` of them above `top_score`.
+
+    remove_dc (round 6, an analysis option, off by default): a random 3x3 convolution over ReLU features answers
+    mostly to the features' MEAN (the calibrated CenterPoint-Voxel maps reach |logit| 450 at the zero-padded border);
+    with it every tap's weight vector is first made orthogonal to the mean first-stage feature vector (measured through
+    the head itself with one-hot probe weights).  tools/prof/amp_voxel_twins.py used it to show that this offset is NOT
+    what separates the AMP dense graph's detections from the fp32 graph's on that model (profiles/r06_amp_voxel_twins.txt).
+
+    In place; the caller copies the state dict to a CPU twin afterwards."""
     import math
 
     import torch
@@ -264,17 +273,35 @@ def trained_like_heads(model, points, fraction: float = 0.01, top_fraction: floa
 
     thr = float(model.test_cfg["score_threshold"])
     with torch.no_grad():
-        for task in model.bbox_head.tasks:
-            task.hm[-1].bias.zero_()
+        x = model.dense_forward(model.extract_pillars(points, dense=False))
+        convs = [task.hm[-1] for task in model.bbox_head.tasks]
+        if remove_dc:
+            saved = [c.weight.clone() for c in convs]
+            hc = int(convs[0].weight.shape[1])
+            mean_f = torch.zeros(len(convs), hc, dtype=torch.float64, device=saved[0].device)
+            for c0 in range(hc):  # one-hot probes: class 0's map IS first-stage channel c0 of that task's hm branch
+                for c in convs:
+                    c.weight.zero_()
+                    c.bias.zero_()
+                    c.weight[0, c0, c.weight.shape[2] // 2, c.weight.shape[3] // 2] = 1.0
+                model.invalidate()
+                preds, _ = model.bbox_head(x)
+                for t, p in enumerate(preds):
+                    mean_f[t, c0] = p["hm"][:, 0].double().mean()
+            for t, (c, w) in enumerate(zip(convs, saved)):
+                m = mean_f[t].to(w.dtype)
+                along = (w * m.view(1, -1, 1, 1)).sum(1, keepdim=True) / (m * m).sum().clamp(min=1e-30)
+                c.weight.copy_(w - along * m.view(1, -1, 1, 1))
+        for c in convs:
+            c.bias.zero_()
         model.invalidate()
-        preds, _ = model.bbox_head(model.dense_forward(model.extract_pillars(points, dense=False)))
-        for task, p in zip(model.bbox_head.tasks, preds):
+        preds, _ = model.bbox_head(x)
+        for conv, p in zip(convs, preds):
             hm = p["hm"].float().transpose(0, 1).reshape(p["hm"].shape[1], -1)  # [classes, B * H * W] logits, bias 0
             n = hm.shape[1]
             lo = hm.kthvalue(max(1, int(round(n * (1.0 - fraction)))), dim=1).values
             hi = hm.kthvalue(max(1, int(round(n * (1.0 - top_fraction)))), dim=1).values
             gain = (logit(top_score) - logit(thr)) / (hi - lo).clamp(min=1e-12)
-            conv = task.hm[-1]
             conv.weight.mul_(gain.to(conv.weight.dtype).view(-1, 1, 1, 1))
             conv.bias.copy_(logit(thr) - gain * lo)
         model.invalidate()

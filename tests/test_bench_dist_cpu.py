@@ -42,6 +42,8 @@ def test_eight_ranks_over_gloo_with_extras():
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["frames_gathered"] == 16
+    assert line["collective_backend"] == "gloo" and line["config"]["launch"] and line["config"]["launch_reason"]
+    assert all(0.0 <= v <= 1.0 for _, v in _fracs(line))
     assert line["result_hand_off"] == "overlap" and line["scaling"] == "weak"
     ss = line["extras"]["strong_scaling"]
     assert ss["scaling"] == "strong" and ss["frames"] == 32 and ss["frames_per_rank"] == 4
@@ -49,6 +51,53 @@ def test_eight_ranks_over_gloo_with_extras():
     assert line["extras"]["h2d_inclusive"]["value"] > 0
     assert line["extras"]["h2d_overlapped"]["value"] > 0  # the double-buffered stage (dist.H2DStage) on every rank
     assert "cpu_affinity_rank0" in line["config"]
+
+
+def _fracs(node, path=""):
+    """Every `frac` anywhere in a bench line (recursively), with its path."""
+    found = []
+    if isinstance(node, dict):
+        for k, v in node.items():
+            if k == "frac" and v is not None:
+                found.append((path + "/frac", v))
+            else:
+                found += _fracs(v, path + "/" + str(k))
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            found += _fracs(v, f"{path}[{i}]")
+    return found
+
+
+def test_roofline_objects_are_priced_per_pipe():
+    """Round 5's AMP / bf16x3 lines divided fp16 work by the fp32 peak (frac 1.32 and 1.20).  The helpers every
+    workload now builds its roofline objects with price each part against the pipe it runs on: the mix's peak is the
+    rate with every part at ITS peak, so a correct flop count cannot give frac > 1."""
+    sys.path.insert(0, ROOT)
+    from benchlib.common import MFMA_PEAK_TFLOPS, hbm_roofline, mfma_roofline
+
+    assert MFMA_PEAK_TFLOPS == {"f32": 157.3, "f16": 2500.0, "bf16": 2500.0, "bf16x3": 2500.0 / 6.0}
+    # round 5's AMP dense graph: 127.2 GFLOP x 16 frames in 3.234 ms on the fp16 pipe = 629 TFLOP/s = 0.25
+    r = mfma_roofline({"f16": 127.2e9 * 16}, 3.234, 16)
+    assert r["peak"] == 2500.0 and abs(r["achieved"] - 629.3) < 1.0 and abs(r["frac"] - 0.2517) < 1e-3
+    # a mix: each part exactly at its pipe's peak -> frac 1 (never above)
+    t_ms = (1e12 / 157.3e12 + 6e12 / (2500e12 / 6)) * 1e3
+    r = mfma_roofline({"f32": 1e12, "bf16x3": 6e12}, t_ms)
+    assert abs(r["frac"] - 1.0) < 1e-9 and 157.3 < r["peak"] < 2500.0 / 6 and set(r["pipes"]) == {"f32", "bf16x3"}
+    # the same flops booked on the wrong (fp32) pipe would have read 3.5: the denominators differ by that much
+    assert abs(mfma_roofline({"f32": 7e12}, t_ms)["frac"] - 7e12 / (t_ms * 1e-3) / 157.3e12) < 1e-9
+    h = hbm_roofline(295.68e6, 0.1329, 16, traffic=498.8e6, traffic_source="profiles/r05_b16_traffic.json")
+    assert abs(h["frac"] - 0.278) < 1e-3 and h["traffic_source"].endswith("r05_b16_traffic.json")
+    assert h["algorithmic_bytes_per_unit"] == 295.68e6 / 16
+
+
+def test_stub_line_fracs_and_launch_fields():
+    r = _run(["--gpus", "2", "--stub-ops", "--steps", "2", "--warmup", "1", "--batch", "2", "--strong-frames", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    fr = _fracs(line)
+    assert len(fr) >= 2 and all(0.0 <= v <= 1.0 for _, v in fr), fr
+    assert line["config"]["launch"].startswith("eager") and line["config"]["launch_reason"]
+    assert line["rooflines"]["stub_mfma"]["pipes"]["bf16x3"]["peak"] == 2500.0 / 6.0
 
 
 def test_sync_gather_mode_still_works():
