@@ -355,7 +355,7 @@ class _Conv3x3:
             self.packed["f16"] = _conv.pack_conv3x3_f16_weight(self.w)
         wp, b, cout = self.packed["f16"], self.b, self.cout
         if tiles is not None:
-            t = int(wp.shape[3])
+            t = int(wp.shape[4])  # [cout / T][cin / 16][9][2][T][8]
             wp, b, cout = wp[tiles[0]:tiles[1]], self.b[tiles[0] * t:tiles[1] * t], (tiles[1] - tiles[0]) * t
         return _conv.conv3x3_f16_bias_relu(x_h, wp, b, cout, relu=True, out_f32_nchw=out_f32_nchw, out=out)
 

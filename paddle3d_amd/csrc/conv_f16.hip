@@ -11,17 +11,19 @@
 //     contiguous bytes: the staged patch is a plain copy (no transpose, no conversion) and a lane's B operand of
 //     v_mfma_f32_32x32x16_f16 (8 consecutive k of one column) is ONE aligned ds_read_b128; weights are packed on the host
 //     as [cout tile][cin / 16][tap][co][16 ci] fp16, so the A operand is one ds_read_b128 too and a chunk is one linear
-//     copy.  pd3_f32_nchw_to_f16_nhwc converts at the fp32 boundaries (after a stride-2 convolution, in front of the
+//     copy (round 6: in LDS the two 8-channel halves of the pixels live in two planes and the weights are packed
+//     [tap][half][co][8], so that the 32 lanes of an operand read 32 consecutive 16-byte slots -- no bank conflict).
+//     pd3_f32_nchw_to_f16_nhwc converts at the fp32 boundaries (after a stride-2 convolution, in front of the
 //     head); the last layer of a chain writes fp32 NCHW for the fp32 kernels behind it.
-//   * workgroup = 8 waves = M x N = (64 MB) output channels x (8 / MB slabs of 4 rows x 32 columns): a wave owns 64
-//     channels x 128 pixels = 2 x 4 MFMA blocks (128 accumulators), reads 2 A + 4 B fragments (6 KB) per 8 MFMAs (256
-//     matrix-pipe cycles): 24 B/clk per SIMD, 3/4 of the LDS's 128 B/clk per CU.  Per 16-channel chunk the workgroup ingests
-//     9 x M x 32 B of weights + (rows + 2) x 34 x 32 B of patch = 56 KB (MB = 2) for 4608 pipe cycles: 12 B/clk, inside the
-//     ~14 B/clk the L2 -> CU path sustains.  MB = 2 (128 channels x 16 rows) where cout % 128 == 0, MB = 1
-//     (64 channels x 32 rows) for the 64-channel layers.
-//   * LDS double-buffered (113 KB), chunk c + 1 travels global -> registers while chunk c is multiplied: one barrier per chunk.
+//   * workgroup = 8 waves = (64 MB) output channels x 16 rows x 32 columns: a wave owns 64 channels x J = 2 MB rows = 2 x J
+//     MFMA blocks; MB = 2 (128 channels) where cout % 128 == 0, MB = 1 for the 64-channel layers.  LDS: two patch buffers
+//     of a 32-channel block (4 planes x 640 pixels x 16 B = 40 KB each) + two weight buffers of a 16-channel sub-chunk
+//     (36 KB / 18 KB each): 152 KB / 116 KB, one workgroup per CU; everything arrives by LDS-DMA one sub-chunk (weights)
+//     or one block (patch) ahead of its use, one barrier per sub-chunk.  See the kernel's header for what round 6 measured.
 #include "../../include/paddle3d_amd.h"
 #include "common.hpp"
+
+#include <algorithm>
 
 namespace pd3 {
 
@@ -38,154 +40,294 @@ constexpr int kCfThreads = 512;
 template <int MB>
 struct CfShape {
   static constexpr int M = 64 * MB;                  // output channels per workgroup
-  static constexpr int SLABS = 8 / MB;               // 4-row pixel slabs per workgroup
-  static constexpr int R = 4 * SLABS;                // output rows per workgroup
-  static constexpr int PATCH = (R + 2) * kCfPW * kCfKc;   // halfs
-  static constexpr int WTS = 9 * M * kCfKc;               // halfs
-  static constexpr int PPIECES = PATCH / 8;          // 16-byte pieces
-  static constexpr int WPIECES = WTS / 8;
-  static constexpr int PPT = (PPIECES + kCfThreads - 1) / kCfThreads;
-  static constexpr int WPT = (WPIECES + kCfThreads - 1) / kCfThreads;
-  static constexpr size_t LDS = (size_t)2 * (PATCH + WTS) * sizeof(_Float16);
+  static constexpr int J = 2 * MB;                   // output rows per wave (each wave: 64 channels x J rows x 32 columns)
+  static constexpr int R = 16;                       // output rows per workgroup: MB = 2: 2 channel blocks x 4 slabs of 4
+                                                     // rows, MB = 1: 8 slabs of 2 rows
+  static constexpr int NPIX = (R + 2) * kCfPW;       // staged pixels (612)
+  static constexpr int NPP = (NPIX + 63) / 64 * 64;  // ... per plane, padded to whole LDS-DMA pieces (640)
+  static constexpr int PG = NPP / 64;                // 64-pixel groups of the patch (10)
+  static constexpr int PGW = (PG + 7) / 8;           // ... per wave
+  // LDS: the patch travels in BLOCKS of 32 input channels = four planes [8-channel slot s][pixel][8 halfs] (a lane's B
+  // operand = one 16-byte entry, the 32 lanes of a half wave read 32 consecutive entries: conflict-free ds_read_b128);
+  // the weights in SUB-CHUNKS of 16 channels, [tap][kh][co][8] exactly as the host packs them.  Two buffers of each.
+  static constexpr int PATCH = 4 * NPP * 8;          // halfs per patch buffer (40 KB)
+  static constexpr int WTS = 9 * M * kCfKc;          // halfs per weight buffer
+  static constexpr int WI = WTS / 512;               // LDS-DMA pieces (1 KB) of a sub-chunk's weights
+  static constexpr int WPW = (WI + 7) / 8;           // ... per wave
+  static constexpr int ES = 68;                      // halfs per pixel line of the epilogue's staging tile (136 B)
+  // the epilogue's staging tiles (8 waves x 32 pixels x 68 halfs = 34 KB): MB = 2 in the weight buffer that is idle
+  // between two items, MB = 1 (18 KB weight buffers) behind the operand buffers
+  static constexpr int ETILES = 8 * 32 * ES;
+  static constexpr size_t LDS = (size_t)(2 * (PATCH + WTS) + (MB == 1 ? ETILES : 0)) * sizeof(_Float16);
+  static_assert(MB == 1 || ETILES <= WTS, "the staging tiles fit a weight buffer");
+  static_assert(LDS <= 160 * 1024, "one workgroup per CU");
 };
+
+// One 1 KB piece global memory -> LDS by buffer_load_dwordx4 ... lds: lane l's 16 bytes from byte offset `voff` (+ the
+// uniform `soff`) of the buffer [base, base + bytes) -- an offset beyond the buffer reads as zeros -- to lds + 16 l.
+// (A plain function of plain types on purpose: inside a kernel TEMPLATE the address-space cast / the buffer-resource type
+// make the host pass of hipcc 7.2 drop the kernel's stub without a diagnostic -- an undefined symbol at load time.)
+__device__ __forceinline__ void cf_dma_piece(const _Float16* base, int bytes, _Float16* lds, unsigned voff, int soff) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base), 0, bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
 
 // out_mode 0: fp16 NHWC (the next fp16 layer's input); 1: fp32 NCHW (what every fp32 kernel of the graph reads); 2: both
 // (a block's last layer: fp16 NHWC for the next block's stride-2 convolution, fp32 NCHW for the FPN level -- out2)
+//
+// Round 6 (profiles/r06_conv_f16.txt): the round-5 form ran at 0.22-0.35 of the fp16 pipe with the matrix pipe 36 % busy.
+// Switching its parts off showed a chunk taking 9000 cycles for 4608 of MFMAs, the prologue (one chunk's 56 KB) 6 us and
+// the fp16 epilogue a quarter to a third of a launch; the counters, a two-way LDS bank conflict on every operand read.
+// What it all came from:
+//   * INGEST.  A 16-channel chunk is 32 of the 128 .. 768 bytes of a pixel in NHWC, and a lane fetched 16 of them: every
+//     request pulled a whole cache line out of L2 for an eighth of its bytes, eight times over per layer -- the L2 -> CU path
+//     moved 4.4 useful bytes per clock and CU (the fp32 Winograd kernel's whole-line fetches: 14).  Now the patch travels
+//     in blocks of 32 channels, the four 16-byte pieces of a pixel's 64 bytes requested back to back by one wave (one L2
+//     request per line and block), by buffer_load ... lds straight into LDS: no staging registers, no store pass, the
+//     zero padding = out-of-range offsets.
+//   * OPERANDS.  The two channel halves of a pixel side by side made a ds_read_b128's 16-lane groups touch every other
+//     16-byte entry (two-way conflict); with 32 VGPRs holding the next chunk the A operand of a tap was read right in front
+//     of its MFMAs, an exposed LDS round trip per tap.  Now: planes per 8-channel slot, and the operands of the next tap /
+//     column offset are read while the current one multiplies (for one column offset the wave's rows and the three
+//     row offsets share J + 2 row fragments).
+//   * EPILOGUE.  32 eight-byte stores per lane, 256 .. 2304 bytes apart.  Now through a per-wave LDS tile: a lane stores
+//     16 contiguous bytes, a store instruction eight whole 128-byte channel lines.
+//   * PHASES.  With one workgroup per CU (152 KB of LDS) nothing ran beside a workgroup's prologue (a block of patch and a
+//     sub-chunk of weights: 5-6 k cycles) -- a quarter of the time of a 64-input-channel layer's workgroup.  A workgroup
+//     now walks `ipw` consecutive work items (channel tile fastest, so the head's nine / eighteen channel tiles of one
+//     pixel tile follow each other): the next item's first pieces are sent during the current item's last sub-chunk, and
+//     the patch of a layer with <= 64 input channels stays resident while the pixel tile does not change.
 template <int MB, int OUT_MODE>
 __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_f16_kernel(const _Float16* __restrict__ x,
                                                                     const _Float16* __restrict__ wp,
                                                                     const float* __restrict__ bias,
                                                                     void* __restrict__ out, int cin, int cout, int h,
-                                                                    int w, int relu, int ptiles,
+                                                                    int w, int relu, int ptiles, int ipw,
                                                                     float* __restrict__ out2 = nullptr) {
   using S = CfShape<MB>;
+  constexpr int J = S::J;
   extern __shared__ __attribute__((aligned(16))) _Float16 cf_smem[];
-  const int lane = lane_id(), wave = wave_id();
+  const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(wave_id());
   const int tiles_x = (w + kCfCols - 1) / kCfCols, tiles_y = (h + S::R - 1) / S::R;  // partial border tiles are masked
-  // XCD-aware order (as the fp32 kernels): pixel tile pt lives on XCD pt % 8 with all its channel tiles
   const int nct = cout / S::M;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int ct = slot % nct, pt = (slot / nct) * 8 + xcd;
-  if (pt >= ptiles) return;
-  const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
-  const int y0 = ty * S::R, x0 = tx * kCfCols;
-  const int chunks = cin / kCfKc;
-  const _Float16* xin = x + (int64_t)n * h * w * cin;
-  const cf_h8* wsrc = reinterpret_cast<const cf_h8*>(wp) + (int64_t)ct * chunks * S::WPIECES;
+  const int subs = cin / kCfKc, blocks = (subs + 1) >> 1;
+  const int wbytes = (int)((int64_t)subs * S::WTS * 2);
+  _Float16* Pbuf = cf_smem;
+  _Float16* Wbuf = cf_smem + 2 * S::PATCH;
+  // the epilogue's staging tiles: MB = 2 in the weight buffer that is idle between two items, MB = 1 behind the buffers
+  _Float16* Ebase = MB == 2 ? nullptr : cf_smem + 2 * (S::PATCH + S::WTS);
 
-  // staging pattern (identical for every chunk): patch piece e = (pixel, half of its 16 channels)
-  int pofs[S::PPT];
-  unsigned plive = 0;
-#pragma unroll
-  for (int i = 0; i < S::PPT; ++i) {
-    const int e = min((int)threadIdx.x + i * kCfThreads, S::PPIECES - 1);
-    const int pix = e >> 1, hf = e & 1;
-    const int pr = pix / kCfPW, pc = pix - pr * kCfPW;
-    const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
-    const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
-    pofs[i] = ok ? (gy * w + gx) * cin + 8 * hf : 0;
-    plive |= ok ? (1u << i) : 0u;
-  }
-  cf_h8 preg[S::PPT], wreg[S::WPT];
-  auto fetch = [&](int c) {
-    const _Float16* xc = xin + c * kCfKc;
-#pragma unroll
-    for (int i = 0; i < S::PPT; ++i) preg[i] = *reinterpret_cast<const cf_h8*>(xc + pofs[i]);
-    const cf_h8* wc = wsrc + (int64_t)c * S::WPIECES;
-#pragma unroll
-    for (int i = 0; i < S::WPT; ++i) wreg[i] = wc[min((int)threadIdx.x + i * kCfThreads, S::WPIECES - 1)];
-  };
-  auto stash = [&](int buf) {
-    _Float16* P = cf_smem + buf * (S::PATCH + S::WTS);
-    _Float16* W = P + S::PATCH;
-#pragma unroll
-    for (int i = 0; i < S::PPT; ++i) {
-      const int e = (int)threadIdx.x + i * kCfThreads;
-      const cf_h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (S::PPIECES % kCfThreads == 0 || e < S::PPIECES)
-        *reinterpret_cast<cf_h8*>(P + e * 8) = ((plive >> i) & 1u) ? preg[i] : z;
-    }
-#pragma unroll
-    for (int i = 0; i < S::WPT; ++i) {
-      const int e = (int)threadIdx.x + i * kCfThreads;
-      if (S::WPIECES % kCfThreads == 0 || e < S::WPIECES) *reinterpret_cast<cf_h8*>(W + e * 8) = wreg[i];
-    }
-  };
-
-  const int mw = wave % MB, nw = wave / MB;  // the wave's 64-channel block and its 4-row slab
+  // XCD-aware order (as the fp32 kernels): work item = (pixel tile pt, channel tile ct); virtual block vb lives on XCD
+  // vb % 8, its slot vb / 8 = (pixel tile group, ct) with ct fastest.  This workgroup walks slots s0 .. s0 + ipw - 1.
+  const int xcd = blockIdx.x & 7;
+  const int s0 = (blockIdx.x >> 3) * ipw;
+  const int nslots = ((ptiles + 7) >> 3) * nct;
   const int l31 = lane & 31, kh = lane >> 5;
-  cf_f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int mw = wave % MB, nw = wave / MB;  // the wave's 64-channel block and its slab of J rows
 
-  fetch(0);
-  stash(0);
-  __syncthreads();
-  for (int c = 0; c < chunks; ++c) {
-    const bool more = c + 1 < chunks;
-    if (more) fetch(c + 1);
-    const _Float16* P = cf_smem + (c & 1) * (S::PATCH + S::WTS);
-    const _Float16* W = P + S::PATCH;
-    // A: lane (m = l31, k = 8 kh ..) of channel block i, tap t;  B: lane (n = l31, k = 8 kh ..) of pixel row j
-    const _Float16* wa = W + ((mw * 64 + l31) * kCfKc + 8 * kh);
-    const _Float16* pb = P + (((nw * 4) * kCfPW + l31) * kCfKc + 8 * kh);
+  struct Item {
+    int ct, pt, n, y0, x0;
+    bool valid;
+  };
+  auto item_of = [&](int sl) {
+    Item it;
+    it.ct = sl % nct;
+    it.pt = (sl / nct) * 8 + xcd;
+    it.valid = sl < nslots && sl < s0 + ipw && it.pt < ptiles;
+    const int tx = it.pt % tiles_x, ty = (it.pt / tiles_x) % tiles_y;
+    it.n = it.pt / (tiles_x * tiles_y);
+    it.y0 = ty * S::R;
+    it.x0 = tx * kCfCols;
+    return it;
+  };
+  // the wave's 64-pixel groups of the patch: group g = wave, wave + 8; lane = staged pixel 64 g + lane, whose byte offset
+  // in the frame (or an out-of-range offset: zeros) is pvo[]
+  auto offsets = [&](const Item& it, unsigned (&pvo)[S::PGW]) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int dy = t / 3, dx = t - 3 * dy;
-      cf_h8 a[2], b[4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const cf_h8*>(wa + (t * S::M + i * 32) * kCfKc);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const cf_h8*>(pb + ((j + dy) * kCfPW + dx) * kCfKc);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    for (int i = 0; i < S::PGW; ++i) {
+      const int pix = (wave + 8 * i) * 64 + lane;
+      const int pr = pix / kCfPW, pc = pix - pr * kCfPW;
+      const int gy = it.y0 - 1 + pr, gx = it.x0 - 1 + pc;
+      const bool ok = pix < S::NPIX && gy >= 0 && gy < h && gx >= 0 && gx < w;
+      pvo[i] = ok ? (unsigned)((gy * w + gx) * cin * 2) : 0x7ffffff0u;
     }
-    if (more) stash((c + 1) & 1);
-    __syncthreads();
-  }
+  };
+  const int xbytes = (int)((int64_t)h * w * cin * 2);
+  // block blk of an item's patch (input channels 32 blk .. 32 blk + 31): per pixel group the four 16-byte slots back to
+  // back -- the same 64 cache lines four times in a row, so that L2 hands every line out once
+  auto dma_patch = [&](const Item& it, const unsigned (&pvo)[S::PGW], int blk, int buf) {
+    const _Float16* xin = x + (int64_t)it.n * h * w * cin;
+    _Float16* P = Pbuf + buf * S::PATCH;
+#pragma unroll
+    for (int i = 0; i < S::PGW; ++i) {
+      const int g = wave + 8 * i;
+      if (S::PG % 8 == 0 || g < S::PG) {
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) cf_dma_piece(xin, xbytes, P + (sl * S::NPP + g * 64) * 8, pvo[i], blk * 64 + sl * 16);
+      }
+    }
+  };
+  // sub-chunk sc of channel tile ct's weights (input channels 16 sc .. 16 sc + 15): linear, packed in LDS order
+  auto dma_w = [&](int ct, int sc, int buf) {
+    const _Float16* wct = wp + (int64_t)ct * subs * S::WTS;
+    _Float16* W = Wbuf + buf * S::WTS;
+#pragma unroll
+    for (int i = 0; i < S::WPW; ++i)
+      if (S::WI % 8 == 0 || wave + 8 * i < S::WI)
+        cf_dma_piece(wct, wbytes, W + (wave + 8 * i) * 512, lane * 16, (sc * S::WTS + (wave + 8 * i) * 512) * 2);
+  };
 
-  // epilogue: D[row = (reg & 3) + 8 (reg >> 2) + 4 kh][col = l31] of block (i, j): channel co0 + 32 i + row, pixel
-  // (y0 + 4 nw + j, x0 + l31)
-  const int co0 = ct * S::M + mw * 64;
-  const int xg = x0 + l31;
+  Item cur = item_of(s0);
+  if (!cur.valid) return;
+  unsigned pvo[S::PGW], pvn[S::PGW];
+  offsets(cur, pvo);
+  int wb = 0;         // weight buffer of the current sub-chunk
+  int p0 = 0;         // patch buffer of the current item's block 0 (block b: p0 ^ (b & 1))
+  bool fresh = true;  // only block 0 of the current item's patch has been sent so far
+  dma_patch(cur, pvo, 0, 0);
+  dma_w(cur.ct, 0, 0);
+  __syncthreads();  // (drains vmcnt: the pieces have landed)
+
+  // Waves w and w + 4 share a SIMD and its matrix pipe; the older one (w < 4) wins the arbitration, so the pair runs its
+  // two MFMA streams one after the other (cycle stamps: 3200 cycles for waves 0-3, which then wait 2700 at the barrier,
+  // 5500 for waves 4-7).  Sending the next pieces costs a wave 100-400 cycles of issue per piece (64 lanes, 64 cache lines)
+  // -- with both waves sending first, the pipe idled that long in every sub-chunk.  So the halves send at different times:
+  // waves 4-7 FIRST (while waves 0-3 multiply), waves 0-3 AFTER their MFMAs (while waves 4-7 multiply).
+  const bool send_first = wave >= 4;
+  for (int it_i = 0; it_i < ipw; ++it_i) {
+    const Item nxt = item_of(s0 + it_i + 1);
+    // the next item needs its patch sent unless it is the same pixel tile and the whole patch (<= 2 blocks) is resident
+    const bool nxt_patch = nxt.valid && (nxt.pt != cur.pt || blocks > 2);
+    if (nxt_patch) offsets(nxt, pvn);
+    const int p0n = nxt_patch ? (p0 ^ ((blocks - 1) & 1) ^ 1) : p0;
+    // the accumulators start at the bias (D's row = (reg & 3) + 8 (reg >> 2) + 4 kh of channel block i): its loads hide
+    // behind the first sub-chunk and the epilogue has no add left
+    const int co0 = cur.ct * S::M + mw * 64;
+    cf_f32x16 acc[2][J];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    float bv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bv[r] = bias ? bias[co0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh] : 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int yg = y0 + nw * 4 + j;
-      float v[16];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        v[r] = acc[i][j][r] + bv[r];
-        if (relu) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (yg >= h || xg >= w) continue;  // a border tile's pixels outside the map (round 5: 180 x 180 maps of config 4)
-      if (OUT_MODE == 0 || OUT_MODE == 2) {
-        _Float16* o = reinterpret_cast<_Float16*>(out) + (((int64_t)n * h + yg) * w + xg) * cout + co0 + 32 * i + 4 * kh;
+        const float bvr = bias ? bias[co0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh] : 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const cf_h4 pk = {(_Float16)v[4 * q], (_Float16)v[4 * q + 1], (_Float16)v[4 * q + 2], (_Float16)v[4 * q + 3]};
-          *reinterpret_cast<cf_h4*>(o + 8 * q) = pk;
+        for (int j = 0; j < J; ++j) acc[i][j][r] = bvr;
+      }
+    // (block 0 of this item is in buffer p0: sent by the prologue / during the item before; blocks b >= 1 are sent during
+    // sub-chunk 2 b - 2 unless the whole patch is resident from the item before: `fresh`)
+    const bool stream_blocks = fresh;
+    for (int sc = 0; sc < subs; ++sc) {
+      const int blk = sc >> 1, k = sc & 1;
+      auto send = [&]() {
+        if (k == 0 && blk + 1 < blocks && stream_blocks) dma_patch(cur, pvo, blk + 1, p0 ^ ((blk + 1) & 1));
+        if (sc + 1 < subs) {
+          dma_w(cur.ct, sc + 1, wb ^ 1);
+        } else if (nxt.valid) {  // the last sub-chunk: the next item's first pieces
+          if (nxt_patch) dma_patch(nxt, pvn, 0, p0n);
+          dma_w(nxt.ct, 0, wb ^ 1);
+        }
+      };
+      if (send_first) send();
+      const _Float16* P = Pbuf + (p0 ^ (blk & 1)) * S::PATCH;
+      const _Float16* W = Wbuf + wb * S::WTS;
+      // A: lane (m = l31, k = 8 kh ..) of channel block i, tap t;  B: lane (n = l31, k = 8 kh ..) of staged pixel row r at
+      // column offset dx -- for one dx the wave's J output rows and the three dy share J + 2 row fragments
+      const _Float16* wa = W + (kh * S::M + mw * 64 + l31) * 8;
+      const _Float16* pb = P + ((2 * k + kh) * S::NPP + (nw * J) * kCfPW + l31) * 8;
+      auto ld_a = [&](int t, cf_h8 (&a)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const cf_h8*>(wa + (t * 2 * S::M + i * 32) * 8);
+      };
+      auto ld_b = [&](int dx, cf_h8 (&b)[J + 2]) {
+#pragma unroll
+        for (int r = 0; r < J + 2; ++r) b[r] = *reinterpret_cast<const cf_h8*>(pb + (r * kCfPW + dx) * 8);
+      };
+      cf_h8 a[2][2], b[2][J + 2];
+      ld_b(0, b[0]);
+      ld_a(0, a[0]);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int step = dx * 3 + dy;
+          // the operands of the NEXT step go out before this step's MFMAs (the fences keep the compiler from sinking them)
+          if (dy < 2) {
+            ld_a((dy + 1) * 3 + dx, a[(step + 1) & 1]);
+          } else if (dx < 2) {
+            ld_a(dx + 1, a[(step + 1) & 1]);
+          }
+          if (dy == 0 && dx < 2) ld_b(dx + 1, b[(dx + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[step & 1][i], b[dx & 1][j + dy], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (OUT_MODE == 1 || OUT_MODE == 2) {
-        float* o = (OUT_MODE == 1 ? reinterpret_cast<float*>(out) : out2) +
-                   (((int64_t)n * cout + co0 + 32 * i + 4 * kh) * h + yg) * w + xg;
+      if (!send_first) send();
+      __syncthreads();  // what was sent during this sub-chunk has landed (vmcnt(0)), every wave is done with this one
+      wb ^= 1;
+    }
+
+    // epilogue: D[row = (reg & 3) + 8 (reg >> 2) + 4 kh][col = l31] of block (i, j): channel co0 + 32 i + row, pixel
+    // (y0 + J nw + j, x0 + l31).  (wb now names the buffer with the NEXT item's first weights; the other one is idle.)
+    const int xg = cur.x0 + l31;
+    // this wave's tile [32 pixels][64 channels], lines of 68 halfs
+    _Float16* E = (MB == 2 ? Wbuf + (wb ^ 1) * S::WTS : Ebase) + wave * (32 * S::ES);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int yg = cur.y0 + nw * J + j;
+      if (OUT_MODE == 0 || OUT_MODE == 2) {
+        // registers -> the wave's LDS tile (8-byte stores, lines 136 bytes apart: conflict-free) -> 16 bytes per lane,
+        // eight lanes per pixel: every global store instruction writes eight whole 128-byte channel lines
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            // ReLU on the packed halfs: max(round(x), 0) = round(max(x, 0))
+            cf_h4 pk = {(_Float16)acc[i][j][4 * q], (_Float16)acc[i][j][4 * q + 1], (_Float16)acc[i][j][4 * q + 2],
+                        (_Float16)acc[i][j][4 * q + 3]};
+            if (relu) pk = __builtin_elementwise_max(pk, (cf_h4){0, 0, 0, 0});
+            *reinterpret_cast<cf_h4*>(E + l31 * S::ES + 32 * i + 8 * q + 4 * kh) = pk;
+          }
+        cf_h8 piece[4];  // (LDS operations of one wave execute in order: the reads see the stores above)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          piece[k] = *reinterpret_cast<const cf_h8*>(E + (8 * k + (lane >> 3)) * S::ES + (lane & 7) * 8);
+        if (yg < h) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int px = cur.x0 + 8 * k + (lane >> 3);
+            if (px < w)
+              *reinterpret_cast<cf_h8*>(reinterpret_cast<_Float16*>(out) + (((int64_t)cur.n * h + yg) * w + px) * cout +
+                                        co0 + (lane & 7) * 8) = piece[k];
+          }
+        }
+      }
+      if ((OUT_MODE == 1 || OUT_MODE == 2) && yg < h && xg < w) {
         const int64_t plane = (int64_t)h * w;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], o + ((r & 3) + 8 * (r >> 2)) * plane);
+        for (int i = 0; i < 2; ++i) {
+          float* o = (OUT_MODE == 1 ? reinterpret_cast<float*>(out) : out2) +
+                     (((int64_t)cur.n * cout + co0 + 32 * i + 4 * kh) * h + yg) * w + xg;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = relu ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r];
+            __builtin_nontemporal_store(v, o + ((r & 3) + 8 * (r >> 2)) * plane);
+          }
+        }
       }
     }
+    if (!nxt.valid) break;
+    if (MB == 2) __syncthreads();  // the staging tiles lie in a weight buffer: the next item's sub-chunk 1 is sent into it
+    if (nxt_patch) {
+#pragma unroll
+      for (int i = 0; i < S::PGW; ++i) pvo[i] = pvn[i];
+    }
+    p0 = p0n;
+    fresh = nxt_patch;
+    cur = nxt;
   }
 }
 
@@ -277,8 +419,8 @@ __global__ __launch_bounds__(256 * MW, 1) void conv3x3_s2_f16_kernel(const _Floa
     for (int i = 0; i < S::PPT; ++i) {
       const int e = (int)threadIdx.x + i * S::THREADS;
       const cf_h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (kCs2PPieces % S::THREADS == 0 || e < kCs2PPieces)
-        *reinterpret_cast<cf_h8*>(P + e * 8) = ((plive >> i) & 1u) ? preg[i] : z;
+      if (kCs2PPieces % S::THREADS == 0 || e < kCs2PPieces)  // [channel half][staged pixel][8], as the stride-1 kernel
+        *reinterpret_cast<cf_h8*>(P + (e & 1) * (kCs2Patch / 2) + (e >> 1) * 8) = ((plive >> i) & 1u) ? preg[i] : z;
     }
 #pragma unroll
     for (int i = 0; i < S::WPT; ++i) {
@@ -305,17 +447,18 @@ __global__ __launch_bounds__(256 * MW, 1) void conv3x3_s2_f16_kernel(const _Floa
     if (more) fetch(c + 1);
     const _Float16* P = cf_smem + (c & 1) * (kCs2Patch + S::WTS);
     const _Float16* W = P + kCs2Patch;
-    const _Float16* wa = W + ((mw * 64 + l31) * kCfKc + 8 * kh);
+    const _Float16* wa = W + (kh * S::M + mw * 64 + l31) * 8;
+    const _Float16* pp = P + kh * (kCs2Patch / 2);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int dy = t / 3, dx = t - 3 * dy;
       cf_h8 a[2], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const cf_h8*>(wa + (t * S::M + i * 32) * kCfKc);
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const cf_h8*>(wa + (t * 2 * S::M + i * 32) * 8);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int pr = 2 * (nw * 2 + j) + dy;
-        b[j] = *reinterpret_cast<const cf_h8*>(P + (((pr * 2 + (dx & 1)) * kCs2Half + l31 + (dx >> 1)) * kCfKc + 8 * kh));
+        b[j] = *reinterpret_cast<const cf_h8*>(pp + ((pr * 2 + (dx & 1)) * kCs2Half + l31 + (dx >> 1)) * 8);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -481,11 +624,20 @@ static int launch_conv_f16(const void* x, const void* wp, const float* bias, int
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS);
   if (e != hipSuccess) return (int)e;
   const int64_t ptiles = (int64_t)batch * ceil_div(h, S::R) * ceil_div(w, kCfCols);
-  const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / S::M);
-  if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
+  const int nct = cout / S::M;
+  const int64_t nslots = (ptiles + 7) / 8 * nct;  // work items per XCD lane (pixel tile group x channel tile)
+  if (nslots * 8 >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
+  // items per workgroup: as many as leave >= 2 workgroups per CU, whole pixel tiles' worth of channel tiles where possible
+  // (a patch of <= 64 input channels then stays resident over its channel tiles)
+  int ipw = (int)std::min<int64_t>(16, std::max<int64_t>(1, nslots * 8 / 512));
+  if (nct > 1 && ipw >= nct) ipw = ipw / nct * nct;
+  else if (nct > 1 && nct % ipw != 0) {
+    while (nct % ipw != 0) --ipw;
+  }
+  const int64_t nwg = 8 * ceil_div(nslots, ipw);
   conv3x3_f16_kernel<MB, OUT_MODE><<<(unsigned)nwg, kCfThreads, S::LDS, s>>>(
       static_cast<const _Float16*>(x), static_cast<const _Float16*>(wp), bias, out, cin, cout, h, w, relu, (int)ptiles,
-      out2);
+      ipw, out2);
   return launch_status();
 }
 

@@ -232,12 +232,13 @@ def f16_supported(cin: int, cout: int, h: int, w: int) -> bool:
 
 
 def pack_conv3x3_f16_weight(weight: torch.Tensor, tile: int | None = None) -> torch.Tensor:
-    """[Cout, Cin, 3, 3] fp32 -> fp16 [Cout/T][Cin/16][9 taps (dy*3+dx)][T co][16 ci]: a 16-channel chunk of a
-    workgroup's weights is one contiguous piece, a lane's A operand (8 consecutive ci of one co) 16 aligned bytes."""
+    """[Cout, Cin, 3, 3] fp32 -> fp16 [Cout/T][Cin/16][9 taps (dy*3+dx)][2 halves][T co][8 ci]: a 16-channel chunk of a
+    workgroup's weights is one contiguous piece in exactly its LDS order; a lane's A operand (8 consecutive ci of one co)
+    is 16 aligned bytes and the 32 lanes of a channel block read 32 consecutive slots (no LDS bank conflict)."""
     cout, cin = weight.shape[:2]
     t = f16_tile(cout) if tile is None else tile
     assert weight.shape[2:] == (3, 3) and cout % t == 0 and cin % 16 == 0 and t in (64, 128)
-    w = weight.to(torch.float16).reshape(cout // t, t, cin // 16, 16, 9).permute(0, 2, 4, 1, 3)
+    w = weight.to(torch.float16).reshape(cout // t, t, cin // 16, 2, 8, 9).permute(0, 2, 5, 3, 1, 4)
     return w.contiguous()
 
 
@@ -256,7 +257,7 @@ def conv3x3_f16_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: i
     if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous():
         raise RuntimeError("conv3x3_f16_bias_relu: x must be a contiguous fp16 NHWC tensor on the GPU")
     n, h, w, cin = x.shape
-    tile = int(w_packed.shape[3])
+    tile = int(w_packed.shape[4])
     if out is None:
         out = (torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device) if out_f32_nchw
                else torch.empty((n, h, w, cout), dtype=torch.float16, device=x.device))
@@ -271,7 +272,7 @@ def conv3x3_f16_bias_relu_dual(x: torch.Tensor, w_packed: torch.Tensor, bias, co
     if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous():
         raise RuntimeError("conv3x3_f16_bias_relu: x must be a contiguous fp16 NHWC tensor on the GPU")
     n, h, w, cin = x.shape
-    tile = int(w_packed.shape[3])
+    tile = int(w_packed.shape[4])
     oh = torch.empty((n, h, w, cout), dtype=torch.float16, device=x.device)
     of = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
     check(lib().pd3_conv3x3_f16_bias_relu_dual(ptr(x), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
@@ -290,7 +291,7 @@ def conv3x3_s2_f16_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout
     if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous():
         raise RuntimeError("conv3x3_s2_f16_bias_relu: x must be a contiguous fp16 NHWC tensor on the GPU")
     n, h, w, cin = x.shape
-    assert int(w_packed.shape[3]) == 128
+    assert int(w_packed.shape[4]) == 128
     out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, cout), dtype=torch.float16, device=x.device)
     check(lib().pd3_conv3x3_s2_f16_bias_relu(ptr(x), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
                                              ptr(out), stream_ptr(x.device)), "conv3x3_s2_f16_bias_relu")
@@ -307,7 +308,7 @@ def scatter_conv3x3_s2_f16_bias_relu(canvas, w_packed: torch.Tensor, bias, cout:
     f, inv = canvas.features, canvas.inv
     fh = f if f.dtype == torch.float16 else f.half()
     n, cin, ny, nx = canvas.shape
-    tile = int(w_packed.shape[3])
+    tile = int(w_packed.shape[4])
     out = torch.empty((n, ny // 2, nx // 2, cout), dtype=torch.float16, device=f.device)
     check(lib().pd3_scatter_conv3x3_s2_f16_bias_relu(ptr(fh), ptr(inv), ptr(w_packed), ptr(bias), n, cin, cout, ny, nx,
                                                      int(bool(relu)), ptr(out), tile, stream_ptr(f.device)),

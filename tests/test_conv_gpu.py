@@ -325,7 +325,7 @@ def test_conv3x3_f16_refuses_shapes_it_does_not_take():
     assert not conv.f16_supported(8, 64, 32, 32) and not conv.f16_supported(64, 96, 32, 32)
     x = torch.zeros(1, 32, 32, 24, dtype=torch.float16, device="cuda")  # 24 input channels: not whole 16-channel chunks
     with pytest.raises(Paddle3DAmdError, match="status -3"):
-        conv.conv3x3_f16_bias_relu(x, torch.zeros(1, 1, 9, 64, 16, dtype=torch.float16, device="cuda"), None, 64)
+        conv.conv3x3_f16_bias_relu(x, torch.zeros(1, 1, 9, 2, 64, 8, dtype=torch.float16, device="cuda"), None, 64)
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 64), (1, 128, 128, 16, 128), (1, 8, 64, 24, 68), (1, 64, 192, 12, 64),
