@@ -365,7 +365,20 @@ def _valid_w(t) -> int:
     return int(getattr(t, "_pd3_valid_w", t.shape[3]))
 
 
+def _f16_nhwc_to_f32_nchw(xh):
+    """fp16 NHWC [n, h, w, c] -> the fp32 kernels' form: fp32 NCHW with rows zero-padded to a multiple of 4 (pitch4) and
+    the real width tagged -- a 90-wide fp16 stage must not reach an fp32 kernel as rows of 90."""
+    x = xh.permute(0, 3, 1, 2).float()
+    w = int(x.shape[3])
+    pad = _conv.pitch4(w) - w
+    if pad:
+        x = torch.nn.functional.pad(x, (0, pad))
+    return _tag_valid_w(x.contiguous(), w)
+
+
 def _tag_valid_w(t, wv):
+    if t.dtype == torch.float16:  # fp16 NHWC stage outputs: rows are exactly as wide as the map (dim 3 = channels)
+        return t
     if wv != t.shape[3]:
         t._pd3_valid_w = int(wv)
     return t
@@ -459,12 +472,14 @@ class SecondBackbone(_InferenceCache, nn.Module):
                 # one conversion in front (none behind an fp16 stride-2 layer); the last layer of the run writes fp32
                 # NCHW for the kernels behind it, and fp16 NHWC as well where the next block can open on it
                 if xh is None and x.dtype == torch.float16:  # (a stage left as fp16 NHWC whose successor stays fp32)
-                    x = x.permute(0, 3, 1, 2).float().contiguous()
+                    x = _f16_nhwc_to_f32_nchw(x)
                 h_now = int(xh.shape[1]) if xh is not None else int(x.shape[2])
                 w_now = int(xh.shape[2]) if xh is not None else int(x.shape[3])
                 run = li
                 while (self.amp and run < len(layers) and wv == w_now and layers[run].f16_ok(h_now, w_now)):
                     run += 1
+                if run > li and w_now % 4 and not (run == len(layers) and self.amp_out_f16):
+                    run = li  # the run would end in fp32 NCHW rows of a width the fp32 kernels do not take: stay fp32
                 if run > li:
                     if xh is None:
                         xh = _conv.to_f16_nhwc(x)
@@ -483,7 +498,7 @@ class SecondBackbone(_InferenceCache, nn.Module):
                     li = run
                     continue
                 if xh is not None:  # an fp16 stride-2 layer with no fp16 run behind it: back to fp32 NCHW
-                    x = xh.permute(0, 3, 1, 2).float().contiguous()
+                    x = _f16_nhwc_to_f32_nchw(xh)
                     continue
                 x, wv = conv(x, wv)
                 li += 1
@@ -530,12 +545,14 @@ class SecondFPN(_InferenceCache, nn.Module):
         return self._cache
 
     # ---- mixed precision (CenterPoint.set_amp): every level as one fp16 gather-GEMM over the pixels ------------------
-    def _amp_level(self, i, p, n, h, w, dev):
+    def _amp_level(self, i, p, n, h, w, dev, tag=None):
         """Static pieces of level i on an [n, h, w, cin] fp16 NHWC input: the neighbour table over the output pixels
         (a kernel = stride convolution reads s x s input pixels, a transposed one exactly one, at the tap its position
         selects), its tile order, and the weight as [taps][cin][cout] in the fp16 kernel's operand order."""
-        key = (i, n, h, w)
+        key = (i, n, h, w, str(dev))  # (per device: a model moved with .to() must not reuse the old device's tables)
         cache = self.__dict__.setdefault("_amp_tables", {})
+        if len(cache) > 64:  # (input shapes seen so far: bounded, the tables are rebuilt in a millisecond)
+            cache.clear()
         if key not in cache:
             conv = self.deblocks[i][0]
             s = int(conv.stride[0])
@@ -554,8 +571,9 @@ class SecondFPN(_InferenceCache, nn.Module):
                 nbr = torch.stack(cols, 1).int().contiguous()
             order = _sp3.tile_order(nbr) if tr and s > 1 else None
             cache[key] = (nbr, order, ho, wo)
-        wkey = ("w", i)
-        tag = _param_signature(self)
+        wkey = ("w", i, str(dev))
+        if tag is None:
+            tag = _param_signature(self)
         if wkey not in cache or cache[wkey][0] != tag:
             conv, bn = self.deblocks[i][0], self.deblocks[i][1]
             tr = isinstance(conv, nn.ConvTranspose2d)
@@ -580,9 +598,10 @@ class SecondFPN(_InferenceCache, nn.Module):
         plan, ctot = self._plan()
         n = int(xs[0].shape[0])
         out = None
+        tag = _param_signature(self)  # once per forward, not once per level
         for i, (p, x) in enumerate(zip(plan, xs)):
             h, w = int(x.shape[1]), int(x.shape[2])
-            (nbr, order, ho, wo), parts = self._amp_level(i, p, n, h, w, x.device)
+            (nbr, order, ho, wo), parts = self._amp_level(i, p, n, h, w, x.device, tag)
             if out is None:
                 out = torch.empty((n, ho, wo, ctot), dtype=torch.float16, device=x.device)
             elif tuple(out.shape[1:3]) != (ho, wo):
@@ -597,7 +616,7 @@ class SecondFPN(_InferenceCache, nn.Module):
         plan, ctot = self._plan()
         if all(x.dtype == torch.float16 for x in xs):
             return self.forward_f16(xs)
-        xs = [x.permute(0, 3, 1, 2).float().contiguous() if x.dtype == torch.float16 else x for x in xs]
+        xs = [_f16_nhwc_to_f32_nchw(x) if x.dtype == torch.float16 else x for x in xs]
         sizes = {(int(x.shape[2] * p["scale"]), int(_valid_w(x) * p["scale"])) for p, x in zip(plan, xs)}
         if len(sizes) != 1 or len(plan) != len(xs):
             raise Paddle3DAmdError(f"SecondFPN: the levels do not meet at one resolution ({sorted(sizes)})")
@@ -843,12 +862,14 @@ class CenterPoint(nn.Module):
         return self
 
     def set_amp(self, enabled: bool = True):
-        """Mixed precision for the dense graph, the reference's `amp_cfg: level O2` configurations
-        (configs/centerpoint/centerpoint_pillars_02voxel_nuscenes_10sweep_ampO2_ultra.yml:5-9): the stride-1 3x3
-        convolutions of the backbone and the head (98 % of the graph's multiplies) run on the fp16 matrix cores with fp32
-        accumulation (csrc/conv_f16.hip), fp16 NHWC activations between them; the stride-2 convolutions, the FPN, the
-        final head convolutions, the front half and the post-processing stay fp32.  Off by default; layers the fp16
-        kernel does not take (maps that are not a multiple of 32 wide) stay fp32."""
+        """Mixed precision, the reference's `amp_cfg: level O2` configurations
+        (configs/centerpoint/centerpoint_pillars_02voxel_nuscenes_10sweep_ampO2_ultra.yml:5-9): the WHOLE dense graph
+        in fp16 NHWC on the fp16 matrix cores with fp32 accumulation (csrc/conv_f16.hip) -- the scatter-fused stride-2
+        first layer, the stride-1 and stride-2 layers of the backbone, the FPN levels (fp16 gather-GEMMs into the
+        concatenated map), the head's shared / first-stage convolutions and its grouped final convolutions (which write
+        the fp32 maps the post-processing reads); a sparse middle encoder from 16 -> 32 channels on.  The front half (PFN
+        / VoxelMean), the post-processing and every bias / BatchNorm fold stay fp32.  Off by default; a layer the fp16
+        kernels do not take (cin % 16, cout % 64) falls back to its fp32 kernel with one conversion on either side."""
         for m in (self.backbone, self.bbox_head, self.middle_encoder):
             if hasattr(m, "amp"):
                 m.amp = bool(enabled)

@@ -1360,13 +1360,11 @@ extern "C" int pd3_sparse_tile_order(const int32_t* nbr, const int32_t* n_out, i
   if (!nbr || !order || n_out_cap <= 0 || kernel_volume <= 0 || kernel_volume > 31) return PD3_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t lds = (size_t)2 * kSpWindow * sizeof(uint32_t);
-  static bool raised = false;  // (the attribute is per function, not per device state that could go stale)
-  if (!raised) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_tile_order_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    raised = true;
-  }
+  // raised on every launch like every other large-LDS kernel of the library (a host-side table write): a process-wide
+  // flag would be unsynchronised and, if the attribute is kept per device, wrong for a second GPU in the process
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_tile_order_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
   sp_tile_order_kernel<<<(unsigned)ceil_div(n_out_cap, kSpWindow), kSpOrderThreads, lds, s>>>(
       nbr, n_out, n_out_cap, kernel_volume, order);
   return launch_status();
