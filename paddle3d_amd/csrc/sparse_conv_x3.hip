@@ -132,7 +132,9 @@ __global__ __launch_bounds__(64 * (8 / RB), RB == 1 ? 1 : 2) void sp_gemm_rows_x
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][rb][r] = 0.f;
   sx_b8 wreg[WPT];
-  sx_b8 bcur[RB][S][3];                          // the pieces of the current step's gathered values
+  // the pieces of the current step's gathered values and (RB == 1) of the next step's: with a second set a wave can cut
+  // the next step's values BEFORE its own MFMAs, i.e. while its SIMD partner multiplies (see `step`)
+  sx_b8 bpa[RB][S][3], bpb[RB == 1 ? RB : 1][RB == 1 ? S : 1][3];
   sx_f32x4 raw_a[RB][S][2], raw_b[RB][S][2];     // the values of the next step and of the one behind it, as loaded
   const sx_f32x4 fz = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(64 * (8 / RB), RB == 1 ? 1 : 2) void sp_gemm_rows_x
       }
     }
   };
-  auto split_b = [&](int k, const sx_f32x4 (&src)[RB][S][2], const int (&jv)[RB]) {
+  auto split_b = [&](int k, const sx_f32x4 (&src)[RB][S][2], const int (&jv)[RB], sx_b8 (&bcur)[RB][S][3]) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       if (!((blk_mask[rb] >> k) & 1u)) continue;
@@ -211,16 +213,25 @@ __global__ __launch_bounds__(64 * (8 / RB), RB == 1 ? 1 : 2) void sp_gemm_rows_x
   fetch_b(k, c, raw_a, j_a);
   fetch_b(k2, c2, raw_b, j_b);
   stash_w(Ws);
-  if ((wave_mask >> k) & 1u) split_b(k, raw_a, j_a);
+  if ((wave_mask >> k) & 1u) split_b(k, raw_a, j_a, bpa);
   __syncthreads();
   // one step: `near` holds the next step's values (in flight since the step before), `far` takes the loads of the step
   // behind it
-  auto step = [&](sx_f32x4 (&near)[RB][S][2], int (&jn)[RB], sx_f32x4 (&far)[RB][S][2], int (&jf)[RB]) {
+  // RB == 1 (512 threads): waves w and w + 4 share a SIMD; the older one wins the matrix pipe, so the pair's two MFMA
+  // streams run one after the other (cycle counters, 128 -> 128: MFMAs 1950 cycles for waves 0-3, which then cut their
+  // next values and wait 1700 cycles at the barrier; waves 4-7: 2750 of MFMAs behind the partner's, THEN 700 cycles of
+  // cutting with the pipe idle).  The younger half therefore cuts the next step's values BEFORE its MFMAs -- into the
+  // second set of piece registers -- while the older half multiplies; the older half cuts after its MFMAs as before.
+  const bool cut_first = RB == 1 && wave >= 4;
+  auto step = [&](sx_f32x4 (&near)[RB][S][2], int (&jn)[RB], sx_f32x4 (&far)[RB][S][2], int (&jf)[RB],
+                  sx_b8 (&bcur)[RB][S][3], sx_b8 (&bnext)[RB][S][3]) {
     const bool more = k2 >= 0;
     int k3 = k2, c3 = c2;
     if (more) next_step(k3, c3);
     fetch_w(more ? k2 : k, more ? c2 : c);
     fetch_b(k3, c3, far, jf);
+    const bool cut = more && ((wave_mask >> k2) & 1u);
+    if (cut_first && cut) split_b(k2, near, jn, bnext);
     if ((wave_mask >> k) & 1u) {
       // A: lane (m = l31, kh) of piece p, channel block i, K-step s: 8 bf16 at line (p COUT + 32 i + l31), piece 2 s + kh
       const __bf16* wl = Ws + buf * WSZ + l31 * LINE + kh * 8;
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(64 * (8 / RB), RB == 1 ? 1 : 2) void sp_gemm_rows_x
       }
     }
     stash_w(Ws + (buf ^ 1) * WSZ);
-    if (more && ((wave_mask >> k2) & 1u)) split_b(k2, near, jn);
+    if (!cut_first && cut) split_b(k2, near, jn, bnext);
     __syncthreads();
     buf ^= 1;
     k = k2;
@@ -254,10 +265,18 @@ __global__ __launch_bounds__(64 * (8 / RB), RB == 1 ? 1 : 2) void sp_gemm_rows_x
     k2 = k3;
     c2 = c3;
   };
-  while (k >= 0) {
-    step(raw_b, j_b, raw_a, j_a);
-    if (k < 0) break;
-    step(raw_a, j_a, raw_b, j_b);
+  if constexpr (RB == 1) {
+    while (k >= 0) {
+      step(raw_b, j_b, raw_a, j_a, bpa, bpb);
+      if (k < 0) break;
+      step(raw_a, j_a, raw_b, j_b, bpb, bpa);
+    }
+  } else {
+    while (k >= 0) {  // (one set of pieces: the next step's values are cut into the set the finished MFMAs read)
+      step(raw_b, j_b, raw_a, j_a, bpa, bpa);
+      if (k < 0) break;
+      step(raw_a, j_a, raw_b, j_b, bpa, bpa);
+    }
   }
   // epilogue: D[m = (reg & 3) + 8 (reg >> 2) + 4 kh][n = l31] of block (i, rb): channel 32 i + m, output row n of the
   // wave's block rb; four consecutive channels (regs 4 q .. 4 q + 3) leave as one 16-byte store
