@@ -172,6 +172,20 @@ def bench_camera_pool(args, rank, world, dev):
     alg = 4 * (n_pts * (1 + C) + 3 * n_pts + 2 * n_int) + 4 * out_elems   # SURVEY 8(d), gathered operands once per use
     compulsory = 4 * (int(depth.numel()) + int(feat.numel()) + 3 * n_pts + 2 * n_int + out_elems)
     lifted_bytes = 4 * B * 6 * lss.D * lss.fH * lss.fW * C
+    # HBM-side traffic of the pooling launch from the committed PMC passes (tools/gpu_kernel_traffic.sh: the run launches
+    # the kernel in its lifted form first, then on split operands: the later dispatches are the fused form), + the zero
+    # fill of the output the entry point issues in front of it; one scene per launch
+    traffic, traffic_src = None, None
+    try:
+        import glob
+
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_camera_pool_kernel_traffic.json")))[-1]
+        kt = [v for k, v in json.load(open(path))["kernels"].items() if "bev_pool_fwd" in k][0]
+        if B == 1:
+            traffic = float(min(kt["fetch_bytes_x2_each"]) + min(kt["write_bytes_each"]) + 4 * out_elems)
+            traffic_src = "profiles/" + os.path.basename(path)
+    except Exception:  # noqa: BLE001 -- no committed profile: null
+        pass
     line = {
         "metric": "frames/sec BEVFusion camera->BEV pooling (LiftSplatShoot.voxel_pooling, config 5 shape)",
         "value": world * B * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -185,7 +199,7 @@ def bench_camera_pool(args, rank, world, dev):
                    "host_syncs_per_step": 1,
                    "note": "one host read of (kept points, intervals) per step to size the index tensors, like the "
                            "reference's boolean-mask filter (:340-341)"},
-        "roofline": hbm_roofline(alg, per_op_ms["pool"], B,
+        "roofline": hbm_roofline(alg, per_op_ms["pool"], B, traffic, traffic_src,
                                  kernel="bev_pool_fwd_kernel on split operands (pd3_bev_pool_v2, prepare mode 2)",
                                  compulsory_bytes_per_launch=compulsory,
                                  note="algorithmic bytes per SURVEY 8(d)'s bev_pool formula (every gathered row counted "
