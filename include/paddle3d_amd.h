@@ -552,11 +552,14 @@ int pd3_stable_argsort(const void *keys, int64_t n, int mode, uint32_t max_key, 
  * `amp_cfg: level O2`, cuDNN fp16 convolutions there); an option of the host classes (`model.set_amp(True)`), never the
  * fp32 default.
  *   x            [batch, h, w, cin] fp16 NHWC (16-byte aligned; pd3_f32_nchw_to_f16_nhwc makes it from an fp32 map)
- *   w_packed_f16 [cout / T][cin / 16][9 taps][T][16] fp16, T = channels_per_tile (paddle3d_amd/ops/conv.py:
+ *   w_packed_f16 [cout / T][cin / 16][9 taps (dy * 3 + dx)][2 halves][T][8] fp16, T = channels_per_tile: element
+ *                (ct, c, t, kh, co, e) = W[ct T + co][16 c + 8 kh + e][dy][dx] -- a 16-channel sub-chunk of a channel tile
+ *                is one contiguous piece in exactly its LDS order (round 6; paddle3d_amd/ops/conv.py:
  *                pack_conv3x3_f16_weight), bias [cout] fp32 or NULL
  *   out          out_mode 0: [batch, h, w, cout] fp16 NHWC (the next fp16 layer's input);
  *                out_mode 1: [batch, cout, h, w] fp32 NCHW (what the fp32 kernels of the graph read)
- *   channels_per_tile 128 (workgroup = 128 channels x 16 rows x 32 columns) or 64 (64 channels x 32 rows x 32 columns)
+ *   channels_per_tile 128 or 64 (workgroup = T channels x 16 rows x 32 columns, walking several (pixel tile, channel
+ *                tile) items)
  *   requires cin % 16 == 0, cout % T == 0; else PD3_EUNSUPPORTED (the caller runs fp32).  Maps that are not whole
  *   tiles (config 4's 180 x 180) run with masked border tiles.
  */
