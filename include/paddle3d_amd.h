@@ -152,6 +152,27 @@ int pd3_scatter_conv3x3_bias_relu(const float *voxel_features, const int32_t *in
                                   const float *bias, int batch, int cin, int cout, int ny, int nx, int stride,
                                   int relu, float *out, int out_w, void *stream);
 
+/* The same pair -- PointPillarsScatter (pillar_scatter.py:57-93) + the strided 3x3 / pad 1 convolution that opens
+ * SecondBackbone (second_backbone.py:84-98) -- as a SPARSE convolution over the occupied pillars (round 6): a nuScenes
+ * canvas is 11 % occupied, an output pixel sees 2.5 of its nine cells on average and 60 % of the pixels see none.
+ *   pd3_pillar_conv_rulebook: from the inverse map [batch, ny * nx] (pd3_pointpillars_inverse_map) the rulebook of the
+ *     active output pixels in raster order: nbr [capacity, 9] int32 (pillar row of tap ky * 3 + kx or -1), out_cell
+ *     [capacity] (pixel b * ho * wo + oy * wo + ox of a row), cell_row [batch, ho * wo] (row of a pixel or -1), n_out [1]
+ *     (device: the row count; rows beyond `capacity` are dropped -- batch * ho * wo can never overflow), ho = (ny - 1) /
+ *     stride + 1.  The rulebook feeds pd3_sparse_tile_order + pd3_sparse_conv3d_features_bf16x3 / _f16 (kernel_volume 9,
+ *     in_feats = the pillar features, n_out as the device row count).  order (optional, [pd3_sparse_tile_order_entries(
+ *     capacity)] int32): the rulebook's tile order by a counting sort over the 512 possible tap masks -- the same
+ *     scheduling hint pd3_sparse_tile_order computes with its general sorting network.
+ *   pd3_rows_to_dense_fill: rows [n, channels] fp32 -> out [batch, channels, h, w] NCHW through cell_row; a pixel without
+ *     a row holds fill[c] (= relu(bias[c]): what the dense convolution computes from nine zeros); h * w % 4 == 0,
+ *     channels % 4 == 0. */
+size_t pd3_pillar_conv_rulebook_workspace(int batch, int ny, int nx, int stride);
+int pd3_pillar_conv_rulebook(const int32_t *inverse_map, int batch, int ny, int nx, int stride, int32_t *nbr,
+                             int32_t *out_cell, int32_t *cell_row, int32_t *n_out, int capacity, int32_t *order,
+                             void *workspace, size_t workspace_bytes, void *stream);
+int pd3_rows_to_dense_fill(const float *rows, const int32_t *cell_row, const float *fill, int batch, int channels, int h,
+                           int w, float *out, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * pillar feature net (PFN) -- replaces PillarFeatureNet.forward / PFNLayer.forward in eval mode,
  * paddle3d/models/voxel_encoders/pillar_encoder.py:156-210 / :81-105 (decorate with cluster and

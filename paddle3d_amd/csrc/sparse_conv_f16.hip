@@ -70,11 +70,21 @@ __global__ __launch_bounds__(256, 2) void sp_gemm_rows_f16_kernel(SpGemmF16Args 
     if (threadIdx.x < 9) masks[threadIdx.x] = 0u;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < kSfRows * 32; e += 256) {
-    const int i = e >> 5, k = e & 31;
-    if (k < K) {
-      const int r = rows[i];
-      nbs[i * K + k] = r >= 0 ? a.nbr[(int64_t)r * K + k] : -1;
+{  // rulebook rows of the tile -> LDS, eight loads per thread in flight (see sparse_conv_x3.hip)
+    const int total = kSfRows * K;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * 256) {
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = min(e0 + u * 256, total - 1);
+        const int i = e / K, k = e - i * K;
+        const int r = rows[i];
+        v[u] = a.nbr[(int64_t)max(r, 0) * K + k];
+        v[u] = r >= 0 ? v[u] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e0 + u * 256 < total) nbs[e0 + u * 256] = v[u];
     }
   }
   __syncthreads();

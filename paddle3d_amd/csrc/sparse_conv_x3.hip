@@ -96,11 +96,27 @@ __global__ __launch_bounds__(64 * (8 / RB), RB == 1 ? 1 : 2) void sp_gemm_rows_x
     if (threadIdx.x < 9) masks[threadIdx.x] = 0u;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < kSxRows * 32; e += THREADS) {
-    const int i = e >> 5, k = e & 31;
-    if (k < K) {
-      const int r = rows[i];
-      nbs[i * K + k] = r >= 0 ? a.nbr[(int64_t)r * K + k] : -1;
+  // the tile's rulebook rows -> LDS.  Element e = (row i, offset k) in rulebook order, eight loads per thread in flight at a
+  // time (round 6: the loop as first written -- one (row, k < 32) element per trip, the load behind an LDS read -- ran its
+  // trips one memory round trip after the other: 35 k cycles per tile, unnoticed beside 54 steps of a 27-offset layer,
+  // 40 % of a tile of the 9-offset pillar convolution)
+  {
+    const int total = kSxRows * K;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * THREADS) {
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * THREADS;
+        const int i = min(e, total - 1) / K, k = min(e, total - 1) - i * K;
+        const int r = rows[i];
+        v[u] = a.nbr[(int64_t)max(r, 0) * K + k];
+        v[u] = r >= 0 ? v[u] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * THREADS;
+        if (e < total) nbs[e] = v[u];
+      }
     }
   }
   __syncthreads();

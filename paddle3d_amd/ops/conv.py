@@ -16,7 +16,7 @@ __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pitch4", "p
            "f16_supported", "f16_tile", "pack_conv3x3_f16_weight", "conv3x3_f16_bias_relu", "to_f16_nhwc",
            "pack_grouped_weight_f16", "grouped_conv3x3_small_f16", "conv3x3_f16_bias_relu_dual",
            "s2_f16_supported", "conv3x3_s2_f16_bias_relu", "scatter_conv_s2_f16_supported",
-           "scatter_conv3x3_s2_f16_bias_relu"]
+           "scatter_conv3x3_s2_f16_bias_relu", "scatter_conv_sparse_supported", "scatter_conv3x3_sparse"]
 
 
 def pitch4(w: int) -> int:
@@ -69,6 +69,50 @@ def scatter_conv3x3_bias_relu(canvas, w_packed: torch.Tensor, bias, cout: int, r
                                               int(bool(relu)), ptr(out), wo, stream_ptr(f.device)),
           "scatter_conv3x3_bias_relu")
     return out
+
+
+def scatter_conv_sparse_supported(cin: int, cout: int, ny: int, nx: int, stride: int) -> bool:
+    """Shapes scatter_conv3x3_sparse serves: the bf16x3 gather-GEMM's (cin % 16 == 0, cout 64 or 128), stride 2, an
+    output plane that is a whole number of float4."""
+    ho, wo = (ny - 1) // stride + 1, (nx - 1) // stride + 1
+    return stride == 2 and cin % 16 == 0 and cout in (64, 128) and wo % 4 == 0 and (ho * wo) % 4 == 0
+
+
+def scatter_conv3x3_sparse(canvas, weight: torch.Tensor, bias: torch.Tensor, packed=None, relu: bool = True):
+    """PointPillarsScatter + conv3x3 / pad 1 / stride 2 + bias + ReLU as a SPARSE convolution over the occupied pillars
+    (pd3_pillar_conv_rulebook -> tile order -> the bf16x3 gather-GEMM = fp32 arithmetic on the bf16 matrix cores ->
+    pd3_rows_to_dense_fill): a nuScenes canvas is 11 % occupied, 8.7 x fewer products than the dense kernel multiplies.
+    canvas: ops.pointpillars_scatter.SparseCanvas; weight [cout, cin, 3, 3] (BatchNorm folded), bias [cout].  Returns
+    ([B, cout, ny / 2, nx / 2] fp32 NCHW, packed weight for reuse).  No host sync: every array lives at the worst-case
+    capacity (all output pixels), the row count stays on the device.  Against scatter + the dense kernel the values
+    differ by the summation order (1e-6 relative; the dense kernel multiplies the empty taps' zeros)."""
+    from . import sparse_conv3d as sp
+    from ._common import workspace
+
+    f, inv = canvas.features, canvas.inv
+    n, cin, ny, nx = canvas.shape
+    cout = int(weight.shape[0])
+    ho, wo = (ny - 1) // 2 + 1, (nx - 1) // 2 + 1
+    cap = n * ho * wo
+    dev = f.device
+    L = lib()
+    nbr = torch.empty((cap, 9), dtype=torch.int32, device=dev)
+    out_cell = torch.empty((cap,), dtype=torch.int32, device=dev)
+    cell_row = torch.empty((n, ho * wo), dtype=torch.int32, device=dev)
+    n_out = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws = workspace(L.pd3_pillar_conv_rulebook_workspace(n, ny, nx, 2), dev)
+    order = torch.empty((int(L.pd3_sparse_tile_order_entries(cap)),), dtype=torch.int32, device=dev)
+    check(L.pd3_pillar_conv_rulebook(ptr(inv), n, ny, nx, 2, ptr(nbr), ptr(out_cell), ptr(cell_row), ptr(n_out), cap,
+                                     ptr(order), ptr(ws), ws.numel(), stream_ptr(dev)), "pillar_conv_rulebook")
+    idx = sp.SparseIndices(None, nbr, cap, (1, ho, wo), 9, order, n_out)
+    if packed is None:  # [kd = 1, kh, kw, cin, cout]: offset ky * 3 + kx, as the rulebook numbers the taps
+        packed = sp.pack_weight_bf16x3(weight.permute(2, 3, 1, 0).reshape(1, 3, 3, cin, cout).contiguous())
+    rows = sp.features_bf16x3(f, idx, packed, cin, cout, bias, None, None, None, relu)
+    fill = torch.relu(bias) if relu else bias
+    out = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=dev)
+    check(L.pd3_rows_to_dense_fill(ptr(rows), ptr(cell_row), ptr(fill.contiguous()), n, cout, ho, wo, ptr(out),
+                                   stream_ptr(dev)), "rows_to_dense_fill")
+    return out, packed
 
 
 def winograd_supported(cin: int, cout: int, h: int, w: int) -> bool:

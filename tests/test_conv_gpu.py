@@ -1,4 +1,5 @@
 """conv3x3_bias_relu (fp32 MFMA) vs torch conv2d on the CPU (fp32)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -281,6 +282,88 @@ def test_scatter_fused_into_stride2_conv(ny, nx, batch):
     assert got.shape == want.shape
     assert torch.equal(got, want)
     assert torch.equal(ps.SparseCanvas(feats, coords, batch, ny, nx).dense(), canvas)
+
+
+@pytest.mark.parametrize("ny,nx,batch,occ", [(512, 512, 2, 0.11), (496, 432, 2, 0.11), (64, 96, 3, 0.3), (40, 24, 1, 0.02),
+                                             (64, 64, 1, 0.0)])
+@pytest.mark.parametrize("cout", [64, 128])
+def test_scatter_conv_as_sparse_convolution(ny, nx, batch, occ, cout):
+    """PointPillarsScatter + the strided first convolution as a SPARSE convolution over the occupied pillars (round 6,
+    pd3_pillar_conv_rulebook -> tile order -> bf16x3 gather-GEMM -> pd3_rows_to_dense_fill) against the dense statement:
+    an fp64 convolution of the scattered canvas.  The rulebook is exact (active pixels, their nine pillar rows, the
+    inverse); the values carry the fp32 gather-GEMM's error -- within 2x the dense fp32 kernel's own error against fp64
+    and far inside the 1e-3 contract; pixels without an occupied cell hold relu(bias) exactly.  Duplicate cells (highest
+    row wins), padding rows, an empty canvas."""
+    import torch
+    import torch.nn.functional as F
+
+    from paddle3d_amd._lib import lib
+    from paddle3d_amd.ops import conv
+    from paddle3d_amd.ops import pointpillars_scatter as ps
+    from paddle3d_amd.ops._common import check, ptr, stream_ptr, workspace
+
+    torch.manual_seed(ny * 7 + nx + cout)
+    cin = 64
+    m = max(8, int(ny * nx * occ)) * batch
+    coords = torch.stack([torch.randint(0, batch, (m,)), torch.zeros(m, dtype=torch.long),
+                          torch.randint(0, ny, (m,)), torch.randint(0, nx, (m,))], 1).int()
+    coords[::97, 0] = -1
+    coords[5] = coords[3]
+    if occ == 0.0:
+        coords[:, 0] = -1                    # nothing on the canvas at all
+    feats = (torch.randn(m, cin) * torch.exp(torch.randn(m, cin))).cuda()
+    w = (torch.randn(cout, cin, 3, 3) * 0.05).cuda()
+    b = torch.randn(cout).cuda()
+    coords = coords.cuda()
+    sc = ps.SparseCanvas(feats, coords, batch, ny, nx)
+    assert conv.scatter_conv_sparse_supported(cin, cout, ny, nx, 2)
+    got, packed = conv.scatter_conv3x3_sparse(sc, w, b)
+    again, _ = conv.scatter_conv3x3_sparse(sc, w, b, packed)
+    assert torch.equal(got, again)           # run-to-run identical
+    canvas = sc.dense()
+    ref64 = F.relu(F.conv2d(canvas.double().cpu(), w.double().cpu(), b.double().cpu(), stride=2, padding=1))
+    dense32 = conv.conv3x3_bias_relu(canvas, conv.pack_conv3x3_weight(w), b, cout, relu=True, stride=2)[..., : nx // 2]
+    assert got.shape == ref64.shape == (batch, cout, ny // 2, nx // 2)
+    mag = max(1.0, float(ref64.abs().max()))
+    err = float((got.double().cpu() - ref64).abs().max())
+    err_dense = float((dense32.double().cpu() - ref64).abs().max())
+    assert err <= max(2.0 * err_dense, 2e-6 * mag) and err < 1e-3, (err, err_dense, mag)
+    # pixels that see no occupied cell: relu(bias), bit for bit
+    occd = (canvas.abs().sum(1, keepdim=True) > 0).float()
+    active = F.max_pool2d(F.pad(occd, (1, 1, 1, 1)), 3, 2)[..., : ny // 2, : nx // 2] > 0
+    fill = torch.relu(b).view(1, -1, 1, 1).expand_as(got)
+    assert torch.equal(got[(~active).expand_as(got)], fill[(~active).expand_as(got)])
+    # the rulebook itself against NumPy
+    L = lib()
+    ho, wo = ny // 2, nx // 2
+    cap = batch * ho * wo
+    nbr = torch.empty((cap, 9), dtype=torch.int32, device="cuda")
+    out_cell = torch.empty((cap,), dtype=torch.int32, device="cuda")
+    cell_row = torch.empty((batch, ho * wo), dtype=torch.int32, device="cuda")
+    n_out = torch.empty((1,), dtype=torch.int32, device="cuda")
+    ws = workspace(L.pd3_pillar_conv_rulebook_workspace(batch, ny, nx, 2), feats.device)
+    order = torch.empty((int(L.pd3_sparse_tile_order_entries(cap)),), dtype=torch.int32, device="cuda")
+    check(L.pd3_pillar_conv_rulebook(ptr(sc.inv), batch, ny, nx, 2, ptr(nbr), ptr(out_cell), ptr(cell_row), ptr(n_out), cap,
+                                     ptr(order), ptr(ws), ws.numel(), stream_ptr(feats.device)), "pillar_conv_rulebook")
+    inv = np.pad(sc.inv.cpu().numpy().reshape(batch, ny, nx), ((0, 0), (1, 1), (1, 1)), constant_values=-1)
+    want_nbr = np.stack([inv[:, ky:ky + ny:2, kx:kx + nx:2] for ky in range(3) for kx in range(3)], -1).reshape(-1, 9)
+    act = (want_nbr >= 0).any(1)
+    n = int(n_out.item())
+    assert n == int(act.sum()) == int(active.sum())
+    np.testing.assert_array_equal(out_cell[:n].cpu().numpy(), np.nonzero(act)[0])          # raster order
+    np.testing.assert_array_equal(nbr[:n].cpu().numpy(), want_nbr[act])
+    want_cr = np.full(cap, -1, np.int32)
+    want_cr[np.nonzero(act)[0]] = np.arange(n, dtype=np.int32)
+    np.testing.assert_array_equal(cell_row.cpu().numpy().reshape(-1), want_cr)
+    # the tile order: every window a permutation of its rows (then -1), grouped by tap mask in ascending order
+    od = order.cpu().numpy()
+    masks = ((want_nbr[act] >= 0) * (1 << np.arange(9))).sum(1)
+    for w0 in range(0, len(od), 2048):   # (grouped per 2048 rows: any permutation inside a window of 8192 is valid)
+        nv = min(max(n - w0, 0), 2048)
+        win = od[w0:w0 + 2048]
+        assert (win[nv:] == -1).all()
+        np.testing.assert_array_equal(np.sort(win[:nv]), np.arange(w0, w0 + nv))
+        assert (np.diff(masks[win[:nv]]) >= 0).all()
 
 
 # ---- mixed precision: the fp16 matrix-core form of the stride-1 layers (csrc/conv_f16.hip) -----------------------------
