@@ -666,6 +666,24 @@ int pd3_patch_conv_bias_relu(const float *x, const float *w_packed, const float 
                              int cin, int cout, int h, int w, int w_valid, int relu, float *out,
                              int out_channels_total, int out_channel_offset, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * patch_conv_x3_bias_relu -- modes 0, 1, 2 of patch_conv_bias_relu (same reference layers, second_fpn.py:99-157, same
+ * tensors and output placement) in fp32 arithmetic on the bf16 matrix cores: every fp32 operand as three bf16 pieces whose
+ * sum IS the value, six piece products accumulated in fp32 (csrc/sparse_conv_x3.hip; error vs fp64 = that of the fp32
+ * kernel, tested).  One persistent kernel, 128 GEMM rows x 256 pixels per work item.
+ *   w_packed: bf16 [row tile][step][16384]: a step's A pieces as the LDS image the kernel fetches, [piece 3][row 128][40]
+ *   (32 values of K, 8 of padding) + 1024 of padding (paddle3d_amd/ops/conv.py:pack_patch_weight_x3):
+ *     mode 0: row tile = 128 output channels, step = (dy, 16 input channels), k = (ci, dx); needs cin % 16 == 0,
+ *             cout % 128 == 0, h % 2 == 0, w % 64 == 0
+ *     mode 1: row tile = 128 output channels, step = 32 input channels; needs cin % 32 == 0, cout % 128 == 0
+ *     mode 2: row tile = (dy, 64 output channels), rows (dx, co), step = 32 input channels; needs cin % 32 == 0,
+ *             cout % 64 == 0; w = row pitch of x, w_valid its real width
+ *   bias [cout] or NULL; x 16-byte aligned; out 8-byte aligned; every tensor below 2 GB; PD3_EUNSUPPORTED otherwise
+ */
+int pd3_patch_conv_x3_bias_relu(const float *x, const void *w_packed, const float *bias, int mode, int batch, int cin,
+                                int cout, int h, int w, int w_valid, int relu, float *out, int out_channels_total,
+                                int out_channel_offset, void *stream);
+
 /*
  * ssd_postprocess -- SSDHead.post_process of PointPillars for a whole batch (paddle3d/models/detection/
  * pointpillars/pointpillars_head.py:86-196: PointPillarsCoder.decode (pointpillars_coder.py:126-148), the

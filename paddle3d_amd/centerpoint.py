@@ -548,7 +548,7 @@ class SecondFPN(_InferenceCache, nn.Module):
                                            "(conv 1 / 2, transposed conv 1 / 2 / 4) layer (status -3)")
                 cout = int(w.shape[1] if tr else w.shape[0])
                 cin = int(w.shape[0] if tr else w.shape[1])
-                plan.append(dict(mode=mode, w=_conv.pack_patch_weight(w, mode, tr), b=b, cin=cin, cout=cout, off=off,
+                plan.append(dict(mode=mode, w=_conv.pack_patch_weight(w, mode, tr), wraw=w, tr=tr, b=b, cin=cin, cout=cout, off=off,
                                  scale={0: 0.5, 1: 1, 2: 2, 3: 4}[mode]))
                 off += cout
             self._store_cache((plan, off))
@@ -639,6 +639,14 @@ class SecondFPN(_InferenceCache, nn.Module):
             if p["mode"] < 2 and _valid_w(x) != x.shape[3]:
                 raise Paddle3DAmdError(f"patch_conv: unsupported configuration (mode {p['mode']} on a map of width "
                                        f"{_valid_w(x)}, not a multiple of 4) (status -3)")
+            if _conv.PATCH_BF16X3 and _conv.patch_x3_supported(p["mode"], p["cin"], p["cout"], int(x.shape[2]),
+                                                               int(x.shape[3])):
+                # fp32 arithmetic on the bf16 matrix cores (three pieces per operand, csrc/conv_patch_x3.hip)
+                if "wx3" not in p:
+                    p["wx3"] = _conv.pack_patch_weight_x3(p["wraw"], p["mode"], p["tr"])
+                _conv.patch_conv_x3_bias_relu(x, p["wx3"], p["b"], p["mode"], p["cout"], out, p["off"], relu=True,
+                                              w_valid=_valid_w(x))
+                continue
             _conv.patch_conv_bias_relu(x, p["w"], p["b"], p["mode"], p["cout"], out, p["off"], relu=True,
                                        w_valid=_valid_w(x))
         return out

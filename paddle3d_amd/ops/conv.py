@@ -11,6 +11,7 @@ from ._common import check, lib, ptr, require_gpu, stream_ptr
 __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pitch4", "pack_grouped_weight", "grouped_conv3x3_small",
            "grouped_small_supported", "winograd_supported", "pack_winograd_weight", "conv3x3_winograd_bias_relu",
            "patch_mode", "patch_supported", "pack_patch_weight", "patch_conv_bias_relu",
+           "patch_x3_supported", "pack_patch_weight_x3", "patch_conv_x3_bias_relu", "split_bf16x3",
            "winograd43_supported", "winograd43_tile", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu",
            "WINOGRAD43_PP_MIN_CIN", "winograd43_pp_supported", "pack_winograd43_lane_weight", "conv3x3_winograd43_pp_bias_relu",
            "f16_supported", "f16_tile", "pack_conv3x3_f16_weight", "conv3x3_f16_bias_relu", "to_f16_nhwc",
@@ -230,6 +231,69 @@ def patch_conv_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, mode: in
                                          w if w_valid is None else int(w_valid), int(bool(relu)), ptr(out),
                                          out.shape[1], int(channel_offset), stream_ptr(xx.device)),
           "patch_conv_bias_relu")
+    return out
+
+
+# SecondFPN's levels in fp32 arithmetic on the bf16 matrix cores (three pieces per operand, six products; round 6).
+# False: the fp32-MFMA kernel everywhere.
+PATCH_BF16X3 = True
+
+
+def patch_x3_supported(mode: int, cin: int, cout: int, h: int, w: int) -> bool:
+    """pd3_patch_conv_x3_bias_relu's shapes ([h, w] = input map, w its row pitch)."""
+    if mode == 0:
+        return cin % 16 == 0 and cout % 128 == 0 and h % 2 == 0 and w % 64 == 0
+    if mode == 1:
+        return cin % 32 == 0 and cout % 128 == 0 and (h * w) % 4 == 0
+    if mode == 2:
+        return cin % 32 == 0 and cout % 64 == 0 and (h * w) % 4 == 0
+    return False
+
+
+def split_bf16x3(a: torch.Tensor) -> torch.Tensor:
+    """[...] fp32 -> [3, ...] bf16 pieces with hi + mid + lo == a exactly (round to nearest even at every cut)."""
+    a = a.float()
+    hi = a.bfloat16()
+    r1 = a - hi.float()
+    mid = r1.bfloat16()
+    lo = (r1 - mid.float()).bfloat16()
+    return torch.stack([hi, mid, lo])
+
+
+def pack_patch_weight_x3(weight: torch.Tensor, mode: int, transpose: bool) -> torch.Tensor:
+    """The layer's GEMM A matrix as bf16 pieces in the bf16x3 kernel's order: [row tile][step][16384] bf16 = per step the
+    LDS image the kernel fetches as it is, [piece 3][row 128][40] (32 values of K + 8 of padding) + 1024 of padding
+    (include/paddle3d_amd.h: pd3_patch_conv_x3_bias_relu).  Conv2D weights are [cout, cin, k, k], Conv2DTranspose
+    weights [cin, cout, k, k]."""
+    w = weight.detach().float()
+    if mode == 0:
+        cout, cin = int(w.shape[0]), int(w.shape[1])
+        a = w.reshape(cout // 128, 128, cin // 16, 16, 2, 2).permute(0, 4, 2, 1, 3, 5)  # [mt][dy][c][row][ci][dx]
+        a = a.reshape(cout // 128, 2 * (cin // 16), 128, 32)
+    elif mode == 1:
+        m = w[:, :, 0, 0].t() if transpose else w[:, :, 0, 0]                            # [co][ci]
+        cout, cin = int(m.shape[0]), int(m.shape[1])
+        a = m.reshape(cout // 128, 128, cin // 32, 32).permute(0, 2, 1, 3)
+    elif mode == 2:
+        cin, cout = int(w.shape[0]), int(w.shape[1])
+        a = w.reshape(cin // 32, 32, cout // 64, 64, 2, 2).permute(4, 2, 0, 5, 3, 1)     # [dy][cb][st][dx][col][k]
+        a = a.reshape(2 * (cout // 64), cin // 32, 128, 32)
+    else:
+        raise ValueError(f"pack_patch_weight_x3: mode {mode}")
+    pc = split_bf16x3(a.contiguous()).permute(1, 2, 0, 3, 4)                            # [mt][step][piece][128][32]
+    pc = torch.nn.functional.pad(pc, (0, 8)).reshape(pc.shape[0], pc.shape[1], 3 * 128 * 40)
+    return torch.nn.functional.pad(pc, (0, 16384 - 3 * 128 * 40)).contiguous()
+
+
+def patch_conv_x3_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, mode: int, cout: int, out: torch.Tensor,
+                            channel_offset: int = 0, relu: bool = True, w_valid: int | None = None) -> torch.Tensor:
+    """patch_conv_bias_relu on the bf16x3 kernel (w_packed from pack_patch_weight_x3)."""
+    xx = require_gpu(x, "patch_conv_x3_bias_relu")
+    n, cin, h, w = xx.shape
+    check(lib().pd3_patch_conv_x3_bias_relu(ptr(xx), ptr(w_packed), ptr(bias), int(mode), n, cin, cout, h, w,
+                                            w if w_valid is None else int(w_valid), int(bool(relu)), ptr(out),
+                                            out.shape[1], int(channel_offset), stream_ptr(xx.device)),
+          "patch_conv_x3_bias_relu")
     return out
 
 

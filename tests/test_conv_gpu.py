@@ -214,6 +214,77 @@ def test_patch_conv_matches_torch(mode):
     assert (got[:, :off] == -7.0).all() and (got[:, off + cout:] == -7.0).all()
 
 
+@pytest.mark.parametrize("mode,n,cin,cout,h,w,wv", [
+    (0, 2, 64, 128, 32, 64, 64),      # CenterPoint's first level in small: two steps of dy x four 16-channel chunks
+    (0, 3, 16, 256, 12, 64, 64),      # two row tiles, an output plane (6 x 32) below one pixel tile
+    (0, 1, 32, 128, 20, 192, 192),    # planes that are no multiple of the 256-pixel tile (10 x 96 output pixels)
+    (1, 2, 128, 128, 16, 48, 48),
+    (1, 1, 32, 256, 45, 180, 180),    # ONE step per item: every step crosses an item boundary
+    (1, 9, 64, 128, 7, 12, 12),       # nine tiny planes: 9 pixel tiles -> a partial last group of 8
+    (2, 2, 256, 128, 16, 32, 32),     # CenterPoint's third level in small: (dy, 64-channel block) = 4 row tiles
+    (2, 1, 64, 64, 45, 92, 90),       # row pitch 92, real width 90 (CenterPoint-Voxel)
+    (2, 3, 32, 192, 9, 12, 12),
+])
+@pytest.mark.parametrize("relu", [True, False])
+def test_patch_conv_bf16x3_is_fp32_arithmetic(mode, n, cin, cout, h, w, wv, relu):
+    """SecondFPN's levels on the bf16 matrix cores with three pieces per operand (csrc/conv_patch_x3.hip): against the
+    float64 layer its error is that of the fp32-MFMA kernel (<= 2x, and < 2e-6 of the magnitude -- a 16-bit operand format
+    would leave 2e-4), values spread over e^+-3; channels outside [off, off + cout) are not touched."""
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator().manual_seed(mode * 1000 + cin + cout + h)
+    off, ctot = 32, cout + 96
+    x = torch.randn(n, cin, h, w, generator=g) * torch.exp(3 * (2 * torch.rand(n, cin, h, w, generator=g) - 1))
+    if wv < w:
+        x[..., wv:] = 0
+    b = torch.randn(cout, generator=g)
+    tr = mode == 2
+    if mode == 0:
+        wt = torch.randn(cout, cin, 2, 2, generator=g) / (cin * 4) ** 0.5
+        ref = F.conv2d(x.double(), wt.double(), b.double(), stride=2)
+    elif mode == 1:
+        wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+        ref = F.conv2d(x.double(), wt.double(), b.double())
+    else:
+        wt = torch.randn(cin, cout, 2, 2, generator=g) / cin ** 0.5
+        ref = F.conv_transpose2d(x[..., :wv].double(), wt.double(), b.double(), stride=2)
+    if relu:
+        ref = torch.relu(ref)
+    assert conv.patch_x3_supported(mode, cin, cout, h, w)
+    wp = conv.pack_patch_weight_x3(wt.cuda(), mode, tr)
+    steps = {0: 2 * (cin // 16), 1: cin // 32, 2: cin // 32}[mode]
+    assert wp.dtype == torch.bfloat16 and tuple(wp.shape[1:]) == (steps, 16384)
+    out = torch.full((n, ctot, ref.shape[2], ref.shape[3]), -7.0, device="cuda")
+    conv.patch_conv_x3_bias_relu(x.cuda(), wp, b.cuda(), mode, cout, out, off, relu=relu, w_valid=wv)
+    got = out.cpu()
+    assert (got[:, :off] == -7.0).all() and (got[:, off + cout:] == -7.0).all()
+    err = (got[:, off:off + cout].double() - ref).abs().max().item()
+    out32 = torch.full_like(out, -7.0)
+    conv.patch_conv_bias_relu(x.cuda(), conv.pack_patch_weight(wt.cuda(), mode, tr), b.cuda(), mode, cout, out32, off,
+                              relu=relu, w_valid=wv)
+    err32 = (out32.cpu()[:, off:off + cout].double() - ref).abs().max().item()
+    mag = ref.abs().max().item()
+    print(f"mode {mode}: bf16x3 {err:.3e}, fp32 kernel {err32:.3e}, magnitude {mag:.1f}")
+    assert err <= 2 * err32 + 1e-7 * mag and err < 2e-6 * mag
+    out2 = torch.full_like(out, -7.0)
+    conv.patch_conv_x3_bias_relu(x.cuda(), wp, b.cuda(), mode, cout, out2, off, relu=relu, w_valid=wv)
+    assert torch.equal(out, out2)  # run-to-run identical
+
+
+def test_patch_conv_bf16x3_refuses_what_it_cannot_do():
+    from paddle3d_amd._lib import Paddle3DAmdError
+    from paddle3d_amd.ops import conv
+
+    x = torch.zeros(1, 24, 8, 8, device="cuda")
+    wp = torch.zeros(1, 1, 16384, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(1, 128, 8, 8, device="cuda")
+    assert not conv.patch_x3_supported(1, 24, 128, 8, 8)
+    with pytest.raises(Paddle3DAmdError):
+        conv.patch_conv_x3_bias_relu(x, wp, None, 1, 128, out)
+    with pytest.raises(Paddle3DAmdError):  # mode 3 stays on the fp32 kernel
+        conv.patch_conv_x3_bias_relu(torch.zeros(1, 32, 8, 8, device="cuda"), wp, None, 3, 128, out)
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 32, 128), (1, 4, 32, 8, 64), (1, 128, 96, 16, 64),
                                             (1, 384, 64, 24, 96), (3, 16, 32, 8, 32), (1, 24, 32, 8, 64),
                                             (2, 16, 64, 45, 180), (1, 8, 32, 5, 12), (1, 40, 32, 62, 124)])
