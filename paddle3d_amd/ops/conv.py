@@ -12,6 +12,7 @@ __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pitch4", "p
            "grouped_small_supported", "winograd_supported", "pack_winograd_weight", "conv3x3_winograd_bias_relu",
            "patch_mode", "patch_supported", "pack_patch_weight", "patch_conv_bias_relu",
            "patch_x3_supported", "pack_patch_weight_x3", "patch_conv_x3_bias_relu", "split_bf16x3",
+           "conv3x3_s2_x3_supported", "pack_conv3x3_s2_x3_weight", "conv3x3_s2_x3_bias_relu",
            "winograd43_supported", "winograd43_tile", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu",
            "WINOGRAD43_PP_MIN_CIN", "winograd43_pp_supported", "pack_winograd43_lane_weight", "conv3x3_winograd43_pp_bias_relu",
            "f16_supported", "f16_tile", "pack_conv3x3_f16_weight", "conv3x3_f16_bias_relu", "to_f16_nhwc",
@@ -294,6 +295,37 @@ def patch_conv_x3_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, mode:
                                             w if w_valid is None else int(w_valid), int(bool(relu)), ptr(out),
                                             out.shape[1], int(channel_offset), stream_ptr(xx.device)),
           "patch_conv_x3_bias_relu")
+    return out
+
+
+# The stride-2 block openers in fp32 arithmetic on the bf16 matrix cores (round 6).  False: the fp32 implicit GEMM.
+S2_BF16X3 = True
+
+
+def conv3x3_s2_x3_supported(cin: int, cout: int, h: int, w: int, batch: int = 1) -> bool:
+    """pd3_conv3x3_s2_x3_bias_relu's shapes ([h, w] = input map, w its row pitch = real width)."""
+    return (cin % 16 == 0 and cout % 128 == 0 and cout <= 1024 and h % 2 == 0 and w % 64 == 0
+            and batch * max(cin, cout) * h * w * 4 < 0x7ffffff0)
+
+
+def pack_conv3x3_s2_x3_weight(weight: torch.Tensor) -> torch.Tensor:
+    """[cout, cin, 3, 3] -> bf16 [cout/128][(cin/16) * 3][24576]: per step (16-channel chunk, ky) the kernel's LDS image
+    [piece 3][row 128][56] with k = kx * 16 + channel (include/paddle3d_amd.h: pd3_conv3x3_s2_x3_bias_relu)."""
+    w = weight.detach().float()
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    a = w.reshape(cout // 128, 128, cin // 16, 16, 3, 3).permute(0, 2, 4, 1, 5, 3)      # [mt][c][ky][row][kx][ci]
+    a = a.reshape(cout // 128, (cin // 16) * 3, 128, 48)
+    pc = split_bf16x3(a.contiguous()).permute(1, 2, 0, 3, 4)                            # [mt][step][piece][128][48]
+    pc = torch.nn.functional.pad(pc, (0, 8)).reshape(pc.shape[0], pc.shape[1], 3 * 128 * 56)
+    return torch.nn.functional.pad(pc, (0, 24576 - 3 * 128 * 56)).contiguous()
+
+
+def conv3x3_s2_x3_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, relu: bool = True) -> torch.Tensor:
+    xx = require_gpu(x, "conv3x3_s2_x3_bias_relu")
+    n, cin, h, w = xx.shape
+    out = torch.empty((n, cout, h // 2, w // 2), dtype=torch.float32, device=xx.device)
+    check(lib().pd3_conv3x3_s2_x3_bias_relu(ptr(xx), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
+                                            ptr(out), stream_ptr(xx.device)), "conv3x3_s2_x3_bias_relu")
     return out
 
 

@@ -271,6 +271,50 @@ def test_patch_conv_bf16x3_is_fp32_arithmetic(mode, n, cin, cout, h, w, wv, relu
     assert torch.equal(out, out2)  # run-to-run identical
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [
+    (2, 64, 128, 32, 64),      # CenterPoint's first opener in small: 12 steps, one channel tile
+    (1, 128, 256, 16, 128),    # the second opener: 24 steps, two channel tiles, two column tiles (left column from the map)
+    (3, 16, 128, 12, 64),      # 6 output rows: two of a tile's eight waves own no row
+    (1, 32, 384, 36, 192),     # 18 output rows (partial third row tile), three column tiles, three channel tiles
+    (9, 16, 128, 2, 64),       # nine images of ONE output row: a partial last group of 8 tiles
+])
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv3x3_s2_bf16x3_is_fp32_arithmetic(n, cin, cout, h, w, relu):
+    """The stride-2 block openers on the bf16 matrix cores with three pieces per operand (csrc/conv_s2_x3.hip): against
+    the float64 convolution the error is that of the fp32 implicit GEMM (<= 2x) and < 2e-6 of the magnitude; values spread
+    over e^+-3; padding rows / the padding column enter as exact zeros (a map of ones with the border taps isolated)."""
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g) * torch.exp(3 * (2 * torch.rand(n, cin, h, w, generator=g) - 1))
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), stride=2, padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    assert conv.conv3x3_s2_x3_supported(cin, cout, h, w, n)
+    wp = conv.pack_conv3x3_s2_x3_weight(wt.cuda())
+    assert wp.dtype == torch.bfloat16 and tuple(wp.shape) == (cout // 128, 3 * (cin // 16), 24576)
+    got = conv.conv3x3_s2_x3_bias_relu(x.cuda(), wp, b.cuda(), cout, relu=relu)
+    err = (got.cpu().double() - ref).abs().max().item()
+    got32 = conv.conv3x3_bias_relu(x.cuda(), conv.pack_conv3x3_weight(wt.cuda()), b.cuda(), cout, relu=relu, stride=2)
+    err32 = (got32.cpu().double() - ref).abs().max().item()
+    mag = ref.abs().max().item()
+    print(f"bf16x3 {err:.3e}, fp32 kernel {err32:.3e}, magnitude {mag:.1f}")
+    assert err <= 2 * err32 + 1e-7 * mag and err < 2e-6 * mag
+    assert torch.equal(got, conv.conv3x3_s2_x3_bias_relu(x.cuda(), wp, b.cuda(), cout, relu=relu))  # run-to-run identical
+    # the taps one at a time on a map of ones: every output counts the taps that fall inside the image, exactly
+    ones = torch.ones(1, cin, h, w)
+    for ky in range(3):
+        for kx in range(3):
+            w1 = torch.zeros(cout, cin, 3, 3)
+            w1[:, :, ky, kx] = 1.0
+            want = F.conv2d(ones, w1, None, stride=2, padding=1)
+            got1 = conv.conv3x3_s2_x3_bias_relu(ones.cuda(), conv.pack_conv3x3_s2_x3_weight(w1.cuda()), None, cout,
+                                                relu=False).cpu()
+            assert torch.equal(got1, want), (ky, kx)
+
+
 def test_patch_conv_bf16x3_refuses_what_it_cannot_do():
     from paddle3d_amd._lib import Paddle3DAmdError
     from paddle3d_amd.ops import conv
