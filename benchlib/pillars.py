@@ -27,24 +27,47 @@ def dense_flops():
     return s1 + s2 + other, s1 / 4 + s2 + other
 
 
-def dense_flops_by_pipe(model=None):
-    """Executed flops per scene of the fp32 dense graph, split by the matrix pipe each layer's kernel issues on: the
-    Winograd layers on the fp32 pipe; the direct layers (stride-2 openers, FPN levels) on the fp32 pipe, or -- when the
-    model runs them as bf16x3 (`model.backbone.split_bf16`, csrc/conv_x3.hip) -- as fp32-equivalent flops on the bf16
-    pipe; the final grouped 3x3 convolutions (70 channels) on the fp32 pipe."""
+def dense_flops_by_pipe(model=None, first_layer_pairs=None):
+    """Executed flops per scene of the fp32 dense graph, split by the matrix pipe each layer's kernel issues on:
+    * the 52 Winograd layers and the final grouped 3x3 convolutions (70 channels) on the fp32 pipe;
+    * the two stride-2 block openers and the three FPN levels as fp32-equivalent flops on the bf16 pipe where the
+      library runs them as bf16x3 (ops.conv.S2_BF16X3 / PATCH_BF16X3: csrc/conv_s2_x3.hip, conv_patch_x3.hip), else on
+      the fp32 pipe;
+    * the first layer (PointPillarsScatter + 64 -> 64 stride 2): as a sparse convolution over the occupied pillars
+      (`backbone.sparse_first`) it executes `first_layer_pairs` (pillar, tap) products of 2 * 64 * 64 flops on the bf16x3
+      pipe -- counted on the batch, an eighth of the dense layer's multiplies; else the dense layer on the fp32 pipe."""
+    from paddle3d_amd.ops import conv as _conv
+
     def conv(cin, cout, k, h):
         return 2 * cin * cout * k * k * h * h
 
     wino = (3 * conv(64, 64, 3, 256) + 5 * conv(128, 128, 3, 128) + 5 * conv(256, 256, 3, 64) + conv(384, 64, 3, 128) +
             36 * conv(64, 64, 3, 128)) / 4
-    direct = (conv(64, 64, 3, 256) + conv(64, 128, 3, 128) + conv(128, 256, 3, 64) + conv(64, 128, 2, 128) +
-              conv(128, 128, 1, 128) + 2 * 256 * 128 * 128 * 128)
+    openers = conv(64, 128, 3, 128) + conv(128, 256, 3, 64)
+    fpn = conv(64, 128, 2, 128) + conv(128, 128, 1, 128) + 2 * 256 * 128 * 128 * 128
     final = conv(64, 70, 3, 128)
-    x3 = bool(model is not None and getattr(getattr(model, "backbone", None), "split_bf16", False))
-    out = {"f32": wino + final + (0 if x3 else direct)}
-    if x3:
-        out["bf16x3"] = direct
-    return out
+    out = {"f32": wino + final, "bf16x3": 0.0}
+    out["bf16x3" if _conv.S2_BF16X3 else "f32"] += openers
+    out["bf16x3" if _conv.PATCH_BF16X3 else "f32"] += fpn
+    sparse_first = bool(model is not None and getattr(getattr(model, "backbone", None), "sparse_first", False))
+    if sparse_first and first_layer_pairs is not None:
+        out["bf16x3"] += first_layer_pairs * 2 * 64 * 64
+    else:
+        out["f32"] += conv(64, 64, 3, 256)
+    return {k: v for k, v in out.items() if v}
+
+
+def first_layer_pairs(coors, ny=512, nx=512):
+    """(pillar, tap) pairs of the stride-2 3x3 / pad 1 first layer over the occupied pillars `coors` [.., 4] (batch, z, y, x;
+    batch < 0 = unused row): an input row y feeds output row y / 2 (even y) or (y - 1) / 2 and (y + 1) / 2 (odd y, the
+    second only inside the map); columns alike."""
+    c = coors.reshape(-1, coors.shape[-1]).to(torch.int64)
+    c = c[c[:, 0] >= 0]
+    y, x = c[:, 2], c[:, 3]
+    ho, wo = (ny - 1) // 2 + 1, (nx - 1) // 2 + 1
+    fy = 1 + ((y % 2 == 1) & ((y + 1) // 2 < ho)).to(torch.int64)
+    fx = 1 + ((x % 2 == 1) & ((x + 1) // 2 < wo)).to(torch.int64)
+    return int((fy * fx).sum().item())
 
 
 def pfn_flops(v, mfma_per_scene=None):
@@ -462,7 +485,9 @@ def bench_pillars(args, rank, world, dev):
 
     d_direct, d_exec = dense_flops()
     with torch.no_grad():
-        pfn_mfma = pfn_packed_mfma(model.voxelizer(pts)[2], P) / B
+        vox_out = model.voxelizer(pts)
+        pfn_mfma = pfn_packed_mfma(vox_out[2], P) / B
+        first_pairs = first_layer_pairs(vox_out[1]) / B
     p_direct, p_exec = pfn_flops(V, pfn_mfma)
     rooflines = dict(
         hard_voxelize=dict(hbm("hard_voxelize", "hard_voxelize", op_ms),
@@ -501,12 +526,14 @@ def bench_pillars(args, rank, world, dev):
                  "AMP: the whole dense graph is direct-form implicit GEMM on the fp16 matrix cores (csrc/conv_f16.hip: "
                  "no Winograd), so executed = direct-form flops, priced against the fp16 pipe's 2.5 PFLOP/s")
             if amp else
-            mfma(per_op_ms["dense"], d_direct, dense_flops_by_pipe(model),
+            mfma(per_op_ms["dense"], d_direct, dense_flops_by_pipe(model, first_pairs),
                  "achieved / frac = executed flops: the 52 stride-1 3x3 layers run Winograd F(4x4,3x3) on the fp32 "
-                 "matrix cores (a quarter of the direct multiplies); the 3 stride-2 layers and the FPN levels run direct "
-                 "GEMMs (fp32 pipe, or fp32 arithmetic as bf16x3 where `pipes` says so); peak = the mix's own ceiling; "
-                 "direct_form_tflops = 127.2 GFLOP/scene / time (may exceed the peak: fewer multiplies are issued than "
-                 "counted)")))
+                 "matrix cores (a quarter of the direct multiplies); the two stride-2 block openers and the FPN levels run "
+                 "direct GEMMs in fp32 arithmetic on the bf16 pipe (three pieces per operand, six products: `pipes`); the "
+                 f"first layer runs as a sparse convolution over the occupied pillars ({first_pairs:.0f} (pillar, tap) "
+                 "products per scene counted on this batch instead of the dense layer's 589 824); peak = the mix's own "
+                 "ceiling; direct_form_tflops = 127.2 GFLOP/scene / time (may exceed the peak: fewer multiplies are "
+                 "issued than counted)")))
     line = {
         "metric": ("scenes/sec CenterPoint-Pillars nuScenes 300k-pt sweeps" +
                    (" (AMP O2: fp16 matrix cores in the stride-1 convolutions)" if amp else "")),

@@ -90,6 +90,38 @@ def test_roofline_objects_are_priced_per_pipe():
     assert h["algorithmic_bytes_per_unit"] == 295.68e6 / 16
 
 
+def test_dense_graph_flops_follow_the_kernels_that_run():
+    """The dense graph's roofline books every layer on the pipe its kernel issues on (round 6: the stride-2 openers and the
+    FPN levels moved to bf16x3, the first layer became a sparse convolution whose products are counted on the batch)."""
+    import types
+
+    import torch
+
+    sys.path.insert(0, ROOT)
+    from benchlib.pillars import dense_flops, dense_flops_by_pipe, first_layer_pairs
+    from paddle3d_amd.ops import conv
+
+    direct, executed = dense_flops()
+    model = types.SimpleNamespace(backbone=types.SimpleNamespace(sparse_first=True))
+    old = conv.S2_BF16X3, conv.PATCH_BF16X3
+    try:
+        conv.S2_BF16X3 = conv.PATCH_BF16X3 = False
+        plain = dense_flops_by_pipe(None)
+        assert set(plain) == {"f32"} and abs(plain["f32"] - executed) < 1e-3 * executed  # everything on the fp32 pipe
+        conv.S2_BF16X3 = conv.PATCH_BF16X3 = True
+        now = dense_flops_by_pipe(model, first_layer_pairs=67000.0)
+        first_dense = 2 * 64 * 64 * 9 * 256 * 256
+        moved = 2 * 9 * 128 * 128 * 64 * 128 + 2 * 9 * 64 * 64 * 128 * 256 + 2 * 4 * 64 * 128 * 128 * 128 + \
+            2 * 128 * 128 * 128 * 128 + 2 * 256 * 128 * 128 * 128
+        assert abs(now["bf16x3"] - (moved + 67000.0 * 2 * 64 * 64)) < 1.0
+        assert abs(now["f32"] - (executed - moved - first_dense)) < 1e-3 * executed
+    finally:
+        conv.S2_BF16X3, conv.PATCH_BF16X3 = old
+    # pairs of the stride-2 3x3 / pad 1 layer: even coordinate -> one output, odd -> two (one at the far border)
+    coors = torch.tensor([[[0, 0, 0, 0], [0, 0, 1, 1], [0, 0, 2, 3], [0, 0, 511, 511], [0, 0, 511, 10], [-1, 0, 0, 0]]])
+    assert first_layer_pairs(coors) == 1 + 4 + 2 + 1 + 1
+
+
 def test_stub_line_fracs_and_launch_fields():
     r = _run(["--gpus", "2", "--stub-ops", "--steps", "2", "--warmup", "1", "--batch", "2", "--strong-frames", "0"])
     assert r.returncode == 0, r.stderr[-2000:]

@@ -69,3 +69,41 @@ with torch.no_grad():
     (out, _p), t_all = timed(lambda: C.scatter_conv3x3_sparse(canvas, conv0.w, conv0.b, packed))
     print(f"scatter_conv3x3_sparse: {t_all:.0f} us (dense fused kernel {t_ref:.0f}); max |sparse - dense| over ALL cells "
           f"{float((out - ref).abs().max()):.2e}")
+    # how much does the tile order's reach matter?  The same rulebook with the rows grouped by mask over windows of
+    # 2048 (the device order), 8192, 65536 and over ALL rows (host-side stable sort: an experiment, not a path)
+    L = C.lib()
+    from paddle3d_amd.ops._common import check, ptr, stream_ptr, workspace
+    n, cin, ny, nx = canvas.shape
+    ho, wo = ny // 2, nx // 2
+    cap = n * ho * wo
+    nbr = torch.empty((cap, 9), dtype=torch.int32, device="cuda")
+    out_cell = torch.empty((cap,), dtype=torch.int32, device="cuda")
+    cell_row = torch.empty((n, ho * wo), dtype=torch.int32, device="cuda")
+    n_out = torch.empty((1,), dtype=torch.int32, device="cuda")
+    ws = workspace(L.pd3_pillar_conv_rulebook_workspace(n, ny, nx, 2), canvas.features.device)
+    order = torch.empty((int(L.pd3_sparse_tile_order_entries(cap)),), dtype=torch.int32, device="cuda")
+    check(L.pd3_pillar_conv_rulebook(ptr(canvas.inv), n, ny, nx, 2, ptr(nbr), ptr(out_cell), ptr(cell_row), ptr(n_out), cap,
+                                     ptr(order), ptr(ws), ws.numel(), stream_ptr(canvas.features.device)), "rulebook")
+    no = int(n_out.item())
+    mask = ((nbr[:no] >= 0).to(torch.int64) << torch.arange(9, device="cuda")).sum(1)
+    for reach in (0, 2048, 8192, 65536, 1 << 30):
+        if reach == 0:
+            od, name = order, "device order (2048)"
+        else:
+            key = (torch.arange(no, device="cuda") // reach) * 512 + mask
+            perm = torch.sort(key, stable=True)[1].to(torch.int32)
+            od = torch.full_like(order, -1)
+            od[:no] = perm
+            name = f"mask groups over {reach if reach < (1 << 30) else 'all'} rows"
+        idx2 = sp.SparseIndices(None, nbr, cap, (1, ho, wo), 9, od, n_out)
+        r2, t2 = timed(lambda: sp.features_bf16x3(canvas.features, idx2, packed, cin, conv0.cout, conv0.b, None, None, None, True))
+        # executed steps: per 256-row tile the taps any row has, x 2 chunks
+        om = mask[od[:no].long()]
+        pad = (-no) % 256
+        om = torch.cat([om, om.new_zeros(pad)]).reshape(-1, 256)
+        tile_or = om[:, 0].clone()
+        for j in range(1, 256):
+            tile_or |= om[:, j]
+        taps = sum(((tile_or >> k) & 1).sum().item() for k in range(9))
+        print(f"{name}: features {t2:.0f} us; taps executed per tile {taps / om.shape[0]:.2f} (pairs per row "
+              f"{float((nbr[:no] >= 0).sum()) / no:.2f})")
