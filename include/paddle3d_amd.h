@@ -579,6 +579,8 @@ int pd3_stable_argsort(const void *keys, int64_t n, int mode, uint32_t max_key, 
  *                pack_conv3x3_f16_weight), bias [cout] fp32 or NULL
  *   out          out_mode 0: [batch, h, w, cout] fp16 NHWC (the next fp16 layer's input);
  *                out_mode 1: [batch, cout, h, w] fp32 NCHW (what the fp32 kernels of the graph read)
+ *                out_mode 3: [batch, cout / 64, h, w, 64] fp16 "group-major" (round 6): the 64 channels of each branch of
+ *                            the head pixel after pixel -- what pd3_grouped_conv3x3_small_f16_gm reads
  *   channels_per_tile 128 or 64 (workgroup = T channels x 16 rows x 32 columns, walking several (pixel tile, channel
  *                tile) items)
  *   requires cin % 16 == 0, cout % T == 0; else PD3_EUNSUPPORTED (the caller runs fp32).  Maps that are not whole
@@ -612,6 +614,14 @@ int pd3_scatter_conv3x3_s2_f16_bias_relu(const void *features_f16, const int32_t
 int pd3_grouped_conv3x3_small_f16(const void *x_f16_nhwc, const void *w_f16, const float *bias, int batch, int groups,
                                   int channels_per_group, int out_per_group, int h, int w, float *out, int out_groups,
                                   int out_group0, void *stream);
+/* The same convolution on the group-major form of the first stage's output (out_mode 3 of pd3_conv3x3_f16_bias_relu):
+ * x [batch, groups, h, w, 64] fp16.  A group's patch rows are contiguous there -- in NHWC its pixels lie groups * 128 bytes
+ * apart and the fetch of a tile runs at a third of the rate of contiguous lines.  Persistent kernel, patches by LDS-DMA
+ * with the XOR swizzle done by the fetch (csrc/conv_f16.hip).  Same arguments, same results bit for bit; the input below
+ * 2 GB (else -3). */
+int pd3_grouped_conv3x3_small_f16_gm(const void *x_f16_group_major, const void *w_f16, const float *bias, int batch,
+                                     int groups, int channels_per_group, int out_per_group, int h, int w, float *out,
+                                     int out_groups, int out_group0, void *stream);
 /* x [batch, channels, h, w] fp32 NCHW -> out [batch, h, w, channels] fp16 NHWC (round to nearest even) */
 int pd3_f32_nchw_to_f16_nhwc(const float *x, int batch, int channels, int h, int w, void *out, void *stream);
 

@@ -137,6 +137,8 @@ _SIGNATURES = {
                                                        C.c_void_p]),
     "pd3_grouped_conv3x3_small_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pd3_grouped_conv3x3_small_f16_gm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pd3_stable_argsort_workspace": (C.c_size_t, [C.c_int64, C.c_uint32]),
     "pd3_stable_argsort": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t,
                                      C.c_void_p]),

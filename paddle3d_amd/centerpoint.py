@@ -354,7 +354,7 @@ class _Conv3x3:
             self.packed["f16"] = _conv.pack_conv3x3_f16_weight(self.w)
         return _conv.conv3x3_f16_bias_relu_dual(x_h, self.packed["f16"], self.b, self.cout, relu=True)
 
-    def f16(self, x_h, out_f32_nchw=False, out=None, tiles=None):
+    def f16(self, x_h, out_f32_nchw=False, out=None, tiles=None, group_major=False):
         """The same layer in mixed precision (AMP): x_h [n, h, w, cin] fp16 NHWC -> fp16 NHWC, or fp32 NCHW for the
         fp32 kernels behind a chain.  tiles = (first, last) channel tile of the packed weight (the head's slices)."""
         if "f16" not in self.packed:
@@ -363,7 +363,8 @@ class _Conv3x3:
         if tiles is not None:
             t = int(wp.shape[4])  # [cout / T][cin / 16][9][2][T][8]
             wp, b, cout = wp[tiles[0]:tiles[1]], self.b[tiles[0] * t:tiles[1] * t], (tiles[1] - tiles[0]) * t
-        return _conv.conv3x3_f16_bias_relu(x_h, wp, b, cout, relu=True, out_f32_nchw=out_f32_nchw, out=out)
+        return _conv.conv3x3_f16_bias_relu(x_h, wp, b, cout, relu=True, out_f32_nchw=out_f32_nchw, out=out,
+                                           group_major=group_major)
 
 
 def _valid_w(t) -> int:
@@ -782,10 +783,13 @@ class CenterHead(_InferenceCache, nn.Module):
             per = _conv.f16_tile(first.cout) // 64
             for c0 in range(0, groups, k):
                 c1 = min(c0 + k, groups)
-                y = buf[: n * (c1 - c0) * 64 * h * w].view(n, h, w, (c1 - c0) * 64)
-                first.f16(x, out_f32_nchw=False, out=y, tiles=(c0 // per, c1 // per))
+                # the slice's first-stage map group-major ([n, branch, h, w, 64], round 6): the final convolution of a
+                # branch then fetches contiguous patch rows (NHWC: 0.48 ms per 16 frames for the 36 branches, this: see
+                # tools/prof/prof_grouped_f16.py)
+                y = buf[: n * (c1 - c0) * 64 * h * w].view(n, c1 - c0, h, w, 64)
+                first.f16(x, out_f32_nchw=False, out=y, tiles=(c0 // per, c1 // per), group_major=True)
                 _conv.grouped_conv3x3_small_f16(y, f["pf16"][c0:c1], f["bf"][c0 * f["cmax"]:c1 * f["cmax"]], c1 - c0,
-                                                out=z, out_groups=groups, out_group0=c0)
+                                                out=z, out_groups=groups, out_group0=c0, group_major=True)
             rets = [dict() for _ in self.tasks]
             for g, (t, head) in enumerate(f["plan"]):
                 rets[t][head] = z[:, g * f["cmax"]:g * f["cmax"] + f["ncls"][g]]

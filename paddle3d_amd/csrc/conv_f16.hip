@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_f16_kernel(const _Float
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const int yg = cur.y0 + nw * J + j;
-      if (OUT_MODE == 0 || OUT_MODE == 2) {
+      if (OUT_MODE == 0 || OUT_MODE == 2 || OUT_MODE == 3) {
         // registers -> the wave's LDS tile (8-byte stores, lines 136 bytes apart: conflict-free) -> 16 bytes per lane,
         // eight lanes per pixel: every global store instruction writes eight whole 128-byte channel lines
 #pragma unroll
@@ -299,9 +299,16 @@ __global__ __launch_bounds__(kCfThreads, 1) void conv3x3_f16_kernel(const _Float
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int px = cur.x0 + 8 * k + (lane >> 3);
-            if (px < w)
-              *reinterpret_cast<cf_h8*>(reinterpret_cast<_Float16*>(out) + (((int64_t)cur.n * h + yg) * w + px) * cout +
-                                        co0 + (lane & 7) * 8) = piece[k];
+            if (px < w) {
+              // OUT_MODE 3: group-major [n][cout / 64][h][w][64] -- the 64 channels of a branch of the head lie pixel
+              // after pixel, so the grouped final convolution fetches whole contiguous patch rows
+              _Float16* o = OUT_MODE == 3
+                                ? reinterpret_cast<_Float16*>(out) +
+                                      ((((int64_t)cur.n * (cout >> 6) + (co0 >> 6)) * h + yg) * w + px) * 64 + (lane & 7) * 8
+                                : reinterpret_cast<_Float16*>(out) + (((int64_t)cur.n * h + yg) * w + px) * cout + co0 +
+                                      (lane & 7) * 8;
+              *reinterpret_cast<cf_h8*>(o) = piece[k];
+            }
           }
         }
       }
@@ -589,6 +596,186 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_f16_kernel(
   }
 }
 
+// The same convolution, persistent and fed by LDS-DMA (round 6).  The form above stages a tile through registers behind a
+// barrier and holds 144 registers of weights: two workgroups per CU, staging and MFMAs of a workgroup one after the other
+// -- 0.48 ms per 16 frames for 1.2 GB of input (2.5 TB/s) with the matrix pipe idle three quarters of the time.  Here a
+// workgroup keeps its group's weights and walks kGpTiles consecutive tiles of ONE (group, frame); the next tile's patch
+// travels by buffer_load_dwordx4 ... lds into the other buffer while the MFMAs of this one run.  A pixel's 128-byte line
+// is fetched whole by 8 lanes, but lane l takes 16-byte piece (l & 7) ^ (l >> 3) of it: the LDS image is XOR-swizzled by
+// the fetch itself (piece p of patch pixel P sits in slot p ^ (P & 7)), so the B operand's ds_read_b128 over 32 consecutive
+// pixels is conflict-free without padded lines -- which a fetch into LDS could not write.  Patch rows are 40 pixels apart
+// (34 used), so P & 7 is the column's: the twelve swizzled read offsets of a lane are constants of the kernel.  Padding =
+// fetches at an out-of-range offset (zeros), no branch.
+constexpr int kGpTiles = 16;
+constexpr unsigned kGpOob = 0x7ffffff0u;
+template <int CO, bool GM>  // GM: x is group-major [n][groups][h][w][64] (out_mode 3 of the stride-1 kernel), else NHWC
+__global__ __launch_bounds__(320, 1) void grouped_conv3x3_small_f16_pp_kernel(
+    const _Float16* __restrict__ x, const _Float16* __restrict__ wg, const float* __restrict__ bias, int groups, int h,
+    int w, float* __restrict__ out, int out_groups, int out_group0, int xbytes, int total, int per_wg) {
+  constexpr int TR = 8, TC = 32, PWP = 40, PBYTES = (TR + 2) * PWP * 128;  // patch row pitch in pixels; bytes of a patch
+  extern __shared__ __attribute__((aligned(16))) unsigned char gp_smem[];   // [3][PBYTES]
+  const int tiles_x = (w + TC - 1) / TC, tiles = tiles_x * ((h + TR - 1) / TR);
+  // work items = (frame, group, tile) in that order; this workgroup walks items [T0, T0 + nt): every CU gets the same
+  // number of tiles whatever the number of groups (a grid of (tile strip, group, frame) left the last round of workgroups
+  // half empty: 4.5 rounds for the head's 18-branch slice)
+  const int T0 = blockIdx.x * per_wg, nt = min(per_wg, total - T0);
+  const int c = groups * 64;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wave == 4) {
+    // THE FETCH WAVE.  A fetch that finds the memory pipe's queue full holds its wave, and a CU ingests a patch (43.5 KB) in
+    // about the time its MFMAs take: issued by the multiplying waves themselves, the two ran one after the other (cycle
+    // stamps: 3100 cycles of sending, THEN 3300 of MFMAs per tile).  This wave does nothing else: the next tile's 50
+    // fetches, vmcnt(0), the barrier that publishes them.
+    // fetch of patch row r, pixels 8 k .. 8 k + 7 (instruction (r, k)): lane l = pixel 8 k + (l >> 3), slot l & 7 <- piece
+    // (l & 7) ^ (l >> 3)
+    const unsigned line = GM ? 128u : 2u * (unsigned)c;  // bytes between neighbouring pixels
+    const unsigned voff_n = (unsigned)(lane >> 3) * line + (unsigned)(((lane & 7) ^ (lane >> 3)) * 16);
+    auto send = [&](int T, unsigned char* dst) {
+      const int ng = T / tiles, t = T - ng * tiles;
+      const int n = ng / groups, g = ng - n * groups;
+      const int ty0 = (t / tiles_x) * TR, tx0 = (t - (t / tiles_x) * tiles_x) * TC;
+      for (int r = 0; r < TR + 2; ++r) {
+        const int gy = ty0 - 1 + r;
+        const int gyc = min(max(gy, 0), h - 1);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const int gx = tx0 - 1 + 8 * k + (lane >> 3);  // this lane's pixel
+          const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w && 8 * k + (lane >> 3) < TC + 2;
+          // uniform part: the first pixel of the instruction, or pixel 0 of the row where that lies left of the image
+          const int gx0 = tx0 - 1 + 8 * k, gxc = max(gx0, 0);
+          const unsigned so = __builtin_amdgcn_readfirstlane(
+              GM ? 128u * (unsigned)(((n * groups + g) * h + gyc) * w + gxc)
+                 : 2u * ((unsigned)((n * h + gyc) * w + gxc) * (unsigned)c + (unsigned)(g * 64)));
+          const unsigned vo = gx0 < 0 ? voff_n - line : voff_n;
+          cf_dma_piece(x, xbytes, reinterpret_cast<_Float16*>(dst + (r * PWP + 8 * k) * 128), ok ? vo : kGpOob, (int)so);
+        }
+      }
+    };
+    // three patches: the fetches of tile it + 2 are in flight while the wave waits for tile it + 1's (50 younger: completion
+    // is in order) -- with two the memory pipe ran empty at every barrier (3.0 TB/s)
+    send(T0, gp_smem);
+    if (nt > 1) {
+      send(T0 + 1, gp_smem + PBYTES);
+      __builtin_amdgcn_s_waitcnt(0x0f70 | (50 & 15) | ((50 >> 4) << 14));  // vmcnt(50)
+    } else {
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int it = 0; it < nt; ++it) {
+      if (it + 2 < nt) {
+        send(T0 + it + 2, gp_smem + ((it + 2) % 3) * PBYTES);
+        __builtin_amdgcn_s_waitcnt(0x0f70 | (50 & 15) | ((50 >> 4) << 14));
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    return;
+  }
+  const int l31 = lane & 31, kh = lane >> 5;
+  cf_h8 aw[36];  // A fragments: W[tap][m = l31][16 s + 8 kh ..] for m < CO, zero rows above
+  float bv[CO];
+  auto load_weights = [&](int g) {
+    const _Float16* wgrp = wg + (int64_t)g * 9 * CO * 64 + (l31 < CO ? l31 : 0) * 64 + 8 * kh;
+    const cf_h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int sk = 0; sk < 4; ++sk) {
+        const cf_h8 v = *reinterpret_cast<const cf_h8*>(wgrp + t * CO * 64 + 16 * sk);
+        aw[t * 4 + sk] = l31 < CO ? v : z;
+      }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) bv[o] = bias ? bias[g * CO + o] : 0.f;
+  };
+  int g_cur = (T0 / tiles) % groups;
+  load_weights(g_cur);
+  // B operand: lane (pixel l31 of tile row ty + j, kh), tap (dy, dx), K-step sk: piece 2 sk + kh of patch pixel
+  // P = (ty + j + dy) * 40 + l31 + dx, in slot (2 sk + kh) ^ (P & 7) = (2 sk + kh) ^ ((l31 + dx) & 7)
+  int boff[3][4];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int sk = 0; sk < 4; ++sk) boff[dx][sk] = (l31 + dx) * 128 + (((2 * sk + kh) ^ ((l31 + dx) & 7)) << 4);
+  const int ty = 2 * wave;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the first patch has landed
+  for (int it = 0; it < nt; ++it) {
+    const int T = T0 + it;
+    const int ng = T / tiles, t = T - ng * tiles;
+    const int n = ng / groups, g = ng - n * groups;
+    if (g != g_cur) {  // (uniform) the walk crossed into the next group: its weights
+      g_cur = g;
+      load_weights(g);
+    }
+    const unsigned char* P = gp_smem + (it % 3) * PBYTES;
+    cf_f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // One wave per SIMD multiplies: nothing hides an LDS read but the wave's own other work, so the B fragments travel a
+    // whole kernel row ahead: the 24 reads of row dy + 1 are in flight while the 24 MFMAs of row dy run.
+    cf_h8 bq[2][24];
+    auto load_row = [&](int dy, cf_h8 (&dst)[24]) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int sk = 0; sk < 4; ++sk)
+            dst[(j * 3 + dx) * 4 + sk] = *reinterpret_cast<const cf_h8*>(P + (ty + j + dy) * (PWP * 128) + boff[dx][sk]);
+    };
+    load_row(0, bq[0]);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      if (dy < 2) load_row(dy + 1, bq[(dy + 1) & 1]);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int sk = 0; sk < 4; ++sk)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aw[(dy * 3 + dx) * 4 + sk], bq[dy & 1][(j * 3 + dx) * 4 + sk],
+                                                            acc[j], 0, 0, 0);
+    }
+    // D[m = (reg & 3) + 8 (reg >> 2) + 4 kh][n = l31]: channels 0 .. CO - 1 are registers 0 .. CO - 1 of the kh = 0 lanes
+    const int ty0 = (t / tiles_x) * TR, tx0 = (t - (t / tiles_x) * tiles_x) * TC;
+    const int xg = tx0 + l31;
+    if (kh == 0 && xg < w) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int y = ty0 + ty + j;
+        if (y < h) {
+#pragma unroll
+          for (int o = 0; o < CO; ++o) {
+            const int ch = (out_group0 + g) * CO + o;
+            out[(((int64_t)n * out_groups * CO + ch) * h + y) * w + xg] = acc[j][o] + bv[o];
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the fetch wave waited for the next patch)
+  }
+}
+
+template <int CO, bool GM>
+static int launch_grouped_pp(const _Float16* x, const _Float16* wg, const float* bias, int batch, int groups, int h, int w,
+                             float* out, int out_groups, int out_group0, hipStream_t s) {
+  constexpr int LDS = 3 * 10 * 40 * 128;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_conv3x3_small_f16_pp_kernel<CO, GM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (e != hipSuccess) return (int)e;
+  const int64_t tiles = ceil_div(w, 32) * ceil_div(h, 8), total = tiles * groups * batch;
+  if (total >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
+  // one workgroup per CU where the work allows it, each with the same number of tiles (at least kGpTiles: the weights and
+  // the first patch of a workgroup are not hidden)
+  const int64_t per_wg = std::max<int64_t>(kGpTiles, ceil_div(total, 256));
+  const int64_t xbytes = (int64_t)batch * h * w * groups * 64 * 2;
+  grouped_conv3x3_small_f16_pp_kernel<CO, GM><<<(unsigned)ceil_div(total, per_wg), 320, LDS, s>>>(
+      x, wg, bias, groups, h, w, out, out_groups, out_group0, (int)xbytes, (int)total, (int)per_wg);
+  return launch_status();
+}
+
 // fp32 NCHW -> fp16 NHWC (the boundary in front of a chain of fp16 layers): one workgroup per (n, y, 64 columns),
 // channels in chunks of 64 through an LDS tile (reads coalesced along x, writes along c)
 __global__ __launch_bounds__(256) void f32_nchw_to_f16_nhwc_kernel(const float* __restrict__ x, int c, int h, int w,
@@ -645,7 +832,8 @@ extern "C" int pd3_conv3x3_f16_bias_relu(const void* x_f16_nhwc, const void* w_p
                                          int cin, int cout, int h, int w, int relu, void* out, int out_mode,
                                          int channels_per_tile, void* stream) {
   if (!x_f16_nhwc || !w_packed_f16 || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return PD3_EINVAL;
-  if ((out_mode != 0 && out_mode != 1) || (channels_per_tile != 64 && channels_per_tile != 128)) return PD3_EINVAL;
+  if ((out_mode != 0 && out_mode != 1 && out_mode != 3) || (channels_per_tile != 64 && channels_per_tile != 128))
+    return PD3_EINVAL;
   if (reinterpret_cast<uintptr_t>(x_f16_nhwc) % 16 != 0 || reinterpret_cast<uintptr_t>(w_packed_f16) % 16 != 0 ||
       reinterpret_cast<uintptr_t>(out) % 16 != 0)
     return PD3_EINVAL;
@@ -653,10 +841,12 @@ extern "C" int pd3_conv3x3_f16_bias_relu(const void* x_f16_nhwc, const void* w_p
   if ((int64_t)h * w * cin >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;  // 32-bit staging offsets
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (channels_per_tile == 128)
-    return out_mode == 0 ? launch_conv_f16<2, 0>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s)
-                         : launch_conv_f16<2, 1>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s);
-  return out_mode == 0 ? launch_conv_f16<1, 0>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s)
-                       : launch_conv_f16<1, 1>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s);
+    return out_mode == 0   ? launch_conv_f16<2, 0>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s)
+           : out_mode == 1 ? launch_conv_f16<2, 1>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s)
+                           : launch_conv_f16<2, 3>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s);
+  return out_mode == 0   ? launch_conv_f16<1, 0>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s)
+         : out_mode == 1 ? launch_conv_f16<1, 1>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s)
+                         : launch_conv_f16<1, 3>(x_f16_nhwc, w_packed_f16, bias, batch, cin, cout, h, w, relu, out, s);
 }
 
 extern "C" int pd3_conv3x3_f16_bias_relu_dual(const void* x_f16_nhwc, const void* w_packed_f16, const float* bias,
@@ -727,9 +917,9 @@ extern "C" int pd3_scatter_conv3x3_s2_f16_bias_relu(const void* features_f16, co
                                      out_f16_nhwc, s);
 }
 
-extern "C" int pd3_grouped_conv3x3_small_f16(const void* x_f16_nhwc, const void* w_f16, const float* bias, int batch,
-                                             int groups, int channels_per_group, int out_per_group, int h, int w,
-                                             float* out, int out_groups, int out_group0, void* stream) {
+static int grouped_small_f16(const void* x_f16_nhwc, const void* w_f16, const float* bias, int batch, int groups,
+                             int channels_per_group, int out_per_group, int h, int w, float* out, int out_groups,
+                             int out_group0, void* stream, bool group_major) {
   if (!x_f16_nhwc || !w_f16 || !out || batch <= 0 || groups <= 0 || h <= 0 || w <= 0 || out_groups < groups ||
       out_group0 < 0 || out_group0 + groups > out_groups)
     return PD3_EINVAL;
@@ -740,6 +930,15 @@ extern "C" int pd3_grouped_conv3x3_small_f16(const void* x_f16_nhwc, const void*
   hipStream_t s = static_cast<hipStream_t>(stream);
   const _Float16* x = static_cast<const _Float16*>(x_f16_nhwc);
   const _Float16* wg = static_cast<const _Float16*>(w_f16);
+  if (group_major) {
+    if ((int64_t)batch * h * w * groups * 64 * 2 >= (int64_t)kGpOob) return PD3_EUNSUPPORTED;  // 32-bit buffer offsets
+    switch (out_per_group) {
+      case 1: return launch_grouped_pp<1, true>(x, wg, bias, batch, groups, h, w, out, out_groups, out_group0, s);
+      case 2: return launch_grouped_pp<2, true>(x, wg, bias, batch, groups, h, w, out, out_groups, out_group0, s);
+      case 3: return launch_grouped_pp<3, true>(x, wg, bias, batch, groups, h, w, out, out_groups, out_group0, s);
+      default: return launch_grouped_pp<4, true>(x, wg, bias, batch, groups, h, w, out, out_groups, out_group0, s);
+    }
+  }
   switch (out_per_group) {
     case 1: grouped_conv3x3_small_f16_kernel<1><<<grid, 256, 0, s>>>(x, wg, bias, groups, h, w, out, out_groups, out_group0); break;
     case 2: grouped_conv3x3_small_f16_kernel<2><<<grid, 256, 0, s>>>(x, wg, bias, groups, h, w, out, out_groups, out_group0); break;
@@ -747,6 +946,20 @@ extern "C" int pd3_grouped_conv3x3_small_f16(const void* x_f16_nhwc, const void*
     default: grouped_conv3x3_small_f16_kernel<4><<<grid, 256, 0, s>>>(x, wg, bias, groups, h, w, out, out_groups, out_group0); break;
   }
   return launch_status();
+}
+
+extern "C" int pd3_grouped_conv3x3_small_f16(const void* x_f16_nhwc, const void* w_f16, const float* bias, int batch,
+                                             int groups, int channels_per_group, int out_per_group, int h, int w,
+                                             float* out, int out_groups, int out_group0, void* stream) {
+  return grouped_small_f16(x_f16_nhwc, w_f16, bias, batch, groups, channels_per_group, out_per_group, h, w, out, out_groups,
+                           out_group0, stream, false);
+}
+
+extern "C" int pd3_grouped_conv3x3_small_f16_gm(const void* x_f16_group_major, const void* w_f16, const float* bias,
+                                                int batch, int groups, int channels_per_group, int out_per_group, int h,
+                                                int w, float* out, int out_groups, int out_group0, void* stream) {
+  return grouped_small_f16(x_f16_group_major, w_f16, bias, batch, groups, channels_per_group, out_per_group, h, w, out,
+                           out_groups, out_group0, stream, true);
 }
 
 extern "C" int pd3_f32_nchw_to_f16_nhwc(const float* x, int batch, int channels, int h, int w, void* out, void* stream) {

@@ -392,17 +392,22 @@ def to_f16_nhwc(x: torch.Tensor) -> torch.Tensor:
 
 
 def conv3x3_f16_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, relu: bool = True,
-                          out_f32_nchw: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
-    """x [n, h, w, cin] fp16 NHWC -> [n, h, w, cout] fp16 NHWC, or (out_f32_nchw) [n, cout, h, w] fp32 NCHW."""
+                          out_f32_nchw: bool = False, out: torch.Tensor | None = None,
+                          group_major: bool = False) -> torch.Tensor:
+    """x [n, h, w, cin] fp16 NHWC -> [n, h, w, cout] fp16 NHWC, or (out_f32_nchw) [n, cout, h, w] fp32 NCHW, or
+    (group_major) [n, cout / 64, h, w, 64] fp16: the head's branches one after the other."""
     if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous():
         raise RuntimeError("conv3x3_f16_bias_relu: x must be a contiguous fp16 NHWC tensor on the GPU")
     n, h, w, cin = x.shape
     tile = int(w_packed.shape[4])
     if out is None:
         out = (torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device) if out_f32_nchw
-               else torch.empty((n, h, w, cout), dtype=torch.float16, device=x.device))
+               else torch.empty((n, cout // 64, h, w, 64) if group_major else (n, h, w, cout), dtype=torch.float16,
+                                device=x.device))
+    assert not (group_major and out_f32_nchw)
     check(lib().pd3_conv3x3_f16_bias_relu(ptr(x), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
-                                          ptr(out), 1 if out_f32_nchw else 0, tile, stream_ptr(x.device)),
+                                          ptr(out), 1 if out_f32_nchw else (3 if group_major else 0), tile,
+                                          stream_ptr(x.device)),
           "conv3x3_f16_bias_relu")
     return out
 
@@ -467,21 +472,27 @@ def pack_grouped_weight_f16(weight: torch.Tensor, groups: int) -> torch.Tensor:
 
 def grouped_conv3x3_small_f16(x_h: torch.Tensor, w_f16: torch.Tensor, bias, groups: int,
                               out: torch.Tensor | None = None, out_groups: int | None = None,
-                              out_group0: int = 0) -> torch.Tensor:
-    """grouped_conv3x3_small on the first stage's fp16 NHWC output: x_h [n, h, w, groups * 64] fp16 -> fp32 NCHW maps
+                              out_group0: int = 0, group_major: bool = False) -> torch.Tensor:
+    """grouped_conv3x3_small on the first stage's fp16 output: x_h [n, h, w, groups * 64] fp16 NHWC -- or (group_major)
+    [n, groups, h, w, 64], what conv3x3_f16_bias_relu(..., group_major=True) leaves -- -> fp32 NCHW maps
     [n, out_groups * co, h, w] (this slice's groups at [out_group0, out_group0 + groups))."""
     if x_h.dtype != torch.float16 or not x_h.is_cuda or not x_h.is_contiguous():
-        raise RuntimeError("grouped_conv3x3_small_f16: x must be a contiguous fp16 NHWC tensor on the GPU")
-    n, h, w, c = x_h.shape
+        raise RuntimeError("grouped_conv3x3_small_f16: x must be a contiguous fp16 tensor on the GPU")
+    if group_major:
+        n, gg, h, w, c64 = x_h.shape
+        c = gg * c64
+        assert c64 == 64
+    else:
+        n, h, w, c = x_h.shape
     co = int(w_f16.shape[2])
     assert c == groups * 64 and tuple(w_f16.shape) == (groups, 9, co, 64)
     total = groups if out_groups is None else int(out_groups)
     if out is None:
         out = torch.empty((n, total * co, h, w), dtype=torch.float32, device=x_h.device)
     assert out.is_contiguous() and tuple(out.shape) == (n, total * co, h, w)
-    check(lib().pd3_grouped_conv3x3_small_f16(ptr(x_h), ptr(w_f16.contiguous()), ptr(bias), n, groups, 64, co, h, w,
-                                              ptr(out), total, int(out_group0), stream_ptr(x_h.device)),
-          "grouped_conv3x3_small_f16")
+    fn = lib().pd3_grouped_conv3x3_small_f16_gm if group_major else lib().pd3_grouped_conv3x3_small_f16
+    check(fn(ptr(x_h), ptr(w_f16.contiguous()), ptr(bias), n, groups, 64, co, h, w, ptr(out), total, int(out_group0),
+             stream_ptr(x_h.device)), "grouped_conv3x3_small_f16")
     return out
 
 

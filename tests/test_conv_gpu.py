@@ -573,6 +573,9 @@ def test_grouped_conv3x3_small_f16_matches_fp32_math_on_fp16_operands(groups, co
     assert got.shape == ref.shape and got.dtype == torch.float32
     per_ch = (got - ref).abs().amax(dim=(0, 2, 3)).cpu().numpy().round(4).tolist()
     assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), per_ch
+    # the group-major form of the input ([n, groups, h, w, 64]: persistent LDS-DMA kernel, round 6): the same bytes
+    xg = xh.view(2, h, w, groups, 64).permute(0, 3, 1, 2, 4).contiguous()
+    assert torch.equal(conv.grouped_conv3x3_small_f16(xg, wp, b, groups, group_major=True), got)
     if groups >= 4:  # the head's slices: groups [2, 4) of the input land at groups [3, 5) of a 6-group output
         out = torch.full((2, 6 * co, h, w), 7.0, device="cuda")
         xs = xh[..., 2 * 64:4 * 64].contiguous()
