@@ -50,7 +50,12 @@ def main():
     tiled = any("vt_route" in k or "vw_route" in k for k in fetch)
     ops = dict(OPS)
     owner = "centerpoint_postprocess" if tiled else "hard_voxelize"
-    ops[owner] = ops[owner] + SHARED
+    shared = SHARED
+    if any("pc_flags" in k for k in fetch):
+        # round 6: the first backbone layer runs as a sparse convolution over the occupied pillars and the step's scans are
+        # its rulebook's (pillar_conv.hip); neither the wave-form voxelizer nor the post-processing launches one
+        shared = tuple(p for p in SHARED if not p.startswith("scan_"))
+    ops[owner] = ops[owner] + shared
     for op, pats in ops.items():
         f = sum(v for k, v in fetch.items() if any(p in k for p in pats))
         w = sum(v for k, v in write.items() if any(p in k for p in pats))
