@@ -106,11 +106,12 @@ __global__ __launch_bounds__(kPxThreads, 1) void patch_gemm_x3_kernel(PxArgs a) 
   px_b8 bpa[S][3], bpb[S][3];
 
   // A pieces of (item i, step st): 32 KB, this wave's four 1 KB pieces of it
+  // (sent by the younger half of the waves alone, eight pieces each: see the schedule below)
   auto fetch_w = [&](int i, int st, unsigned char* dst) {
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(item_mt(i) * nsteps + st) * (unsigned)kPxWBytes +
-                                                       (unsigned)wave * 4096u);
+                                                       (unsigned)(wave - 4) * 8192u);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) px_dma(a.wpk, a.w_bytes, dst + wave * 4096 + j * 1024, lane * 16, so + j * 1024);
+    for (int j = 0; j < 8; ++j) px_dma(a.wpk, a.w_bytes, dst + (wave - 4) * 8192 + j * 1024, lane * 16, so + j * 1024);
   };
   // the wave's rows of step st, always issued (a step past the end re-fetches the last one): four groups of 8 channels
   // (mode 0: of 4 channels x 2 taps)
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(kPxThreads, 1) void patch_gemm_x3_kernel(PxArgs a) 
   advance(ni, ns);
   unsigned fvoff, fsoff;
   b_base(0, fvoff, fsoff);
-  fetch_w(0, 0, Wl);
+  if (wave >= 4) fetch_w(0, 0, Wl);
   fetch_b(fvoff, fsoff, 0, myB);
   if (ni != 0) b_base(min(ni, nit - 1), fvoff, fsoff);
   fetch_b(fvoff, fsoff, ni < nit ? ns : nsteps - 1, myB + kPxSlot);
@@ -235,26 +236,32 @@ __global__ __launch_bounds__(kPxThreads, 1) void patch_gemm_x3_kernel(PxArgs a) 
   PX_VMCNT(4);  // the A pieces and the rows of step 0 have landed (the rows of step 1 may still travel)
   split_b(myB, bpa);
   px_lds_barrier();
-  // Waves w and w + 4 share a SIMD and the older one wins the matrix pipe: the younger half cuts the next step's values
-  // BEFORE its MFMAs, while the older half multiplies (sparse_conv_x3.hip, cycle counters in profiles/r06_sparse_layers.txt).
-  //
-  // What is in flight, in issue order (completion is in order): ... [rows t + 1: 4] | step t: [A t + 1: 4] [rows t + 2: 4]
-  // [stores of the item that ends with step t: NST].  The younger half needs rows t + 1 right after sending its 8: vmcnt(8)
-  // -- or, when step t - 1 ended an item, NST stores lie between the rows and those 8: vmcnt(min(63, NST + 8)).  After its
-  // MFMAs every wave waits for A t + 1 (vmcnt(4): the rows t + 2 keep travelling), which covers rows t + 1 for the older
-  // half; then the barrier publishes A t + 1.
+  // Waves w and w + 4 share a SIMD and the older one wins the matrix pipe: the two MFMA streams of a SIMD run one after the
+  // other.  The older half multiplies at once and does everything else behind its MFMAs; the younger half does everything
+  // else FIRST, under the older half's MFMAs:
+  //   older  (waves 0-3): MFMAs | rows t + 1 have landed: cut them | send own rows t + 2        | stores | barrier
+  //   younger (waves 4-7): send A t + 1 (all of it) and own rows t + 2 | cut rows t + 1 | MFMAs | A t + 1 landed | stores |
+  // A fetch that finds the memory pipe's queue full HOLDS its wave (conv_f16.hip's grouped kernel measured it: 3100 cycles
+  // of sending in front of 3300 of MFMAs): with all eight waves sending at the top of the step -- the first schedule --
+  // nothing multiplied for 700-1700 cycles of every step (cycle stamps, profiles/r06_patch_x3_stamps.txt).
+  // Fetches and stores complete in order, so the waits are counts of what is younger: the younger half needs rows t + 1
+  // behind its 12 fetches (vmcnt(12); or, when step t - 1 ended an item, behind NST stores too: capped at 63); after its
+  // MFMAs, A t + 1 with only the 4 row fetches younger (vmcnt(4)).  The older half sent rows t + 1 in the middle of step
+  // t - 1, younger than them are only that step's stores (vmcnt(NST) or 0).
   const bool cut_first = wave >= 4;
   bool after_epi = false;
   auto step = [&](unsigned char* near, unsigned char* far, px_b8 (&bcur)[S][3], px_b8 (&bnext)[S][3]) {
     const bool more = ni < nit;
     advance(fi, fs);
     if (fs == 0 && fi < nit) b_base(fi, fvoff, fsoff);
-    fetch_w(more ? ni : ci, more ? ns : cs, Wl + (buf ^ 1) * kPxWBytes);
-    fetch_b(fvoff, fsoff, fi < nit ? fs : nsteps - 1, far);
-    if (cut_first && more) {
-      if (after_epi) PX_VMCNT((NST + 8 < 63 ? NST + 8 : 63));
-      else PX_VMCNT(8);
-      split_b(near, bnext);
+    if (cut_first) {
+      fetch_w(more ? ni : ci, more ? ns : cs, Wl + (buf ^ 1) * kPxWBytes);
+      fetch_b(fvoff, fsoff, fi < nit ? fs : nsteps - 1, far);
+      if (more) {
+        if (after_epi) PX_VMCNT((NST + 12 < 63 ? NST + 12 : 63));
+        else PX_VMCNT(12);
+        split_b(near, bnext);
+      }
     }
     {
       // A: lane (m = l31, kh) of piece p, row block i, K-step s: 8 bf16 at line (p 128 + 32 i + l31), position 16 s + 8 kh
@@ -276,8 +283,14 @@ __global__ __launch_bounds__(kPxThreads, 1) void patch_gemm_x3_kernel(PxArgs a) 
         }
       }
     }
-    PX_VMCNT(4);
-    if (!cut_first && more) split_b(near, bnext);
+    if (cut_first) {
+      PX_VMCNT(4);
+    } else {
+      if (after_epi) PX_VMCNT((NST < 63 ? NST : 63));
+      else PX_VMCNT(0);
+      if (more) split_b(near, bnext);
+      fetch_b(fvoff, fsoff, fi < nit ? fs : nsteps - 1, far);
+    }
     after_epi = cs == nsteps - 1;
     if (after_epi) epilogue(ci);
     px_lds_barrier();

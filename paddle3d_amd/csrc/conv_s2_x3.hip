@@ -75,11 +75,13 @@ __global__ __launch_bounds__(kS2Threads, 1) void conv3x3_s2_x3_kernel(S2Args a) 
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   px_b8 bpa[S][3], bpb[S][3];
 
+  // (sent by the younger half of the waves alone, twelve pieces each: a fetch that finds the memory pipe's queue full holds
+  // its wave, and the younger half waits for the older half's MFMAs anyway -- conv_patch_x3.hip)
   auto fetch_w = [&](int i, int st, unsigned char* dst) {
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(item_mt(i) * nsteps + st) * (unsigned)kS2WBytes +
-                                                       (unsigned)wave * 6144u);
+                                                       (unsigned)(wave - 4) * 12288u);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) px_dma(a.wpk, a.w_bytes, dst + wave * 6144 + j * 1024, lane * 16, so + j * 1024);
+    for (int j = 0; j < 12; ++j) px_dma(a.wpk, a.w_bytes, dst + (wave - 4) * 12288 + j * 1024, lane * 16, so + j * 1024);
   };
   // The wave's input row of step st = (chunk c, ky) of item i: lane l of fetch g = (channel 4 g + l / 16, columns
   // 2 ox0 + 4 (l % 16) ..); the fifth fetch = channel l's column 2 ox0 - 1 for l < 16.  A row above the image (or a tile
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(kS2Threads, 1) void conv3x3_s2_x3_kernel(S2Args a) 
     }
   };
   advance(ni, ns);
-  fetch_w(0, 0, Wl);
+  if (wave >= 4) fetch_w(0, 0, Wl);
   fetch_b(0, 0);
   PX_VMCNT(0);
   split_b(bpa);
@@ -167,14 +169,15 @@ __global__ __launch_bounds__(kS2Threads, 1) void conv3x3_s2_x3_kernel(S2Args a) 
   fs = ns;
   fetch_b(min(fi, nit - 1), fi < nit ? fs : nsteps - 1);  // (the slot was read: the row of step 1 goes out)
   px_lds_barrier();
-  // In flight, in issue order: [row t + 1: 5] [stores of the item that ended with step t - 1: NST] | step t: [A t + 1: 6]
-  // ... younger half: wait for the row (6 younger -- or NST + 6, capped), cut, send row t + 2 [5]; MFMAs; wait for A t + 1
-  // (5 younger).  Older half: MFMAs; everything has landed (vmcnt(0)); cut; send row t + 2.
+  // Younger half (waves 4-7), in issue order: [row t + 1: 5] [stores of the item that ended with step t - 1: NST] | step t:
+  // [A t + 1: 12, all of it] -- wait for the row (12 younger, or NST + 12: capped at 63), cut, send row t + 2 [5]; MFMAs; wait
+  // for A t + 1 (5 younger).  Older half: MFMAs at once; then everything of its own has landed (vmcnt(0)); cut; send row
+  // t + 2.
   const bool cut_first = wave >= 4;
   bool after_epi = false;
   auto step = [&](px_b8 (&bcur)[S][3], px_b8 (&bnext)[S][3]) {
     const bool more = ni < nit;
-    fetch_w(more ? ni : ci, more ? ns : cs, Wl + (buf ^ 1) * kS2WBytes);
+    if (cut_first) fetch_w(more ? ni : ci, more ? ns : cs, Wl + (buf ^ 1) * kS2WBytes);
     auto cut_and_send = [&]() {
       if (more) split_b(bnext);
       // the slot is single: its reads are complete before the next row is sent into it (the compiler does not see that the
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(kS2Threads, 1) void conv3x3_s2_x3_kernel(S2Args a) 
     };
     if (cut_first) {
       if (after_epi) PX_VMCNT(63);
-      else PX_VMCNT(6);
+      else PX_VMCNT(12);
       cut_and_send();
     }
     {
