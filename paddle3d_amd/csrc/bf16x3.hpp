@@ -61,4 +61,22 @@ __device__ __forceinline__ void px_st2(float* base, unsigned bytes, unsigned vof
 // counts as an LDS store)
 __device__ __forceinline__ void px_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Items per workgroup of the persistent kernels: one workgroup per CU at a time walks `ipw` consecutive slots of its XCD
+// lane as one stream, the grid is 8 * ceil(nslots / ipw) workgroups.  Chosen to minimise (rounds of 256 workgroups) x (ipw
+// + the half item a workgroup's unhidden first fetches cost): "as many as fill the CUs once" left 136 workgroups of 16
+// items for CenterPoint-Voxel's 264 pixel tiles (16 item times where 8.25 are the work).
+static inline int px_items_per_workgroup(int64_t nslots) {
+  int best = 1;
+  double best_cost = 1e30;
+  for (int ipw = 1; ipw <= 32; ++ipw) {
+    const int64_t nwg = 8 * ((nslots + ipw - 1) / ipw);
+    const double cost = (double)((nwg + 255) / 256) * (ipw + 0.5);
+    if (cost < best_cost - 1e-9) {
+      best_cost = cost;
+      best = ipw;
+    }
+  }
+  return best;
+}
+
 }  // namespace pd3

@@ -385,10 +385,7 @@ extern "C" int pd3_patch_conv_x3_bias_relu(const float* x, const void* w_packed,
   a.ptiles = (int)ptiles;
   const int64_t nslots = ceil_div(ptiles, 8) * a.nmt;
   a.nslots = (int)nslots;
-  // one workgroup per CU walks its slots as one stream; whole pixel tiles (all their row tiles) per workgroup
-  int ipw = (int)std::max<int64_t>(1, ceil_div(nslots * 8, 256));
-  ipw = (int)ceil_div(ipw, a.nmt) * a.nmt;
-  a.ipw = ipw;
+  a.ipw = px_items_per_workgroup(nslots);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (mode == 0) return launch_px<0>(a, s);
   if (mode == 1) return launch_px<1>(a, s);

@@ -42,7 +42,7 @@ struct S2Args {
 };
 
 __global__ __launch_bounds__(kS2Threads, 1) void conv3x3_s2_x3_kernel(S2Args a) {
-  constexpr int NC = kS2M / 32, S = 3, NST = 64;
+  constexpr int NC = kS2M / 32, S = 3;  // (an item ends with 64 stores per lane: the capped vmcnt(63) below)
   extern __shared__ __attribute__((aligned(16))) unsigned char s2_smem[];
   unsigned char* Wl = s2_smem;                                             // [2][48 KB]
   float* bias_s = reinterpret_cast<float*>(s2_smem + kS2Lds);              // [bias_n]
@@ -270,14 +270,12 @@ extern "C" int pd3_conv3x3_s2_x3_bias_relu(const float* x, const void* w_packed,
   a.ptiles = (int)ptiles;
   const int64_t nslots = ceil_div(ptiles, 8) * a.nmt;
   a.nslots = (int)nslots;
-  int ipw = (int)std::max<int64_t>(1, ceil_div(nslots * 8, 256));
-  ipw = (int)ceil_div(ipw, a.nmt) * a.nmt;
-  a.ipw = ipw;
+  a.ipw = px_items_per_workgroup(nslots);
   const size_t lds = kS2Lds + (size_t)cout * sizeof(float);
   const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_s2_x3_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kS2Lds + 4096));
   if (e != hipSuccess) return (int)e;
-  const int64_t nwg = 8 * ceil_div(nslots, ipw);
+  const int64_t nwg = 8 * ceil_div(nslots, a.ipw);
   conv3x3_s2_x3_kernel<<<(unsigned)nwg, kS2Threads, lds, static_cast<hipStream_t>(stream)>>>(a);
   return launch_status();
 }
