@@ -549,6 +549,21 @@ int pd3_conv3x3_winograd43_bias_relu(const float *x, const float *u_packed, cons
  *   order of accumulation over input channels (identical here: ascending) */
 int pd3_conv3x3_winograd43_pp_bias_relu(const float *x, const float *u_lane, const float *bias, int batch, int cin,
                                         int cout, int h, int w, int w_valid, int relu, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * conv3x3_winograd43_ppv_bias_relu -- conv3x3_winograd43_pp_bias_relu for a layer with many output-channel blocks over
+ * one input (CenterHead's 36 first-stage convolutions as one 64 -> 2304 layer, center_head.py:99-118): the input transform
+ * V = B^T d B is computed ONCE by pd3_winograd43_input_transform and fetched by the convolution instead of being redone
+ * by each of its cout / 64 channel blocks (csrc/conv_winograd43_ppv.hip).  Same u_lane, same arguments otherwise, the
+ * same bytes out as the pp form.
+ *   v_pre: pd3_winograd43_input_transform_floats(batch, cin, h, w) floats (16-byte aligned), [pixel tile][cin / 8][tile
+ *          row 2][ci 8][tile 16][36]; cin % 8 == 0 (0 floats / PD3_EUNSUPPORTED otherwise)
+ */
+size_t pd3_winograd43_input_transform_floats(int batch, int cin, int h, int w);
+int pd3_winograd43_input_transform(const float *x, int batch, int cin, int h, int w, int w_valid, float *v_pre,
+                                   void *stream);
+int pd3_conv3x3_winograd43_ppv_bias_relu(const float *v_pre, const float *u_lane, const float *bias, int batch, int cin,
+                                         int cout, int h, int w, int w_valid, int relu, float *out, void *stream);
 /* measurement hook: + cycle counters of one workgroup (blockIdx 8), dbg int64 [8 waves][4] (device): transform /
  * multiply / barrier-wait / kernel cycles (the last with the SIMD id in bits 56+; tools/prof/prof_wino_trace.py) */
 int pd3_conv3x3_winograd43_pp_trace(const float *x, const float *u_lane, const float *bias, int batch, int cin, int cout,

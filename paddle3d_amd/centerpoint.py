@@ -315,6 +315,11 @@ class _Conv3x3:
             # the ping-pong form: the same bytes as the packed form, 2-9 % faster on this model's layers
             if "w43pp" not in self.packed:
                 self.packed["w43pp"] = _conv.pack_winograd43_lane_weight(self.w)
+            if 0 < _conv.WINOGRAD43_PPV_MIN_BLOCKS <= self.cout // 64:
+                # enough channel blocks over this input to compute its Winograd transform once for all of them (round 6)
+                vpre = _conv.winograd43_input_transform(x, w_valid=wv)
+                return _conv.conv3x3_winograd43_ppv_bias_relu(vpre, x.shape, self.packed["w43pp"], self.b, self.cout,
+                                                              relu=True, w_valid=wv), wv
             return _conv.conv3x3_winograd43_pp_bias_relu(x, self.packed["w43pp"], self.b, self.cout, relu=True,
                                                          w_valid=wv), wv
         if self.stride == 1 and _conv.winograd43_supported(self.cin, self.cout, h, wv):
@@ -813,10 +818,18 @@ class CenterHead(_InferenceCache, nn.Module):
             wino = _conv.conv3x3_winograd43_pp_bias_relu if pp else _conv.conv3x3_winograd43_bias_relu
             z = torch.empty((n, groups * f["cmax"], h, w), dtype=torch.float32, device=x.device)
             buf = torch.empty((n * k * 64 * h * w,), dtype=torch.float32, device=x.device)
+            # round 6: all branches read the same 64-channel map, so its Winograd input transform is computed once for the
+            # 36 channel blocks instead of by every one of them (csrc/conv_winograd43_ppv.hip; the same bytes out)
+            vpre = (_conv.winograd43_input_transform(x)
+                    if pp and 0 < _conv.WINOGRAD43_PPV_MIN_BLOCKS <= groups else None)
             for c0 in range(0, groups, k):
                 c1 = min(c0 + k, groups)
                 y = buf[: n * (c1 - c0) * 64 * h * w].view(n, (c1 - c0) * 64, h, w)
-                wino(x, u[c0:c1], first.b[c0 * 64:c1 * 64], (c1 - c0) * 64, relu=True, out=y)
+                if vpre is not None:
+                    _conv.conv3x3_winograd43_ppv_bias_relu(vpre, x.shape, u[c0:c1], first.b[c0 * 64:c1 * 64],
+                                                           (c1 - c0) * 64, relu=True, out=y)
+                else:
+                    wino(x, u[c0:c1], first.b[c0 * 64:c1 * 64], (c1 - c0) * 64, relu=True, out=y)
                 _conv.grouped_conv3x3_small(y, f["pf"][c0:c1], f["bf"][c0 * f["cmax"]:c1 * f["cmax"]], c1 - c0, out=z,
                                             out_groups=groups, out_group0=c0)
         else:

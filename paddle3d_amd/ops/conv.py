@@ -13,6 +13,7 @@ __all__ = ["pack_conv3x3_weight", "conv3x3_bias_relu", "supported", "pitch4", "p
            "patch_mode", "patch_supported", "pack_patch_weight", "patch_conv_bias_relu",
            "patch_x3_supported", "pack_patch_weight_x3", "patch_conv_x3_bias_relu", "split_bf16x3",
            "conv3x3_s2_x3_supported", "pack_conv3x3_s2_x3_weight", "conv3x3_s2_x3_bias_relu",
+           "winograd43_input_transform", "conv3x3_winograd43_ppv_bias_relu",
            "winograd43_supported", "winograd43_tile", "pack_winograd43_weight", "conv3x3_winograd43_bias_relu",
            "WINOGRAD43_PP_MIN_CIN", "winograd43_pp_supported", "pack_winograd43_lane_weight", "conv3x3_winograd43_pp_bias_relu",
            "f16_supported", "f16_tile", "pack_conv3x3_f16_weight", "conv3x3_f16_bias_relu", "to_f16_nhwc",
@@ -326,6 +327,43 @@ def conv3x3_s2_x3_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout:
     out = torch.empty((n, cout, h // 2, w // 2), dtype=torch.float32, device=xx.device)
     check(lib().pd3_conv3x3_s2_x3_bias_relu(ptr(xx), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
                                             ptr(out), stream_ptr(xx.device)), "conv3x3_s2_x3_bias_relu")
+    return out
+
+
+# A Winograd layer with at least this many 64-channel output blocks over one input runs with its input transform computed
+# once (csrc/conv_winograd43_ppv.hip).  Measured at 16 frames (tools/prof/prof_head_ppv.py): the pass writes 2.25 x the
+# input (151 MB in 43-49 us for 64 x 128^2 or 256 x 64^2 planes) and the convolution loses 23-29 % of its time: 2 blocks
+# (128 -> 128: 244 -> 114 + 194 us) do not pay for it, 4 do (256 -> 256: 248 -> 49 + 176), the head's 18 per slice do
+# four times over (1210 -> 931 per slice, one pass for both).  0 = never.
+WINOGRAD43_PPV_MIN_BLOCKS = 4
+
+
+def winograd43_input_transform(x: torch.Tensor, w_valid: int | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """V = B^T d B of every (image, 4 x 4 tile, input channel) of x [n, cin, h, pitch], in the ping-pong kernel's LDS order."""
+    xx = require_gpu(x, "winograd43_input_transform")
+    n, cin, h, w = xx.shape
+    floats = int(lib().pd3_winograd43_input_transform_floats(n, cin, h, w))
+    if floats == 0:
+        raise RuntimeError("winograd43_input_transform: cin must be a multiple of 8")
+    if out is None or out.numel() < floats:
+        out = torch.empty((floats,), dtype=torch.float32, device=xx.device)
+    check(lib().pd3_winograd43_input_transform(ptr(xx), n, cin, h, w, w if w_valid is None else int(w_valid), ptr(out),
+                                               stream_ptr(xx.device)), "winograd43_input_transform")
+    return out
+
+
+def conv3x3_winograd43_ppv_bias_relu(v_pre: torch.Tensor, shape, u_lane: torch.Tensor, bias, cout: int, relu: bool = True,
+                                     out: torch.Tensor | None = None, w_valid: int | None = None) -> torch.Tensor:
+    """conv3x3_winograd43_pp_bias_relu on the pre-transformed input v_pre = winograd43_input_transform(x), shape = x.shape."""
+    n, cin, h, w = (int(v) for v in shape)
+    ul = require_gpu(u_lane, "conv3x3_winograd43_ppv_bias_relu")
+    if ul.numel() != cout * cin * 36:
+        raise RuntimeError("conv3x3_winograd43_ppv_bias_relu: u_lane does not belong to a [cout, cin, 3, 3] weight")
+    if out is None:
+        out = torch.empty((n, cout, h, w), dtype=torch.float32, device=v_pre.device)
+    check(lib().pd3_conv3x3_winograd43_ppv_bias_relu(ptr(v_pre), ptr(ul), ptr(bias), n, cin, cout, h, w,
+                                                     w if w_valid is None else int(w_valid), int(bool(relu)), ptr(out),
+                                                     stream_ptr(v_pre.device)), "conv3x3_winograd43_ppv_bias_relu")
     return out
 
 

@@ -555,6 +555,37 @@ def test_winograd43_pingpong_form(n, cin, cout, h, w, relu):
     assert torch.equal(got, packed)  # the same U, the same order of accumulation: the same bytes
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,wv", [(2, 64, 192, 32, 128, 128), (1, 8, 64, 8, 64, 64), (3, 16, 128, 10, 36, 34),
+                                               (1, 64, 576, 45, 180, 180), (2, 128, 64, 16, 64, 64)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv3x3_winograd43_with_the_input_transformed_once(n, cin, cout, h, w, wv, relu):
+    """The ping-pong Winograd kernel fed with V = B^T d B computed once by a pre-pass (the head's 36 channel blocks share
+    their input): the same bytes as the kernel that transforms for itself -- the same w4_in sequence, the same MFMA order --
+    on whole and partial tiles, padded rows (w_valid < pitch) and image borders."""
+    from paddle3d_amd.ops import conv
+
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    x[..., wv:] = 0
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ul = conv.pack_winograd43_lane_weight(wt.cuda())
+    want = conv.conv3x3_winograd43_pp_bias_relu(x.cuda(), ul, b.cuda(), cout, relu, w_valid=wv)
+    v = conv.winograd43_input_transform(x.cuda(), w_valid=wv)
+    tiles = n * -(-h // 8) * -(-w // 64)
+    assert v.numel() == tiles * (cin // 8) * 2 * 8 * 16 * 36
+    got = conv.conv3x3_winograd43_ppv_bias_relu(v, x.shape, ul, b.cuda(), cout, relu, w_valid=wv)
+    assert torch.equal(got, want)
+    ref = F.conv2d(x[..., :wv].double(), wt.double(), b.double(), padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    assert (got[..., :wv].cpu().double() - ref).abs().max().item() < 1e-3
+    # a slice of the channel blocks (the head's two slices): blocks [1, 2) alone
+    if cout >= 128:
+        part = conv.conv3x3_winograd43_ppv_bias_relu(v, x.shape, ul[1:2], b.cuda()[64:128], 64, relu, w_valid=wv)
+        assert torch.equal(part, want[:, 64:128])
+
+
 @pytest.mark.parametrize("groups,co,h,w", [(6, 3, 32, 64), (4, 1, 20, 45), (36, 3, 16, 32), (2, 4, 9, 33), (3, 2, 128, 128)])
 def test_grouped_conv3x3_small_f16_matches_fp32_math_on_fp16_operands(groups, co, h, w):
     """The AMP form of the final SeparateHead convolutions (fp16 NHWC in, fp32 NCHW out, v_dot2_f32_f16 with fp32
