@@ -332,10 +332,11 @@ def conv3x3_s2_x3_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout:
 
 # A Winograd layer with at least this many 64-channel output blocks over one input runs with its input transform computed
 # once (csrc/conv_winograd43_ppv.hip).  Measured at 16 frames (tools/prof/prof_head_ppv.py): the pass writes 2.25 x the
-# input (151 MB in 43-49 us for 64 x 128^2 or 256 x 64^2 planes) and the convolution loses 23-29 % of its time: 2 blocks
-# (128 -> 128: 244 -> 114 + 194 us) do not pay for it, 4 do (256 -> 256: 248 -> 49 + 176), the head's 18 per slice do
-# four times over (1210 -> 931 per slice, one pass for both).  0 = never.
-WINOGRAD43_PPV_MIN_BLOCKS = 4
+# input (151 MB in 43-52 us for 64 x 128^2 or 256 x 64^2 planes) and the convolution loses 19-29 % of its time: 2 blocks
+# (128 -> 128: 244 -> 114 + 194 us) do not pay for it; 4 (256 -> 256) do alone, with the input cold (248 -> 49 + 176), but
+# not inside the model's step, where the layer's input is still in the caches (213 -> 52 + 173: profiles/
+# r06_b16_launches.txt); the head's 18 per slice do four times over (1140 -> 910 per slice, one pass for both).  0 = never.
+WINOGRAD43_PPV_MIN_BLOCKS = 8
 
 
 def winograd43_input_transform(x: torch.Tensor, w_valid: int | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
