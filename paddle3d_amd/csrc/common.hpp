@@ -3,6 +3,8 @@
 // Build flags that matter for parity (see paddle3d_amd/build.py): -ffp-contract=off (the reference CPU
 // path is plain IEEE fp32 without FMA contraction) and hipcc's default correctly-rounded fp32 divide.
 #pragma once
+#include <mutex>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -19,6 +21,34 @@ constexpr int kWave = 64;  // CDNA wavefront
 static inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize for kernel `fn`, raised when `bytes` exceeds what this process has already
+// asked for on the current device -- NOT set again at every launch.  Round 6: with a captured HIP graph alive, calling
+// hipFuncSetAttribute for one of its kernels again (the eager form of the same operator, a few dozen times) made the
+// graph's later replays compute with wrong launch state (detections lost, then memory faults; tools/prof/
+// graph_replay_check.py reproduces it with the per-launch calls) -- and a call per launch is host time for nothing.
+static inline hipError_t pd3_max_dynamic_lds(const void* fn, int bytes) {
+  struct Entry {
+    const void* fn;
+    int dev, bytes;
+  };
+  static std::mutex mu;
+  static std::vector<Entry> seen;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  for (Entry& x : seen)
+    if (x.fn == fn && x.dev == dev) {
+      if (bytes <= x.bytes) return hipSuccess;
+      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e == hipSuccess) x.bytes = bytes;
+      return e;
+    }
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) seen.push_back({fn, dev, bytes});
+  return e;
 }
 
 __host__ __device__ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

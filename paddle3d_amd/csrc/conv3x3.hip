@@ -251,8 +251,7 @@ static int launch_conv3x3(int64_t tiles, hipStream_t s, const float* x, const fl
                           const int* imap = nullptr) {
   constexpr size_t lds = (size_t)(XB * kCvCi * ((R - 1) * S + 3) * (S * WT + 8) + 2 * kCvK * kCvCo) * sizeof(float);
   // raise the dynamic-LDS cap (per device and per instantiation: set on every launch, it is a host-side table write)
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_mfma_kernel<R, WT, S, XB, FUSED>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3_mfma_kernel<R, WT, S, XB, FUSED>), (int)lds);
   if (e != hipSuccess) return (int)e;
   const int64_t nwg = (tiles + 7) / 8 * 8 * (cout / kCvCo);
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;

@@ -762,8 +762,7 @@ template <int CO, bool GM>
 static int launch_grouped_pp(const _Float16* x, const _Float16* wg, const float* bias, int batch, int groups, int h, int w,
                              float* out, int out_groups, int out_group0, hipStream_t s) {
   constexpr int LDS = 3 * 10 * 40 * 128;
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_conv3x3_small_f16_pp_kernel<CO, GM>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  const hipError_t e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(grouped_conv3x3_small_f16_pp_kernel<CO, GM>), LDS);
   if (e != hipSuccess) return (int)e;
   const int64_t tiles = ceil_div(w, 32) * ceil_div(h, 8), total = tiles * groups * batch;
   if (total >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
@@ -807,8 +806,7 @@ template <int MB, int OUT_MODE>
 static int launch_conv_f16(const void* x, const void* wp, const float* bias, int batch, int cin, int cout, int h, int w,
                            int relu, void* out, hipStream_t s, float* out2 = nullptr) {
   using S = CfShape<MB>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16_kernel<MB, OUT_MODE>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS);
+  hipError_t e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3_f16_kernel<MB, OUT_MODE>), (int)S::LDS);
   if (e != hipSuccess) return (int)e;
   const int64_t ptiles = (int64_t)batch * ceil_div(h, S::R) * ceil_div(w, kCfCols);
   const int nct = cout / S::M;
@@ -872,8 +870,7 @@ static int launch_conv_s2_f16(const void* x, const int32_t* inv, const void* wp,
                               int cout, int h, int w, int relu, void* out, hipStream_t s) {
   using S = Cs2Shape<MW>;
   const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_s2_f16_kernel<MW, GATHER>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS);
+  hipError_t e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3_s2_f16_kernel<MW, GATHER>), (int)S::LDS);
   if (e != hipSuccess) return (int)e;
   const int64_t ptiles = (int64_t)batch * ceil_div(ho, kCs2R) * ceil_div(wo, kCfCols);
   const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / S::M);

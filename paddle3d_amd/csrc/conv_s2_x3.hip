@@ -272,8 +272,7 @@ extern "C" int pd3_conv3x3_s2_x3_bias_relu(const float* x, const void* w_packed,
   a.nslots = (int)nslots;
   a.ipw = px_items_per_workgroup(nslots);
   const size_t lds = kS2Lds + (size_t)cout * sizeof(float);
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_s2_x3_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kS2Lds + 4096));
+  const hipError_t e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3_s2_x3_kernel), (int)(kS2Lds + 4096));
   if (e != hipSuccess) return (int)e;
   const int64_t nwg = 8 * ceil_div(nslots, a.ipw);
   conv3x3_s2_x3_kernel<<<(unsigned)nwg, kS2Threads, lds, static_cast<hipStream_t>(stream)>>>(a);

@@ -260,8 +260,7 @@ extern "C" int pd3_conv3x3_winograd_bias_relu(const float* x, const float* u_pac
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
   dim3 grid((unsigned)nwg);
   {  // dynamic-LDS cap: per device, so it is set on every launch (a host-side table write)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_winograd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgLds);
+    hipError_t e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3_winograd_kernel), (int)kWgLds);
     if (e != hipSuccess) return (int)e;
   }
   conv3x3_winograd_kernel<<<grid, 256, kWgLds, static_cast<hipStream_t>(stream)>>>(x, u_packed, bias, out, cin,

@@ -297,8 +297,7 @@ static int launch_wino43(const float* x, const float* u_packed, const float* bia
                          int h, int w, int wv, int relu, float* out, hipStream_t s) {
   constexpr size_t lds = (size_t)((CB == 4 ? 2 : 1) * (CB * kW4Ci * 16 * kW4Cs + kW4Vsz) + kW4RawSz) * sizeof(float);
   {  // dynamic-LDS cap: per device, so it is set on every launch (a host-side table write)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_winograd43_kernel<CB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(conv3x3_winograd43_kernel<CB>), (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   const int64_t ptiles = (int64_t)batch * ceil_div(h, 4 * kW4TR) * ceil_div(w, 4 * kW4TC);

@@ -356,7 +356,7 @@ static int launch_wino43_pp(const float* x, const float* u_lane, const float* bi
                             int w, int w_valid, int relu, float* out, hipStream_t s, long long* dbg = nullptr) {
   constexpr size_t lds = ((size_t)kPpUsz + 2 * (kPpRawSz + kPpVsz)) * sizeof(float);  // 138,240 B
   const void* fn = reinterpret_cast<const void*>(conv3x3_winograd43_pp_kernel);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = pd3_max_dynamic_lds(fn, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int64_t ptiles = (int64_t)batch * ceil_div(h, 4 * kW4TR) * ceil_div(w, 4 * kW4TC);
   const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / 64);

@@ -290,7 +290,7 @@ extern "C" int pd3_conv3x3_winograd43_ppv_bias_relu(const float* v_pre, const fl
     return PD3_EUNSUPPORTED;  // 32-bit byte offsets inside a channel tile's U and a pixel tile's V
   constexpr size_t lds = ((size_t)kPvUsz + 4 * kPvVsz) * sizeof(float);  // 147 456 B
   const void* fn = reinterpret_cast<const void*>(conv3x3_winograd43_ppv_kernel);
-  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const hipError_t e = pd3_max_dynamic_lds(fn, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int64_t ptiles = (int64_t)batch * ceil_div(h, 4 * kW4TR) * ceil_div(w, 4 * kW4TC);
   const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / 64);

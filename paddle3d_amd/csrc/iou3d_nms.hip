@@ -49,8 +49,7 @@ static int run_nms(const float* boxes, int n, float thresh, int32_t* keep, int32
   {
     const size_t lds = nms_sweep_lds(n);
     if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(nms_sweep_kernel), (int)lds);
       if (e != hipSuccess) return (int)e;
     }
     nms_sweep_kernel<<<1, kNmsSweepThreads, lds, s>>>(mask, nullptr, n, n, cb, keep, num_to_keep);

@@ -993,8 +993,7 @@ static int pfn_dispatch(const float* voxels, const int32_t* num_points, const in
     constexpr size_t lds_ = ((size_t)4 * (LINEV + MAXPV * (C1V + 2) + C1V + 64 + 4 * 64) +                     \
                              (C1V == 32 ? C1V * 64 : 0)) * sizeof(float);                                      \
     if (lds_ > 48 * 1024) {                                                                                    \
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(pfn_two_mfma_kernel<DD, CDV, C1V, MAXPV, LINEV>), \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);              \
+      hipError_t e_ = pd3_max_dynamic_lds(reinterpret_cast<const void*>(pfn_two_mfma_kernel<DD, CDV, C1V, MAXPV, LINEV>), (int)lds_);              \
       if (e_ != hipSuccess) return (int)e_;                                                                    \
     }                                                                                                          \
     pfn_two_mfma_kernel<DD, CDV, C1V, MAXPV, LINEV><<<blocks, 256, lds_, s>>>(a);                              \
@@ -1017,8 +1016,7 @@ static int pfn_dispatch(const float* voxels, const int32_t* num_points, const in
     const size_t lds = ((size_t)4 * (kNv * 64 + 16 * 68 + 16 * 68 + kPc * 8 + rcap + 16 +
                                      (max_points * num_point_dim >= kC1 + 64 ? 0 : kPc * (kC1 + 64)))) * sizeof(float);
     if (lds > 48 * 1024) {
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(pfn_packed_kernel<4, 3, kNv, kC1, kPc, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e_ = pd3_max_dynamic_lds(reinterpret_cast<const void*>(pfn_packed_kernel<4, 3, kNv, kC1, kPc, true>), (int)lds);
       if (e_ != hipSuccess) return (int)e_;
     }
     pfn_packed_kernel<4, 3, kNv, kC1, kPc, true><<<blocks, 256, lds, s>>>(a);
@@ -1034,8 +1032,7 @@ static int pfn_dispatch(const float* voxels, const int32_t* num_points, const in
 #define PD3_PFN_PACKED(DD, CDV, NVV)                                                                               \
   do {                                                                                                            \
     if (lds > 48 * 1024) {                                                                                        \
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(pfn_packed_kernel<DD, CDV, NVV>),         \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+      hipError_t e_ = pd3_max_dynamic_lds(reinterpret_cast<const void*>(pfn_packed_kernel<DD, CDV, NVV>), (int)lds);                  \
       if (e_ != hipSuccess) return (int)e_;                                                                       \
     }                                                                                                             \
     pfn_packed_kernel<DD, CDV, NVV><<<blocks, 256, lds, s>>>(a);                                                  \
@@ -1077,8 +1074,7 @@ static int pfn_dispatch(const float* voxels, const int32_t* num_points, const in
   const size_t bytes = (w_floats + waves * wave_floats) * sizeof(float);
   if (bytes > 160 * 1024) return PD3_EUNSUPPORTED;
   if (bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pfn_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipError_t e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(pfn_kernel), (int)bytes);
     if (e != hipSuccess) return (int)e;
   }
   const int64_t blocks = std::min<int64_t>(ceil_div(num_pillars, waves), 256 * 8);
@@ -1149,9 +1145,7 @@ extern "C" int pd3_pillar_feature_net_indexed(const float* points, int64_t point
 #define PD3_PFN_INDEXED_N(DD, CDV, NVV, NS)                                                                           \
   do {                                                                                                               \
     if (lds > 48 * 1024) {                                                                                           \
-      hipError_t e_ = hipFuncSetAttribute(                                                                           \
-          reinterpret_cast<const void*>(pfn_packed_kernel<DD, CDV, NVV, 32, kPkPillars, false, true, NS>),           \
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                                     \
+      hipError_t e_ = pd3_max_dynamic_lds(reinterpret_cast<const void*>(pfn_packed_kernel<DD, CDV, NVV, 32, kPkPillars, false, true, NS>), (int)lds);                                                     \
       if (e_ != hipSuccess) return (int)e_;                                                                          \
     }                                                                                                                \
     pfn_packed_kernel<DD, CDV, NVV, 32, kPkPillars, false, true, NS><<<blocks, 256, lds, s>>>(a);                    \

@@ -464,8 +464,7 @@ static int cp_postprocess_impl(
   if (selection < 0 || selection > 1) return PD3_EINVAL;
   if (hw <= kTopkMaxHw && hw % 4 == 0 && cap <= kTopkMaxK && selection == 0) {
     const size_t lds = cp_topk_lds(hw);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(cp_topk_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cp_topk_lds(kTopkMaxHw));
+    e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(cp_topk_kernel), (int)cp_topk_lds(kTopkMaxHw));
     if (e != hipSuccess) return (int)e;
     cp_topk_kernel<<<sets, kTopkThreads, lds, s>>>(w.keys_a, w.counts, hw, cap, w.vals_a);
     sidx = w.vals_a;
@@ -481,8 +480,7 @@ static int cp_postprocess_impl(
   {
     const size_t lds = nms_sweep_lds(cap);
     if (lds > 48 * 1024) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(nms_sweep_kernel), (int)lds);
       if (e != hipSuccess) return (int)e;
     }
     nms_sweep_kernel<<<sets, kNmsSweepThreads, lds, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);

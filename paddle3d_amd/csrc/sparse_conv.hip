@@ -1289,8 +1289,7 @@ extern "C" int pd3_sparse_conv3d_features_ordered(const float* in_feats, const i
 #define PD3_SP_ROWS(NBV, TV)                                                                      \
   do {                                                                                            \
     if (lds > 48 * 1024) {                                                                        \
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gemm_rows_kernel<NBV, TV>),        \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+      e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(sp_gemm_rows_kernel<NBV, TV>), (int)lds);              \
       if (e != hipSuccess) return (int)e;                                                         \
     }                                                                                             \
     sp_gemm_rows_kernel<NBV, TV><<<grid, 256, lds, s>>>(a);                                       \
@@ -1320,8 +1319,7 @@ extern "C" int pd3_sparse_conv3d_features_ordered(const float* in_feats, const i
 #define PD3_SP_MFMA(NBV)                                                                          \
   do {                                                                                            \
     if (lds > 48 * 1024) {                                                                        \
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gemm_mfma_kernel<NBV>),            \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+      e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(sp_gemm_mfma_kernel<NBV>), (int)lds);              \
       if (e != hipSuccess) return (int)e;                                                         \
     }                                                                                             \
     sp_gemm_mfma_kernel<NBV><<<grid, 256, lds, s>>>(a, cin_pad, astride, wstride);               \
@@ -1343,15 +1341,13 @@ valu_path:
     const unsigned grid = (unsigned)ceil_div(n_out_cap, kSpRows);
     if (cout <= 64) {
       if (lds > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gather_gemm_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(sp_gather_gemm_kernel<1>), (int)lds);
         if (e != hipSuccess) return (int)e;
       }
       sp_gather_gemm_kernel<1><<<grid, 256, lds, s>>>(a);
     } else {
       if (lds > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gather_gemm_kernel<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(sp_gather_gemm_kernel<2>), (int)lds);
         if (e != hipSuccess) return (int)e;
       }
       sp_gather_gemm_kernel<2><<<grid, 256, lds, s>>>(a);
@@ -1372,8 +1368,7 @@ extern "C" int pd3_sparse_tile_order(const int32_t* nbr, const int32_t* n_out, i
   const size_t lds = (size_t)2 * kSpWindow * sizeof(uint32_t);
   // raised on every launch like every other large-LDS kernel of the library (a host-side table write): a process-wide
   // flag would be unsynchronised and, if the attribute is kept per device, wrong for a second GPU in the process
-  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_tile_order_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const hipError_t e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(sp_tile_order_kernel), (int)lds);
   if (e != hipSuccess) return (int)e;
   sp_tile_order_kernel<<<(unsigned)ceil_div(n_out_cap, kSpWindow), kSpOrderThreads, lds, s>>>(
       nbr, n_out, n_out_cap, kernel_volume, order);

@@ -331,8 +331,7 @@ extern "C" int pd3_gather_gemm_f16(const void* in_feats_f16, const int32_t* nbr,
 #define PD3_SF(NCV, KCV)                                                                           \
   do {                                                                                             \
     if (lds > 48 * 1024) {                                                                         \
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gemm_rows_f16_kernel<NCV, KCV>),    \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+      e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(sp_gemm_rows_f16_kernel<NCV, KCV>), (int)lds);               \
       if (e != hipSuccess) return (int)e;                                                          \
     }                                                                                              \
     sp_gemm_rows_f16_kernel<NCV, KCV><<<grid, 256, lds, s>>>(a);                                   \

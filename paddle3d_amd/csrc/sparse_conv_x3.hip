@@ -408,8 +408,7 @@ extern "C" int pd3_sparse_conv3d_features_bf16x3(const float* in_feats, const in
 #define PD3_SX(NCV, KCV, RBV)                                                                        \
   do {                                                                                               \
     if (lds > 48 * 1024) {                                                                           \
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_gemm_rows_x3_kernel<NCV, KCV, RBV>),  \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+      e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(sp_gemm_rows_x3_kernel<NCV, KCV, RBV>), (int)lds);                 \
       if (e != hipSuccess) return (int)e;                                                            \
     }                                                                                                \
     sp_gemm_rows_x3_kernel<NCV, KCV, RBV><<<grid, 64 * (8 / RBV), lds, s>>>(a);                      \

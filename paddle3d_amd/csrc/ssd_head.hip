@@ -513,8 +513,7 @@ extern "C" int pd3_ssd_postprocess(const float* head_map, int64_t batch_stride, 
   nms_enqueue_mask_pooled(w.pre, w.counts, batch, cap, cb, nms_iou_threshold, w.mask, w.pool, s);
   const size_t lds = nms_sweep_lds(cap);
   if (lds > 48 * 1024) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(nms_sweep_kernel), (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   nms_sweep_kernel<<<batch, kNmsSweepThreads, lds, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);

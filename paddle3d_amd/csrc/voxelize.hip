@@ -435,8 +435,7 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
   // raised per instantiation like every other large-LDS kernel of the library (a host-side table write per launch)
 #define PD3_VW_ROUTE(T, R)                                                                                         \
   do {                                                                                                             \
-    const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(vw_route_kernel<T, R>),                \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);             \
+    const hipError_t e_ = pd3_max_dynamic_lds(reinterpret_cast<const void*>(vw_route_kernel<T, R>), (int)lds_a);             \
     if (e_ != hipSuccess) return (int)e_;                                                                          \
     vw_route_kernel<T, R><<<tile_grid, T, lds_a, s>>>(points, num_points, n, dim, vg, plan.low, plan.gbits,        \
                                                       plan.tiles, batch, max_voxels, w.recs, w.dir, w.vinfo,       \
@@ -447,8 +446,7 @@ static int run_wave(const float* points, const int32_t* num_points, int batch, i
     if (plan.threads != 512 || plan.rounds != 8 || lds_a > 160 * 1024 ||
         (int64_t)batch * plan.tiles * plan.tile * dim > (int64_t)batch * max_voxels * max_pts * dim)
       return PD3_EUNSUPPORTED;
-    const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(vw_route_kernel<512, 8, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+    const hipError_t e_ = pd3_max_dynamic_lds(reinterpret_cast<const void*>(vw_route_kernel<512, 8, true>), (int)lds_a);
     if (e_ != hipSuccess) return (int)e_;
     vw_route_kernel<512, 8, true><<<tile_grid, 512, lds_a, s>>>(points, num_points, n, dim, vg, plan.low, plan.gbits,
                                                                 plan.tiles, batch, max_voxels, w.recs, w.dir, w.vinfo,
