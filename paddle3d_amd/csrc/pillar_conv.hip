@@ -60,10 +60,11 @@ struct EpiPillarRows {
 // 9-bit mask: a counting sort over 512 bins in LDS instead of the general 31-bit bitonic network (76 us for this rulebook:
 // 52 occupied windows = 52 workgroups of latency; this: one pass).  Within a bin the rows arrive in atomic order: which
 // rows share a tile never changes a row's result.
-// (kSpWindow = 8192 rows is the window of sp_window_tile in the gather-GEMMs; any permutation INSIDE such a window is a valid
-// order, so the rows are grouped per 2048: four times the workgroups -- the 52 occupied windows of a 16-frame batch were 52
-// workgroups of latency -- for nearly the same grouping)
-constexpr int kPcWindow = 2048, kPcThreads = 256;
+// (kSpWindow = 8192 rows is the window of sp_window_tile in the gather-GEMMs.  Round 6 first grouped per 2048 rows with 256
+// threads; grouping the whole window -- 1024 threads, still eight rows per thread -- makes a tile execute 4.9 taps instead
+// of 6.8 and the feature kernel 13 % faster (190 -> 165 us per 16 frames) for 21 us more here (28 -> 49: 8192 LDS atomics
+// on 512 bins per workgroup): tools/prof/prof_sparse_first_layer.py, profiles/r06_b16_launches.txt)
+constexpr int kPcWindow = 8192, kPcThreads = 1024;
 __global__ __launch_bounds__(kPcThreads) void pc_rulebook_order_kernel(const int* __restrict__ inv, PcGrid g,
                                                                  const int32_t* __restrict__ out_cell,
                                                                  const int* __restrict__ n_out_dev, int cap,
@@ -106,12 +107,11 @@ __global__ __launch_bounds__(kPcThreads) void pc_rulebook_order_kernel(const int
   }
   if (!order) return;
   __syncthreads();
-  int total;  // thread t owns bins 2 t, 2 t + 1
-  const int h0 = hist[2 * t], h1 = hist[2 * t + 1];
-  const int base = block_exclusive_scan<kPcThreads>(h0 + h1, scr, total);
+  int total;  // thread t < 512 owns bin t
+  const int h0 = t < 512 ? hist[t] : 0;
+  const int base = block_exclusive_scan<kPcThreads>(h0, scr, total);
   __syncthreads();
-  hist[2 * t] = base;  // the bins' cursors
-  hist[2 * t + 1] = base + h0;
+  if (t < 512) hist[t] = base;  // the bins' cursors
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < kPcWindow / kPcThreads; ++r)
@@ -214,7 +214,7 @@ extern "C" int pd3_pillar_conv_rulebook(const int32_t* inverse_map, int batch, i
   EpiPillarRows epi{out_cell, cell_row, capacity};
   enqueue_exclusive_scan(flags, cells, cells, 1, partial, n_out, (int*)nullptr, LoadIdentity{}, epi, s);
   // nbr, and (optional) order [ceil(capacity / 8192) * 8192] int32: slot -> row or -1, the `order` argument of the gather-GEMMs
-  static_assert(kPcThreads * 2 == 512 && 8192 % kPcWindow == 0, "two bins per thread; whole sub-windows per window");
+  static_assert(kPcThreads >= 512 && 8192 % kPcWindow == 0, "a thread per bin; whole sub-windows per window");
   pc_rulebook_order_kernel<<<(unsigned)(ceil_div(capacity, 8192) * (8192 / kPcWindow)), kPcThreads, 0, s>>>(inverse_map, g, out_cell, n_out,
                                                                                      capacity, nbr, order);
   return launch_status();

@@ -473,9 +473,9 @@ def test_scatter_conv_as_sparse_convolution(ny, nx, batch, occ, cout):
     # the tile order: every window a permutation of its rows (then -1), grouped by tap mask in ascending order
     od = order.cpu().numpy()
     masks = ((want_nbr[act] >= 0) * (1 << np.arange(9))).sum(1)
-    for w0 in range(0, len(od), 2048):   # (grouped per 2048 rows: any permutation inside a window of 8192 is valid)
-        nv = min(max(n - w0, 0), 2048)
-        win = od[w0:w0 + 2048]
+    for w0 in range(0, len(od), 8192):   # (grouped per window of 8192 rows)
+        nv = min(max(n - w0, 0), 8192)
+        win = od[w0:w0 + 8192]
         assert (win[nv:] == -1).all()
         np.testing.assert_array_equal(np.sort(win[:nv]), np.arange(w0, w0 + nv))
         assert (np.diff(masks[win[:nv]]) >= 0).all()
