@@ -599,8 +599,10 @@ __global__ __launch_bounds__(256) void grouped_conv3x3_small_f16_kernel(
 // The same convolution, persistent and fed by LDS-DMA (round 6).  The form above stages a tile through registers behind a
 // barrier and holds 144 registers of weights: two workgroups per CU, staging and MFMAs of a workgroup one after the other
 // -- 0.48 ms per 16 frames for 1.2 GB of input (2.5 TB/s) with the matrix pipe idle three quarters of the time.  Here a
-// workgroup keeps its group's weights and walks kGpTiles consecutive tiles of ONE (group, frame); the next tile's patch
-// travels by buffer_load_dwordx4 ... lds into the other buffer while the MFMAs of this one run.  A pixel's 128-byte line
+// workgroup walks a run of consecutive (frame, group, tile) items -- every CU the same number, at least kGpTiles -- with
+// the group's weights in registers (reloaded where the run crosses into the next group); a FIFTH wave does nothing but
+// fetch: the next-but-one tile's patch travels by buffer_load_dwordx4 ... lds into one of three buffers while the four
+// multiplying waves run the MFMAs of this one (see the fetch wave below for why a wave of its own).  A pixel's 128-byte line
 // is fetched whole by 8 lanes, but lane l takes 16-byte piece (l & 7) ^ (l >> 3) of it: the LDS image is XOR-swizzled by
 // the fetch itself (piece p of patch pixel P sits in slot p ^ (P & 7)), so the B operand's ds_read_b128 over 32 consecutive
 // pixels is conflict-free without padded lines -- which a fetch into LDS could not write.  Patch rows are 40 pixels apart

@@ -311,7 +311,6 @@ __global__ __launch_bounds__(kPxThreads, 1) void patch_gemm_x3_kernel(PxArgs a) 
 template <int MODE>
 static int launch_px(const PxArgs& a, hipStream_t s) {
   const size_t lds = kPxLds + (size_t)a.bias_n * sizeof(float);
-  // (every launch: the attribute belongs to the current device's copy of the kernel)
   const hipError_t e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(patch_gemm_x3_kernel<MODE>), (int)(kPxLds + 4096));
   if (e != hipSuccess) return (int)e;
   const int64_t nwg = 8 * ceil_div(a.nslots, a.ipw);
