@@ -248,6 +248,8 @@ __global__ __launch_bounds__(kPxThreads, 1) void patch_gemm_x3_kernel(PxArgs a) 
   // behind its 12 fetches (vmcnt(12); or, when step t - 1 ended an item, behind NST stores too: capped at 63); after its
   // MFMAs, A t + 1 with only the 4 row fetches younger (vmcnt(4)).  The older half sent rows t + 1 in the middle of step
   // t - 1, younger than them are only that step's stores (vmcnt(NST) or 0).
+  // (Tried and dropped: the older half sending the A pieces behind its MFMAs, where it waits 1500-1900 cycles at the
+  // barrier anyway -- 109 -> 124 us for the k2 s2 level: the pieces then arrive late for the barrier.)
   const bool cut_first = wave >= 4;
   bool after_epi = false;
   auto step = [&](unsigned char* near, unsigned char* far, px_b8 (&bcur)[S][3], px_b8 (&bnext)[S][3]) {
