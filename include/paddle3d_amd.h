@@ -713,15 +713,16 @@ int pd3_patch_conv_x3_bias_relu(const float *x, const void *w_packed, const floa
  * conv3x3_s2_x3_bias_relu -- the stride-2 3x3 / pad 1 convolution + bias + ReLU that opens a SECOND block
  * (second_backbone.py:72-120) in fp32 arithmetic on the bf16 matrix cores (three bf16 pieces per operand, six products,
  * fp32 accumulation: csrc/conv_s2_x3.hip; same tensors as conv3x3_bias_relu with stride 2).
- *   x [batch, cin, h, w] fp32 NCHW (16-byte aligned) -> out [batch, cout, h/2, w/2]
+ *   x [batch, cin, h, w] fp32 NCHW (16-byte aligned; w = row pitch, w_valid <= w the real width, pad columns zero: the
+ *   convention of conv3x3_bias_relu) -> out [batch, cout, h/2, out_w], w_valid/2 real columns, the rest of the pitch zero
  *   w_packed: bf16 [cout/128][step = (16-channel chunk, ky)][24576]: a step's A pieces as the LDS image the kernel fetches,
  *             [piece 3][row 128][56] (k = kx * 16 + channel: 48 values, 8 of padding) + 3072 of padding
  *             (paddle3d_amd/ops/conv.py:pack_conv3x3_s2_x3_weight)
- *   needs cin % 16 == 0, cout % 128 == 0 (<= 1024), h % 2 == 0, w % 64 == 0, every tensor below 2 GB;
+ *   needs cin % 16 == 0, cout % 128 == 0 (<= 1024), h % 2 == 0, w_valid % 2 == 0, w % 4 == 0, every tensor below 2 GB;
  *   PD3_EUNSUPPORTED otherwise (the caller runs conv3x3_bias_relu)
  */
 int pd3_conv3x3_s2_x3_bias_relu(const float *x, const void *w_packed, const float *bias, int batch, int cin, int cout,
-                                int h, int w, int relu, float *out, void *stream);
+                                int h, int w, int w_valid, int relu, float *out, int out_w, void *stream);
 
 /*
  * ssd_postprocess -- SSDHead.post_process of PointPillars for a whole batch (paddle3d/models/detection/

@@ -165,7 +165,7 @@ _SIGNATURES = {
                                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                               C.c_void_p]),
     "pd3_conv3x3_s2_x3_bias_relu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                              C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+                                              C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pd3_winograd43_input_transform_floats": (C.c_size_t, [C.c_int] * 4),
     "pd3_winograd43_input_transform": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                  C.c_void_p]),

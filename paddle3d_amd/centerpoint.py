@@ -327,12 +327,13 @@ class _Conv3x3:
                 self.packed["w43"] = _conv.pack_winograd43_weight(self.w)
             return _conv.conv3x3_winograd43_bias_relu(x, self.packed["w43"], self.b, self.cout, relu=True,
                                                       w_valid=wv), wv
-        if (self.stride == 2 and _conv.S2_BF16X3 and wv == int(x.shape[3])
+        if (self.stride == 2 and _conv.S2_BF16X3 and int(x.shape[3]) % 4 == 0
                 and _conv.conv3x3_s2_x3_supported(self.cin, self.cout, h, wv, int(x.shape[0]))):
             # fp32 arithmetic on the bf16 matrix cores (three pieces per operand, csrc/conv_s2_x3.hip)
             if "s2x3" not in self.packed:
                 self.packed["s2x3"] = _conv.pack_conv3x3_s2_x3_weight(self.w)
-            return _conv.conv3x3_s2_x3_bias_relu(x, self.packed["s2x3"], self.b, self.cout, relu=True), wv // 2
+            return _conv.conv3x3_s2_x3_bias_relu(x, self.packed["s2x3"], self.b, self.cout, relu=True,
+                                                 w_valid=wv), wv // 2
         if _conv.supported(self.cin, self.cout, h, wv, self.stride):
             if "direct" not in self.packed:
                 self.packed["direct"] = _conv.pack_conv3x3_weight(self.w)

@@ -35,7 +35,7 @@ struct S2Args {
   const __bf16* wpk;  // [channel tile][step][48 KB]
   const float* bias;
   float* out;
-  int cin, hi, wi, ho, wo, relu;
+  int cin, hi, wi, ho, wo, wov, relu;  // wi / wo: row pitches of x / out; wov: real output width (columns behind it are zero)
   int ptiles, tx, ty;  // pixel tiles; tiles per output row, per image column
   int nmt, nsteps, nslots, ipw, bias_n;
   unsigned x_bytes, out_bytes, w_bytes;
@@ -95,7 +95,10 @@ __global__ __launch_bounds__(kS2Threads, 1) void conv3x3_s2_x3_kernel(S2Args a) 
     const unsigned ib = 4u * (unsigned)iplane;
     const unsigned row = __builtin_amdgcn_readfirstlane(
         4u * ((unsigned)(n * a.cin + c * 16) * (unsigned)iplane + (unsigned)(max(iy, 0) * a.wi + 2 * ox0)));
-    const unsigned voff = row_ok ? (unsigned)(lane >> 4) * ib + (unsigned)(lane & 15) * 16u : kPxOob;
+    // (a piece past the row's pitch is out of range; the pad columns inside the pitch hold zeros by convention)
+    const unsigned voff = row_ok && 2 * ox0 + (lane & 15) * 4 < a.wi
+                              ? (unsigned)(lane >> 4) * ib + (unsigned)(lane & 15) * 16u
+                              : kPxOob;
 #pragma unroll
     for (int g = 0; g < 4; ++g) px_dma(a.x, a.x_bytes, myB + g * 1024, voff, row + (unsigned)(4 * g) * ib);
     const bool left_ok = row_ok && ox0 > 0 && lane < 16;
@@ -127,7 +130,8 @@ __global__ __launch_bounds__(kS2Threads, 1) void conv3x3_s2_x3_kernel(S2Args a) 
     int n, oy, ox0;
     item_pos(i, n, oy, ox0);
     const int mt = item_mt(i);
-    const bool ok = item_pt(i) < a.ptiles && oy < a.ho;
+    const bool ok = item_pt(i) < a.ptiles && oy < a.ho && ox0 + l31 < a.wo;
+    const bool pad = ox0 + l31 >= a.wov;  // a pad column of the output's pitch: zero
     const unsigned ob = 4u * (unsigned)oplane;
     const unsigned voff = ok ? 4u * (unsigned)(4 * kh * oplane + oy * a.wo + ox0 + l31) : kPxOob;
     const unsigned so = (unsigned)(n * (a.nmt * kS2M) + mt * kS2M) * ob;
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(kS2Threads, 1) void conv3x3_s2_x3_kernel(S2Args a) 
         for (int e = 0; e < 4; ++e) {
           float v = acc[i2][4 * q + e] + b4[e];
           if (a.relu) v = fmaxf(v, 0.f);
-          px_st1(a.out, a.out_bytes, voff, so + (unsigned)(i2 * 32 + 8 * q + e) * ob, v);
+          px_st1(a.out, a.out_bytes, voff, so + (unsigned)(i2 * 32 + 8 * q + e) * ob, pad ? 0.f : v);
         }
       }
 #pragma unroll
@@ -237,12 +241,16 @@ __global__ __launch_bounds__(kS2Threads, 1) void conv3x3_s2_x3_kernel(S2Args a) 
 using namespace pd3;
 
 extern "C" int pd3_conv3x3_s2_x3_bias_relu(const float* x, const void* w_packed, const float* bias, int batch, int cin,
-                                           int cout, int h, int w, int relu, float* out, void* stream) {
-  if (!x || !w_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return PD3_EINVAL;
+                                           int cout, int h, int w, int w_valid, int relu, float* out, int out_w,
+                                           void* stream) {
+  if (!x || !w_packed || !out || batch <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || w_valid <= 0 || w_valid > w ||
+      out_w < w_valid / 2)
+    return PD3_EINVAL;
   if (reinterpret_cast<uintptr_t>(w_packed) % 16 != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0 ||
       reinterpret_cast<uintptr_t>(out) % 4 != 0)
     return PD3_EINVAL;
-  if (cin % 16 != 0 || cout % kS2M != 0 || cout > 1024 || h % 2 != 0 || w % 64 != 0) return PD3_EUNSUPPORTED;
+  if (cin % 16 != 0 || cout % kS2M != 0 || cout > 1024 || h % 2 != 0 || w_valid % 2 != 0 || w % 4 != 0)
+    return PD3_EUNSUPPORTED;
   S2Args a;
   a.x = x;
   a.wpk = static_cast<const __bf16*>(w_packed);
@@ -252,12 +260,13 @@ extern "C" int pd3_conv3x3_s2_x3_bias_relu(const float* x, const void* w_packed,
   a.hi = h;
   a.wi = w;
   a.ho = h / 2;
-  a.wo = w / 2;
+  a.wo = out_w;
+  a.wov = w_valid / 2;
   a.relu = relu;
   a.bias_n = cout;
   a.nmt = cout / kS2M;
   a.nsteps = 3 * (cin / 16);
-  a.tx = a.wo / 32;
+  a.tx = (int)ceil_div(a.wo, 32);  // (the pad columns of the output's pitch are written too: zeros)
   a.ty = (int)ceil_div(a.ho, 8);
   const int64_t ptiles = (int64_t)batch * a.tx * a.ty;
   const int64_t xb = (int64_t)batch * cin * h * w * 4, ob = (int64_t)batch * cout * a.ho * a.wo * 4;

@@ -304,9 +304,9 @@ S2_BF16X3 = True
 
 
 def conv3x3_s2_x3_supported(cin: int, cout: int, h: int, w: int, batch: int = 1) -> bool:
-    """pd3_conv3x3_s2_x3_bias_relu's shapes ([h, w] = input map, w its row pitch = real width)."""
-    return (cin % 16 == 0 and cout % 128 == 0 and cout <= 1024 and h % 2 == 0 and w % 64 == 0
-            and batch * max(cin, cout) * h * w * 4 < 0x7ffffff0)
+    """pd3_conv3x3_s2_x3_bias_relu's shapes ([h, w] = input map, w its REAL width: rows live at pitch4(w))."""
+    return (cin % 16 == 0 and cout % 128 == 0 and cout <= 1024 and h % 2 == 0 and w % 2 == 0
+            and batch * max(cin, cout) * h * pitch4(w) * 4 < 0x7ffffff0)
 
 
 def pack_conv3x3_s2_x3_weight(weight: torch.Tensor) -> torch.Tensor:
@@ -321,12 +321,17 @@ def pack_conv3x3_s2_x3_weight(weight: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.pad(pc, (0, 24576 - 3 * 128 * 56)).contiguous()
 
 
-def conv3x3_s2_x3_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, relu: bool = True) -> torch.Tensor:
+def conv3x3_s2_x3_bias_relu(x: torch.Tensor, w_packed: torch.Tensor, bias, cout: int, relu: bool = True,
+                            w_valid: int | None = None) -> torch.Tensor:
+    """x [n, cin, h, pitch] (pitch % 4 == 0, w_valid real columns, the rest zero) -> [n, cout, h / 2, pitch4(w_valid / 2)]
+    with zeros in its own padding columns (conv3x3_bias_relu's convention)."""
     xx = require_gpu(x, "conv3x3_s2_x3_bias_relu")
     n, cin, h, w = xx.shape
-    out = torch.empty((n, cout, h // 2, w // 2), dtype=torch.float32, device=xx.device)
-    check(lib().pd3_conv3x3_s2_x3_bias_relu(ptr(xx), ptr(w_packed), ptr(bias), n, cin, cout, h, w, int(bool(relu)),
-                                            ptr(out), stream_ptr(xx.device)), "conv3x3_s2_x3_bias_relu")
+    wv = w if w_valid is None else int(w_valid)
+    out = torch.empty((n, cout, h // 2, pitch4(wv // 2)), dtype=torch.float32, device=xx.device)
+    check(lib().pd3_conv3x3_s2_x3_bias_relu(ptr(xx), ptr(w_packed), ptr(bias), n, cin, cout, h, w, wv, int(bool(relu)),
+                                            ptr(out), int(out.shape[3]), stream_ptr(xx.device)),
+          "conv3x3_s2_x3_bias_relu")
     return out
 
 

@@ -277,6 +277,8 @@ def test_patch_conv_bf16x3_is_fp32_arithmetic(mode, n, cin, cout, h, w, wv, relu
     (3, 16, 128, 12, 64),      # 6 output rows: two of a tile's eight waves own no row
     (1, 32, 384, 36, 192),     # 18 output rows (partial third row tile), three column tiles, three channel tiles
     (9, 16, 128, 2, 64),       # nine images of ONE output row: a partial last group of 8 tiles
+    (2, 32, 128, 180, 180),    # CenterPoint-Voxel's opener in small: 90 output columns at pitch 92, partial column tile
+    (1, 16, 256, 14, 90),      # an input of pitch 92 with 90 real columns -> 45 real output columns at pitch 48
 ])
 @pytest.mark.parametrize("relu", [True, False])
 def test_conv3x3_s2_bf16x3_is_fp32_arithmetic(n, cin, cout, h, w, relu):
@@ -295,24 +297,29 @@ def test_conv3x3_s2_bf16x3_is_fp32_arithmetic(n, cin, cout, h, w, relu):
     assert conv.conv3x3_s2_x3_supported(cin, cout, h, w, n)
     wp = conv.pack_conv3x3_s2_x3_weight(wt.cuda())
     assert wp.dtype == torch.bfloat16 and tuple(wp.shape) == (cout // 128, 3 * (cin // 16), 24576)
-    got = conv.conv3x3_s2_x3_bias_relu(x.cuda(), wp, b.cuda(), cout, relu=relu)
-    err = (got.cpu().double() - ref).abs().max().item()
-    got32 = conv.conv3x3_bias_relu(x.cuda(), conv.pack_conv3x3_weight(wt.cuda()), b.cuda(), cout, relu=relu, stride=2)
-    err32 = (got32.cpu().double() - ref).abs().max().item()
+    # rows live at a pitch that is a multiple of 4, the pad columns hold zeros (ops/conv.py: pitch4)
+    xp = F.pad(x, (0, conv.pitch4(w) - w)).cuda()
+    wo, wop = w // 2, conv.pitch4(w // 2)
+    got = conv.conv3x3_s2_x3_bias_relu(xp, wp, b.cuda(), cout, relu=relu, w_valid=w)
+    assert tuple(got.shape) == (n, cout, h // 2, wop) and (got[..., wo:] == 0).all()
+    err = (got[..., :wo].cpu().double() - ref).abs().max().item()
+    got32 = conv.conv3x3_bias_relu(xp, conv.pack_conv3x3_weight(wt.cuda()), b.cuda(), cout, relu=relu, stride=2, w_valid=w)
+    err32 = (got32[..., :wo].cpu().double() - ref).abs().max().item()
     mag = ref.abs().max().item()
     print(f"bf16x3 {err:.3e}, fp32 kernel {err32:.3e}, magnitude {mag:.1f}")
     assert err <= 2 * err32 + 1e-7 * mag and err < 2e-6 * mag
-    assert torch.equal(got, conv.conv3x3_s2_x3_bias_relu(x.cuda(), wp, b.cuda(), cout, relu=relu))  # run-to-run identical
+    assert torch.equal(got, conv.conv3x3_s2_x3_bias_relu(xp, wp, b.cuda(), cout, relu=relu, w_valid=w))  # run-to-run identical
     # the taps one at a time on a map of ones: every output counts the taps that fall inside the image, exactly
     ones = torch.ones(1, cin, h, w)
+    onesp = F.pad(ones, (0, conv.pitch4(w) - w)).cuda()
     for ky in range(3):
         for kx in range(3):
             w1 = torch.zeros(cout, cin, 3, 3)
             w1[:, :, ky, kx] = 1.0
             want = F.conv2d(ones, w1, None, stride=2, padding=1)
-            got1 = conv.conv3x3_s2_x3_bias_relu(ones.cuda(), conv.pack_conv3x3_s2_x3_weight(w1.cuda()), None, cout,
-                                                relu=False).cpu()
-            assert torch.equal(got1, want), (ky, kx)
+            got1 = conv.conv3x3_s2_x3_bias_relu(onesp, conv.pack_conv3x3_s2_x3_weight(w1.cuda()), None, cout, relu=False,
+                                                w_valid=w).cpu()
+            assert torch.equal(got1[..., :wo], want) and (got1[..., wo:] == 0).all(), (ky, kx)
 
 
 def test_patch_conv_bf16x3_refuses_what_it_cannot_do():

@@ -17,7 +17,7 @@ def timed(f, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for cin, cout, hw in ((64, 128, 256), (128, 256, 128)):
+for cin, cout, hw in ((64, 128, 256), (128, 256, 128), (128, 256, 180)):
     x = torch.randn(n, cin, hw, hw, device='cuda')
     w = torch.randn(cout, cin, 3, 3, device='cuda') / (cin * 9) ** 0.5
     b = torch.randn(cout, device='cuda')
