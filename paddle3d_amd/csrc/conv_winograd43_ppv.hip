@@ -23,6 +23,7 @@ constexpr int kPvCi = kPvKT * kW4Ci;                       // 8 input channels p
 constexpr int kPvVsz = kPvCi * kW4TC * kW4Cs;              // 4608 floats per (tile row, slot): [8 ci][16 tiles][36]
 constexpr int kPvUHalf = 9 * 64 * 4;                       // 2304 floats: U of one trip for one wave
 constexpr int kPvUsz = kPvKT * 4 * kPvUHalf;               // 18432 floats per slot
+constexpr int kPvMaxBlocks = 18;                           // channel blocks a workgroup walks at most (their bias sits in LDS)
 
 // V[pixel tile pt][slot s][tile row g][ci 8][tile 16][36]: one workgroup = one (pt, s, g) block of 18 432 bytes; thread =
 // (ci, tile): 6 x 6 input values (zero outside the image), B^T along the rows of every column, then along the columns --
@@ -78,24 +79,28 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_ppv_kernel(const fl
                                                                         const float* __restrict__ ulane,
                                                                         const float* __restrict__ bias,
                                                                         float* __restrict__ out, int cin, int cout, int h,
-                                                                        int w, int wv, int relu, int ptiles) {
+                                                                        int w, int wv, int relu, int ptiles, int ipw) {
   constexpr int CO = 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(wave_id());
   const int grp = wave >> 2, cb = wave & 3;  // tile row / 16-channel block of this wave; waves w and w + 4 share a SIMD
   float* Us = smem;                                  // [2 trips][4 cb][9][64 lanes][4]: U of the current slot
   float* Vs = smem + kPvUsz + grp * 2 * kPvVsz;      // [2 buffers][8 ci][16 tiles][36] of this group's tile row
+  float* bias_s = smem + kPvUsz + 4 * kPvVsz;        // [ipw][64]: the bias of this workgroup's channel blocks
   const int tiles_x = (w + 4 * kW4TC - 1) / (4 * kW4TC), tiles_y = (h + 4 * kW4TR - 1) / (4 * kW4TR);
-  const int nct = cout / CO;
+  // a workgroup walks `ipw` consecutive channel blocks of ONE pixel tile (they read the same V): the first fetches of block
+  // i + 1 travel under the output transform of block i, whose stores drain under block i + 1's first slots (cycle stamps of
+  // the one-block form, the head's 64 -> 1152 slice: prologue 5.9 k, eight slot pairs 41.7 k, epilogue 7-9 k cycles)
+  const int ncg = (cout / CO) / ipw;
   const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
-  const int ct = slot_id % nct, pt = (slot_id / nct) * 8 + xcd;
+  const int ct0 = (slot_id % ncg) * ipw, pt = (slot_id / ncg) * 8 + xcd;
   if (pt >= ptiles) return;
   const int tx = pt % tiles_x, ty = (pt / tiles_x) % tiles_y, n = pt / (tiles_x * tiles_y);
   const int y0 = ty * 4 * kW4TR, x0 = tx * 4 * kW4TC;
   const int slots = cin / kPvCi;
+  const bool whole_tiles = h % (4 * kW4TR) == 0 && w % (4 * kW4TC) == 0;
   const int64_t plane = (int64_t)h * w;
   const int bbase = ((lane >> 4) * kW4TC + (lane & 15)) * kW4Cs;
-  const float* uct = ulane + (int64_t)ct * slots * kPvUsz;  // this workgroup's 64 output channels, all slots
   // this pixel tile's V: [slot][tile row][4608]; the group's block of slot s = 18 fetches of 1 KB, wave cb sends pieces
   // cb, cb + 4, .. (five for cb < 2, four otherwise)
   const float* vpt = vpre + (int64_t)pt * slots * 2 * kPvVsz;
@@ -115,11 +120,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_ppv_kernel(const fl
       if (i < 4 || cb < 2) pv_dma(vpt, vbytes, dst + piece * 256, lane * 16, so + piece * 1024);
     }
   };
-  const unsigned ubytes = (unsigned)((int64_t)slots * kPvUsz * 4);
-  auto fetch_u = [&](int s, int hh) {
+  const unsigned ubytes = (unsigned)((int64_t)(cout / CO) * slots * kPvUsz * 4);
+  int ct = ct0;  // the channel block being multiplied
+  auto fetch_u = [&](int c, int s, int hh) {  // half hh of slot s of channel block c
     const int blk = (hh * 4 + cb) * kPvUHalf;
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(((c * slots + s) * kPvUsz + blk) * 4));
 #pragma unroll
-    for (int q = 0; q < 9; ++q) pv_dma(uct, ubytes, Us + blk + q * 256, lane * 16, (unsigned)((s * kPvUsz + blk + q * 256) * 4));
+    for (int q = 0; q < 9; ++q) pv_dma(ulane, ubytes, Us + blk + q * 256, lane * 16, so + (unsigned)(q * 1024));
   };
   // a multiply slot: 72 MFMAs, one stream over both trips, fed by ds_read_b128 alone (as conv_winograd43_pp.hip; no fetch
   // is waited for inside it)
@@ -169,11 +176,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_ppv_kernel(const fl
     }
   };
 
-  // prologue: V of slot 0 (each group its own tile row) and slot 0's U (group 0's waves)
+  // prologue: the bias of the workgroup's blocks, V of slot 0 (each group its own tile row) and slot 0's U (group 0's waves)
+  for (int t = threadIdx.x; t < ipw * CO; t += 512) bias_s[t] = bias ? bias[ct0 * CO + t] : 0.f;
   fetch_v(0);
   if (grp == 0) {
-    fetch_u(0, 0);
-    fetch_u(0, 1);
+    fetch_u(ct0, 0, 0);
+    fetch_u(ct0, 0, 1);
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
   w4_lds_barrier();
@@ -188,8 +196,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_ppv_kernel(const fl
     for (int s = 0; s < slots; ++s) {
       {  // "transform" slot s
         if (G0 && s > 0) {
-          fetch_u(s, 0);
-          fetch_u(s, 1);
+          fetch_u(ct, s, 0);
+          fetch_u(ct, s, 1);
         }
         const bool more = s + 1 < slots;
         if (more) fetch_v(s + 1);
@@ -198,9 +206,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_ppv_kernel(const fl
 #pragma unroll
           for (int g = 0; g < 18; ++g) ua[g] = *reinterpret_cast<const w4_f32x4*>(uptr(g));
         }
-        if (!more) __builtin_amdgcn_s_waitcnt(0x0f70);
-        else if (nv == 5) __builtin_amdgcn_s_waitcnt(0x0f70 | 5);
-        else __builtin_amdgcn_s_waitcnt(0x0f70 | 4);
+        if (s == 0 && ct != ct0) {
+          // (a later block's slot 0: its U and V landed before the barrier that followed the block before; waiting here
+          // would wait for that block's stores)
+        } else if (!more) {
+          __builtin_amdgcn_s_waitcnt(0x0f70);
+        } else if (nv == 5) {
+          __builtin_amdgcn_s_waitcnt(0x0f70 | 5);
+        } else {
+          __builtin_amdgcn_s_waitcnt(0x0f70 | 4);
+        }
       }
       w4_lds_barrier();
       {  // multiply slot s
@@ -212,17 +227,28 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_ppv_kernel(const fl
     }
     if (G0) w4_lds_barrier();
   };
-  if (grp == 0) run(std::true_type{});
-  else run(std::false_type{});
+  // (one straight-line copy of the block loop per group: with the group's role chosen inside the loop the two roles'
+  // registers meet at a join in every trip -- 181 spilled registers, 40 % slower than the one-block form)
+  auto blocks = [&](auto is_g0) {
+  for (int it = 0; it < ipw; ++it) {
+  ct = ct0 + it;
+  run(is_g0);
+  // (behind run()'s last barrier every wave is done with U and with both V buffers)
+  if (it + 1 < ipw) {  // the next block's first fetches travel under this block's output transform
+    fetch_v(0);
+    if (grp == 0) {
+      fetch_u(ct + 1, 0, 0);
+      fetch_u(ct + 1, 0, 1);
+    }
+  }
 
   // epilogue (as conv_winograd43_pp.hip): Y = A^T M A; lane: tile column lane & 15, channels 4 (lane >> 4) + r of the block
   float bv[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) bv[r] = 0.f;
   const int co0 = ct * CO + cb * 16 + 4 * (lane >> 4);
-  if (bias) {
+  {
+    const w4_f32x4 b4 = *reinterpret_cast<const w4_f32x4*>(bias_s + it * CO + cb * 16 + 4 * (lane >> 4));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = bias[co0 + r];
+    for (int r = 0; r < 4; ++r) bv[r] = b4[r];
   }
   const int oy = y0 + 4 * grp, ox = x0 + 4 * (lane & 15);
 #pragma unroll
@@ -252,6 +278,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_winograd43_ppv_kernel(const fl
                                     reinterpret_cast<w4_f32x4*>(o + (int64_t)kk * w));
     }
   }
+  if (it + 1 < ipw) {
+#pragma unroll
+    for (int c = 0; c < 36; ++c) acc[c] = (w4_f32x4){0.f, 0.f, 0.f, 0.f};
+    // the next block's fetches have landed; younger than them are only this block's 16 stores per lane, which drain under
+    // the next block's first slots -- where every wave issued all 16 (whole tiles); with partial tiles a wave may have
+    // skipped some, and the count would let a fetch through: everything then
+    if (whole_tiles) __builtin_amdgcn_s_waitcnt(0x0f70 | (16 & 15) | ((16 >> 4) << 14));  // vmcnt(16)
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    w4_lds_barrier();
+  }
+  }  // blocks of this workgroup
+  };
+  if (grp == 0) blocks(std::true_type{});
+  else blocks(std::false_type{});
 }
 
 }  // namespace pd3
@@ -286,16 +326,24 @@ extern "C" int pd3_conv3x3_winograd43_ppv_bias_relu(const float* v_pre, const fl
   if (reinterpret_cast<uintptr_t>(v_pre) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 16 != 0 ||
       reinterpret_cast<uintptr_t>(u_lane) % 16 != 0)
     return PD3_EINVAL;
-  if ((int64_t)(cin / kPvCi) * kPvUsz >= (int64_t)1 << 29 || (int64_t)(cin / kPvCi) * 2 * kPvVsz >= (int64_t)1 << 29)
-    return PD3_EUNSUPPORTED;  // 32-bit byte offsets inside a channel tile's U and a pixel tile's V
-  constexpr size_t lds = ((size_t)kPvUsz + 4 * kPvVsz) * sizeof(float);  // 147 456 B
+  if ((int64_t)(cout / 64) * (cin / kPvCi) * kPvUsz >= (int64_t)1 << 29 ||
+      (int64_t)(cin / kPvCi) * 2 * kPvVsz >= (int64_t)1 << 29)
+    return PD3_EUNSUPPORTED;  // 32-bit byte offsets inside U and inside a pixel tile's V
+  // channel blocks per workgroup: the largest divisor of cout / 64 (up to kPvMaxBlocks) that still leaves six workgroups per
+  // CU (the head's 18 blocks per slice, 16 frames: 3 / 6 / 9 / 18 blocks per workgroup = 831 / 812 / 830 / 849 us)
+  const int nct = cout / 64;
+  const int64_t ptiles8 = (((int64_t)batch * ceil_div(h, 4 * kW4TR) * ceil_div(w, 4 * kW4TC)) + 7) / 8 * 8;
+  int ipw = 1;
+  for (int d = 2; d <= kPvMaxBlocks; ++d)
+    if (nct % d == 0 && ptiles8 * (nct / d) >= 6 * 256) ipw = d;
+  const size_t lds = ((size_t)kPvUsz + 4 * kPvVsz + kPvMaxBlocks * 64) * sizeof(float);  // 147 456 B + the blocks' bias
   const void* fn = reinterpret_cast<const void*>(conv3x3_winograd43_ppv_kernel);
   const hipError_t e = pd3_max_dynamic_lds(fn, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int64_t ptiles = (int64_t)batch * ceil_div(h, 4 * kW4TR) * ceil_div(w, 4 * kW4TC);
-  const int64_t nwg = (ptiles + 7) / 8 * 8 * (cout / 64);
+  const int64_t nwg = (ptiles + 7) / 8 * 8 * (nct / ipw);
   if (nwg >= (int64_t)1 << 31) return PD3_EUNSUPPORTED;
   conv3x3_winograd43_ppv_kernel<<<(unsigned)nwg, 512, lds, static_cast<hipStream_t>(stream)>>>(
-      v_pre, u_lane, bias, out, cin, cout, h, w, w_valid, relu, (int)ptiles);
+      v_pre, u_lane, bias, out, cin, cout, h, w, w_valid, relu, (int)ptiles, ipw);
   return launch_status();
 }
