@@ -44,6 +44,10 @@ namespace pd3 {
 // at the start of its next transform slot, a whole slot ahead of the barrier that publishes it.  The raw rows are private
 // to a wave (wave cb transforms channels 2 cb, 2 cb + 1 of the slot): it reads, refetches and waits for them itself -- no
 // barrier is involved.
+// Tried in round 6 and dropped: the walk over several work items per workgroup that pays in conv_winograd43_ppv.hip (next
+// item's first fetches under this item's output transform).  Here the item loop costs 34 spilled registers at the 256 this
+// kernel already fills: 64 -> 64 at 256^2 317 -> 310 us with two items per workgroup, the other layers unchanged, four
+// items slower (too few workgroups).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kPpKT = 2;                                   // trips per slot
 constexpr int kPpCi = kPpKT * kW4Ci;                       // 8 input channels per slot
