@@ -183,23 +183,23 @@ PD3_HD uint64_t exp2f_tab(int i) {
   return t[i];
 }
 
-PD3_HD float expf(float x) {
+// |x| >= 88 or NaN: the arguments expf treats before its polynomial
+PD3_HD bool expf_is_special(float x) { return ((f2u(x) >> 20) & 0x7ffu) >= 0x42bu; }
+
+// The polynomial part (every argument that is not special), with the table read through `tab` -- straight-line code,
+// so a caller with several arguments in registers can have the table reads of all of them in flight at once (and
+// keep the table where it likes: postprocess.hip holds it in LDS).  Harmless on a special argument (the index is
+// masked), but the value is then not expf's.
+template <class Tab>
+PD3_HD float expf_main(float x, Tab tab) {
   const double xd = (double)x;
-  const uint32_t abstop = (f2u(x) >> 20) & 0x7ffu;
-  if (abstop >= 0x42bu) {  // |x| >= 88 or NaN
-    if (f2u(x) == 0xff800000u) return 0.0f;
-    if (abstop >= 0x7f8u) return x + x;
-    if (x > 0x1.62e42ep6f) return u2f(0x7f800000u);  // overflow
-    if (x < -0x1.9fe368p6f) return 0.0f;             // underflow
-    if (x < -0x1.9d1d9ep6f) return u2f(1u);          // __math_may_uflowf: 0x1.4p-75f * 0x1.4p-75f
-  }
   const double kInvLn2N = 0x1.71547652b82fep+5, kShift = 0x1.8p+52;
   // e_expf.c with TOINT_INTRINSICS == 0; the FMA build fuses z = InvLn2N * xd into both of its uses
   double kd = __builtin_fma(kInvLn2N, xd, kShift);
   const uint64_t ki = d2u(kd);
   kd -= kShift;
   const double r = __builtin_fma(kInvLn2N, xd, -kd);
-  const uint64_t t = exp2f_tab((int)(ki & 31u)) + (ki << 47);
+  const uint64_t t = tab((int)(ki & 31u)) + (ki << 47);
   const double s = u2d(t);
   const double z = __builtin_fma(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
   const double r2 = r * r;
@@ -207,6 +207,18 @@ PD3_HD float expf(float x) {
   y = __builtin_fma(z, r2, y);
   y = y * s;
   return (float)y;
+}
+
+PD3_HD float expf(float x) {
+  if (expf_is_special(x)) {
+    const uint32_t abstop = (f2u(x) >> 20) & 0x7ffu;
+    if (f2u(x) == 0xff800000u) return 0.0f;
+    if (abstop >= 0x7f8u) return x + x;
+    if (x > 0x1.62e42ep6f) return u2f(0x7f800000u);  // overflow
+    if (x < -0x1.9fe368p6f) return 0.0f;             // underflow
+    if (x < -0x1.9d1d9ep6f) return u2f(1u);          // __math_may_uflowf: 0x1.4p-75f * 0x1.4p-75f
+  }
+  return expf_main(x, [](int i) { return exp2f_tab(i); });
 }
 
 // ---- atanf / atan2f (fdlibm) ------------------------------------------------------------------------------

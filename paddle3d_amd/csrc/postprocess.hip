@@ -5,17 +5,19 @@
 // The reference runs ~20 Paddle/CUDA launches and two blocking host syncs PER TASK (masked_select's
 // numel, the NMS mask copy + host sweep).  Here grid.y / grid.z indexes the task and every count stays
 // on the device:
-//   1. cp_score_kernel   sigmoid->max/argmax, range/score mask on the raw reg / height values, sort key (all cells)
-//   2. top-K selection    key = 0x3F800000 - bits(score) for masked-in cells (descending score, ties in
-//                         cell order = masked_select order + stable argsort), 0x3FFFFFFF otherwise; cp_topk_kernel
-//                         (radix select + ordered compaction + bitonic sort of <= 1024 pairs) or, with selection = 1
-//                         / maps beyond 16 k cells, a full stable radix sort of all keys -- identical results
-//   3. cp_nms_boxes_kernel  the top min(selected, nms_pre_max_size) cells: box decode (exp(dim), atan2), score, class,
-//                         and the box remapped for the NMS (dx<->dy, -rot - pi/2) with its per-box records
+//   1. score              sigmoid->max/argmax, range/score mask on the raw reg / height values, sort key (all cells):
+//                         key = 0x3F800000 - bits(score) for masked-in cells (descending score, ties in cell order =
+//                         masked_select order + stable argsort), 0x3FFFFFFF otherwise
+//   2. top-K selection    the first min(selected, nms_pre_max_size) cells of the stable key order
+//   3. decode             those cells: box (exp(dim), atan2), score, class, and the box remapped for the NMS
+//                         (dx<->dy, -rot - pi/2) with its per-box records
+//      1-3 are ONE kernel, cp_topk_kernel (one workgroup per set: keys computed into LDS, radix select + ordered
+//      compaction + bitonic sort of <= 1024 pairs, decode), or, with selection = 1 / maps beyond 16 k cells / a pre-NMS
+//      cap beyond 1024, cp_score_kernel + a full stable radix sort of all keys + cp_nms_boxes_kernel -- identical results
 //   4. nms_cand_kernel + nms_pairs_kernel + nms_sweep_kernel (nms_kernels.hpp), counts read on the device
 //   5. cp_output_kernel   concatenates the tasks' kept rows (or the reference's fake row) in task order
 // Work is tiny (4.6 MB read per nuScenes frame); the op is launch-latency bound, which is why the
-// launch count (8 for all tasks and frames of a batch) and the absence of syncs are what matter.
+// launch count (5 for all tasks and frames of a batch) and the absence of syncs are what matter.
 #include "../../include/paddle3d_amd.h"
 #include "common.hpp"
 #include "nms_kernels.hpp"
@@ -66,11 +68,25 @@ __device__ __forceinline__ float cp_best_class(const CpHeads& h, const CpCfg& c,
   return best;
 }
 
-// First pass over all cells: score, the mask of postprocess.cu:72-77 on the RAW reg / height values, the sort key
-// of the masked-in cells and their number per set.  Nothing else is written: a cell's box is only ever read if the
-// cell is among the nms_pre_max_size best of its set, and those are decoded by the kernel that lays out the NMS
-// boxes (cp_nms_boxes_kernel) -- a few hundred to a thousand cells per set instead of all 16 k (the box, three exp
-// and an atan2 each, and its 36-byte row were 90 MB of writes per 16 frames).
+// Score, the mask of postprocess.cu:72-77 on the RAW reg / height values and the sort key of one cell (kKeyOut: masked
+// out).  Nothing else is computed for the 16 k cells of a set: a cell's box is only ever read if the cell is among the
+// nms_pre_max_size best of its set, and those are decoded by cp_decode_row -- a few hundred to a thousand cells per set
+// (the box, three exp and an atan2 each, and its 36-byte row were 90 MB of writes per 16 frames).
+__device__ __forceinline__ uint32_t cp_cell_key(const CpHeads& h, const CpCfg& c, int t, int frame, int i) {
+  const int64_t bs = h.batch_stride;
+  const float* regp = h.reg[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
+  const float* heip = h.height[t] + (int64_t)frame * (bs ? bs : (int64_t)c.hw);
+  int arg;
+  const float best = cp_best_class(h, c, t, frame, i, arg);
+  const float x = regp[i], y = regp[i + c.hw], z = heip[i];
+  const bool m = best > c.score_threshold && x <= c.r[3] && y <= c.r[4] && z <= c.r[5] &&
+                 x >= c.r[0] && y >= c.r[1] && z >= c.r[2];
+  if (!m) return kKeyOut;
+  const uint32_t bits = __float_as_uint(best);
+  return bits <= kKeyOne ? kKeyOne - bits : 0u;
+}
+
+// The full-sort selection's first pass: the keys of all cells and the number of masked-in cells per set.
 __global__ __launch_bounds__(256) void cp_score_kernel(CpHeads h, CpCfg c, uint32_t* __restrict__ keys,
                                                        int* __restrict__ counts) {
   const int set = blockIdx.y;  // frame * num_tasks + task
@@ -78,20 +94,8 @@ __global__ __launch_bounds__(256) void cp_score_kernel(CpHeads h, CpCfg c, uint3
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   int selected = 0;
   if (i < c.hw) {
-    const int64_t bs = h.batch_stride;
-    const float* regp = h.reg[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
-    const float* heip = h.height[t] + (int64_t)frame * (bs ? bs : (int64_t)c.hw);
-    int arg;
-    const float best = cp_best_class(h, c, t, frame, i, arg);
-    const float x = regp[i], y = regp[i + c.hw], z = heip[i];
-    const bool m = best > c.score_threshold && x <= c.r[3] && y <= c.r[4] && z <= c.r[5] &&
-                   x >= c.r[0] && y >= c.r[1] && z >= c.r[2];
-    uint32_t key = kKeyOut;
-    if (m) {
-      const uint32_t bits = __float_as_uint(best);
-      key = bits <= kKeyOne ? kKeyOne - bits : 0u;
-      selected = 1;
-    }
+    const uint32_t key = cp_cell_key(h, c, t, frame, i);
+    selected = key != kKeyOut;
     keys[(int64_t)set * c.hw + i] = key;
   }
   // block count of selected cells -> counts[t]
@@ -105,36 +109,150 @@ __global__ __launch_bounds__(256) void cp_score_kernel(CpHeads h, CpCfg c, uint3
   }
 }
 
+struct CpRows {  // the decoded candidates of every set, [set][rank]
+  float *boxes, *scores;
+  int* labels;
+  float* nms_boxes;
+  BoxPre* pre;
+  float4* xyr;
+};
+
+// Row r of a set = its r-th best cell i: decode_kernel :41-70 for the cell (the rows the operator can return: box,
+// score, class), and iou3d_nms_kernel.cu:294-308's remap of the box into NMS layout.
+__device__ __forceinline__ void cp_decode_row(const CpHeads& h, const CpCfg& c, int set, int r, int i, int cap,
+                                              const CpRows& o) {
+  const int t = set % c.num_tasks, frame = set / c.num_tasks;
+  const int64_t bs = h.batch_stride;
+  const float* regp = h.reg[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
+  const float* heip = h.height[t] + (int64_t)frame * (bs ? bs : (int64_t)c.hw);
+  const float* dimp = h.dim[t] + (int64_t)frame * (bs ? bs : (int64_t)3 * c.hw);
+  const float* velp = h.vel[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
+  const float* rotp = h.rot[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
+  int arg;
+  const float best = cp_best_class(h, c, t, frame, i, arg);
+  const int xs = i % c.feat_w, ys = i / c.feat_w;
+  const float x = regp[i], y = regp[i + c.hw], z = heip[i];
+  float* bx = o.boxes + ((int64_t)set * cap + r) * c.dims;
+  bx[0] = (x + xs) * c.down_ratio * c.vx + c.pc_x;
+  bx[1] = (y + ys) * c.down_ratio * c.vy + c.pc_y;
+  bx[2] = z;
+  bx[3] = exp_rn(dimp[i]);  // :151 exp(dim)
+  bx[4] = exp_rn(dimp[i + c.hw]);
+  bx[5] = exp_rn(dimp[i + 2 * c.hw]);
+  const float ang = atan2_rn(rotp[i], rotp[i + c.hw]);
+  if (c.with_velocity) {
+    bx[6] = velp[i];
+    bx[7] = velp[i + c.hw];
+    bx[8] = ang;
+  } else {
+    bx[6] = ang;
+  }
+  o.scores[(int64_t)set * cap + r] = best;
+  o.labels[(int64_t)set * cap + r] = arg;
+  float* q = o.nms_boxes + ((int64_t)set * cap + r) * 7;
+  q[0] = bx[0];
+  q[1] = bx[1];
+  q[2] = bx[2];
+  q[3] = bx[4];
+  q[4] = bx[3];
+  q[5] = bx[5];
+  q[6] = (float)(-(double)ang - 3.141592653589793 / 2);
+  const float nb[7] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6]};
+  const BoxPre bp = box_prepare(nb);  // what the suppression matrix needs of this box
+  o.pre[(int64_t)set * cap + r] = bp;
+  o.xyr[(int64_t)set * cap + r] = make_float4(bp.cx, bp.cy, bp.rad, 0.f);
+}
+
 // Top-K selection instead of a full sort of the score keys: only the first min(count, nms_pre_max_size) cells of
 // the stable ascending-key order are ever used (postprocess.cu:176-206 sorts the masked scores and slices
-// [:nms_pre_max_size]).  One workgroup per set, everything in LDS: the hw keys are loaded once; a 3-pass radix
-// SELECT (10-bit LDS histograms) finds the exact cut-off key and how many cells with that key still fit; the
-// selected cells are compacted in cell order and sorted as (key, cell) pairs by a bitonic network -- the same
-// total order a stable key sort gives.  Writes sidx[set][0 .. K).
+// [:nms_pre_max_size]).  One workgroup per set, everything in LDS, from the head maps to the decoded candidates: the
+// keys of the set's hw cells are COMPUTED into LDS (16 cells per thread; no key array in memory, no count atomics); a
+// 3-pass radix SELECT (10-bit LDS histograms) finds the exact cut-off key and how many cells with that key still fit;
+// the selected cells are compacted in cell order and sorted as (key, cell) pairs by a bitonic network -- the same total
+// order a stable key sort gives; thread r then decodes the r-th cell (cp_decode_row).  Writes counts[set], clears the
+// set's NMS counters and writes the rows [set][0 .. K).
 constexpr int kTopkThreads = 1024;  // one workgroup per set and nothing else on its CU: the kernel is a chain of
                                     // dependent passes, so its time is its latency -- 16 waves shorten every pass
 constexpr int kTopkMaxHw = 16384;   // keys held in LDS
 constexpr int kTopkMaxK = 1024;     // bitonic list
+constexpr int kTopkBatch = 8;       // cells of a thread whose keys are computed side by side
 constexpr int kTopkCopies = 8;      // histogram replicas (lane & 7): scores crowd into a handful of exponent bins, and
                                     // LDS atomics of one wave on one address run one lane at a time
 
-__global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(const uint32_t* __restrict__ keys,
-                                                               const int* __restrict__ counts, int hw,
-                                                               int cap, uint32_t* __restrict__ sidx) {
+__global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg c, int* __restrict__ counts,
+                                                               int* __restrict__ pool_counts, int cap, CpRows rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char topk_smem[];
+  const int hw = c.hw;
   uint32_t* ks = reinterpret_cast<uint32_t*>(topk_smem);                       // [hw]
   unsigned long long* list = reinterpret_cast<unsigned long long*>(ks + hw);   // [kTopkMaxK]
   int* hist = reinterpret_cast<int*>(list + kTopkMaxK);                        // [kTopkCopies][1024]
   int* scr = hist + kTopkCopies * 1024;                                                      // [32]: scan scratch, [30], [31] broadcast
+  uint64_t* etab = reinterpret_cast<uint64_t*>(scr + 32);                                    // [32]: expf's table
   const int set = blockIdx.x;
-  const int count = counts[set];
+  if (threadIdx.x < 32) etab[threadIdx.x] = lm::exp2f_tab((int)threadIdx.x);
+  __syncthreads();
+  // ---- keys of all cells (cp_cell_key, kTopkBatch cells of a thread at a time) ---------------------------------
+  // A cell is a chain of dependent reads (head values -> expf's table -> key); one cell after the other, 16 such
+  // chains per thread were half of this kernel's time.  Here the head values of a batch are fetched together, the
+  // polynomial part of expf runs straight-line on all of them (table reads from LDS, all in flight), and the
+  // arguments expf treats specially (|x| >= 88, NaN) take lm::expf afterwards.
+  int selected = 0;
+  {
+    const int t = set % c.num_tasks, frame = set / c.num_tasks, ncls = h.ncls[t];
+    const int64_t bs = h.batch_stride;
+    const float* hmp = h.hm[t] + (int64_t)frame * (bs ? bs : (int64_t)ncls * hw);
+    const float* regp = h.reg[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * hw);
+    const float* heip = h.height[t] + (int64_t)frame * (bs ? bs : (int64_t)hw);
+    const auto tab = [&](int i) { return etab[i]; };
+    for (int base = 0; base < hw; base += kTopkBatch * kTopkThreads) {
+      int ii[kTopkBatch];
+      float x[kTopkBatch], y[kTopkBatch], z[kTopkBatch], best[kTopkBatch];
+#pragma unroll
+      for (int j = 0; j < kTopkBatch; ++j) {
+        ii[j] = min(base + j * kTopkThreads + (int)threadIdx.x, hw - 1);  // past the end: the last cell again, dropped below
+        x[j] = regp[ii[j]];
+        y[j] = regp[ii[j] + hw];
+        z[j] = heip[ii[j]];
+        best[j] = 0.f;
+      }
+      for (int k = 0; k < ncls; ++k) {
+        float v[kTopkBatch], e[kTopkBatch];
+#pragma unroll
+        for (int j = 0; j < kTopkBatch; ++j) v[j] = -hmp[(int64_t)k * hw + ii[j]];
+#pragma unroll
+        for (int j = 0; j < kTopkBatch; ++j) e[j] = lm::expf_main(v[j], tab);
+#pragma unroll
+        for (int j = 0; j < kTopkBatch; ++j) {
+          if (lm::expf_is_special(v[j])) e[j] = exp_rn(v[j]);
+          const float sg = 1.0f / (1.0f + e[j]);
+          if (k == 0 || sg > best[j]) best[j] = sg;  // cp_best_class
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kTopkBatch; ++j) {
+        const int i = base + j * kTopkThreads + (int)threadIdx.x;
+        const bool m = best[j] > c.score_threshold && x[j] <= c.r[3] && y[j] <= c.r[4] && z[j] <= c.r[5] &&
+                       x[j] >= c.r[0] && y[j] >= c.r[1] && z[j] >= c.r[2];
+        const uint32_t bits = __float_as_uint(best[j]);
+        const uint32_t key = m ? (bits <= kKeyOne ? kKeyOne - bits : 0u) : kKeyOut;
+        if (i < hw) {
+          ks[i] = key;
+          selected += m ? 1 : 0;
+        }
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < kTopkMaxK; i += kTopkThreads) list[i] = ~0ull;
+  int count;
+  block_exclusive_scan<kTopkThreads>(selected, scr, count);  // (its barriers also publish ks / list)
+  if (threadIdx.x == 0) {
+    counts[set] = count;
+    // the two counters the suppression-matrix kernels append through (nms_kernels.hpp NmsPool): no set-up memset
+    pool_counts[set * kNmsCtrStride] = 0;
+    pool_counts[((int)gridDim.x + set) * kNmsCtrStride] = 0;
+  }
   const int K = min(count, cap);
   if (K <= 0) return;
-  const uint32_t* kg = keys + (int64_t)set * hw;
-  for (int i = threadIdx.x * 4; i < hw; i += kTopkThreads * 4)  // hw % 4 == 0 (dispatch): 16-byte loads, all in flight
-    *reinterpret_cast<uint4*>(ks + i) = *reinterpret_cast<const uint4*>(kg + i);
-  for (int i = threadIdx.x; i < kTopkMaxK; i += kTopkThreads) list[i] = ~0ull;
-  __syncthreads();
   // ---- cut-off key kc and the number r of cells with key == kc that are taken (0: take every key < kc) -----
   uint32_t kc = kKeyOut;
   int r = 0;
@@ -221,69 +339,26 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(const uint32_t* _
       __syncthreads();
     }
   }
-  uint32_t* so = sidx + (int64_t)set * hw;
-  for (int i = threadIdx.x; i < K; i += kTopkThreads) so[i] = (uint32_t)(list[i] & 0xffffffffull);
+  for (int r = threadIdx.x; r < K; r += kTopkThreads) cp_decode_row(h, c, set, r, (int)(list[r] & 0xffffffffull), cap, rows);
 }
 
 static inline size_t cp_topk_lds(int hw) {
-  return (size_t)hw * 4 + (size_t)kTopkMaxK * 8 + (size_t)kTopkCopies * 1024 * 4 + 32 * 4;
+  return (size_t)hw * 4 + (size_t)kTopkMaxK * 8 + (size_t)kTopkCopies * 1024 * 4 + 32 * 4 + 32 * 8;
 }
 
-// The nms_pre_max_size best cells of every set, in sorted order: decode_kernel :41-70 for the cell (the rows the
-// operator can return: box, score, class), and iou3d_nms_kernel.cu:294-308's remap of the box into NMS layout.
+// The full-sort selection's last pass: the nms_pre_max_size best cells of every set, in sorted order.
 __global__ __launch_bounds__(256) void cp_nms_boxes_kernel(CpHeads h, CpCfg c, const uint32_t* __restrict__ sidx,
-                                                           const int* __restrict__ counts, int cap,
-                                                           float* __restrict__ boxes, float* __restrict__ scores,
-                                                           int* __restrict__ labels, float* __restrict__ nms_boxes,
-                                                           BoxPre* __restrict__ pre, float4* __restrict__ xyr) {
+                                                           const int* __restrict__ counts, int cap, CpRows rows) {
   const int set = blockIdx.y;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = min(counts[set], cap);
   if (r >= n) return;
-  const int t = set % c.num_tasks, frame = set / c.num_tasks;
-  const int i = (int)sidx[(int64_t)set * c.hw + r];
-  const int64_t bs = h.batch_stride;
-  const float* regp = h.reg[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
-  const float* heip = h.height[t] + (int64_t)frame * (bs ? bs : (int64_t)c.hw);
-  const float* dimp = h.dim[t] + (int64_t)frame * (bs ? bs : (int64_t)3 * c.hw);
-  const float* velp = h.vel[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
-  const float* rotp = h.rot[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
-  int arg;
-  const float best = cp_best_class(h, c, t, frame, i, arg);
-  const int xs = i % c.feat_w, ys = i / c.feat_w;
-  const float x = regp[i], y = regp[i + c.hw], z = heip[i];
-  float* bx = boxes + ((int64_t)set * cap + r) * c.dims;
-  bx[0] = (x + xs) * c.down_ratio * c.vx + c.pc_x;
-  bx[1] = (y + ys) * c.down_ratio * c.vy + c.pc_y;
-  bx[2] = z;
-  bx[3] = exp_rn(dimp[i]);  // :151 exp(dim)
-  bx[4] = exp_rn(dimp[i + c.hw]);
-  bx[5] = exp_rn(dimp[i + 2 * c.hw]);
-  const float ang = atan2_rn(rotp[i], rotp[i + c.hw]);
-  if (c.with_velocity) {
-    bx[6] = velp[i];
-    bx[7] = velp[i + c.hw];
-    bx[8] = ang;
-  } else {
-    bx[6] = ang;
-  }
-  scores[(int64_t)set * cap + r] = best;
-  labels[(int64_t)set * cap + r] = arg;
-  float* o = nms_boxes + ((int64_t)set * cap + r) * 7;
-  o[0] = bx[0];
-  o[1] = bx[1];
-  o[2] = bx[2];
-  o[3] = bx[4];
-  o[4] = bx[3];
-  o[5] = bx[5];
-  o[6] = (float)(-(double)ang - 3.141592653589793 / 2);
-  const float nb[7] = {o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
-  const BoxPre bp = box_prepare(nb);  // what the suppression matrix needs of this box
-  pre[(int64_t)set * cap + r] = bp;
-  xyr[(int64_t)set * cap + r] = make_float4(bp.cx, bp.cy, bp.rad, 0.f);
+  cp_decode_row(h, c, set, r, (int)sidx[(int64_t)set * c.hw + r], cap, rows);
 }
 
-// One workgroup: concatenate tasks in order (postprocess.cu:247-278).
+// Concatenate the tasks' rows in task order (postprocess.cu:247-278).  One workgroup per (task, frame): the row its
+// task starts at is the sum of the earlier tasks' row counts (a few scalar loads), so the tasks copy side by side; the
+// last task's workgroup also clears the rows behind the end and writes the frame's count.
 __global__ __launch_bounds__(256) void cp_output_kernel(
     const float* __restrict__ boxes, const float* __restrict__ scores,
     const int* __restrict__ labels,
@@ -292,7 +367,7 @@ __global__ __launch_bounds__(256) void cp_output_kernel(
     int post_max, float* __restrict__ out_boxes, float* __restrict__ out_scores,
     int64_t* __restrict__ out_labels, int32_t* __restrict__ out_count, float* __restrict__ out_records,
     int max_per_img) {
-  const int frame = blockIdx.x;
+  const int task = blockIdx.x, frame = blockIdx.y;
   const int rows_cap = num_tasks * max(post_max, 1);
   out_boxes += (int64_t)frame * rows_cap * dims;
   out_scores += (int64_t)frame * rows_cap;
@@ -302,23 +377,25 @@ __global__ __launch_bounds__(256) void cp_output_kernel(
   // of by a handful of tensor-library kernels after the fact
   constexpr int kRec = 11;
   float* rec = out_records ? out_records + (int64_t)frame * max_per_img * kRec : nullptr;
+  // rows of a task: the fake row of :190-201 when nothing passed the mask, otherwise the kept boxes up to
+  // nms_post_max_size -- none with a zero pre-NMS cap (num_bboxes_for_nms = min(count, nms_pre_max_size), :212-216)
+  auto rows_of = [&](int tk) {
+    const int st = frame * num_tasks + tk;
+    return counts[st] <= 0 ? 1 : (pre_max > 0 ? min(nkeep[st], post_max) : 0);
+  };
   int offset = 0;
-  for (int task = 0; task < num_tasks; ++task) {
-    const int t = frame * num_tasks + task;  // set index
-    const int sel = counts[t];
-    if (sel <= 0) {  // :190-201 fake row
-      if ((int)threadIdx.x < dims) out_boxes[(int64_t)offset * dims + threadIdx.x] = 0.f;
-      if (threadIdx.x == 0) {
-        out_scores[offset] = -1.f;
-        out_labels[offset] = 0;
-      }
-      if (rec && offset < max_per_img && (int)threadIdx.x < kRec)
-        rec[(int64_t)offset * kRec + threadIdx.x] = threadIdx.x == 9 ? -1.f : 0.f;
-      offset += 1;
-      continue;
+  for (int tk = 0; tk < task; ++tk) offset += rows_of(tk);
+  const int t = frame * num_tasks + task;  // set index
+  const int rows = rows_of(task);
+  if (counts[t] <= 0) {
+    if ((int)threadIdx.x < dims) out_boxes[(int64_t)offset * dims + threadIdx.x] = 0.f;
+    if (threadIdx.x == 0) {
+      out_scores[offset] = -1.f;
+      out_labels[offset] = 0;
     }
-    // num_bboxes_for_nms = min(count, nms_pre_max_size) (postprocess.cu:212-216): none with a zero pre-NMS cap
-    const int rows = pre_max > 0 ? min(nkeep[t], post_max) : 0;
+    if (rec && offset < max_per_img && (int)threadIdx.x < kRec)
+      rec[(int64_t)offset * kRec + threadIdx.x] = threadIdx.x == 9 ? -1.f : 0.f;
+  } else {
     for (int r = threadIdx.x; r < rows; r += blockDim.x) {
       const int pos = keep[(int64_t)t * cap + r];  // index into the sorted order = row of the decoded candidates
       const float* bx = boxes + ((int64_t)t * cap + pos) * dims;
@@ -334,8 +411,9 @@ __global__ __launch_bounds__(256) void cp_output_kernel(
         q[10] = (float)lb;
       }
     }
-    offset += rows;
   }
+  if (task != num_tasks - 1) return;
+  offset += rows;
   // rows behind the last one read zero (the outputs need no clearing by the caller)
   for (int r = offset + (int)threadIdx.x; r < rows_cap; r += blockDim.x) {
     for (int k = 0; k < dims; ++k) out_boxes[(int64_t)r * dims + k] = 0.f;
@@ -456,26 +534,24 @@ static int cp_postprocess_impl(
   for (int k = 0; k < 6; ++k) c.r[k] = post_center_range[k];
   c.score_threshold = score_threshold;
 
-  hipError_t e = hipMemsetAsync(w.counts, 0, (size_t)((char*)(w.pool.counts + (size_t)sets * 2 * kNmsCtrStride) - (char*)w.counts), s);
-  if (e != hipSuccess) return (int)e;
-  dim3 dgrid((hw + 255) / 256, sets);
-  cp_score_kernel<<<dgrid, 256, 0, s>>>(h, c, w.keys_a, w.counts);
-  const uint32_t* sidx;
+  hipError_t e;
   if (selection < 0 || selection > 1) return PD3_EINVAL;
-  if (hw <= kTopkMaxHw && hw % 4 == 0 && cap <= kTopkMaxK && selection == 0) {
+  const CpRows rows{w.boxes, w.scores, w.labels, w.nms_boxes, w.pre, w.pool.xyr};
+  if (hw <= kTopkMaxHw && cap <= kTopkMaxK && selection == 0) {
     const size_t lds = cp_topk_lds(hw);
     e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(cp_topk_kernel), (int)cp_topk_lds(kTopkMaxHw));
     if (e != hipSuccess) return (int)e;
-    cp_topk_kernel<<<sets, kTopkThreads, lds, s>>>(w.keys_a, w.counts, hw, cap, w.vals_a);
-    sidx = w.vals_a;
+    cp_topk_kernel<<<sets, kTopkThreads, lds, s>>>(h, c, w.counts, w.pool.counts, cap, rows);
   } else {
+    e = hipMemsetAsync(w.counts, 0, (size_t)((char*)(w.pool.counts + (size_t)sets * 2 * kNmsCtrStride) - (char*)w.counts), s);
+    if (e != hipSuccess) return (int)e;
+    dim3 dgrid((hw + 255) / 256, sets);
+    cp_score_kernel<<<dgrid, 256, 0, s>>>(h, c, w.keys_a, w.counts);
     const int where = enqueue_radix_sort(w.keys_a, w.vals_a, w.keys_b, w.vals_b, hw, hw, sets,
                                          plan, /*identity_vals=*/true, w.hist, w.partial, s);
-    sidx = where ? w.vals_b : w.vals_a;
+    dim3 bgrid((cap + 255) / 256, sets);
+    cp_nms_boxes_kernel<<<bgrid, 256, 0, s>>>(h, c, where ? w.vals_b : w.vals_a, w.counts, cap, rows);
   }
-  dim3 bgrid((cap + 255) / 256, sets);
-  cp_nms_boxes_kernel<<<bgrid, 256, 0, s>>>(h, c, sidx, w.counts, cap, w.boxes, w.scores, w.labels, w.nms_boxes, w.pre,
-                                            w.pool.xyr);
   nms_enqueue_mask_pooled(w.pre, w.counts, sets, cap, cb, nms_iou_threshold, w.mask, w.pool, s);
   {
     const size_t lds = nms_sweep_lds(cap);
@@ -485,7 +561,7 @@ static int cp_postprocess_impl(
     }
     nms_sweep_kernel<<<sets, kNmsSweepThreads, lds, s>>>(w.mask, w.counts, 0, cap, cb, w.keep, w.nkeep);
   }
-  cp_output_kernel<<<batch, 256, 0, s>>>(w.boxes, w.scores, w.labels, w.counts, w.keep, w.nkeep, h,
+  cp_output_kernel<<<dim3(num_tasks, batch), 256, 0, s>>>(w.boxes, w.scores, w.labels, w.counts, w.keep, w.nkeep, h,
                                      num_tasks, hw, c.dims, cap, nms_pre_max_size, nms_post_max_size, out_bboxes,
                                      out_scores, out_labels, out_count, out_records, max_per_img);
   return launch_status();
