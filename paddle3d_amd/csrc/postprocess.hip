@@ -19,6 +19,7 @@
 // Work is tiny (4.6 MB read per nuScenes frame); the op is launch-latency bound, which is why the
 // launch count (5 for all tasks and frames of a batch) and the absence of syncs are what matter.
 #include "../../include/paddle3d_amd.h"
+#include "bf16x3.hpp"
 #include "common.hpp"
 #include "nms_kernels.hpp"
 #include "radix_sort.hpp"
@@ -117,47 +118,65 @@ struct CpRows {  // the decoded candidates of every set, [set][rank]
   float4* xyr;
 };
 
-// Row r of a set = its r-th best cell i: decode_kernel :41-70 for the cell (the rows the operator can return: box,
-// score, class), and iou3d_nms_kernel.cu:294-308's remap of the box into NMS layout.
-__device__ __forceinline__ void cp_decode_row(const CpHeads& h, const CpCfg& c, int set, int r, int i, int cap,
-                                              const CpRows& o) {
-  const int t = set % c.num_tasks, frame = set / c.num_tasks;
+// The head values of one cell a box is made of.
+struct CpCell {
+  float x, y, z, d0, d1, d2, r0, r1, v0, v1;
+};
+
+__device__ __forceinline__ CpCell cp_gather_cell(const CpHeads& h, const CpCfg& c, int t, int frame, int i) {
   const int64_t bs = h.batch_stride;
   const float* regp = h.reg[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
   const float* heip = h.height[t] + (int64_t)frame * (bs ? bs : (int64_t)c.hw);
   const float* dimp = h.dim[t] + (int64_t)frame * (bs ? bs : (int64_t)3 * c.hw);
   const float* velp = h.vel[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
   const float* rotp = h.rot[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * c.hw);
-  int arg;
-  const float best = cp_best_class(h, c, t, frame, i, arg);
-  const int xs = i % c.feat_w, ys = i / c.feat_w;
-  const float x = regp[i], y = regp[i + c.hw], z = heip[i];
-  float* bx = o.boxes + ((int64_t)set * cap + r) * c.dims;
-  bx[0] = (x + xs) * c.down_ratio * c.vx + c.pc_x;
-  bx[1] = (y + ys) * c.down_ratio * c.vy + c.pc_y;
-  bx[2] = z;
-  bx[3] = exp_rn(dimp[i]);  // :151 exp(dim)
-  bx[4] = exp_rn(dimp[i + c.hw]);
-  bx[5] = exp_rn(dimp[i + 2 * c.hw]);
-  const float ang = atan2_rn(rotp[i], rotp[i + c.hw]);
+  CpCell v;
+  v.x = regp[i], v.y = regp[i + c.hw], v.z = heip[i];
+  v.d0 = dimp[i], v.d1 = dimp[i + c.hw], v.d2 = dimp[i + 2 * c.hw];
+  v.r0 = rotp[i], v.r1 = rotp[i + c.hw];
+  v.v0 = v.v1 = 0.f;
   if (c.with_velocity) {
-    bx[6] = velp[i];
-    bx[7] = velp[i + c.hw];
+    v.v0 = velp[i];
+    v.v1 = velp[i + c.hw];
+  }
+  return v;
+}
+
+// Row r of a set = its r-th best cell i, whose head values, score and class the caller has: decode_kernel :41-70 for
+// the cell (the rows the operator can return: box, score, class), and iou3d_nms_kernel.cu:294-308's remap of the box
+// into NMS layout.  exp3(a, b, c, out) = exp_rn of three values.
+template <class Exp3>
+__device__ __forceinline__ void cp_decode_row(const CpCfg& c, int set, int r, int i, int cap, const CpRows& o,
+                                              const CpCell& v, float best, int arg, Exp3 exp3) {
+  const int xs = i % c.feat_w, ys = i / c.feat_w;
+  const float x = v.x, y = v.y, z = v.z, d0 = v.d0, d1 = v.d1, d2 = v.d2, r0 = v.r0, r1 = v.r1, v0 = v.v0, v1 = v.v1;
+  float ed[3];
+  exp3(d0, d1, d2, ed);  // :151 exp(dim)
+  // every value is kept in a register: read back through the row pointers, each one is a store -> load round trip
+  // (the rows may alias as far as the compiler knows), and six of them in a row were most of this function's time
+  const float cx = (x + xs) * c.down_ratio * c.vx + c.pc_x;
+  const float cy = (y + ys) * c.down_ratio * c.vy + c.pc_y;
+  const float ang = atan2_rn(r0, r1);
+  float* bx = o.boxes + ((int64_t)set * cap + r) * c.dims;
+  bx[0] = cx;
+  bx[1] = cy;
+  bx[2] = z;
+  bx[3] = ed[0];
+  bx[4] = ed[1];
+  bx[5] = ed[2];
+  if (c.with_velocity) {
+    bx[6] = v0;
+    bx[7] = v1;
     bx[8] = ang;
   } else {
     bx[6] = ang;
   }
   o.scores[(int64_t)set * cap + r] = best;
   o.labels[(int64_t)set * cap + r] = arg;
+  const float nb[7] = {cx, cy, z, ed[1], ed[0], ed[2], (float)(-(double)ang - 3.141592653589793 / 2)};
   float* q = o.nms_boxes + ((int64_t)set * cap + r) * 7;
-  q[0] = bx[0];
-  q[1] = bx[1];
-  q[2] = bx[2];
-  q[3] = bx[4];
-  q[4] = bx[3];
-  q[5] = bx[5];
-  q[6] = (float)(-(double)ang - 3.141592653589793 / 2);
-  const float nb[7] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6]};
+#pragma unroll
+  for (int k = 0; k < 7; ++k) q[k] = nb[k];
   const BoxPre bp = box_prepare(nb);  // what the suppression matrix needs of this box
   o.pre[(int64_t)set * cap + r] = bp;
   o.xyr[(int64_t)set * cap + r] = make_float4(bp.cx, bp.cy, bp.rad, 0.f);
@@ -175,7 +194,7 @@ constexpr int kTopkThreads = 1024;  // one workgroup per set and nothing else on
                                     // dependent passes, so its time is its latency -- 16 waves shorten every pass
 constexpr int kTopkMaxHw = 16384;   // keys held in LDS
 constexpr int kTopkMaxK = 1024;     // bitonic list
-constexpr int kTopkBatch = 8;       // cells of a thread whose keys are computed side by side
+constexpr int kTopkBatch = 4;       // cells of a thread whose keys are computed side by side
 constexpr int kTopkCopies = 8;      // histogram replicas (lane & 7): scores crowd into a handful of exponent bins, and
                                     // LDS atomics of one wave on one address run one lane at a time
 
@@ -184,10 +203,11 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg 
   extern __shared__ __attribute__((aligned(16))) unsigned char topk_smem[];
   const int hw = c.hw;
   uint32_t* ks = reinterpret_cast<uint32_t*>(topk_smem);                       // [hw]
-  unsigned long long* list = reinterpret_cast<unsigned long long*>(ks + hw);   // [kTopkMaxK]
+  unsigned long long* list = reinterpret_cast<unsigned long long*>(ks + max(hw, 12 * kTopkMaxK));  // [kTopkMaxK]
   int* hist = reinterpret_cast<int*>(list + kTopkMaxK);                        // [kTopkCopies][1024]
   int* scr = hist + kTopkCopies * 1024;                                                      // [32]: scan scratch, [30], [31] broadcast
   uint64_t* etab = reinterpret_cast<uint64_t*>(scr + 32);                                    // [32]: expf's table
+  unsigned char* cls = reinterpret_cast<unsigned char*>(etab + 32);                          // [hw]: best class of a cell
   const int set = blockIdx.x;
   if (threadIdx.x < 32) etab[threadIdx.x] = lm::exp2f_tab((int)threadIdx.x);
   __syncthreads();
@@ -205,15 +225,24 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg 
     const float* heip = h.height[t] + (int64_t)frame * (bs ? bs : (int64_t)hw);
     const auto tab = [&](int i) { return etab[i]; };
     for (int base = 0; base < hw; base += kTopkBatch * kTopkThreads) {
-      int ii[kTopkBatch];
-      float x[kTopkBatch], y[kTopkBatch], z[kTopkBatch], best[kTopkBatch];
+      int ii[kTopkBatch], arg[kTopkBatch];
+      float best[kTopkBatch];
+      unsigned in_range = 0;  // bit j: cell j passes the mask on reg / height
+      {
+        float x[kTopkBatch], y[kTopkBatch], z[kTopkBatch];
 #pragma unroll
-      for (int j = 0; j < kTopkBatch; ++j) {
-        ii[j] = min(base + j * kTopkThreads + (int)threadIdx.x, hw - 1);  // past the end: the last cell again, dropped below
-        x[j] = regp[ii[j]];
-        y[j] = regp[ii[j] + hw];
-        z[j] = heip[ii[j]];
-        best[j] = 0.f;
+        for (int j = 0; j < kTopkBatch; ++j) {
+          ii[j] = min(base + j * kTopkThreads + (int)threadIdx.x, hw - 1);  // past the end: the last cell again, dropped below
+          x[j] = regp[ii[j]];
+          y[j] = regp[ii[j] + hw];
+          z[j] = heip[ii[j]];
+          best[j] = 0.f;
+          arg[j] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < kTopkBatch; ++j)
+          if (x[j] <= c.r[3] && y[j] <= c.r[4] && z[j] <= c.r[5] && x[j] >= c.r[0] && y[j] >= c.r[1] && z[j] >= c.r[2])
+            in_range |= 1u << j;
       }
       for (int k = 0; k < ncls; ++k) {
         float v[kTopkBatch], e[kTopkBatch];
@@ -225,18 +254,21 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg 
         for (int j = 0; j < kTopkBatch; ++j) {
           if (lm::expf_is_special(v[j])) e[j] = exp_rn(v[j]);
           const float sg = 1.0f / (1.0f + e[j]);
-          if (k == 0 || sg > best[j]) best[j] = sg;  // cp_best_class
+          if (k == 0 || sg > best[j]) {  // cp_best_class
+            best[j] = sg;
+            arg[j] = k;
+          }
         }
       }
 #pragma unroll
       for (int j = 0; j < kTopkBatch; ++j) {
         const int i = base + j * kTopkThreads + (int)threadIdx.x;
-        const bool m = best[j] > c.score_threshold && x[j] <= c.r[3] && y[j] <= c.r[4] && z[j] <= c.r[5] &&
-                       x[j] >= c.r[0] && y[j] >= c.r[1] && z[j] >= c.r[2];
+        const bool m = best[j] > c.score_threshold && ((in_range >> j) & 1u);
         const uint32_t bits = __float_as_uint(best[j]);
         const uint32_t key = m ? (bits <= kKeyOne ? kKeyOne - bits : 0u) : kKeyOut;
         if (i < hw) {
           ks[i] = key;
+          cls[i] = (unsigned char)arg[j];
           selected += m ? 1 : 0;
         }
       }
@@ -311,17 +343,35 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg 
   int tot_less, tot_eq;
   int pos_less = block_exclusive_scan<kTopkThreads>(nless, scr, tot_less);
   int pos_eq = block_exclusive_scan<kTopkThreads>(neq, scr, tot_eq);
+  // entry = key : cell : position in this (cell-ordered) list -- the order of (key, cell) with the way back to the position
   for (int i = c0; i < c1; ++i) {
     const uint32_t k = ks[i];
     if (k < kc) {
-      list[pos_less++] = ((unsigned long long)k << 32) | (uint32_t)i;
+      list[pos_less] = ((unsigned long long)k << 32) | (uint32_t)(i << 10) | (uint32_t)pos_less;
+      ++pos_less;
     } else if (k == kc) {
-      if (pos_eq < r) list[tot_less + pos_eq] = ((unsigned long long)k << 32) | (uint32_t)i;
+      if (pos_eq < r) list[tot_less + pos_eq] = ((unsigned long long)k << 32) | (uint32_t)(i << 10) | (uint32_t)(tot_less + pos_eq);
       ++pos_eq;
     }
   }
   __syncthreads();
-  // ---- bitonic sort of the (key, cell) pairs, padded with ~0 -------------------------------------------------
+  // ---- the head values of the selected cells: fetched NOW, by thread p for the p-th cell in cell order ---------
+  // Ten reads of four bytes from ten planes per cell are the slowest thing the decode does (17 of its 22 us when it
+  // came after the sort).  Issued here they are in flight during the sort, whose barriers (px_lds_barrier) wait for
+  // LDS only; neighbouring threads hold neighbouring cells, which share cache lines where selections cluster.
+  const int p = threadIdx.x;
+  const int t_of = set % c.num_tasks, frame_of = set / c.num_tasks;
+  int my_cell = 0;
+  float my_best = 0.f;
+  CpCell my{};
+  if (p < K) {
+    const unsigned long long ent = list[p];
+    my_cell = (int)((uint32_t)ent >> 10);
+    my_best = __uint_as_float(kKeyOne - (uint32_t)(ent >> 32));  // the score is in the key (a sigmoid is <= 1)
+    my = cp_gather_cell(h, c, t_of, frame_of, my_cell);
+  }
+  const int my_cls = cls[my_cell];
+  // ---- bitonic sort of the entries, padded with ~0 ------------------------------------------------------------
   int n2 = 64;
   while (n2 < K) n2 <<= 1;  // uniform
   for (int size = 2; size <= n2; size <<= 1) {
@@ -336,14 +386,49 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg 
           list[hi] = a;
         }
       }
-      __syncthreads();
+      px_lds_barrier();
     }
   }
-  for (int r = threadIdx.x; r < K; r += kTopkThreads) cp_decode_row(h, c, set, r, (int)(list[r] & 0xffffffffull), cap, rows);
+  // ---- position -> rank, then the fetched values travel to their rank through LDS (the keys' 64 KB are free) ------
+  unsigned short* rank_of = reinterpret_cast<unsigned short*>(hist);  // [kTopkMaxK]
+  float* vals = reinterpret_cast<float*>(ks);                          // [12][kTopkMaxK]
+  if (p < K) rank_of[(uint32_t)list[p] & 1023u] = (unsigned short)p;
+  px_lds_barrier();
+  if (p < K) {
+    const int rk = rank_of[p];
+    const float row[10] = {my.x, my.y, my.z, my.d0, my.d1, my.d2, my.r0, my.r1, my.v0, my.v1};
+#pragma unroll
+    for (int k = 0; k < 10; ++k) vals[k * kTopkMaxK + rk] = row[k];
+    vals[10 * kTopkMaxK + rk] = my_best;
+    vals[11 * kTopkMaxK + rk] = __int_as_float((my_cell << 8) | my_cls);
+  }
+  px_lds_barrier();
+  // ---- decode: thread r takes the r-th row --------------------------------------------------------------------------
+  if (p < K) {
+    CpCell v;
+    v.x = vals[p], v.y = vals[kTopkMaxK + p], v.z = vals[2 * kTopkMaxK + p];
+    v.d0 = vals[3 * kTopkMaxK + p], v.d1 = vals[4 * kTopkMaxK + p], v.d2 = vals[5 * kTopkMaxK + p];
+    v.r0 = vals[6 * kTopkMaxK + p], v.r1 = vals[7 * kTopkMaxK + p];
+    v.v0 = vals[8 * kTopkMaxK + p], v.v1 = vals[9 * kTopkMaxK + p];
+    const float best = vals[10 * kTopkMaxK + p];
+    const int cc = __float_as_int(vals[11 * kTopkMaxK + p]);
+    const auto tab = [&](int i) { return etab[i]; };
+    cp_decode_row(c, set, p, cc >> 8, cap, rows, v, best, cc & 255, [&](float a, float b, float d, float* e) {
+      e[0] = lm::expf_main(a, tab);
+      e[1] = lm::expf_main(b, tab);
+      e[2] = lm::expf_main(d, tab);
+      if (lm::expf_is_special(a)) e[0] = exp_rn(a);
+      if (lm::expf_is_special(b)) e[1] = exp_rn(b);
+      if (lm::expf_is_special(d)) e[2] = exp_rn(d);
+    });
+  }
 }
 
+// LDS of cp_topk_kernel: keys (later the 12 x 1024 values on their way to rank order), list, histograms, scan scratch,
+// expf's table, classes
+static inline size_t cp_topk_keys_bytes(int hw) { return std::max((size_t)hw * 4, (size_t)12 * kTopkMaxK * 4); }
 static inline size_t cp_topk_lds(int hw) {
-  return (size_t)hw * 4 + (size_t)kTopkMaxK * 8 + (size_t)kTopkCopies * 1024 * 4 + 32 * 4 + 32 * 8;
+  return cp_topk_keys_bytes(hw) + (size_t)kTopkMaxK * 8 + (size_t)kTopkCopies * 1024 * 4 + 32 * 4 + 32 * 8 + (size_t)hw;
 }
 
 // The full-sort selection's last pass: the nms_pre_max_size best cells of every set, in sorted order.
@@ -353,7 +438,15 @@ __global__ __launch_bounds__(256) void cp_nms_boxes_kernel(CpHeads h, CpCfg c, c
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = min(counts[set], cap);
   if (r >= n) return;
-  cp_decode_row(h, c, set, r, (int)sidx[(int64_t)set * c.hw + r], cap, rows);
+  const int i = (int)sidx[(int64_t)set * c.hw + r];
+  int arg;
+  const float best = cp_best_class(h, c, set % c.num_tasks, set / c.num_tasks, i, arg);
+  const CpCell v = cp_gather_cell(h, c, set % c.num_tasks, set / c.num_tasks, i);
+  cp_decode_row(c, set, r, i, cap, rows, v, best, arg, [](float a, float b, float d, float* e) {
+    e[0] = exp_rn(a);
+    e[1] = exp_rn(b);
+    e[2] = exp_rn(d);
+  });
 }
 
 // Concatenate the tasks' rows in task order (postprocess.cu:247-278).  One workgroup per (task, frame): the row its
@@ -537,7 +630,9 @@ static int cp_postprocess_impl(
   hipError_t e;
   if (selection < 0 || selection > 1) return PD3_EINVAL;
   const CpRows rows{w.boxes, w.scores, w.labels, w.nms_boxes, w.pre, w.pool.xyr};
-  if (hw <= kTopkMaxHw && cap <= kTopkMaxK && selection == 0) {
+  bool byte_classes = true;
+  for (int t = 0; t < num_tasks; ++t) byte_classes = byte_classes && hm_channels[t] <= 256;
+  if (hw <= kTopkMaxHw && cap <= kTopkMaxK && byte_classes && selection == 0) {
     const size_t lds = cp_topk_lds(hw);
     e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(cp_topk_kernel), (int)cp_topk_lds(kTopkMaxHw));
     if (e != hipSuccess) return (int)e;
