@@ -25,6 +25,7 @@
 #include "radix_sort.hpp"
 
 #include <algorithm>
+#include <cstring>
 
 namespace pd3 {
 
@@ -198,17 +199,21 @@ constexpr int kTopkBatch = 4;       // cells of a thread whose keys are computed
 constexpr int kTopkCopies = 8;      // histogram replicas (lane & 7): scores crowd into a handful of exponent bins, and
                                     // LDS atomics of one wave on one address run one lane at a time
 
+// Where cell i's key sits in LDS: one word of padding per 16 cells, so that the compaction's threads (16 consecutive
+// cells each at 16 k cells) read 64 different banks instead of 4.
+__device__ __forceinline__ int kidx(int i) { return i + (i >> 4); }
+
 __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg c, int* __restrict__ counts,
-                                                               int* __restrict__ pool_counts, int cap, CpRows rows) {
+                                                               int* __restrict__ pool_counts, int cap, CpRows rows, int key_bits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char topk_smem[];
   const int hw = c.hw;
   uint32_t* ks = reinterpret_cast<uint32_t*>(topk_smem);                       // [hw]
-  unsigned long long* list = reinterpret_cast<unsigned long long*>(ks + max(hw, 12 * kTopkMaxK));  // [kTopkMaxK]
+  unsigned long long* list = reinterpret_cast<unsigned long long*>(ks + ((max(hw + hw / 16 + 1, 12 * kTopkMaxK) + 1) & ~1));  // [kTopkMaxK]
   int* hist = reinterpret_cast<int*>(list + kTopkMaxK);                        // [kTopkCopies][1024]
   int* scr = hist + kTopkCopies * 1024;                                                      // [32]: scan scratch, [30], [31] broadcast
   uint64_t* etab = reinterpret_cast<uint64_t*>(scr + 32);                                    // [32]: expf's table
   unsigned char* cls = reinterpret_cast<unsigned char*>(etab + 32);                          // [hw]: best class of a cell
-  const int set = blockIdx.x;
+  const int set = blockIdx.x, sets = gridDim.x;
   if (threadIdx.x < 32) etab[threadIdx.x] = lm::exp2f_tab((int)threadIdx.x);
   __syncthreads();
   // ---- keys of all cells (cp_cell_key, kTopkBatch cells of a thread at a time) ---------------------------------
@@ -224,35 +229,49 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg 
     const float* regp = h.reg[t] + (int64_t)frame * (bs ? bs : (int64_t)2 * hw);
     const float* heip = h.height[t] + (int64_t)frame * (bs ? bs : (int64_t)hw);
     const auto tab = [&](int i) { return etab[i]; };
+    // software pipeline: the reads of batch b + 1 (reg, height, the first class map) and of class k + 1 are issued
+    // before batch b / class k is computed
+    int ii_n[kTopkBatch];
+    float x_n[kTopkBatch], y_n[kTopkBatch], z_n[kTopkBatch], v_n[kTopkBatch];
+    const auto fetch = [&](int base) {
+#pragma unroll
+      for (int j = 0; j < kTopkBatch; ++j) {
+        ii_n[j] = min(base + j * kTopkThreads + (int)threadIdx.x, hw - 1);  // past the end: the last cell again, dropped below
+        x_n[j] = regp[ii_n[j]];
+        y_n[j] = regp[ii_n[j] + hw];
+        z_n[j] = heip[ii_n[j]];
+        v_n[j] = hmp[ii_n[j]];
+      }
+    };
+    fetch(0);
     for (int base = 0; base < hw; base += kTopkBatch * kTopkThreads) {
       int ii[kTopkBatch], arg[kTopkBatch];
-      float best[kTopkBatch];
+      float best[kTopkBatch], v[kTopkBatch];
       unsigned in_range = 0;  // bit j: cell j passes the mask on reg / height
-      {
-        float x[kTopkBatch], y[kTopkBatch], z[kTopkBatch];
 #pragma unroll
-        for (int j = 0; j < kTopkBatch; ++j) {
-          ii[j] = min(base + j * kTopkThreads + (int)threadIdx.x, hw - 1);  // past the end: the last cell again, dropped below
-          x[j] = regp[ii[j]];
-          y[j] = regp[ii[j] + hw];
-          z[j] = heip[ii[j]];
-          best[j] = 0.f;
-          arg[j] = 0;
+      for (int j = 0; j < kTopkBatch; ++j) {
+        ii[j] = ii_n[j];
+        v[j] = v_n[j];
+        if (x_n[j] <= c.r[3] && y_n[j] <= c.r[4] && z_n[j] <= c.r[5] && x_n[j] >= c.r[0] && y_n[j] >= c.r[1] &&
+            z_n[j] >= c.r[2])
+          in_range |= 1u << j;
+        best[j] = 0.f;
+        arg[j] = 0;
+      }
+      if (base + kTopkBatch * kTopkThreads < hw) fetch(base + kTopkBatch * kTopkThreads);
+      for (int k = 0; k < ncls; ++k) {
+        float e[kTopkBatch], vk[kTopkBatch];
+#pragma unroll
+        for (int j = 0; j < kTopkBatch; ++j) vk[j] = -v[j];
+        if (k + 1 < ncls) {
+#pragma unroll
+          for (int j = 0; j < kTopkBatch; ++j) v[j] = hmp[(int64_t)(k + 1) * hw + ii[j]];
         }
 #pragma unroll
-        for (int j = 0; j < kTopkBatch; ++j)
-          if (x[j] <= c.r[3] && y[j] <= c.r[4] && z[j] <= c.r[5] && x[j] >= c.r[0] && y[j] >= c.r[1] && z[j] >= c.r[2])
-            in_range |= 1u << j;
-      }
-      for (int k = 0; k < ncls; ++k) {
-        float v[kTopkBatch], e[kTopkBatch];
-#pragma unroll
-        for (int j = 0; j < kTopkBatch; ++j) v[j] = -hmp[(int64_t)k * hw + ii[j]];
-#pragma unroll
-        for (int j = 0; j < kTopkBatch; ++j) e[j] = lm::expf_main(v[j], tab);
+        for (int j = 0; j < kTopkBatch; ++j) e[j] = lm::expf_main(vk[j], tab);
 #pragma unroll
         for (int j = 0; j < kTopkBatch; ++j) {
-          if (lm::expf_is_special(v[j])) e[j] = exp_rn(v[j]);
+          if (lm::expf_is_special(vk[j])) e[j] = exp_rn(vk[j]);
           const float sg = 1.0f / (1.0f + e[j]);
           if (k == 0 || sg > best[j]) {  // cp_best_class
             best[j] = sg;
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg 
         const uint32_t bits = __float_as_uint(best[j]);
         const uint32_t key = m ? (bits <= kKeyOne ? kKeyOne - bits : 0u) : kKeyOut;
         if (i < hw) {
-          ks[i] = key;
+          ks[kidx(i)] = key;
           cls[i] = (unsigned char)arg[j];
           selected += m ? 1 : 0;
         }
@@ -281,24 +300,29 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg 
     counts[set] = count;
     // the two counters the suppression-matrix kernels append through (nms_kernels.hpp NmsPool): no set-up memset
     pool_counts[set * kNmsCtrStride] = 0;
-    pool_counts[((int)gridDim.x + set) * kNmsCtrStride] = 0;
+    pool_counts[(sets + set) * kNmsCtrStride] = 0;
   }
   const int K = min(count, cap);
   if (K <= 0) return;
   // ---- cut-off key kc and the number r of cells with key == kc that are taken (0: take every key < kc) -----
+  // Radix select over the key_bits bits a masked-in key can have (scores above the threshold: 25 bits at 0.1 -- the
+  // bits above are zero, and a digit taken from them put all cells into 27 bins), ten bits at a time from the top;
+  // it stops as soon as the bin holding the cut-off is needed whole, which after two digits (16 k cells over a million
+  // bins) it nearly always is.
   uint32_t kc = kKeyOut;
   int r = 0;
   if (count > K) {
     uint32_t prefix = 0;  // decided high bits
     int need = K;         // rank of the cut-off inside the still-undecided set (1-based)
-    for (int pass = 0; pass < 3; ++pass) {
-      const int shift = 20 - 10 * pass;
+    int hi = key_bits;    // bits [0, hi) are undecided
+    while (hi > 0) {
+      const int w = min(hi, 10), shift = hi - w;
       for (int i = threadIdx.x; i < kTopkCopies * 1024; i += kTopkThreads) hist[i] = 0;
       __syncthreads();
       for (int i = threadIdx.x; i < hw; i += kTopkThreads) {
-        const uint32_t k = ks[i];
-        if (pass == 0 || (k >> (shift + 10)) == prefix)
-          atomicAdd(&hist[(threadIdx.x & (kTopkCopies - 1)) * 1024 + ((k >> shift) & 1023u)], 1);
+        const uint32_t k = ks[kidx(i)];
+        if ((k >> hi) == prefix)
+          atomicAdd(&hist[(threadIdx.x & (kTopkCopies - 1)) * 1024 + ((k >> shift) & ((1u << w) - 1u))], 1);
       }
       __syncthreads();
       // thread t owns bins kBpt t .. kBpt t + kBpt - 1: exclusive prefix over bins, find the bin holding rank `need`
@@ -318,15 +342,23 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg 
 #pragma unroll
       for (int j = 0; j < kBpt; ++j) {
         if (need > cum && need <= cum + hh[j]) {  // exactly one (thread, j) satisfies this
+          scr[29] = hh[j];
           scr[30] = b0 + j;
           scr[31] = need - cum;
         }
         cum += hh[j];
       }
       __syncthreads();
-      prefix = (prefix << 10) | (uint32_t)scr[30];
+      const int in_bin = scr[29];
+      prefix = (prefix << w) | (uint32_t)scr[30];
       need = scr[31];
+      hi = shift;
       __syncthreads();
+      if (need == in_bin) {  // the whole bin is taken: every key below the next prefix, none at it
+        prefix = (prefix + 1u) << hi;
+        need = 0;
+        break;
+      }
     }
     kc = prefix;
     r = need;
@@ -336,7 +368,7 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg 
   const int c0 = threadIdx.x * ept, c1 = min(c0 + ept, hw);
   int nless = 0, neq = 0;
   for (int i = c0; i < c1; ++i) {
-    const uint32_t k = ks[i];
+    const uint32_t k = ks[kidx(i)];
     nless += k < kc ? 1 : 0;
     neq += k == kc ? 1 : 0;
   }
@@ -345,7 +377,7 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg 
   int pos_eq = block_exclusive_scan<kTopkThreads>(neq, scr, tot_eq);
   // entry = key : cell : position in this (cell-ordered) list -- the order of (key, cell) with the way back to the position
   for (int i = c0; i < c1; ++i) {
-    const uint32_t k = ks[i];
+    const uint32_t k = ks[kidx(i)];
     if (k < kc) {
       list[pos_less] = ((unsigned long long)k << 32) | (uint32_t)(i << 10) | (uint32_t)pos_less;
       ++pos_less;
@@ -371,23 +403,33 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg 
     my = cp_gather_cell(h, c, t_of, frame_of, my_cell);
   }
   const int my_cls = cls[my_cell];
-  // ---- bitonic sort of the entries, padded with ~0 ------------------------------------------------------------
-  int n2 = 64;
-  while (n2 < K) n2 <<= 1;  // uniform
-  for (int size = 2; size <= n2; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = threadIdx.x; t < (n2 >> 1); t += kTopkThreads) {
-        const int lo = 2 * t - (t & (stride - 1));
-        const int hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const unsigned long long a = list[lo], b = list[hi];
-        if ((a > b) == up) {
-          list[lo] = b;
-          list[hi] = a;
+  // ---- bitonic sort of the entries, padded with ~0: one compare-exchange per thread and step ---------------------
+  // Thread t of wave w works on entries [128 w, 128 w + 128) at every stride up to 64 -- entries no other wave touches
+  // at such a step -- so those steps follow each other in the wave's own LDS order; a barrier is only needed around the
+  // steps with a stride of 128 and more: 10 of them at 1024 entries instead of one after each of the 55 steps.
+  {
+    int n2 = 64;
+    while (n2 < K) n2 <<= 1;  // uniform
+    const int t = threadIdx.x;
+    for (int size = 2; size <= n2; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        if (t < (n2 >> 1)) {
+          const int lo = 2 * t - (t & (stride - 1));
+          const int hi = lo + stride;
+          const bool up = (lo & size) == 0;
+          const unsigned long long a = list[lo], b = list[hi];
+          if ((a > b) == up) {
+            list[lo] = b;
+            list[hi] = a;
+          }
         }
+        if (stride >= 2 * kWave || (stride == 1 && size >= 2 * kWave))
+          px_lds_barrier();
+        else
+          asm volatile("" ::: "memory");
       }
-      px_lds_barrier();
     }
+    px_lds_barrier();
   }
   // ---- position -> rank, then the fetched values travel to their rank through LDS (the keys' 64 KB are free) ------
   unsigned short* rank_of = reinterpret_cast<unsigned short*>(hist);  // [kTopkMaxK]
@@ -426,9 +468,9 @@ __global__ __launch_bounds__(kTopkThreads) void cp_topk_kernel(CpHeads h, CpCfg 
 
 // LDS of cp_topk_kernel: keys (later the 12 x 1024 values on their way to rank order), list, histograms, scan scratch,
 // expf's table, classes
-static inline size_t cp_topk_keys_bytes(int hw) { return std::max((size_t)hw * 4, (size_t)12 * kTopkMaxK * 4); }
+static inline size_t cp_topk_keys_words(int hw) { return std::max((size_t)hw + (size_t)hw / 16 + 1, (size_t)12 * kTopkMaxK); }
 static inline size_t cp_topk_lds(int hw) {
-  return cp_topk_keys_bytes(hw) + (size_t)kTopkMaxK * 8 + (size_t)kTopkCopies * 1024 * 4 + 32 * 4 + 32 * 8 + (size_t)hw;
+  return cp_topk_keys_words(hw) * 4 + 8 + (size_t)kTopkMaxK * 8 + (size_t)kTopkCopies * 1024 * 4 + 32 * 4 + 32 * 8 + (size_t)hw;
 }
 
 // The full-sort selection's last pass: the nms_pre_max_size best cells of every set, in sorted order.
@@ -636,7 +678,13 @@ static int cp_postprocess_impl(
     const size_t lds = cp_topk_lds(hw);
     e = pd3_max_dynamic_lds(reinterpret_cast<const void*>(cp_topk_kernel), (int)cp_topk_lds(kTopkMaxHw));
     if (e != hipSuccess) return (int)e;
-    cp_topk_kernel<<<sets, kTopkThreads, lds, s>>>(h, c, w.counts, w.pool.counts, cap, rows);
+    // bits a masked-in key can have: key = bits(1.0f) - bits(score) with score in (threshold, 1]
+    uint32_t thr_bits;
+    memcpy(&thr_bits, &score_threshold, 4);
+    const uint32_t top = (score_threshold > 0.f && thr_bits < kKeyOne) ? kKeyOne - thr_bits : kKeyOne;
+    int key_bits = 1;
+    while (key_bits < 30 && (top >> key_bits) != 0) ++key_bits;
+    cp_topk_kernel<<<sets, kTopkThreads, lds, s>>>(h, c, w.counts, w.pool.counts, cap, rows, key_bits);
   } else {
     e = hipMemsetAsync(w.counts, 0, (size_t)((char*)(w.pool.counts + (size_t)sets * 2 * kNmsCtrStride) - (char*)w.counts), s);
     if (e != hipSuccess) return (int)e;
