@@ -143,10 +143,16 @@ static inline int nms_pool_per_set(int cap) {
 static __global__ __launch_bounds__(64) void nms_cand_kernel(const int* __restrict__ counts, int sets, int cap,
                                                              int cb_cap, unsigned long long* __restrict__ mask,
                                                              NmsPool pl) {
-  const int set = blockIdx.z;
+  // grid.x walks the upper triangle of the cb_cap x cb_cap tiles row by row (a square grid started as many waves
+  // again only to end them)
+  const int set = blockIdx.y;
   const int n = min(counts[set], cap);
-  const int row_blk = blockIdx.y, col_blk = blockIdx.x;
-  if (col_blk < row_blk) return;
+  int row_blk = 0, col_blk = blockIdx.x;
+  for (int len = cb_cap; col_blk >= len; --len) {  // row r holds cb_cap - r tiles
+    col_blk -= len;
+    ++row_blk;
+  }
+  col_blk += row_blk;
   if (row_blk * 64 >= n || col_blk * 64 >= n) return;
   const int lane = threadIdx.x;
   const float4* ps = pl.xyr + (int64_t)set * cap;
@@ -155,21 +161,18 @@ static __global__ __launch_bounds__(64) void nms_cand_kernel(const int* __restri
   const bool live = row < n;
   const float4 me = live ? ps[row] : make_float4(0.f, 0.f, 0.f, 0.f);
   const float mx = me.x, my = me.y, mr = me.z;
-  // lane i holds column i's centre and radius; the walk reads them with v_readlane (no branch, no memory access
-  // inside the loop): all 64 columns are tested, the columns past the set's last box and, in a
-  // diagonal tile, the columns up to the row itself are masked off afterwards
-  const float4 cc = lane < col_size ? ps[col0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int ccx = __float_as_int(cc.x), ccy = __float_as_int(cc.y), ccr = __float_as_int(cc.z);
+  // a column's centre and radius are the same for all lanes: read through the scalar cache (wave-uniform index into a
+  // read-only array -> s_load), they are SGPR operands of the test and cost no vector instruction (round 5 moved them
+  // lane to lane with three v_readlane per column: a quarter of the loop).  All 64 columns are tested; the columns
+  // past the set's last box and, in a diagonal tile, the columns up to the row itself are masked off afterwards
   unsigned long long bits = 0ull;
 #pragma unroll 1
-  for (int g8 = 0; g8 < 64; g8 += 8) {  // eight columns per trip: their 24 scalars fit the SGPR file without spills
+  for (int g8 = 0; g8 < 64; g8 += 8) {  // eight columns per trip: their 32 scalars fit the SGPR file without spills
     unsigned byte = 0u;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float cx = __int_as_float(__builtin_amdgcn_readlane(ccx, g8 + j));
-      const float cy = __int_as_float(__builtin_amdgcn_readlane(ccy, g8 + j));
-      const float cr = __int_as_float(__builtin_amdgcn_readlane(ccr, g8 + j));
-      const float dx = mx - cx, dy = my - cy, r = mr + cr + 0.25f;
+      const float4 cc = ps[min(col0 + g8 + j, cap - 1)];
+      const float dx = mx - cc.x, dy = my - cc.y, r = mr + cc.z + 0.25f;
       const bool cand = !(dx * dx + dy * dy > r * r);  // the same test box_overlap starts with
       byte |= cand ? 1u << j : 0u;
     }
@@ -256,7 +259,7 @@ static __global__ __launch_bounds__(256) void nms_pairs_kernel(const BoxPre* __r
 // The rotated-box bit matrix of `sets` sets (counts on the device): candidate pass, then the pooled pairs.
 static inline void nms_enqueue_mask_pooled(const BoxPre* pre, const int* counts, int sets, int cap, int cb, float thresh,
                                            unsigned long long* mask, const NmsPool& pl, hipStream_t s) {
-  nms_cand_kernel<<<dim3(cb, cb, sets), 64, 0, s>>>(counts, sets, cap, cb, mask, pl);
+  nms_cand_kernel<<<dim3(cb * (cb + 1) / 2, sets), 64, 0, s>>>(counts, sets, cap, cb, mask, pl);
   nms_pairs_kernel<<<dim3(kNmsPairWgs, sets), 256, 0, s>>>(pre, counts, sets, cap, cb, thresh, mask, pl);
 }
 
