@@ -307,9 +307,15 @@ __global__ __launch_bounds__(kSsdTopkThreads) void ssd_topk_kernel(const uint32_
           list[hi] = a;
         }
       }
-      __syncthreads();
+      // thread t of wave w works on entries [128 w, 128 w + 128) at every stride up to 64: those steps follow each
+      // other in the wave's own LDS order, a barrier is only needed around the strides of 128 and more
+      if (stride >= 2 * kWave || (stride == 1 && size >= 2 * kWave))
+        __syncthreads();
+      else
+        asm volatile("" ::: "memory");
     }
   }
+  __syncthreads();
   if (t < K) sidx[(int64_t)frame * n + t] = (uint32_t)(list[t] & 0xffffffffull);
 }
 
@@ -326,14 +332,11 @@ __global__ __launch_bounds__(256) void ssd_nms_boxes_kernel(const float* __restr
   const uint32_t a = sidx[(int64_t)frame * num_anchors + r];
   const float* bx = boxes + ((int64_t)frame * num_anchors + a) * 7;
   float* o = nms_boxes + ((int64_t)frame * cap + r) * 7;
-  o[0] = bx[0];
-  o[1] = bx[1];
-  o[2] = bx[2];
-  o[3] = bx[4];
-  o[4] = bx[3];
-  o[5] = bx[5];
-  o[6] = (-bx[6]) - 1.57079632679489661923f;
-  const float nb[7] = {o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
+  // (registers first: read back through `o`, every value is a store -> load round trip -- the rows may alias as far
+  // as the compiler knows)
+  const float nb[7] = {bx[0], bx[1], bx[2], bx[4], bx[3], bx[5], (-bx[6]) - 1.57079632679489661923f};
+#pragma unroll
+  for (int k = 0; k < 7; ++k) o[k] = nb[k];
   const BoxPre bp = box_prepare(nb);  // what the suppression matrix needs of this box
   pre[(int64_t)frame * cap + r] = bp;
   xyr[(int64_t)frame * cap + r] = make_float4(bp.cx, bp.cy, bp.rad, 0.f);
