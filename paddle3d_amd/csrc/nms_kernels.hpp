@@ -316,25 +316,34 @@ static __global__ __launch_bounds__(kNmsSweepThreads) void nms_sweep_kernel(cons
     unsigned long long diag = 0ull;
     if (lane < rows)
       diag = in_lds ? mlds[(nb * 64 + lane) * cbs + nb] : m[(int64_t)(nb * 64 + lane) * cb_cap + nb];
-    // The serial resolve of the diagonal word, on the SCALAR unit with constant lane indices (round 5): the rolled loop
-    // with a runtime trip count cost ~80 cycles per row (two v_readlane with an SGPR lane select, a 64-bit VALU chain);
-    // unrolled, the 128 readlanes are independent and what is left per row is a test and two conditional ORs on SGPRs.
+    // The serial resolve of the diagonal word, on the SCALAR unit with constant lane indices (round 5: the rolled loop
+    // with a runtime trip count cost ~80 cycles per row).  One wave alone on its CU issues an instruction every four or
+    // five cycles, so what counts is the NUMBER of instructions per row (round 6, cycle stamps: 53 cycles per row = nine
+    // instructions).  Row t only has bits above t (upper triangle), so (a) bit t of `cur` is final once row t - 1 is
+    // done: the kept rows are simply ~cur at the end, no per-row bookkeeping; (b) rows 0..31 decide on the low word
+    // alone and rows 32..63 on the high word alone (their low words are zero): 32-bit tests and ORs, the high words of
+    // the kept rows 0..31 collected on the side.  Seven instructions per row for the first half, four for the second.
     // Rows past `rows` carry a zero word and are masked out of keepbits afterwards.
     const unsigned long long cur0 = remv[nb];  // uniform
     // (the builtin returns int: through `unsigned` first, or the low word's bit 31 sign-extends into the high word)
-    const unsigned cur_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(cur0 >> 32));
-    const unsigned cur_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(cur0 & 0xffffffffull));
-    unsigned long long cur = ((unsigned long long)cur_hi << 32) | (unsigned long long)cur_lo;
-    unsigned long long keepbits = 0ull;
+    unsigned cur_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(cur0 >> 32));
+    unsigned cur_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(cur0 & 0xffffffffull));
     const unsigned dlo = (unsigned)(diag & 0xffffffffull), dhi = (unsigned)(diag >> 32);
 #pragma unroll
-    for (int t = 0; t < 64; ++t) {
+    for (int t = 0; t < 32; ++t) {
       const unsigned lo = __builtin_amdgcn_readlane(dlo, t);
       const unsigned hi = __builtin_amdgcn_readlane(dhi, t);
-      const bool keep = !((cur >> t) & 1ull);
-      keepbits |= keep ? (1ull << t) : 0ull;
-      cur |= keep ? (((unsigned long long)hi << 32) | lo) : 0ull;
+      const bool keep = !((cur_lo >> t) & 1u);
+      cur_lo |= keep ? lo : 0u;
+      cur_hi |= keep ? hi : 0u;
     }
+#pragma unroll
+    for (int t = 32; t < 64; ++t) {
+      const unsigned hi = __builtin_amdgcn_readlane(dhi, t);
+      const bool keep = !((cur_hi >> (t - 32)) & 1u);
+      cur_hi |= keep ? hi : 0u;
+    }
+    unsigned long long keepbits = ~(((unsigned long long)cur_hi << 32) | (unsigned long long)cur_lo);
     keepbits &= rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
     // append kept rows in order
     if (lane < rows && ((keepbits >> lane) & 1ull))
@@ -343,17 +352,22 @@ static __global__ __launch_bounds__(kNmsSweepThreads) void nms_sweep_kernel(cons
     // OR the kept rows' words into the later column blocks
     if (in_lds) {
       // cbs <= 16 here: lane = (row group g, word jj); every lane ORs 16 of the block's 64 rows (independent LDS loads,
-      // pipelined; rows that were not kept contribute 0), the four groups are combined across the wave
+      // pipelined; rows that were not kept -- or lie past the set's last box: their keep bit is zero, and the LDS area
+      // is sized for whole blocks of 64 rows -- contribute 0: the row's keep bit as an all-ones / all-zeros word, one
+      // and-or per half), the four groups are combined across the wave
       const int g = lane >> 4, j = nb + 1 + (lane & 15);
-      unsigned long long acc = 0ull;
+      unsigned lo = 0u, hi = 0u;
       if (j < cbs) {
-#pragma unroll 8
-        for (int t = g * 16; t < min(g * 16 + 16, rows); ++t) {
-          const unsigned long long v = mlds[(nb * 64 + t) * cbs + j];
-          acc |= ((keepbits >> t) & 1ull) ? v : 0ull;
+        const int k16 = (int)((keepbits >> (g * 16)) & 0xffffull);
+        const unsigned long long* src = mlds + (nb * 64 + g * 16) * cbs + j;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const unsigned long long v = src[t * cbs];
+          const unsigned m = (unsigned)-((k16 >> t) & 1);
+          lo |= (unsigned)(v & 0xffffffffull) & m;
+          hi |= (unsigned)(v >> 32) & m;
         }
       }
-      unsigned lo = (unsigned)(acc & 0xffffffffull), hi = (unsigned)(acc >> 32);
       lo |= (unsigned)__shfl_xor((int)lo, 16, 64);
       hi |= (unsigned)__shfl_xor((int)hi, 16, 64);
       lo |= (unsigned)__shfl_xor((int)lo, 32, 64);
@@ -383,7 +397,8 @@ static __global__ __launch_bounds__(kNmsSweepThreads) void nms_sweep_kernel(cons
 // few hundred candidates), so the matrix area is sized for min(cap, kNmsLdsBoxes) boxes.
 static inline size_t nms_sweep_lds(int cap) {
   const int c = cap < kNmsLdsBoxes ? cap : kNmsLdsBoxes;
-  return (size_t)kNmsMaxWords * 8 + (size_t)c * ((c + 63) / 64) * 8;
+  const int cb = (c + 63) / 64;
+  return (size_t)kNmsMaxWords * 8 + (size_t)cb * 64 * cb * 8;  // whole blocks of 64 rows (the sweep's OR step reads them all)
 }
 
 }  // namespace pd3
