@@ -231,6 +231,50 @@ def test_postprocess_topk_select_equals_full_sort(oracle, pre):
     np.testing.assert_array_equal(b.view(np.uint32), rb.view(np.uint32))
 
 
+@pytest.mark.parametrize("thr", [0.1, 0.0, -1.0, 0.5, 0.9999, 1.0])
+def test_postprocess_extreme_head_values_and_thresholds(oracle, thr):
+    """The one-kernel selection evaluates expf in two parts (polynomial on every argument, the special arguments
+    |x| >= 88 / inf / NaN afterwards) and walks only the key bits a score above the threshold can have: heat maps and
+    box sizes with huge, infinite and NaN entries, thresholds from below 0 to 1, against the full-sort kernels (which
+    call the whole expf per cell): same rows, bit for bit."""
+    tasks = synth.center_head_outputs(11, feat_h=64, feat_w=64, n_peaks=40)
+    rng = np.random.default_rng(5)
+    for t in tasks:
+        hm = t["hm"].reshape(-1)
+        idx = rng.choice(hm.size, 400, replace=False)
+        hm[idx[:80]] = rng.uniform(88.0, 200.0, 80).astype(np.float32)     # exp(-x) underflows: score 1.0
+        hm[idx[80:160]] = -rng.uniform(88.0, 200.0, 80).astype(np.float32)  # exp(-x) overflows: score 0.0
+        hm[idx[160:200]] = np.float32(np.inf)
+        hm[idx[200:240]] = np.float32(-np.inf)
+        hm[idx[240:280]] = np.float32(np.nan)
+        hm[idx[280:400]] = rng.uniform(-104.0, -86.0, 120).astype(np.float32)  # around expf's overflow threshold
+        dm = t["dim"].reshape(-1)
+        jdx = rng.choice(dm.size, 60, replace=False)
+        dm[jdx[:20]] = np.float32(89.0)    # exp overflows to inf
+        dm[jdx[20:40]] = np.float32(-104.0)  # exp underflows (denormal / zero)
+        dm[jdx[40:]] = np.float32(-87.5)
+    from paddle3d_amd.ops import centerpoint_postprocess as cp
+
+    lists = {k: [_cuda(t[k]) for t in tasks] for k in ("hm", "reg", "height", "dim", "vel", "rot")}
+
+    def run(full_sort):
+        bb, ss, ll, nn = cp.centerpoint_postprocess_device(
+            lists["hm"], lists["reg"], lists["height"], lists["dim"], lists["vel"], lists["rot"], CP_CFG["voxel_size"],
+            CP_CFG["point_cloud_range"], CP_CFG["post_center_range"], LABEL_OFFSETS * len(tasks), CP_CFG["down_ratio"],
+            thr, CP_CFG["nms_iou_threshold"], 300, 83, True, full_sort=full_sort)
+        k = int(nn.item())
+        return bb[0, :k].cpu().numpy(), ss[0, :k].cpu().numpy(), ll[0, :k].cpu().numpy()
+
+    b, s, l = run(False)
+    b2, s2, l2 = run(True)
+    assert b.shape == b2.shape and b.shape[0] > 0
+    np.testing.assert_array_equal(l, l2)
+    np.testing.assert_array_equal(s.view(np.uint32), s2.view(np.uint32))
+    np.testing.assert_array_equal(b.view(np.uint32), b2.view(np.uint32))
+    if thr < 1.0:  # scores of exactly 1.0 exist (heat-map entries beyond +88) and lead every task's list
+        assert s.max() == 1.0
+
+
 def test_postprocess_batch_check():
     from paddle3d_amd.ops import centerpoint_postprocess as cp
 
