@@ -143,11 +143,12 @@ __global__ __launch_bounds__(kPcThreads) void pc_rulebook_order_kernel(const int
   }
 }
 
-// rows [n, C] -> out [B, C, plane] NCHW through cell_row, a cell without a row holds fill[c].  Workgroup = 128 consecutive
-// cells x 64 channels through an LDS tile [channel][cell]: a lane fetches 16 bytes of its cell's row (the eight fetches of
+// rows [n, C] -> out [B, C, plane] NCHW through cell_row, a cell without a row holds fill[c].  Workgroup = 256 consecutive
+// cells x 32 channels through an LDS tile [channel][cell]: a lane fetches 16 bytes of its cell's row (the eight fetches of
 // a cell's 128-byte half row come back to back), writes them along the cell axis (conflict-free) and the tile leaves as
-// 512-byte channel segments with streaming stores.
-constexpr int kRdCells = 128, kRdCh = 64, kRdPitch = kRdCells + 4;
+// 1 KB channel segments.  Plain stores: the next layer reads the map at once, and what of it stays in the last-level
+// cache is worth more than what streaming stores save here (128 x 64 tiles with streaming stores: 74 us, this: 63).
+constexpr int kRdCells = 256, kRdCh = 32, kRdPitch = kRdCells + 4;
 __global__ __launch_bounds__(256) void rows_to_dense_tile_kernel(const float* __restrict__ rows,
                                                                  const int* __restrict__ cell_row,
                                                                  const float* __restrict__ fill, int channels,
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void rows_to_dense_tile_kernel(const float* __
   __shared__ __attribute__((aligned(16))) float tile[kRdCh * kRdPitch];
   const int b = blockIdx.z, c0 = blockIdx.y * kRdCh;
   const int64_t cell0 = (int64_t)blockIdx.x * kRdCells;
-  const int px = threadIdx.x & (kRdCells - 1), half = threadIdx.x >> 7;  // cell of the tile, 32-channel half
+  const int px = threadIdx.x & (kRdCells - 1), half = threadIdx.x / kRdCells;  // cell of the tile, 32-channel half
   const int64_t cell = cell0 + px;
   const int id = cell < plane ? cell_row[(int64_t)b * plane + cell] : -1;
   typedef float pc_f32x4 __attribute__((ext_vector_type(4)));
@@ -176,8 +177,8 @@ __global__ __launch_bounds__(256) void rows_to_dense_tile_kernel(const float* __
     const int e = i * 256 + threadIdx.x;
     const int c = e / (kRdCells / 4), p4 = e - c * (kRdCells / 4);
     if (cell0 + p4 * 4 < plane)
-      __builtin_nontemporal_store(*reinterpret_cast<const pc_f32x4*>(tile + c * kRdPitch + p4 * 4),
-                                  reinterpret_cast<pc_f32x4*>(out + ((int64_t)b * channels + c0 + c) * plane + cell0 + p4 * 4));
+      *reinterpret_cast<pc_f32x4*>(out + ((int64_t)b * channels + c0 + c) * plane + cell0 + p4 * 4) =
+          *reinterpret_cast<const pc_f32x4*>(tile + c * kRdPitch + p4 * 4);
   }
 }
 
