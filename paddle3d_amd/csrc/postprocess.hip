@@ -186,11 +186,13 @@ __device__ __forceinline__ void cp_decode_row(const CpCfg& c, int set, int r, in
 // Top-K selection instead of a full sort of the score keys: only the first min(count, nms_pre_max_size) cells of
 // the stable ascending-key order are ever used (postprocess.cu:176-206 sorts the masked scores and slices
 // [:nms_pre_max_size]).  One workgroup per set, everything in LDS, from the head maps to the decoded candidates: the
-// keys of the set's hw cells are COMPUTED into LDS (16 cells per thread; no key array in memory, no count atomics); a
-// 3-pass radix SELECT (10-bit LDS histograms) finds the exact cut-off key and how many cells with that key still fit;
-// the selected cells are compacted in cell order and sorted as (key, cell) pairs by a bitonic network -- the same total
-// order a stable key sort gives; thread r then decodes the r-th cell (cp_decode_row).  Writes counts[set], clears the
-// set's NMS counters and writes the rows [set][0 .. K).
+// keys of the set's hw cells are COMPUTED into LDS (no key array in memory, no count atomics); a radix SELECT (10-bit
+// LDS histograms over the bits a selected key can have) finds the exact cut-off key and how many cells with that key
+// still fit; the selected cells are compacted in cell order -- their head values are requested at this point -- and
+// sorted as (key, cell) pairs by a bitonic network: the same total order a stable key sort gives; the fetched values
+// move to their rank through LDS and thread r decodes the r-th cell (cp_decode_row).  Writes counts[set], clears the
+// set's NMS counters and writes the rows [set][0 .. K).  Every phase was timed by returning early after it
+// (DESIGN_HISTORY 4.4): the kernel is a chain of latencies, and each comment below names the one it removes.
 constexpr int kTopkThreads = 1024;  // one workgroup per set and nothing else on its CU: the kernel is a chain of
                                     // dependent passes, so its time is its latency -- 16 waves shorten every pass
 constexpr int kTopkMaxHw = 16384;   // keys held in LDS
