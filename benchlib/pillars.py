@@ -339,7 +339,7 @@ def bench_pillars(args, rank, world, dev):
         canvas = model.scatter(feats, coors.view(b * v, 4), b)
         mark(3)
         x = model.dense_forward(canvas)
-        preds, _ = model.bbox_head(x)
+        preds, _ = model.bbox_head(x, want_shared=False)  # (as CenterPoint.test_forward calls it)
         mark(4)
         _bx, _sc, _lb, cnt, rec = model.bbox_head.predict_by_custom_op(preds, cfg, device_only=True,
                                                                       records=max_per_img)

@@ -87,7 +87,7 @@ def bench_voxel(args, rank, world, dev):
         x = model.middle_encoder(feats, coors, b)
         mark(2)
         x = model.dense_forward(x)
-        preds, _ = model.bbox_head(x)
+        preds, _ = model.bbox_head(x, want_shared=False)  # (as CenterPoint.test_forward calls it)
         mark(3)
         _bx, _sc, _lb, cnt, rec = model.bbox_head.predict_by_custom_op(preds, cfg, device_only=True,
                                                                       records=cfg["max_per_img"])

@@ -745,8 +745,10 @@ class CenterHead(_InferenceCache, nn.Module):
                 groups=len(finals), ncls=[int(f[0].shape[0]) for f in finals]))
         return self._cache
 
-    def forward(self, x):
-        """x [B, C, H, W] -> (per task dict of head maps, shared feature map), center_head.py:212-220."""
+    def forward(self, x, want_shared=True):
+        """x [B, C, H, W] -> (per task dict of head maps, shared feature map), center_head.py:212-220.
+        want_shared=False (the model's own test_forward, which drops the shared map): under AMP the second item is None
+        instead of the shared map converted back to fp32 NCHW (an 18 us pass per 16 frames nobody reads)."""
         self._require_eval()
         f = self._plan()
         nhwc = x.dtype == torch.float16  # the neck's map as fp16 NHWC (the whole dense graph under AMP)
@@ -801,7 +803,7 @@ class CenterHead(_InferenceCache, nn.Module):
                 rets[t][head] = z[:, g * f["cmax"]:g * f["cmax"] + f["ncls"][g]]
             # the shared map in the reference's layout and dtype in both modes (center_head.py:212-220 returns
             # `ret_dicts, x` with x fp32 [n, 64, h, w]); one 16 MB elementwise pass per 16 frames
-            return rets, x.permute(0, 3, 1, 2).float()
+            return rets, (x.permute(0, 3, 1, 2).float() if want_shared else None)
         chunked = (k < groups and f["hc"] == 64 and first.stride == 1 and _conv.winograd43_supported(first.cin, first.cout, h, w)
                    and w % 4 == 0)
         if chunked:
@@ -981,7 +983,7 @@ class CenterPoint(nn.Module):
             with (checked() if (checked is not None and not device_only) else contextlib.nullcontext()):
                 x = self.extract_pillars(pts, lens, dense=False)
             x = self.dense_forward(x)
-            preds, _ = self.bbox_head(x)
+            preds, _ = self.bbox_head(x, want_shared=False)
             out = self.bbox_head.predict_by_custom_op(preds, self.test_cfg, device_only=device_only)
             if device_only or take is None or not take():
                 break
